@@ -1,0 +1,94 @@
+"""Synthetic weights / 21-mer feature batches for tests and bench.  NumPy only.
+
+The generators are this repo's own (numpy.random.default_rng); the reference has none.
+"""
+import numpy as np
+
+SEQ_LEN = 21
+
+
+def codecv1_lut():
+    """PacBio CodecV1 frame decode table (same values as reference utils/process_utils.py:426-449)."""
+    lut = np.empty(256, dtype=np.int64)
+    i = np.arange(64)
+    lut[0:64] = i
+    lut[64:128] = 64 + 2 * i
+    lut[128:192] = 192 + 4 * i
+    lut[192:256] = 448 + 8 * i
+    return lut
+
+
+def state_dict_shapes(seq_len=21, num_layers=3, num_classes=2, hidden=256, n_embed=8, n_vocab=5, feas_ccs=3):
+    """Key -> shape of ModelAttRNN(attbigru2s).state_dict() (reference models.py:18-66)."""
+    shapes = {"embed.weight": (n_vocab, n_embed)}
+    for layer in range(num_layers):
+        k_in = n_embed + feas_ccs if layer == 0 else 2 * hidden
+        for sfx in ("", "_reverse"):
+            shapes[f"rnn.weight_ih_l{layer}{sfx}"] = (3 * hidden, k_in)
+            shapes[f"rnn.weight_hh_l{layer}{sfx}"] = (3 * hidden, hidden)
+            shapes[f"rnn.bias_ih_l{layer}{sfx}"] = (3 * hidden,)
+            shapes[f"rnn.bias_hh_l{layer}{sfx}"] = (3 * hidden,)
+    shapes["_att3.Wa.weight"] = (hidden, 2 * hidden)
+    shapes["_att3.Ua.weight"] = (hidden, 2 * hidden)
+    shapes["_att3.va.weight"] = (1, hidden)
+    shapes["fc1.weight"] = (num_classes, 4 * hidden)
+    shapes["fc1.bias"] = (num_classes,)
+    return shapes
+
+
+def synth_weights(seed, num_layers=3, hidden=256, fc_bias=True):
+    """Random-init weights with the reference's init ranges: GRU / Linear default U(-1/sqrt(fan), 1/sqrt(fan)),
+    embed and fc1.weight U(-0.1, 0.1) (models.py:71-75).  fc_bias=True draws a small non-zero fc1.bias so
+    that parity tests exercise it (the reference zero-inits it; trained checkpoints do not keep it zero)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for key, shape in state_dict_shapes(num_layers=num_layers, hidden=hidden).items():
+        if key.startswith("rnn."):
+            bound = 1.0 / np.sqrt(hidden)
+        elif key.startswith("_att3."):
+            bound = 1.0 / np.sqrt(shape[-1])
+        elif key == "fc1.bias":
+            bound = 0.05 if fc_bias else 0.0
+        else:
+            bound = 0.1
+        out[key] = rng.uniform(-bound, bound, size=shape).astype(np.float32)
+    return out
+
+
+def synth_sites(n, seed, pseudo_read=15000):
+    """n CpG sites of synthetic 21-mer features, both strands (SURVEY.md §8d recipe).
+
+    Returns dict: kmer1/kmer2 uint8 (n,21) codes 0..4 with index 10 = C(1), 11 = G(2) and 0.1 % N(4) elsewhere;
+    ipd1/pw1/ipd2/pw2 float32 (n,21) = CodecV1-decoded clipped-gamma codes, z-scored per 15 kb pseudo-read,
+    rounded to 6 dp; npass1/npass2 float32 (n,) integer-valued U[3,30]."""
+    rng = np.random.default_rng(seed)
+    lut = codecv1_lut()
+    d = {}
+    for s in (1, 2):
+        kmer = rng.integers(0, 4, size=(n, SEQ_LEN), dtype=np.uint8)
+        nmask = rng.random((n, SEQ_LEN)) < 0.001
+        kmer[nmask] = 4
+        kmer[:, 10] = 1
+        kmer[:, 11] = 2
+        d[f"kmer{s}"] = kmer
+        for name in ("ipd", "pw"):
+            total = n * SEQ_LEN
+            codes = np.clip(rng.gamma(2.0, 12.0, size=total), 0, 255).astype(np.int64)
+            frames = lut[codes].astype(np.float64)
+            out = np.empty(total, dtype=np.float64)
+            for a in range(0, total, pseudo_read):
+                seg = frames[a:a + pseudo_read]
+                sd = seg.std()
+                out[a:a + pseudo_read] = 0.0 if sd == 0 else (seg - seg.mean()) / sd
+            d[f"{name}{s}"] = np.around(out, 6).astype(np.float32).reshape(n, SEQ_LEN)
+        d[f"npass{s}"] = rng.integers(3, 31, size=n).astype(np.float32)
+    return d
+
+
+def synth_h0(n, seed, num_layers=3, hidden=256):
+    """Explicit N(0,1) initial states for both strands: two arrays (2*num_layers, n, hidden) float32
+    (reference layout models.py:77-87; strand-1 draw first)."""
+    rng = np.random.default_rng(seed)
+    h1 = rng.standard_normal((2 * num_layers, n, hidden), dtype=np.float32)
+    h2 = rng.standard_normal((2 * num_layers, n, hidden), dtype=np.float32)
+    return h1, h2

@@ -1,0 +1,224 @@
+"""CPU oracle (NumPy restatement) of the ccsmeth `call_mods` attbigru2s hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ccsmeth_amd/ may import this module; only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
+
+Parity status: PINNED by outputs of the reference itself.  The reference ships no tests and no golden
+vectors; this restatement is pinned against tests/golden/*.npz, which were produced by
+importing /root/reference/ccsmeth in the build container (tests/golden/make_golden.py, h0 injected by
+wrapping torch.randn) and are checked in tests/test_oracle_golden.py.
+
+Third-party arithmetic: the GRU cell is torch.nn.GRU (ATen `_VF.gru`; reference pins torch>=1.2,<=2.1.0 in
+requirements.txt:4, environment.yml:10); its published equations are restated in `gru_direction` below and
+anchored on the reference's call sites models.py:54-55 (ctor) and models.py:125-130 (calls).
+
+Every function cites the reference file:line it follows (paths relative to /root/reference/).
+"""
+import math
+
+import numpy as np
+
+# ccsmeth/utils/process_utils.py:64-73
+N_VOCAB = 5
+NEMBED_BASE = 8
+# ccsmeth/utils/process_utils.py:26-29 — every IUPAC code other than ACGT maps to 4
+BASE2CODE_DNA = {'A': 0, 'C': 1, 'G': 2, 'T': 3, 'N': 4, 'W': 4, 'S': 4, 'M': 4, 'K': 4, 'R': 4,
+                 'Y': 4, 'B': 4, 'V': 4, 'D': 4, 'H': 4, 'Z': 4}
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def gru_direction(x, h0, w_ih, w_hh, b_ih, b_hh, reverse):
+    """One direction of one nn.GRU layer (batch_first).  x (N,L,K), h0 (N,H) -> out (N,L,H), h_n (N,H).
+
+    torch.nn.GRU equations (gate row order [r; z; n], reference call site models.py:125-130):
+      gi = x_t W_ih^T + b_ih ; gh = h W_hh^T + b_hh
+      r = sigmoid(gi_r + gh_r); z = sigmoid(gi_z + gh_z); n = tanh(gi_n + r * gh_n)
+      h' = (h - n) * z + n          (ATen gru_cell form of (1-z)*n + z*h)
+    """
+    n_b, seq_len, _ = x.shape
+    hid = h0.shape[1]
+    h = h0.astype(x.dtype, copy=True)
+    out = np.empty((n_b, seq_len, hid), dtype=x.dtype)
+    gi_all = x @ w_ih.T + b_ih  # (N,L,3H)
+    steps = range(seq_len - 1, -1, -1) if reverse else range(seq_len)
+    for t in steps:
+        gi = gi_all[:, t, :]
+        gh = h @ w_hh.T + b_hh
+        r = _sigmoid(gi[:, :hid] + gh[:, :hid])
+        z = _sigmoid(gi[:, hid:2 * hid] + gh[:, hid:2 * hid])
+        n = np.tanh(gi[:, 2 * hid:] + r * gh[:, 2 * hid:])
+        h = (h - n) * z + n
+        out[:, t, :] = h
+    return out, h
+
+
+def bigru(x, h0, weights, num_layers, prefix="rnn."):
+    """Stacked bidirectional GRU.  h0 (2*num_layers, N, H), index 2l = layer-l forward, 2l+1 = backward
+    (models.py:77-87 init_hidden layout; torch h_0 convention).  Returns (out (N,L,2H), h_n (2*layers,N,H))."""
+    h_n = []
+    inp = x
+    for layer in range(num_layers):
+        outs = []
+        for d, sfx in enumerate(("", "_reverse")):
+            o, hn = gru_direction(inp, h0[2 * layer + d],
+                                  weights[f"{prefix}weight_ih_l{layer}{sfx}"], weights[f"{prefix}weight_hh_l{layer}{sfx}"],
+                                  weights[f"{prefix}bias_ih_l{layer}{sfx}"], weights[f"{prefix}bias_hh_l{layer}{sfx}"],
+                                  reverse=bool(d))
+            outs.append(o)
+            h_n.append(hn)
+        inp = np.concatenate(outs, axis=2)
+    return inp, np.stack(h_n, 0)
+
+
+def attention(last_hidden, enc_out, wa, ua, va):
+    """Bahdanau attention pool, utils/attention.py:48-70.
+    last_hidden (N,2H) query, enc_out (N,L,2H).  e = va . tanh(Wa q + Ua k); a = softmax_L(e); c = sum_t a_t k_t."""
+    q = last_hidden @ wa.T                       # (N,A)            attention.py:69  Wa(last_hidden)
+    k = enc_out @ ua.T                           # (N,L,A)          attention.py:69  Ua(encoder_outputs)
+    e = np.tanh(q[:, None, :] + k) @ va.reshape(-1)  # (N,L)        attention.py:70
+    e = e - e.max(axis=1, keepdims=True)
+    a = np.exp(e)
+    a = a / a.sum(axis=1, keepdims=True)         # attention.py:55 softmax over L
+    ctx = np.einsum("nl,nlc->nc", a, enc_out)    # attention.py:57-58
+    return ctx, a
+
+
+def strand_input(embed_w, kmer, ipd, pw, npass):
+    """models.py:91-106: x = cat(embed[kmer.int()], ipd, pw, npass) -> (N,L,11); feature order = 8 embedding dims,
+    ipd, pw, npass (is_npass=True, is_stds/is_sn/is_map False: call_modifications.py:652-663 defaults)."""
+    kmer = np.asarray(kmer)
+    idx = kmer.astype(np.int32)                  # models.py:91  kmer.int()  (truncation toward zero)
+    emb = embed_w[idx]
+    n_b, seq_len = idx.shape
+    npass = np.asarray(npass, dtype=embed_w.dtype)
+    if npass.ndim == 1:
+        npass = np.repeat(npass[:, None], seq_len, axis=1)   # call_modifications.py:96  [npass]*len(kmer)
+    feats = [emb, np.asarray(ipd, embed_w.dtype)[..., None], np.asarray(pw, embed_w.dtype)[..., None], npass[..., None]]
+    return np.concatenate(feats, axis=2)
+
+
+def attbigru2s_forward(weights, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0_1, h0_2,
+                       num_layers=3, dtype=np.float64):
+    """ModelAttRNN(model_type="attbigru2s").forward, models.py:89-150, with h0 pinned (the reference draws
+    torch.randn per strand, models.py:77-87,125-130 — strand 1 first).  Returns (logits (N,2), probs (N,2))."""
+    w = {k: np.asarray(v, dtype=dtype) for k, v in weights.items()}
+    ctxs = []
+    for kmer, ipd, pw, npass, h0 in ((kmer1, ipd1, pw1, npass1, h0_1), (kmer2, ipd2, pw2, npass2, h0_2)):
+        x = strand_input(w["embed.weight"], kmer, np.asarray(ipd, dtype), np.asarray(pw, dtype), np.asarray(npass, dtype))
+        out, h_n = bigru(x, np.asarray(h0, dtype), w, num_layers)
+        # models.py:135-137: last layer's (fwd, bwd) final states -> (N, 2H)
+        q = np.concatenate([h_n[2 * (num_layers - 1)], h_n[2 * (num_layers - 1) + 1]], axis=1)
+        ctx, _ = attention(q, out, w["_att3.Wa.weight"], w["_att3.Ua.weight"], w["_att3.va.weight"])
+        ctxs.append(ctx)
+    feat = np.concatenate(ctxs, axis=1)                         # models.py:145
+    logits = feat @ w["fc1.weight"].T + w["fc1.bias"]           # models.py:148 (dropout = identity in eval)
+    m = logits.max(axis=1, keepdims=True)
+    p = np.exp(logits - m)
+    probs = p / p.sum(axis=1, keepdims=True)                    # models.py:150 Softmax(1)
+    return logits, probs
+
+
+def prob1_norm_round6(probs_f32):
+    """call_modifications.py:217-224: per site, in float32, round(prob_1 / (prob_0 + prob_1), 6) using the NumPy
+    float32 scalar __round__ (not float64)."""
+    probs_f32 = np.asarray(probs_f32, dtype=np.float32)
+    out = np.empty(probs_f32.shape[0], dtype=np.float32)
+    for i in range(probs_f32.shape[0]):
+        p0, p1 = probs_f32[i, 0], probs_f32[i, 1]
+        out[i] = round(p1 / (p0 + p1), 6)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Host-side rows: feature extraction, batching, MM/ML encode.
+# ---------------------------------------------------------------------------------------------------------
+
+def codecv1_to_frame2():
+    """utils/process_utils.py:426-449: 256-entry CodecV1 LUT.  0-63 -> id; 64-127 -> 64+2k; 128-191 -> 192+4k;
+    192-255 -> 448+8k (max 952)."""
+    lut = [0] * 256
+    for i in range(64):
+        lut[i] = i
+        lut[64 + i] = 64 + 2 * i
+        lut[128 + i] = 192 + 4 * i
+        lut[192 + i] = 448 + 8 * i
+    return lut
+
+
+def complement_seq(seq):
+    """utils/process_utils.py:106-118 (DNA): reverse complement with the IUPAC pair table of
+    process_utils.py:12-15; any base outside the table -> 'N' (process_utils.py:100-103)."""
+    iupac = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A', 'N': 'N', 'W': 'W', 'S': 'S', 'M': 'K', 'K': 'M',
+             'R': 'Y', 'Y': 'R', 'B': 'V', 'V': 'B', 'D': 'H', 'H': 'D', 'Z': 'Z'}
+    return ''.join(iupac.get(b, 'N') for b in reversed(seq))
+
+
+def normalize_signals_zscore(signals):
+    """extract_features.py:181-199 (normalize_method='zscore'): float64 mean/std(ddof=0) over the WHOLE read,
+    all-zero if std == 0, np.around(., 6)."""
+    signals = np.asarray(signals)
+    sshift, sscale = np.mean(signals), np.std(signals)
+    if sscale == 0.0:
+        norm = [0.] * len(signals)
+    else:
+        norm = (signals - sshift) / sscale
+    return np.around(norm, decimals=6)
+
+
+def motif_sites(seq, motif="CG", mod_loc=0):
+    """utils/process_utils.py:122-137 get_refloc_of_methysite_in_motif for one motif."""
+    m = len(motif)
+    return [i + mod_loc for i in range(0, len(seq) - m + 1) if seq[i:i + m] == motif]
+
+
+def extract_read_features(seq, fi, ri, fp, rp, fn, rn, seq_len=21, motif="CG", mod_loc=0):
+    """extract_features.py:261-406 in denovo mode with defaults (norm zscore, is_sn/is_map no, no_decode False).
+    seq = forward sequence; fi/ri/fp/rp = uint8 CodecV1 codes (len == len(seq)); fn/rn = pass counts.
+    Returns a list of per-site tuples (loc, fkmer, fn, f_ipd(21), f_pw(21), rkmer, rn, r_ipd(21), r_pw(21))."""
+    lut = np.asarray(codecv1_to_frame2())
+    n = len(seq)
+    if not (len(fi) == n and len(fp) == n and len(ri) == n and len(rp) == n):
+        return []                                              # extract_features.py:320-325
+    ipd_f = normalize_signals_zscore(lut[np.asarray(fi, dtype=int)])   # :327-334
+    ipd_r = normalize_signals_zscore(lut[np.asarray(ri, dtype=int)])   # ri/rp are NOT flipped (:314-319)
+    pw_f = normalize_signals_zscore(lut[np.asarray(fp, dtype=int)])
+    pw_r = normalize_signals_zscore(lut[np.asarray(rp, dtype=int)])
+    seq_rc = complement_seq(seq)
+    nb = (seq_len - 1) // 2
+    rev_offset = (len(motif) - 1 - mod_loc) - mod_loc          # :341
+    rows = []
+    for loc in motif_sites(seq, motif, mod_loc):
+        rev_loc = loc + rev_offset
+        rl = n - 1 - rev_loc                                   # rev_loc_in_rev :346
+        if nb <= loc < n - nb and nb <= rl < n - nb:           # :347
+            rows.append((loc, seq[loc - nb:loc + nb + 1], fn, ipd_f[loc - nb:loc + nb + 1], pw_f[loc - nb:loc + nb + 1],
+                         seq_rc[rl - nb:rl + nb + 1], rn, ipd_r[rl - nb:rl + nb + 1], pw_r[rl - nb:rl + nb + 1]))
+    return rows
+
+
+def convert_locs_to_mmtag(locs, seq_fwd, base="C"):
+    """_bam2modbam.py:187-203: for each called C (sorted locs) its ordinal among ALL `base` in seq_fwd,
+    delta-coded (first, o_i - 1 - o_{i-1}).  AssertionError if empty or the last loc is not a `base`."""
+    assert len(locs) > 0
+    all_locs = [i for i, b in enumerate(seq_fwd) if b == base]
+    orders = [-1] * len(locs)
+    oi = 0
+    for bi in range(len(all_locs)):
+        if oi >= len(locs):
+            break
+        if all_locs[bi] == locs[oi]:
+            orders[oi] = bi
+            oi += 1
+    assert orders[-1] != -1
+    mm = [orders[0]]
+    for i in range(1, len(orders)):
+        mm.append(orders[i] - 1 - orders[i - 1])
+    return mm
+
+
+def convert_probs_to_mltag(probs):
+    """_bam2modbam.py:206-208: floor(p*256), 255 if p >= 1."""
+    return [math.floor(p * 256) if p < 1 else 255 for p in probs]

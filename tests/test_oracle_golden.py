@@ -1,0 +1,115 @@
+"""Pin the NumPy oracle against outputs of the reference itself (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from ccsmeth_amd.utils import synth
+from oracle import attbigru2s_oracle as orc
+
+FWD = np.load(os.path.join(GOLDEN, "forward_golden.npz"))
+FWD_META = json.load(open(os.path.join(GOLDEN, "forward_golden.json")))
+PIPE = np.load(os.path.join(GOLDEN, "pipeline_golden.npz"))
+PIPE_META = json.load(open(os.path.join(GOLDEN, "pipeline_golden.json")))
+
+
+def _case_inputs(meta):
+    w = synth.synth_weights(meta["weight_seed"], num_layers=meta["num_layers"], hidden=meta["hidden"])
+    s = synth.synth_sites(meta["n"], meta["site_seed"])
+    h1, h2 = synth.synth_h0(meta["n"], meta["h0_seed"], num_layers=meta["num_layers"], hidden=meta["hidden"])
+    return w, s, h1, h2
+
+
+@pytest.mark.parametrize("name", sorted(FWD_META))
+def test_forward_matches_reference(name):
+    meta = FWD_META[name]
+    w, s, h1, h2 = _case_inputs(meta)
+    logits, probs = orc.attbigru2s_forward(w, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"],
+                                           s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2,
+                                           num_layers=meta["num_layers"], dtype=np.float64)
+    assert np.abs(logits - FWD[name + "_logits"]).max() < 5e-6
+    assert np.abs(probs - FWD[name + "_probs"]).max() < 2e-6
+
+
+def test_forward_float32_oracle_close():
+    meta = FWD_META["b21_n64"]
+    w, s, h1, h2 = _case_inputs(meta)
+    _, probs = orc.attbigru2s_forward(w, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"],
+                                      s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2, dtype=np.float32)
+    assert np.abs(probs - FWD["b21_n64_probs"]).max() < 1e-5
+
+
+def test_codecv1_table():
+    assert orc.codecv1_to_frame2() == PIPE["codecv1"].tolist()
+    assert synth.codecv1_lut().tolist() == PIPE["codecv1"].tolist()
+
+
+def test_complement_and_base_codes():
+    for s, rc in PIPE_META["complement"].items():
+        assert orc.complement_seq(s) == rc
+    assert orc.BASE2CODE_DNA == PIPE_META["base2code_dna"]
+
+
+@pytest.mark.parametrize("read", PIPE_META["reads"], ids=lambda r: r["name"])
+def test_extract_features_rows(read):
+    name = read["name"]
+    rows = orc.extract_read_features(read["seq"], PIPE[name + "_fi"], PIPE[name + "_ri"], PIPE[name + "_fp"],
+                                     PIPE[name + "_rp"], read["fn"], read["rn"])
+    assert len(rows) == read["n_sites"]
+    if not rows:
+        return
+    assert [r[0] for r in rows] == PIPE[name + "_loc"].tolist()
+    assert ["".join(map(chr, k)) for k in PIPE[name + "_fkmer"]] == [r[1] for r in rows]
+    assert ["".join(map(chr, k)) for k in PIPE[name + "_rkmer"]] == [r[5] for r in rows]
+    for col, key in ((3, "_fipd"), (4, "_fpw"), (7, "_ripd"), (8, "_rpw")):
+        got = np.array([r[col] for r in rows])
+        assert np.array_equal(got, PIPE[name + key]), key   # float64, rounded to 6 dp: bit-exact
+    assert all(r[2] == read["fn"] and r[6] == read["rn"] for r in rows)
+    assert all(r[1][10:12] == "CG" and r[5][10:12] == "CG" for r in rows)
+
+
+def test_mm_ml_encode():
+    for case in PIPE_META["mm_extra"]:
+        if case["mm"] == "AssertionError":
+            with pytest.raises(AssertionError):
+                orc.convert_locs_to_mmtag(case["locs"], case["seq"])
+        else:
+            assert orc.convert_locs_to_mmtag(case["locs"], case["seq"]) == case["mm"]
+    assert orc.convert_probs_to_mltag(PIPE_META["ml_extra"]["probs"]) == PIPE_META["ml_extra"]["ml"]
+    reads = {r["name"]: r for r in PIPE_META["reads"]}
+    holeids = PIPE_META["pred_holeid"]
+    for name, exp in PIPE_META["mmml"].items():
+        lp = sorted((int(l), p) for l, p, h in zip(PIPE["pred_loc"], PIPE["pred_prob"], holeids) if h == name)
+        locs, probs = zip(*lp)
+        assert orc.convert_locs_to_mmtag(locs, reads[name]["seq"]) == exp["mm"]
+        assert orc.convert_probs_to_mltag(probs) == exp["ml"]
+
+
+def test_call_mods2s_probabilities():
+    """_call_mods2s (call_modifications.py:170-227) end to end on the extracted rows with pinned h0."""
+    cm = PIPE_META["call_mods"]
+    w = synth.synth_weights(cm["weight_seed"])
+    fk, rk = PIPE["batch_fkmers"], PIPE["batch_rkmers"]
+    n = fk.shape[0]
+    fipd, fpw, ripd, rpw = [], [], [], []
+    for read in PIPE_META["reads"]:
+        if read["n_sites"]:
+            nm = read["name"]
+            fipd.append(PIPE[nm + "_fipd"]); fpw.append(PIPE[nm + "_fpw"])
+            ripd.append(PIPE[nm + "_ripd"]); rpw.append(PIPE[nm + "_rpw"])
+    fipd, fpw, ripd, rpw = (np.concatenate(a).astype(np.float32) for a in (fipd, fpw, ripd, rpw))
+    got = []
+    bs = cm["batch_size"]
+    for bi, i in enumerate(range(0, n, bs)):
+        sl = slice(i, i + bs)
+        m = fk[sl].shape[0]
+        h1, h2 = synth.synth_h0(m, cm["h0_seed_base"] + bi)
+        _, probs = orc.attbigru2s_forward(w, fk[sl], fipd[sl], fpw[sl], PIPE["batch_fpasss"][sl].astype(np.float32),
+                                          rk[sl], ripd[sl], rpw[sl], PIPE["batch_rpasss"][sl].astype(np.float32),
+                                          h1, h2, dtype=np.float64)
+        got.append(orc.prob1_norm_round6(probs.astype(np.float32)))
+    got = np.concatenate(got)
+    assert np.abs(got - PIPE["pred_prob"]).max() <= 2e-6
+    assert cm["batch_num"] == (n + bs - 1) // bs
