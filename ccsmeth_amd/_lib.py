@@ -1,0 +1,96 @@
+"""ctypes binding of libccsm (include/ccsm.h).  The HIP extension is mandatory: there is no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libccsm.so")
+
+SEQ_LEN, HIDDEN, LAYERS, CLASSES = 21, 256, 3, 2
+OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = range(6)
+H0_EXPLICIT, H0_ZERO, H0_DEVICE_RNG = 0, 1, 2
+PRECISION_SPLIT3, PRECISION_SPLIT2, PRECISION_FP16 = 3, 2, 1
+
+_FP = C.POINTER(C.c_float)
+
+
+class Config(C.Structure):
+    _fields_ = [("seq_len", C.c_int32), ("num_layers", C.c_int32), ("num_classes", C.c_int32), ("hidden_size", C.c_int32),
+                ("is_npass", C.c_int32), ("is_sn", C.c_int32), ("is_map", C.c_int32), ("is_stds", C.c_int32),
+                ("model_type", C.c_char_p), ("precision", C.c_int32)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("embed_weight", C.c_void_p),
+                ("weight_ih", (C.c_void_p * 2) * LAYERS), ("weight_hh", (C.c_void_p * 2) * LAYERS),
+                ("bias_ih", (C.c_void_p * 2) * LAYERS), ("bias_hh", (C.c_void_p * 2) * LAYERS),
+                ("att_wa", C.c_void_p), ("att_ua", C.c_void_p), ("att_va", C.c_void_p),
+                ("fc1_weight", C.c_void_p), ("fc1_bias", C.c_void_p)]
+
+
+class Strand(C.Structure):
+    _fields_ = [("kmer", C.c_void_p), ("ipd", C.c_void_p), ("pw", C.c_void_p), ("npass", C.c_void_p)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("strand", Strand * 2), ("kmer_is_f32", C.c_int32), ("npass_per_base", C.c_int32)]
+
+
+class H0(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("h0", C.c_void_p * 2), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+class CcsmError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("libccsm status %d: %s" % (status, text))
+        self.status = status
+
+
+_lib = None
+
+# every symbol include/ccsm.h declares (checked by tests/test_cabi_symbols.py without a GPU)
+EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspace_destroy", "ccsm_forward_host",
+           "ccsm_submit_host", "ccsm_wait_host", "ccsm_forward_device", "ccsm_last_error", "ccsm_version",
+           "ccsm_model_precision", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
+           "ccsm_selftest_mfma", "ccsm_debug_read")
+
+
+def load():
+    """Load libccsm.so (built in-tree by __graft_entry__.build()).  Raises if it is missing: the product has no
+    other execution path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libccsm.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    try:  # share ONE HIP runtime with PyTorch when it is in the process (same SONAME libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, ci = C.c_void_p, C.c_int
+    lib.ccsm_create.argtypes = [C.POINTER(Config), C.POINTER(Weights), ci, C.POINTER(vp)]
+    lib.ccsm_destroy.argtypes = [vp]
+    lib.ccsm_destroy.restype = None
+    lib.ccsm_workspace_create.argtypes = [vp, ci, C.POINTER(vp)]
+    lib.ccsm_workspace_destroy.argtypes = [vp]
+    lib.ccsm_workspace_destroy.restype = None
+    lib.ccsm_forward_host.argtypes = [vp, vp, ci, C.POINTER(Batch), C.POINTER(H0), vp, vp, vp]
+    lib.ccsm_submit_host.argtypes = [vp, vp, ci, C.POINTER(Batch), C.POINTER(H0), vp]
+    lib.ccsm_wait_host.argtypes = [vp, vp, vp]
+    lib.ccsm_forward_device.argtypes = [vp, vp, ci, C.POINTER(Batch), C.POINTER(H0), vp, vp, vp]
+    lib.ccsm_last_error.restype = C.c_char_p
+    lib.ccsm_version.restype = C.c_char_p
+    lib.ccsm_model_precision.argtypes = [vp]
+    lib.ccsm_workspace_bytes.argtypes = [vp]
+    lib.ccsm_workspace_bytes.restype = C.c_size_t
+    lib.ccsm_workspace_set_timing.argtypes = [vp, ci]
+    lib.ccsm_workspace_last_timing.argtypes = [vp, _FP]
+    lib.ccsm_selftest_mfma.argtypes = [ci, _FP]
+    lib.ccsm_debug_read.argtypes = [vp, ci, vp, C.c_size_t]
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status != OK:
+        raise CcsmError(status, load().ccsm_last_error().decode())

@@ -1,0 +1,542 @@
+// libccsm host side: C-ABI (include/ccsm.h), weight fragment packing, workspaces, kernel sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ccsm.h"
+#include "ccsm_kernels.hip"
+
+using namespace ccsm;
+
+namespace {
+
+thread_local std::string g_err;
+
+ccsm_status fail(ccsm_status st, const std::string& msg) {
+    g_err = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(CCSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+constexpr int kNBGru = 2;   // batch tiles (of 32 rows) per GRU workgroup
+constexpr int kNBAtt = 2;   // batch tiles per attention workgroup
+constexpr int kRowPad = 64; // rows are padded to a multiple of 32 * max(kNBGru, kNBAtt)
+
+inline int rows_padded(int n_sites) { return ((2 * n_sites + kRowPad - 1) / kRowPad) * kRowPad; }
+
+struct HalfPair {
+    _Float16 hi, lo;
+};
+inline HalfPair split_host(float v) {
+    HalfPair p;
+    p.hi = (_Float16)v;
+    p.lo = (_Float16)(v - (float)p.hi);
+    return p;
+}
+inline int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }  // MFMA 32x32 C row of reg r, lane half hh
+
+}  // namespace
+
+struct ccsm_model {
+    int device = 0;
+    int precision = 3;
+    uint4* wst[kLayers] = {nullptr, nullptr, nullptr};  // [dir][wave][KX+16][gate][hl][64]
+    float* bias[kLayers] = {nullptr, nullptr, nullptr};  // [dir][wave][4][hh][16]
+    uint4* wa = nullptr;                                 // [wave][32][hl][64]
+    uint4* ua = nullptr;
+    float* va = nullptr;                                 // [wave][hh][16]
+    float* fcw = nullptr;                                // (2,1024)
+    float* fcb = nullptr;                                // (2)
+    float* embed = nullptr;                              // (5,8)
+};
+
+struct ccsm_workspace {
+    int device = 0;
+    int max_sites = 0;
+    int rows_p = 0;
+    size_t bytes = 0;
+    uint4* x0 = nullptr;
+    uint4* act[2] = {nullptr, nullptr};
+    float* h0buf = nullptr;
+    float* part = nullptr;
+    // device staging for the host-pointer path
+    uint8_t* d_in = nullptr;   // features of both strands
+    float* d_h0 = nullptr;     // explicit h0 (2 x 6 x max_sites x 256), allocated on first explicit use
+    float* d_out = nullptr;    // logits | probs
+    uint8_t* p_in = nullptr;   // pinned host mirrors
+    float* p_h0 = nullptr;
+    float* p_out = nullptr;
+    size_t in_bytes = 0;
+    int pending_sites = 0;
+    hipStream_t pending_stream = nullptr;
+    bool timing = false;
+    hipEvent_t ev[8] = {};
+    bool ev_ok = false;
+    bool timed = false;
+};
+
+namespace {
+
+// One (layer) weight stream: A fragments of [W_ih | W_hh], x-part k-blocks first.
+void pack_wstream(int layer, const float* const wih[2], const float* const whh[2], std::vector<_Float16>& out) {
+    const int kx = layer_kx(layer);
+    const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
+    const int kt = kx + kKBH;
+    out.assign((size_t)2 * kWaves * kt * kGates * 2 * 512, (_Float16)0.f);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave)
+            for (int kb = 0; kb < kt; ++kb)
+                for (int g = 0; g < kGates; ++g)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 31, q = lane >> 5;
+                        const int row = g * kHidden + kUnitTile * wave + i;
+                        const size_t base = ((((size_t)(dir * kWaves + wave) * kt + kb) * kGates + g) * 2) * 512 + lane * 8;
+                        for (int j = 0; j < 8; ++j) {
+                            float v;
+                            if (kb < kx) {
+                                const int k = 16 * kb + 8 * q + j;
+                                v = k < k_in ? wih[dir][(size_t)row * k_in + k] : 0.f;
+                            } else {
+                                const int k = 16 * (kb - kx) + 8 * q + j;
+                                v = whh[dir][(size_t)row * kHidden + k];
+                            }
+                            const HalfPair p = split_host(v);
+                            out[base + j] = p.hi;
+                            out[base + 512 + j] = p.lo;
+                        }
+                    }
+}
+
+void pack_bias(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
+    out.assign((size_t)2 * kWaves * 4 * 32, 0.f);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave)
+            for (int set = 0; set < 4; ++set)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int r = 0; r < 16; ++r) {
+                        const int u = kUnitTile * wave + crow(r, hh);
+                        float v;
+                        if (set == 0) v = bih[dir][u] + bhh[dir][u];
+                        else if (set == 1) v = bih[dir][kHidden + u] + bhh[dir][kHidden + u];
+                        else if (set == 2) v = bih[dir][2 * kHidden + u];
+                        else v = bhh[dir][2 * kHidden + u];
+                        out[(((size_t)(dir * kWaves + wave) * 4 + set) * 2 + hh) * 16 + r] = v;
+                    }
+}
+
+// Attention projection (256 x 512) as A fragments [wave][kb 32][hl][64][8]
+void pack_att(const float* w, std::vector<_Float16>& out) {
+    out.assign((size_t)kWaves * kKB12 * 2 * 512, (_Float16)0.f);
+    for (int wave = 0; wave < kWaves; ++wave)
+        for (int kb = 0; kb < kKB12; ++kb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, q = lane >> 5;
+                const size_t base = (((size_t)wave * kKB12 + kb) * 2) * 512 + lane * 8;
+                for (int j = 0; j < 8; ++j) {
+                    const HalfPair p = split_host(w[(size_t)(kUnitTile * wave + i) * 2 * kHidden + 16 * kb + 8 * q + j]);
+                    out[base + j] = p.hi;
+                    out[base + 512 + j] = p.lo;
+                }
+            }
+}
+
+template <typename T>
+ccsm_status upload(T** dst, const void* src, size_t bytes) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), bytes));
+    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return CCSM_OK;
+}
+
+template <int NPASS>
+ccsm_status launch_forward(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const StrandDev& s1, const StrandDev& s2,
+                           int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a, const float* h0b,
+                           uint64_t seed, uint64_t offset, float* logits, float* probs, hipStream_t st) {
+    const int rows_p = rows_padded(n_sites);
+    const int tiles = rows_p / 32;
+    const bool tm = ws->timing && ws->ev_ok;
+    if (tm) HIP_TRY(hipEventRecord(ws->ev[0], st));
+    {
+        const size_t total4 = (size_t)2 * kLayers * rows_p * (kHidden / 4);
+        const int grid = (int)std::min<size_t>((total4 + 255) / 256, 4096);
+        hipLaunchKernelGGL(prep_h0_kernel, dim3(grid), dim3(256), 0, st, ws->h0buf, h0a, h0b, n_sites, rows_p, h0_mode, seed,
+                           offset);
+        const int total = tiles * kSeqLen * 64;
+        hipLaunchKernelGGL(pack_x0_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws->x0, s1, s2, m->embed, n_sites,
+                           rows_p, kmer_is_f32, npass_per_base);
+    }
+    if (tm) HIP_TRY(hipEventRecord(ws->ev[1], st));
+    const size_t lds = (size_t)kKBH * kNBGru * 2 * 1024;
+    const dim3 ggrid(2 * (tiles / kNBGru));
+    const size_t slab = (size_t)2 * rows_p * kHidden;  // floats per layer (two directions)
+    hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB0, NPASS>), ggrid, dim3(512), lds, st, ws->x0, ws->act[0], m->wst[0],
+                       m->bias[0], ws->h0buf, rows_p);
+    if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
+    hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[0], ws->act[1], m->wst[1],
+                       m->bias[1], ws->h0buf + slab, rows_p);
+    if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
+    hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[1], ws->act[0], m->wst[2],
+                       m->bias[2], ws->h0buf + 2 * slab, rows_p);
+    if (tm) HIP_TRY(hipEventRecord(ws->ev[4], st));
+    hipLaunchKernelGGL((attn_fc_kernel<kNBAtt, NPASS>), dim3(tiles / kNBAtt), dim3(512), 0, st, ws->act[0], m->wa, m->ua, m->va,
+                       m->fcw, ws->part, n_sites);
+    if (tm) HIP_TRY(hipEventRecord(ws->ev[5], st));
+    hipLaunchKernelGGL(finalize_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, st, ws->part, m->fcb, logits, probs, n_sites);
+    if (tm) {
+        HIP_TRY(hipEventRecord(ws->ev[6], st));
+        ws->timed = true;
+    }
+    HIP_TRY(hipGetLastError());
+    return CCSM_OK;
+}
+
+ccsm_status dispatch_forward(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const StrandDev& s1, const StrandDev& s2,
+                             int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a, const float* h0b,
+                             uint64_t seed, uint64_t offset, float* logits, float* probs, hipStream_t st) {
+    switch (m->precision) {
+        case 3: return launch_forward<3>(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st);
+        case 2: return launch_forward<2>(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st);
+        case 1: return launch_forward<1>(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st);
+    }
+    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 1, 2 or 3");
+}
+
+ccsm_status check_call(const ccsm_model* m, const ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0) {
+    if (!m || !ws || !b) return fail(CCSM_ERR_INVALID_ARG, "model, workspace and batch must be non-NULL");
+    if (n_sites <= 0) return fail(CCSM_ERR_INVALID_ARG, "n_sites must be > 0");
+    if (n_sites > ws->max_sites) return fail(CCSM_ERR_CAPACITY, "n_sites exceeds the workspace's max_sites");
+    if (ws->device != m->device) return fail(CCSM_ERR_INVALID_ARG, "workspace and model live on different devices");
+    for (int s = 0; s < 2; ++s)
+        if (!b->strand[s].kmer || !b->strand[s].ipd || !b->strand[s].pw || !b->strand[s].npass)
+            return fail(CCSM_ERR_INVALID_ARG, "batch strand pointers must be non-NULL");
+    if (h0) {
+        if (h0->mode < 0 || h0->mode > 2) return fail(CCSM_ERR_INVALID_ARG, "unknown h0 mode");
+        if (h0->mode == CCSM_H0_EXPLICIT && (!h0->h0[0] || !h0->h0[1]))
+            return fail(CCSM_ERR_INVALID_ARG, "explicit h0 needs both strand tensors");
+    }
+    return CCSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ccsm_last_error(void) { return g_err.c_str(); }
+const char* ccsm_version(void) { return "libccsm 0.1.0 (gfx950)"; }
+int ccsm_model_precision(const ccsm_model* m) { return m ? m->precision : 0; }
+size_t ccsm_workspace_bytes(const ccsm_workspace* ws) { return ws ? ws->bytes : 0; }
+
+ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int device, ccsm_model** out) {
+    if (!cfg || !w || !out) return fail(CCSM_ERR_INVALID_ARG, "cfg, weights and out must be non-NULL");
+    *out = nullptr;
+    if (!cfg->model_type || std::strcmp(cfg->model_type, "attbigru2s") != 0)
+        return fail(CCSM_ERR_UNSUPPORTED, "--model_type not right! (this build implements attbigru2s)");
+    if (cfg->seq_len != kSeqLen || cfg->num_layers != kLayers || cfg->num_classes != kClasses || cfg->hidden_size != kHidden)
+        return fail(CCSM_ERR_UNSUPPORTED, "this build implements seq_len 21, layer_rnn 3, class_num 2, hid_rnn 256");
+    if (!cfg->is_npass || cfg->is_sn || cfg->is_map || cfg->is_stds)
+        return fail(CCSM_ERR_UNSUPPORTED, "this build implements is_npass=yes, is_sn=no, is_map=no, is_stds=no");
+    const int prec = cfg->precision == 0 ? 3 : cfg->precision;
+    if (prec < 1 || prec > 3) return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default), 1, 2 or 3");
+    if (!w->embed_weight || !w->att_wa || !w->att_ua || !w->att_va || !w->fc1_weight || !w->fc1_bias)
+        return fail(CCSM_ERR_INVALID_ARG, "weights: NULL tensor");
+    for (int l = 0; l < kLayers; ++l)
+        for (int d = 0; d < 2; ++d)
+            if (!w->weight_ih[l][d] || !w->weight_hh[l][d] || !w->bias_ih[l][d] || !w->bias_hh[l][d])
+                return fail(CCSM_ERR_INVALID_ARG, "weights: NULL rnn tensor");
+    HIP_TRY(hipSetDevice(device));
+    ccsm_model* m = new (std::nothrow) ccsm_model();
+    if (!m) return fail(CCSM_ERR_NOMEM, "out of host memory");
+    m->device = device;
+    m->precision = prec;
+    ccsm_status st = CCSM_OK;
+    std::vector<_Float16> hbuf;
+    std::vector<float> fbuf;
+    for (int l = 0; l < kLayers && st == CCSM_OK; ++l) {
+        pack_wstream(l, w->weight_ih[l], w->weight_hh[l], hbuf);
+        st = upload(&m->wst[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
+        if (st != CCSM_OK) break;
+        pack_bias(w->bias_ih[l], w->bias_hh[l], fbuf);
+        st = upload(&m->bias[l], fbuf.data(), fbuf.size() * sizeof(float));
+    }
+    if (st == CCSM_OK) { pack_att(w->att_wa, hbuf); st = upload(&m->wa, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
+    if (st == CCSM_OK) { pack_att(w->att_ua, hbuf); st = upload(&m->ua, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
+    if (st == CCSM_OK) {
+        fbuf.assign((size_t)kWaves * 2 * 16, 0.f);
+        for (int wave = 0; wave < kWaves; ++wave)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int r = 0; r < 16; ++r) fbuf[(wave * 2 + hh) * 16 + r] = w->att_va[kUnitTile * wave + crow(r, hh)];
+        st = upload(&m->va, fbuf.data(), fbuf.size() * sizeof(float));
+    }
+    if (st == CCSM_OK) st = upload(&m->fcw, w->fc1_weight, sizeof(float) * kClasses * 4 * kHidden);
+    if (st == CCSM_OK) st = upload(&m->fcb, w->fc1_bias, sizeof(float) * kClasses);
+    if (st == CCSM_OK) st = upload(&m->embed, w->embed_weight, sizeof(float) * kVocab * kEmbed);
+    if (st == CCSM_OK) {
+        // 64 KiB of dynamic LDS for the hidden-state fragments
+        const int lds = kKBH * kNBGru * 2 * 1024;
+        hipError_t e = hipSuccess;
+#define CCSM_SET_LDS(NP)                                                                                                  \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_kernel<kNBGru, kKB0, NP>),     \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);                         \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_kernel<kNBGru, kKB12, NP>),    \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (prec == 3) { CCSM_SET_LDS(3) } else if (prec == 2) { CCSM_SET_LDS(2) } else { CCSM_SET_LDS(1) }
+#undef CCSM_SET_LDS
+        if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
+    if (st != CCSM_OK) {
+        ccsm_destroy(m);
+        return st;
+    }
+    *out = m;
+    return CCSM_OK;
+}
+
+void ccsm_destroy(ccsm_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (int l = 0; l < kLayers; ++l) {
+        (void)hipFree(m->wst[l]);
+        (void)hipFree(m->bias[l]);
+    }
+    (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);
+    (void)hipFree(m->fcw); (void)hipFree(m->fcb); (void)hipFree(m->embed);
+    delete m;
+}
+
+ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_workspace** out) {
+    if (!m || !out) return fail(CCSM_ERR_INVALID_ARG, "model and out must be non-NULL");
+    *out = nullptr;
+    if (max_sites <= 0 || max_sites > (1 << 22)) return fail(CCSM_ERR_INVALID_ARG, "max_sites must be in [1, 4194304]");
+    HIP_TRY(hipSetDevice(m->device));
+    ccsm_workspace* ws = new (std::nothrow) ccsm_workspace();
+    if (!ws) return fail(CCSM_ERR_NOMEM, "out of host memory");
+    ws->device = m->device;
+    ws->max_sites = max_sites;
+    ws->rows_p = rows_padded(max_sites);
+    const size_t tiles = ws->rows_p / 32;
+    const size_t x0_b = tiles * kSeqLen * kKB0 * 2 * 1024;
+    const size_t act_b = tiles * kSeqLen * kKB12 * 2 * 1024;
+    const size_t h0_b = (size_t)2 * kLayers * ws->rows_p * kHidden * sizeof(float);
+    const size_t part_b = (size_t)ws->rows_p * 2 * sizeof(float);
+    // host-path staging: per strand kmer f32|u8 (N,21) + ipd + pw (N,21) f32 + npass (N,21) f32 worst case
+    ws->in_bytes = (size_t)2 * max_sites * kSeqLen * 4 * sizeof(float);
+    const size_t out_b = (size_t)max_sites * 4 * sizeof(float);
+    ccsm_status st = CCSM_OK;
+    auto dmalloc = [&](void** p, size_t b) -> ccsm_status {
+        HIP_TRY(hipMalloc(p, b));
+        ws->bytes += b;
+        return CCSM_OK;
+    };
+    if (st == CCSM_OK) st = dmalloc((void**)&ws->x0, x0_b);
+    if (st == CCSM_OK) st = dmalloc((void**)&ws->act[0], act_b);
+    if (st == CCSM_OK) st = dmalloc((void**)&ws->act[1], act_b);
+    if (st == CCSM_OK) st = dmalloc((void**)&ws->h0buf, h0_b);
+    if (st == CCSM_OK) st = dmalloc((void**)&ws->part, part_b);
+    if (st == CCSM_OK) st = dmalloc((void**)&ws->d_in, ws->in_bytes);
+    if (st == CCSM_OK) st = dmalloc((void**)&ws->d_out, out_b);
+    if (st == CCSM_OK) {
+        hipError_t e = hipHostMalloc((void**)&ws->p_in, ws->in_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&ws->p_out, out_b, hipHostMallocDefault);
+        if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    if (st == CCSM_OK) {
+        ws->ev_ok = true;
+        for (int i = 0; i < 8; ++i)
+            if (hipEventCreate(&ws->ev[i]) != hipSuccess) ws->ev_ok = false;
+    }
+    if (st != CCSM_OK) {
+        ccsm_workspace_destroy(ws);
+        return st;
+    }
+    *out = ws;
+    return CCSM_OK;
+}
+
+void ccsm_workspace_destroy(ccsm_workspace* ws) {
+    if (!ws) return;
+    (void)hipSetDevice(ws->device);
+    if (ws->pending_sites) (void)hipStreamSynchronize(ws->pending_stream);
+    (void)hipFree(ws->x0); (void)hipFree(ws->act[0]); (void)hipFree(ws->act[1]);
+    (void)hipFree(ws->h0buf); (void)hipFree(ws->part); (void)hipFree(ws->d_in); (void)hipFree(ws->d_h0);
+    (void)hipFree(ws->d_out);
+    if (ws->p_in) (void)hipHostFree(ws->p_in);
+    if (ws->p_h0) (void)hipHostFree(ws->p_h0);
+    if (ws->p_out) (void)hipHostFree(ws->p_out);
+    if (ws->ev_ok)
+        for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ws->ev[i]);
+    delete ws;
+}
+
+ccsm_status ccsm_forward_device(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0,
+                                float* logits, float* probs, void* stream) {
+    ccsm_status st = check_call(m, ws, n_sites, b, h0);
+    if (st != CCSM_OK) return st;
+    if (!logits || !probs) return fail(CCSM_ERR_INVALID_ARG, "logits and probs must be non-NULL");
+    HIP_TRY(hipSetDevice(m->device));
+    StrandDev s1{b->strand[0].kmer, b->strand[0].ipd, b->strand[0].pw, b->strand[0].npass};
+    StrandDev s2{b->strand[1].kmer, b->strand[1].ipd, b->strand[1].pw, b->strand[1].npass};
+    const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
+    return dispatch_forward(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
+                            h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
+                            static_cast<hipStream_t>(stream));
+}
+
+ccsm_status ccsm_submit_host(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0,
+                             void* stream) {
+    ccsm_status st = check_call(m, ws, n_sites, b, h0);
+    if (st != CCSM_OK) return st;
+    if (ws->pending_sites) return fail(CCSM_ERR_INVALID_ARG, "workspace already has a batch in flight (call ccsm_wait_host)");
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    // ---- stage the features into one pinned block: per strand [kmer | ipd | pw | npass]
+    const size_t n = (size_t)n_sites;
+    const size_t kmer_b = n * kSeqLen * (b->kmer_is_f32 ? 4 : 1);
+    const size_t kmer_pad = (kmer_b + 15) & ~(size_t)15;
+    const size_t f_b = n * kSeqLen * sizeof(float);
+    const size_t np_b = b->npass_per_base ? f_b : ((n * sizeof(float) + 15) & ~(size_t)15);
+    const size_t strand_b = kmer_pad + 2 * f_b + np_b;
+    if (2 * strand_b > ws->in_bytes) return fail(CCSM_ERR_CAPACITY, "staging buffer too small");
+    StrandDev sd[2];
+    for (int s = 0; s < 2; ++s) {
+        uint8_t* hp = ws->p_in + s * strand_b;
+        uint8_t* dp = ws->d_in + s * strand_b;
+        std::memcpy(hp, b->strand[s].kmer, kmer_b);
+        std::memcpy(hp + kmer_pad, b->strand[s].ipd, f_b);
+        std::memcpy(hp + kmer_pad + f_b, b->strand[s].pw, f_b);
+        std::memcpy(hp + kmer_pad + 2 * f_b, b->strand[s].npass, b->npass_per_base ? f_b : n * sizeof(float));
+        sd[s].kmer = dp;
+        sd[s].ipd = reinterpret_cast<const float*>(dp + kmer_pad);
+        sd[s].pw = reinterpret_cast<const float*>(dp + kmer_pad + f_b);
+        sd[s].npass = reinterpret_cast<const float*>(dp + kmer_pad + 2 * f_b);
+    }
+    HIP_TRY(hipMemcpyAsync(ws->d_in, ws->p_in, 2 * strand_b, hipMemcpyHostToDevice, hs));
+    const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
+    const float *h0a = nullptr, *h0b = nullptr;
+    if (mode == CCSM_H0_EXPLICIT) {
+        // 12 KiB per site: parity/test path only (never stream h0 in production)
+        const size_t cap = (size_t)2 * 2 * kLayers * ws->max_sites * kHidden * sizeof(float);
+        if (!ws->d_h0) {
+            HIP_TRY(hipMalloc((void**)&ws->d_h0, cap));
+            ws->bytes += cap;
+            HIP_TRY(hipHostMalloc((void**)&ws->p_h0, cap, hipHostMallocDefault));
+        }
+        const size_t hb = (size_t)2 * kLayers * n * kHidden * sizeof(float);
+        std::memcpy(ws->p_h0, h0->h0[0], hb);
+        std::memcpy(reinterpret_cast<uint8_t*>(ws->p_h0) + hb, h0->h0[1], hb);
+        HIP_TRY(hipMemcpyAsync(ws->d_h0, ws->p_h0, 2 * hb, hipMemcpyHostToDevice, hs));
+        h0a = ws->d_h0;
+        h0b = ws->d_h0 + hb / sizeof(float);
+    }
+    float* d_logits = ws->d_out;
+    float* d_probs = ws->d_out + n * 2;
+    st = dispatch_forward(m, ws, n_sites, sd[0], sd[1], b->kmer_is_f32, b->npass_per_base, mode, h0a, h0b, h0 ? h0->seed : 0,
+                          h0 ? h0->offset : 0, d_logits, d_probs, hs);
+    if (st != CCSM_OK) return st;
+    HIP_TRY(hipMemcpyAsync(ws->p_out, ws->d_out, n * 4 * sizeof(float), hipMemcpyDeviceToHost, hs));
+    ws->pending_sites = n_sites;
+    ws->pending_stream = hs;
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_wait_host(ccsm_workspace* ws, float* logits, float* probs) {
+    if (!ws || !logits || !probs) return fail(CCSM_ERR_INVALID_ARG, "workspace, logits and probs must be non-NULL");
+    if (!ws->pending_sites) return fail(CCSM_ERR_INVALID_ARG, "no batch in flight on this workspace");
+    HIP_TRY(hipSetDevice(ws->device));
+    const size_t n = (size_t)ws->pending_sites;
+    ws->pending_sites = 0;
+    HIP_TRY(hipStreamSynchronize(ws->pending_stream));
+    std::memcpy(logits, ws->p_out, n * 2 * sizeof(float));
+    std::memcpy(probs, ws->p_out + n * 2, n * 2 * sizeof(float));
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_forward_host(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0,
+                              float* logits, float* probs, void* stream) {
+    if (!logits || !probs) return fail(CCSM_ERR_INVALID_ARG, "logits and probs must be non-NULL");
+    ccsm_status st = ccsm_submit_host(m, ws, n_sites, b, h0, stream);
+    if (st != CCSM_OK) return st;
+    return ccsm_wait_host(ws, logits, probs);
+}
+
+ccsm_status ccsm_workspace_set_timing(ccsm_workspace* ws, int enable) {
+    if (!ws) return fail(CCSM_ERR_INVALID_ARG, "workspace must be non-NULL");
+    ws->timing = enable != 0;
+    ws->timed = false;
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]) {
+    if (!ws || !out_ms) return fail(CCSM_ERR_INVALID_ARG, "workspace and out must be non-NULL");
+    if (!ws->timed) return fail(CCSM_ERR_INVALID_ARG, "no timed forward on this workspace");
+    HIP_TRY(hipSetDevice(ws->device));
+    HIP_TRY(hipEventSynchronize(ws->ev[6]));
+    float prep = 0.f, fin = 0.f;
+    HIP_TRY(hipEventElapsedTime(&prep, ws->ev[0], ws->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[0], ws->ev[1], ws->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[1], ws->ev[2], ws->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[2], ws->ev[3], ws->ev[4]));
+    HIP_TRY(hipEventElapsedTime(&out_ms[3], ws->ev[4], ws->ev[5]));
+    HIP_TRY(hipEventElapsedTime(&fin, ws->ev[5], ws->ev[6]));
+    out_ms[4] = prep + fin;
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_t bytes) {
+    if (!ws || !host_dst) return fail(CCSM_ERR_INVALID_ARG, "workspace and dst must be non-NULL");
+    HIP_TRY(hipSetDevice(ws->device));
+    const size_t tiles = ws->rows_p / 32;
+    const void* src = nullptr;
+    size_t cap = 0;
+    switch (which) {
+        case 0: src = ws->x0; cap = tiles * kSeqLen * kKB0 * 2 * 1024; break;
+        case 1: src = ws->act[0]; cap = tiles * kSeqLen * kKB12 * 2 * 1024; break;
+        case 2: src = ws->act[1]; cap = tiles * kSeqLen * kKB12 * 2 * 1024; break;
+        case 3: src = ws->h0buf; cap = (size_t)2 * kLayers * ws->rows_p * kHidden * sizeof(float); break;
+        case 4: src = ws->part; cap = (size_t)ws->rows_p * 2 * sizeof(float); break;
+        default: return fail(CCSM_ERR_INVALID_ARG, "unknown buffer id");
+    }
+    if (bytes > cap) return fail(CCSM_ERR_CAPACITY, "debug read larger than the buffer");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err) {
+    if (!max_abs_err) return fail(CCSM_ERR_INVALID_ARG, "max_abs_err must be non-NULL");
+    HIP_TRY(hipSetDevice(device));
+    std::vector<_Float16> a(32 * 16), b(16 * 32);
+    std::vector<float> c(32 * 32), ref(32 * 32, 0.f);
+    uint32_t s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((int)(s >> 20) - 2048) / 512.0f; };
+    for (auto& v : a) v = (_Float16)rnd();
+    for (auto& v : b) v = (_Float16)rnd();   // asymmetric B (transpose-detecting)
+    for (int i = 0; i < 32; ++i)
+        for (int j = 0; j < 32; ++j)
+            for (int k = 0; k < 16; ++k) ref[i * 32 + j] += (float)a[i * 16 + k] * (float)b[k * 32 + j];
+    _Float16 *da = nullptr, *db = nullptr;
+    float* dc = nullptr;
+    HIP_TRY(hipMalloc((void**)&da, a.size() * 2));
+    HIP_TRY(hipMalloc((void**)&db, b.size() * 2));
+    HIP_TRY(hipMalloc((void**)&dc, c.size() * 4));
+    HIP_TRY(hipMemcpy(da, a.data(), a.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b.data(), b.size() * 2, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, 0, da, db, dc);
+    HIP_TRY(hipMemcpy(c.data(), dc, c.size() * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
+    float me = 0.f;
+    for (int i = 0; i < 32 * 32; ++i) me = std::max(me, std::abs(c[i] - ref[i]));
+    *max_abs_err = me;
+    return CCSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,564 @@
+// libccsm device code: hand-written HIP for gfx950 (CDNA4 / MI355X) of the ccsmeth attbigru2s forward.
+//
+// Reference behaviour being reproduced (paths relative to /root/reference/):
+//   ccsmeth/models.py:89-150        ModelAttRNN.forward (embedding+kinetics concat, 2-strand shared 3-layer BiGRU,
+//                                   additive attention pool, FC, softmax)
+//   ccsmeth/utils/attention.py:48-70  Bahdanau attention
+//   torch.nn.GRU (ATen gru_cell)    r,z,n gate equations, h' = (h - n) * z + n
+//
+// Design: the contraction work (244 MFLOP / CpG site) runs on v_mfma_f32_32x32x16_f16 with
+// split-fp16 operands (v = hi + lo; products hi*hi + lo*hi + hi*lo accumulate in fp32, i.e. ~22-bit mantissa
+// products, fp32-class accuracy) in the transposed form  G^T[unit][row] = W[unit][k] * X^T[k][row]  so that the MFMA
+// result layout (a lane holds 16 units of ONE batch row) converts to the next step's B operand with a single
+// half-wave exchange.  One workgroup = 8 waves = 32*NB batch rows of one direction; wave w owns hidden units
+// [32w, 32w+32) of all three gates; weights stream from L2 straight into registers as pre-packed fragments;
+// the hidden state lives in LDS as fragments; layer outputs go to HBM as fragments for the next layer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ccsm_layout.h"
+
+namespace ccsm {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ half8 as_half8(uint4 v) { return __builtin_bit_cast(half8, v); }
+__device__ __forceinline__ half4 as_half4(uint2 v) { return __builtin_bit_cast(half4, v); }
+
+__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(a), as_half8(b), c, 0, 0, 0);
+}
+
+// v = hi + lo split.  hi = RNE fp16(v); lo = fp16(v - hi) (exact difference in fp32).
+__device__ __forceinline__ void split16(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+__device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
+    half2v t = {a, b};
+    return __builtin_bit_cast(uint32_t, t);
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
+
+// NPASS: 3 = hi*hi + hi*lo + lo*hi (default, fp32-class); 2 = hi*hi + hi*lo (fp16 weights, split activations);
+//        1 = hi*hi (plain fp16 operands).  Pass p uses weight fragment (p == 2 ? lo : hi) and activation
+//        fragment (p == 1 ? lo : hi).  Callers issue pass-major so that consecutive MFMAs hit different accumulators.
+template <int P>
+__device__ __forceinline__ f32x16 mma_pass(const uint4 (&w)[2], const uint4 (&x)[2], f32x16 c) {
+    return mfma16(w[P == 2 ? 1 : 0], x[P == 1 ? 1 : 0], c);
+}
+template <int NPASS>
+__device__ __forceinline__ f32x16 mma_split(const uint4 (&w)[2], const uint4 (&x)[2], f32x16 c) {
+    c = mma_pass<0>(w, x, c);
+    if constexpr (NPASS >= 2) c = mma_pass<1>(w, x, c);
+    if constexpr (NPASS >= 3) c = mma_pass<2>(w, x, c);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller: device-side N(0,1) initial states (production mode; the reference draws
+// torch.randn on the CPU, unseeded in its workers — models.py:77-87 — so only the distribution is defined).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&out)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// h0buf[ld][row][256] fp32, ld = 2*layer + dir, rows = strand-major (row < n_sites: strand 1, else strand 2).
+// mode 0: explicit (src1/src2 = (6, n_sites, 256) per strand, reference init_hidden layout); 1: zeros; 2: Philox N(0,1).
+__global__ void prep_h0_kernel(float* __restrict__ h0buf, const float* __restrict__ src1, const float* __restrict__ src2,
+                               int n_sites, int rows_p, int mode, uint64_t seed, uint64_t offset) {
+    const size_t total4 = (size_t)2 * kLayers * rows_p * (kHidden / 4);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int u4 = (int)(i % (kHidden / 4));
+        const size_t rr = i / (kHidden / 4);
+        const int row = (int)(rr % rows_p);
+        const int ld = (int)(rr / rows_p);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < 2 * n_sites && mode != 1) {
+            const int strand = row >= n_sites;
+            const int site = row - strand * n_sites;
+            if (mode == 0) {
+                const float* src = strand ? src2 : src1;
+                v = *reinterpret_cast<const float4*>(src + ((size_t)ld * n_sites + site) * kHidden + u4 * 4);
+            } else {
+                // counter = (offset + site, strand*6+ld, u4) -> 4 uniforms -> 4 normals (2 Box-Muller pairs)
+                const uint64_t gs = offset + (uint64_t)site;
+                uint32_t r[4];
+                philox4x32_10((uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)(strand * 6 + ld), (uint32_t)u4,
+                              (uint32_t)seed, (uint32_t)(seed >> 32), r);
+                const float k2pi = 6.283185307179586f, inv = 2.3283064365386963e-10f;  // 2^-32
+                const float u0 = ((float)r[0] + 1.0f) * inv, u1 = (float)r[1] * inv;
+                const float u2 = ((float)r[2] + 1.0f) * inv, u3 = (float)r[3] * inv;
+                const float ra = sqrtf(-2.0f * __logf(fminf(u0, 1.0f))), rb = sqrtf(-2.0f * __logf(fminf(u2, 1.0f)));
+                v = make_float4(ra * __cosf(k2pi * u1), ra * __sinf(k2pi * u1), rb * __cosf(k2pi * u3), rb * __sinf(k2pi * u3));
+            }
+        }
+        *reinterpret_cast<float4*>(h0buf + i * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Layer-0 input fragments: x = cat(embed[kmer.int()], ipd, pw, npass) (models.py:91-106), 11 features padded to
+// one k-block of 16.  x0[tile][t][0][hl][lane] with lane (n,g): g=0 -> embedding dims 0..7, g=1 -> ipd,pw,npass,0...
+// ---------------------------------------------------------------------------------------------------------
+struct StrandDev {
+    const void* kmer;   // (N,21) u8 codes, or f32 if kmer_is_f32
+    const float* ipd;   // (N,21)
+    const float* pw;    // (N,21)
+    const float* npass; // (N) or (N,21) if npass_per_base
+};
+
+__global__ void pack_x0_kernel(uint4* __restrict__ x0, StrandDev s1, StrandDev s2, const float* __restrict__ embed,
+                               int n_sites, int rows_p, int kmer_is_f32, int npass_per_base) {
+    const int total = (rows_p / 32) * kSeqLen * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        const int tt = i >> 6;
+        const int t = tt % kSeqLen;
+        const int tile = tt / kSeqLen;
+        const int n = lane & 31, g = lane >> 5;
+        const int row = tile * 32 + n;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (row < 2 * n_sites) {
+            const int strand = row >= n_sites;
+            const int site = row - strand * n_sites;
+            const StrandDev& s = strand ? s2 : s1;
+            const size_t e = (size_t)site * kSeqLen + t;
+            if (g == 0) {
+                int code = kmer_is_f32 ? (int)reinterpret_cast<const float*>(s.kmer)[e]
+                                       : (int)reinterpret_cast<const uint8_t*>(s.kmer)[e];
+                code = code < 0 ? 0 : (code >= kVocab ? kVocab - 1 : code);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = embed[code * kEmbed + j];
+            } else {
+                v[0] = s.ipd[e];
+                v[1] = s.pw[e];
+                v[2] = npass_per_base ? s.npass[e] : s.npass[site];
+            }
+        }
+        _Float16 hi[8], lo[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split16(v[j], hi[j], lo[j]);
+        uint4* dst = x0 + ((size_t)(tile * kSeqLen + t) * 2) * kFragU4 + lane;
+        dst[0] = make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
+        dst[kFragU4] = make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One bidirectional GRU layer.  grid = 2 * (rows_p / (32*NB)); block = 512 (8 waves, 2 per SIMD, <=256 VGPR).
+// blockIdx.x & 1 = direction, so even XCDs (blockIdx % 8) hold the forward weights in L2 and odd XCDs the backward.
+//
+//   xin  : input fragments  [tile][t][KX][hl][64] uint4        (KX = 1 layer 0, 32 layers 1-2)
+//   out  : output fragments [tile][t][32][hl][64] uint4        (forward units -> kb 0..15, backward -> 16..31)
+//   wst  : weight stream    [dir][wave][KX+16][gate][hl][64]   (x-part k-blocks first, then h-part)
+//   bias : [dir][wave][4 sets: r=b_ir+b_hr, z=b_iz+b_hz, nx=b_in, nh=b_hn][hh][16] in MFMA C-row order
+//   h0   : [dir][rows_p][256] fp32 (this layer's two slabs)
+// ---------------------------------------------------------------------------------------------------------
+template <int NB, int KX, int NPASS>
+__global__ __launch_bounds__(512, 2) void gru_layer_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
+                                                            const uint4* __restrict__ wst, const float* __restrict__ bias,
+                                                            const float* __restrict__ h0, int rows_p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // h fragments [kb 16][bt NB][hl 2][64 lanes][16 B]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dir = blockIdx.x & 1;
+    const int tile0 = (blockIdx.x >> 1) * NB;
+    const int n = lane & 31, hh = lane >> 5;
+    constexpr int KT = KX + kKBH;
+
+    auto hfrag = [&](int kb, int bt, int hl) -> char* { return smem + (((kb * NB + bt) * 2 + hl) << 10); };
+
+    // ---- h0 -> LDS fragments: this wave converts its own two k-blocks (its own 32 units) for every batch tile
+    {
+        const float* h0d = h0 + (size_t)dir * rows_p * kHidden;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            const float* src = h0d + ((size_t)(tile0 + bt) * 32 + n) * kHidden;
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                const int kb = 2 * wave + kbl;
+                const float4 a = *reinterpret_cast<const float4*>(src + kb * 16 + hh * 8);
+                const float4 b = *reinterpret_cast<const float4*>(src + kb * 16 + hh * 8 + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                _Float16 hi[8], lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split16(v[j], hi[j], lo[j]);
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) =
+                    make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) =
+                    make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint4* wp = wst + (size_t)(dir * kWaves + wave) * KT * (kGates * 2 * kFragU4) + lane;
+    const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
+
+    for (int s = 0; s < kSeqLen; ++s) {
+        const int t = dir ? (kSeqLen - 1 - s) : s;
+        f32x16 acc[4][NB];
+        // The bias table is loop-invariant; launder the pointer so the 64 values are re-read (L1/L2 hits) every step
+        // instead of being hoisted into 64 permanently live VGPRs (which spills the accumulators).
+        const float* bps = bp;
+        asm volatile("" : "+v"(bps));
+#pragma unroll
+        for (int set = 0; set < 4; ++set) {
+            f32x16 b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(bps + set * 32 + q * 4);
+                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) acc[set][bt] = b;
+        }
+
+        // Weight / activation fragment movers.  The k-loops below are kept ROLLED with two named register sets
+        // (A/B) so that exactly one k-block of operands is in flight behind the one being multiplied.
+        auto load_w = [&](uint4 (&wf)[kGates][2], int kbt) {
+#pragma unroll
+            for (int g = 0; g < kGates; ++g)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) wf[g][hl] = wp[((kbt * kGates + g) * 2 + hl) * kFragU4];
+        };
+        const uint4* xp = xin + ((size_t)tile0 * kSeqLen + t) * KX * 2 * kFragU4 + lane;
+        auto load_x = [&](uint4 (&xf)[NB][2], int kb) {
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) xf[bt][hl] = xp[((size_t)bt * kSeqLen * KX + kb) * 2 * kFragU4 + hl * kFragU4];
+        };
+        auto load_h = [&](uint4 (&hf)[NB][2], int kb) {
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) hf[bt][hl] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, hl) + lane * 16);
+        };
+        // pass-major issue order: consecutive MFMAs always target different accumulators
+        auto mul_x = [&](const uint4 (&wf)[kGates][2], const uint4 (&xf)[NB][2]) {
+#define CCSM_XPASS(P)                                                                                   \
+    _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < kGates; ++g) \
+        acc[g][bt] = mma_pass<P>(wf[g], xf[bt], acc[g][bt]);
+            CCSM_XPASS(0)
+            if constexpr (NPASS >= 2) { CCSM_XPASS(1) }
+            if constexpr (NPASS >= 3) { CCSM_XPASS(2) }
+#undef CCSM_XPASS
+        };
+        auto mul_h = [&](const uint4 (&wf)[kGates][2], const uint4 (&hf)[NB][2]) {
+#define CCSM_HPASS(P)                                                \
+    _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) {                \
+        acc[0][bt] = mma_pass<P>(wf[0], hf[bt], acc[0][bt]);           \
+        acc[1][bt] = mma_pass<P>(wf[1], hf[bt], acc[1][bt]);           \
+        acc[3][bt] = mma_pass<P>(wf[2], hf[bt], acc[3][bt]);           \
+    }
+            CCSM_HPASS(0)
+            if constexpr (NPASS >= 2) { CCSM_HPASS(1) }
+            if constexpr (NPASS >= 3) { CCSM_HPASS(2) }
+#undef CCSM_HPASS
+        };
+
+        uint4 wA[kGates][2], wB[kGates][2], bA[NB][2], bB[NB][2];
+        // ---------------- x-part: acc[g] += W_ih[g] * x_t^T -------------------------------------------------
+        load_w(wA, 0);
+        load_x(bA, 0);
+        if constexpr (KX == 1) {
+            mul_x(wA, bA);
+        } else {
+#pragma unroll 1
+            for (int kb = 0; kb < KX; kb += 2) {
+                load_w(wB, kb + 1);
+                load_x(bB, kb + 1);
+                mul_x(wA, bA);
+                if (kb + 2 < KX) {
+                    load_w(wA, kb + 2);
+                    load_x(bA, kb + 2);
+                }
+                mul_x(wB, bB);
+            }
+        }
+        load_w(wA, KX);   // first recurrent weight k-block: in flight across the barrier
+        __syncthreads();  // B1: every wave's h_{t-1} fragments are in LDS
+
+        // ---------------- h-part: acc[r,z] += W_hh[r,z] * h^T ; acc[nh] += W_hn * h^T ------------------------
+        load_h(bA, 0);
+#pragma unroll 1
+        for (int kb = 0; kb < kKBH; kb += 2) {
+            load_w(wB, KX + kb + 1);
+            load_h(bB, kb + 1);
+            mul_h(wA, bA);
+            if (kb + 2 < kKBH) {
+                load_w(wA, KX + kb + 2);
+                load_h(bA, kb + 2);
+            }
+            mul_h(wB, bB);
+        }
+
+        // ---------------- h_{t-1} of this wave's own units, in MFMA C layout: reg r <-> unit (r&3)+8(r>>2)+4hh --
+        float hprev[NB][16];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kb = 2 * wave + (q >> 1);
+                const int src_lane = n + 32 * (q & 1);
+                const half4 hi = as_half4(*reinterpret_cast<const uint2*>(hfrag(kb, bt, 0) + src_lane * 16 + hh * 8));
+                const half4 lo = as_half4(*reinterpret_cast<const uint2*>(hfrag(kb, bt, 1) + src_lane * 16 + hh * 8));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hprev[bt][4 * q + e] = (float)hi[e] + (float)lo[e];
+            }
+        __syncthreads();  // B2: every wave has finished reading h_{t-1}
+
+        // ---------------- gates, new state, fragment write-back (LDS for the next step, HBM for the next layer) --
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            uint32_t phi[8], plo[8];  // packed pairs: index 2*q + (e>>1)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float hn2[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float rr = sigmoid_f(acc[0][bt][r + e]);
+                    const float zz = sigmoid_f(acc[1][bt][r + e]);
+                    const float nn = tanh_f(acc[2][bt][r + e] + rr * acc[3][bt][r + e]);
+                    hn2[e] = (hprev[bt][r + e] - nn) * zz + nn;  // ATen gru_cell: (h - n) * z + n
+                }
+                _Float16 h0a, l0a, h1a, l1a;
+                split16(hn2[0], h0a, l0a);
+                split16(hn2[1], h1a, l1a);
+                phi[r >> 1] = pack2(h0a, h1a);
+                plo[r >> 1] = pack2(l0a, l1a);
+            }
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                // regs 8kbl..8kbl+3 ("a": q even) and 8kbl+4..8kbl+7 ("b": q odd); packed index base 4*kbl
+                uint4 v[2];
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    const uint32_t* p = hl ? plo : phi;
+                    const uint32_t a0 = p[4 * kbl + 0], a1 = p[4 * kbl + 1], b0 = p[4 * kbl + 2], b1 = p[4 * kbl + 3];
+                    const uint32_t own0 = hh ? b0 : a0, own1 = hh ? b1 : a1;
+                    const uint32_t snd0 = hh ? a0 : b0, snd1 = hh ? a1 : b1;
+                    const uint32_t rcv0 = __shfl_xor(snd0, 32), rcv1 = __shfl_xor(snd1, 32);
+                    v[hl] = hh ? make_uint4(rcv0, rcv1, own0, own1) : make_uint4(own0, own1, rcv0, rcv1);
+                }
+                const int kb = 2 * wave + kbl;
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) = v[0];
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) = v[1];
+                uint4* o = out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4 + lane;
+                o[0] = v[0];
+                o[kFragU4] = v[1];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Attention pool + FC partials (utils/attention.py:48-70, models.py:135-148), one strand-row at a time.
+//   q = Wa h_n ; K_t = Ua out_t ; e_t = va . tanh(q + K_t) ; a = softmax_t(e) ; c = sum_t a_t out_t
+//   logits = fc1 [c_strand1 | c_strand2] + b.  Since fc1 is linear, fc1_s . c = sum_t a_t (fc1_s . out_t): the
+//   2x512 dot products p[t][row][class] are taken while the out_t fragments are in registers for the Ua GEMM, so
+//   out is read once and c is never materialised.  Output: part[row][2] = strand-half of the logits.
+// grid = rows_p / (32*NB); block 512; wave w owns attention units [32w, 32w+32).
+//   wa / ua : [wave][kb 32][hl][64] uint4 ; va : [wave][hh][16] floats (C-row order) ; fcw : fc1.weight (2,1024) fp32
+// ---------------------------------------------------------------------------------------------------------
+template <int NB, int NPASS>
+__global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
+                                                          const uint4* __restrict__ ua, const float* __restrict__ va,
+                                                          const float* __restrict__ fcw, float* __restrict__ part,
+                                                          int n_sites) {
+    constexpr int TG = 3;                      // timesteps per Ua pass (21 = 7 * 3)
+    constexpr int ROWS = 32 * NB;
+    __shared__ float s_epart[kWaves][kSeqLen][ROWS];
+    __shared__ float s_pfc[kSeqLen][ROWS][4];  // [t][row][strand*2 + class]
+    __shared__ float s_fcw[kClasses * 4 * kHidden];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile0 = blockIdx.x * NB;
+    const int n = lane & 31, hh = lane >> 5;
+
+    for (int i = threadIdx.x; i < kSeqLen * ROWS * 4; i += blockDim.x) (&s_pfc[0][0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < kClasses * 4 * kHidden; i += blockDim.x) s_fcw[i] = fcw[i];
+    __syncthreads();
+
+    const uint4* wap = wa + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
+    const uint4* uap = ua + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
+    auto ofrag = [&](int bt, int t, int kb, int hl) -> const uint4* {
+        return out2 + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + kb) * 2 * kFragU4 + hl * kFragU4 + lane;
+    };
+
+    // ---- q = Wa h_n, h_n = [fwd final state = out[t=L-1][0:256] | bwd final state = out[t=0][256:512]] (models.py:135-137)
+    f32x16 qacc[NB];
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qacc[bt][r] = 0.f;
+#pragma unroll 4
+    for (int kb = 0; kb < kKB12; ++kb) {
+        const uint4 w[2] = {wap[(kb * 2 + 0) * kFragU4], wap[(kb * 2 + 1) * kFragU4]};
+        const int tq = kb < kKBH ? kSeqLen - 1 : 0;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            const uint4 x[2] = {*ofrag(bt, tq, kb, 0), *ofrag(bt, tq, kb, 1)};
+            qacc[bt] = mma_split<NPASS>(w, x, qacc[bt]);
+        }
+    }
+    float vav[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vav[r] = va[(wave * 2 + hh) * 16 + r];
+
+    // ---- K_t = Ua out_t for 3 timesteps per pass, e partials, fc partials
+    for (int tg = 0; tg < kSeqLen / TG; ++tg) {
+        const int t0 = tg * TG;
+        f32x16 kacc[TG][NB];
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) kacc[tt][bt][r] = 0.f;
+        float pf[TG][NB][4];
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pf[tt][bt][c] = 0.f;
+
+#pragma unroll 2
+        for (int kb = 0; kb < kKB12; ++kb) {
+            const uint4 w[2] = {uap[(kb * 2 + 0) * kFragU4], uap[(kb * 2 + 1) * kFragU4]};
+            const bool fc_owner = (kb & (kWaves - 1)) == wave;   // wave-uniform: each k-block's fc partial taken once
+            float fw[4][8];
+            if (fc_owner) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)  // c = strand*2 + class -> fc1.weight[class][strand*512 + k]
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        fw[c][j] = s_fcw[(c & 1) * 4 * kHidden + (c >> 1) * 2 * kHidden + kb * 16 + hh * 8 + j];
+            }
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    const uint4 x[2] = {*ofrag(bt, t0 + tt, kb, 0), *ofrag(bt, t0 + tt, kb, 1)};
+                    kacc[tt][bt] = mma_split<NPASS>(w, x, kacc[tt][bt]);
+                    if (fc_owner) {
+                        const half8 xh = as_half8(x[0]), xl = as_half8(x[1]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xv = (float)xh[j] + (float)xl[j];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) pf[tt][bt][c] += fw[c][j] * xv;
+                        }
+                    }
+                }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt)
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                float e = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e += vav[r] * tanh_f(qacc[bt][r] + kacc[tt][bt][r]);
+                e += __shfl_xor(e, 32);
+                if (hh == 0) s_epart[wave][t0 + tt][bt * 32 + n] = e;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float v = pf[tt][bt][c];
+                    v += __shfl_xor(v, 32);
+                    if (hh == 0) atomicAdd(&s_pfc[t0 + tt][bt * 32 + n][c], v);
+                }
+            }
+    }
+    __syncthreads();
+
+    // ---- softmax over t and the strand-half of the logits
+    if (threadIdx.x < ROWS) {
+        const int rl = threadIdx.x;
+        const int row = tile0 * 32 + rl;
+        float e[kSeqLen];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < kSeqLen; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) v += s_epart[w][t][rl];
+            e[t] = v;
+            m = fmaxf(m, v);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < kSeqLen; ++t) { e[t] = __expf(e[t] - m); den += e[t]; }
+        const float inv = 1.0f / den;
+        const int strand = row >= n_sites;
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < kSeqLen; ++t) {
+            const float a = e[t] * inv;
+            l0 += a * s_pfc[t][rl][strand * 2 + 0];
+            l1 += a * s_pfc[t][rl][strand * 2 + 1];
+        }
+        part[(size_t)row * 2 + 0] = l0;
+        part[(size_t)row * 2 + 1] = l1;
+    }
+}
+
+// logits = strand-1 half + strand-2 half + fc1.bias ; probs = softmax(logits)   (models.py:145-150)
+__global__ void finalize_kernel(const float* __restrict__ part, const float* __restrict__ fcb, float* __restrict__ logits,
+                                float* __restrict__ probs, int n_sites) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sites) return;
+    const float l0 = part[(size_t)i * 2 + 0] + part[((size_t)n_sites + i) * 2 + 0] + fcb[0];
+    const float l1 = part[(size_t)i * 2 + 1] + part[((size_t)n_sites + i) * 2 + 1] + fcb[1];
+    const float m = fmaxf(l0, l1);
+    const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+    const float inv = 1.0f / (e0 + e1);
+    logits[(size_t)i * 2 + 0] = l0;
+    logits[(size_t)i * 2 + 1] = l1;
+    probs[(size_t)i * 2 + 0] = e0 * inv;
+    probs[(size_t)i * 2 + 1] = e1 * inv;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA layout self-test: C = A * B for one 32x32x16 tile with the fragment conventions used above
+// (A[i][k] at lane i+32*(k>>3), elem k&7; B[k][j] likewise; C[i][j] at lane j+32*((i>>2)&1), reg (i&3)+4*(i>>3)).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void mfma_selftest_kernel(const _Float16* __restrict__ a /*32x16*/, const _Float16* __restrict__ b /*16x32*/,
+                                     float* __restrict__ c /*32x32*/) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 31, g = lane >> 5;
+    half8 af, bf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        af[j] = a[n * 16 + 8 * g + j];
+        bf[j] = b[(8 * g + j) * 32 + n];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * g;
+        c[i * 32 + n] = acc[r];
+    }
+}
+
+}  // namespace ccsm

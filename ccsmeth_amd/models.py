@@ -1,0 +1,276 @@
+"""Host-side mirror of the reference model interface for the call_mods hot path.
+
+`ModelAttRNN` keeps the constructor signature, `forward` argument order, `state_dict` key names, `.eval()`,
+`.cuda(dev)` and `get_model_type()` of reference ccsmeth/models.py:17-150, so that
+ccsmeth/call_modifications.py:315-369 (construct, load checkpoint, strip a DDP "module." prefix, eval, cuda) and
+:201-208 (the 16-tensor call) work unchanged, but every FLOP runs in libccsm's HIP kernels on gfx950.
+There is no CPU path: constructing the device model without the extension or without a GPU raises.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from .utils.synth import state_dict_shapes
+
+
+def _f32c(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class DeviceModel:
+    """Owns one ccsm_model (weights packed as MFMA fragments in HBM) and a pool of workspaces."""
+
+    def __init__(self, state_dict, device=0, precision=0, model_type="attbigru2s", seq_len=21, num_layers=3,
+                 num_classes=2, hidden_size=256, is_npass=True, is_sn=False, is_map=False, is_stds=False):
+        lib = _lib.load()
+        self._lib = lib
+        self._keep = {k: _f32c(v) for k, v in state_dict.items()}
+        w = _lib.Weights()
+        ptr = lambda k: self._keep[k].ctypes.data  # noqa: E731
+        w.embed_weight = ptr("embed.weight")
+        for layer in range(_lib.LAYERS):
+            for d, sfx in enumerate(("", "_reverse")):
+                w.weight_ih[layer][d] = ptr(f"rnn.weight_ih_l{layer}{sfx}")
+                w.weight_hh[layer][d] = ptr(f"rnn.weight_hh_l{layer}{sfx}")
+                w.bias_ih[layer][d] = ptr(f"rnn.bias_ih_l{layer}{sfx}")
+                w.bias_hh[layer][d] = ptr(f"rnn.bias_hh_l{layer}{sfx}")
+        w.att_wa, w.att_ua, w.att_va = ptr("_att3.Wa.weight"), ptr("_att3.Ua.weight"), ptr("_att3.va.weight")
+        w.fc1_weight, w.fc1_bias = ptr("fc1.weight"), ptr("fc1.bias")
+        cfg = _lib.Config(seq_len, num_layers, num_classes, hidden_size, int(is_npass), int(is_sn), int(is_map),
+                          int(is_stds), model_type.encode(), int(precision))
+        handle = C.c_void_p()
+        _lib.check(lib.ccsm_create(C.byref(cfg), C.byref(w), int(device), C.byref(handle)))
+        self.handle = handle
+        self.device = int(device)
+        self.precision = lib.ccsm_model_precision(handle)
+        self._workspaces = []
+
+    def workspace(self, max_sites):
+        ws = Workspace(self, max_sites)
+        self._workspaces.append(ws)
+        return ws
+
+    def close(self):
+        for ws in self._workspaces:
+            ws.close()
+        self._workspaces = []
+        if self.handle:
+            self._lib.ccsm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Workspace:
+    def __init__(self, model, max_sites):
+        self.model = model
+        self.max_sites = int(max_sites)
+        handle = C.c_void_p()
+        _lib.check(model._lib.ccsm_workspace_create(model.handle, self.max_sites, C.byref(handle)))
+        self.handle = handle
+        self._keep = None
+
+    def close(self):
+        if self.handle:
+            self.model._lib.ccsm_workspace_destroy(self.handle)
+            self.handle = None
+
+    @staticmethod
+    def _batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of):
+        b = _lib.Batch()
+        n = None
+        keep = []
+        kmer_f32 = None
+        per_base = None
+        for s, (kmer, ipd, pw, npass) in enumerate(((kmer1, ipd1, pw1, npass1), (kmer2, ipd2, pw2, npass2))):
+            kmer, kf = ptr_of(kmer, kmer=True)
+            ipd, _ = ptr_of(ipd)
+            pw, _ = ptr_of(pw)
+            npass, _ = ptr_of(npass)
+            keep += [kmer, ipd, pw, npass]
+            ns = kmer[1][0]
+            if n is None:
+                n, kmer_f32 = ns, kf
+                per_base = len(npass[1]) == 2
+            if ns != n or kf != kmer_f32 or (len(npass[1]) == 2) != per_base:
+                raise ValueError("both strands must have the same batch size and layouts")
+            for t, name in ((kmer, "kmer"), (ipd, "ipd"), (pw, "pw")):
+                if tuple(t[1]) != (n, _lib.SEQ_LEN):
+                    raise ValueError("%s must have shape (N, %d)" % (name, _lib.SEQ_LEN))
+            if tuple(npass[1]) not in ((n,), (n, _lib.SEQ_LEN)):
+                raise ValueError("npass must have shape (N,) or (N, 21)")
+            b.strand[s].kmer, b.strand[s].ipd, b.strand[s].pw, b.strand[s].npass = kmer[0], ipd[0], pw[0], npass[0]
+        b.kmer_is_f32 = int(kmer_f32)
+        b.npass_per_base = int(per_base)
+        return b, n, keep
+
+    @staticmethod
+    def _h0(h0, n, ptr_of, seed, offset):
+        h = _lib.H0()
+        keep = []
+        if h0 is None:
+            h.mode = _lib.H0_DEVICE_RNG
+        elif isinstance(h0, str) and h0 == "zero":
+            h.mode = _lib.H0_ZERO
+        else:
+            h.mode = _lib.H0_EXPLICIT
+            for s in range(2):
+                t, _ = ptr_of(h0[s])
+                if tuple(t[1]) != (2 * _lib.LAYERS, n, _lib.HIDDEN):
+                    raise ValueError("h0 tensors must have shape (6, N, 256)")
+                keep.append(t)
+                h.h0[s] = t[0]
+        h.seed, h.offset = int(seed), int(offset)
+        return h, keep
+
+    def forward_host(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None):
+        """NumPy in / NumPy out through the pinned staging ring (ccsm_forward_host)."""
+        def ptr_of(a, kmer=False):
+            a = np.asarray(a)
+            if kmer and a.dtype == np.uint8:
+                a = np.ascontiguousarray(a)
+                return (a.ctypes.data, a.shape, a), False
+            a = _f32c(a)
+            return (a.ctypes.data, a.shape, a), True
+        b, n, keep = self._batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of)
+        h, keep2 = self._h0(h0, n, ptr_of, seed, offset)
+        logits = np.empty((n, 2), np.float32)
+        probs = np.empty((n, 2), np.float32)
+        _lib.check(self.model._lib.ccsm_forward_host(self.model.handle, self.handle, n, C.byref(b), C.byref(h),
+                                                     logits.ctypes.data, probs.ctypes.data, stream))
+        return logits, probs
+
+    def forward_torch(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None,
+                      out=None):
+        """torch CUDA tensors in / out, asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        dev = torch.device("cuda", self.model.device)
+
+        def ptr_of(a, kmer=False):
+            if not isinstance(a, torch.Tensor):
+                a = torch.as_tensor(a)
+            if kmer and a.dtype == torch.uint8:
+                a = a.to(dev).contiguous()
+                return (a.data_ptr(), tuple(a.shape), a), False
+            a = a.to(device=dev, dtype=torch.float32).contiguous()
+            return (a.data_ptr(), tuple(a.shape), a), True
+        b, n, keep = self._batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of)
+        h, keep2 = self._h0(h0, n, ptr_of, seed, offset)
+        if out is None:
+            logits = torch.empty((n, 2), dtype=torch.float32, device=dev)
+            probs = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        else:
+            logits, probs = out
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self.model._lib.ccsm_forward_device(self.model.handle, self.handle, n, C.byref(b), C.byref(h),
+                                                       logits.data_ptr(), probs.data_ptr(), stream))
+        self._keep = (keep, keep2)   # inputs must outlive the asynchronous kernels
+        return logits, probs
+
+    def set_timing(self, enable=True):
+        _lib.check(self.model._lib.ccsm_workspace_set_timing(self.handle, int(enable)))
+
+    def last_timing(self):
+        out = (C.c_float * 5)()
+        _lib.check(self.model._lib.ccsm_workspace_last_timing(self.handle, out))
+        return list(out)
+
+
+class ModelAttRNN:
+    """Drop-in for reference ccsmeth.models.ModelAttRNN(model_type="attbigru2s") on the inference path.
+
+    Same constructor (models.py:18-22), same forward signature (models.py:89-90) returning (logits, softmax(logits)),
+    same state_dict keys.  Extra keyword-only knobs, absent from the reference: `h0` on forward (pin the initial
+    states; the reference draws them from an unseeded torch.randn — models.py:77-87), `precision` and `seed`."""
+
+    def __init__(self, seq_len=21, num_layers=3, num_classes=2, dropout_rate=0.5, hidden_size=256,
+                 is_npass=True, is_sn=False, is_map=False, is_stds=False, model_type="attbigru2s", device=0,
+                 *, precision=0, seed=1234, max_batch=4096):
+        if model_type not in ("attbigru2s",):
+            raise ValueError("--model_type not set right!")      # models.py:57
+        self.model_type = model_type
+        self.device = device
+        self.seq_len, self.num_layers, self.num_classes, self.hidden_size = seq_len, num_layers, num_classes, hidden_size
+        self.is_npass, self.is_sn, self.is_map, self.is_stds = is_npass, is_sn, is_map, is_stds
+        self.dropout_rate = dropout_rate   # identity at inference (model.eval())
+        self.precision, self.seed, self.max_batch = precision, seed, max_batch
+        self._shapes = state_dict_shapes(seq_len, num_layers, num_classes, hidden_size)
+        self._state = OrderedDict((k, np.zeros(s, np.float32)) for k, s in self._shapes.items())
+        self._dev = None
+        self._ws = None
+        self._calls = 0
+
+    def get_model_type(self):
+        return self.model_type
+
+    # ---- checkpoint contract (call_modifications.py:342-358) -------------------------------------------------
+    def state_dict(self):
+        return OrderedDict((k, v.copy()) for k, v in self._state.items())
+
+    def load_state_dict(self, sd):
+        """Strict, like torch: a key/shape mismatch raises RuntimeError, which is what makes the reference retry
+        with the 7-character "module." prefix stripped (call_modifications.py:350-358)."""
+        def to_np(v):
+            return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+        missing = [k for k in self._shapes if k not in sd]
+        unexpected = [k for k in sd if k not in self._shapes]
+        if missing or unexpected:
+            raise RuntimeError("Error(s) in loading state_dict for ModelAttRNN: missing %s unexpected %s" % (missing, unexpected))
+        for k, shape in self._shapes.items():
+            a = to_np(sd[k])
+            if tuple(a.shape) != tuple(shape):
+                raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(a.shape), tuple(shape)))
+            self._state[k] = np.ascontiguousarray(a, dtype=np.float32)
+        self._release()
+
+    def eval(self):
+        return self
+
+    def cuda(self, device=None):
+        if device is not None:
+            self.device = device
+        self._ensure()
+        return self
+
+    def _release(self):
+        if self._dev is not None:
+            self._dev.close()
+        self._dev = self._ws = None
+
+    def _ensure(self, n=1):
+        if self._dev is None:
+            self._dev = DeviceModel(self._state, self.device, self.precision, self.model_type, self.seq_len,
+                                    self.num_layers, self.num_classes, self.hidden_size, self.is_npass, self.is_sn,
+                                    self.is_map, self.is_stds)
+        if self._ws is None or self._ws.max_sites < n:
+            if self._ws is not None:
+                self._ws.close()
+            self._ws = self._dev.workspace(max(n, self.max_batch))
+
+    def forward(self, kmer, kpass, ipd_means, ipd_stds, pw_means, pw_stds, sns, maps,
+                kmer2, kpass2, ipd_means2, ipd_stds2, pw_means2, pw_stds2, sns2, maps2, *, h0=None):
+        """models.py:89-150.  ipd_stds/pw_stds/sns/maps are accepted and ignored exactly as the reference ignores
+        them when is_stds/is_sn/is_map are off."""
+        import torch
+        n = int(kmer.shape[0])
+        self._ensure(n)
+        is_torch = isinstance(kmer, torch.Tensor)
+        if is_torch:
+            logits, probs = self._ws.forward_torch(kmer, ipd_means, pw_means, kpass, kmer2, ipd_means2, pw_means2, kpass2,
+                                                   h0=h0, seed=self.seed, offset=self._calls)
+            if not kmer.is_cuda:   # reference on a CPU-tensor call returns CPU tensors
+                logits, probs = logits.cpu(), probs.cpu()
+        else:
+            logits, probs = self._ws.forward_host(kmer, ipd_means, pw_means, kpass, kmer2, ipd_means2, pw_means2, kpass2,
+                                                  h0=h0, seed=self.seed, offset=self._calls)
+        self._calls += n
+        return logits, probs
+
+    __call__ = forward

@@ -1,0 +1,155 @@
+/* libccsm — C-ABI of the MI355X-native (gfx950) ccsmeth `call_mods` attbigru2s hot path.
+ *
+ * The reference (PengNi/ccsmeth v0.5.0, pure Python) has no FFI; its seam for this path is the Python call
+ *   model(*16 tensors)                      ccsmeth/call_modifications.py:201-208   (_call_mods2s)
+ * plus the constructor / load_state_dict contract at ccsmeth/call_modifications.py:315-358 and the model
+ * definition ccsmeth/models.py:17-150 (ModelAttRNN, model_type="attbigru2s"), ccsmeth/utils/attention.py:30-70.
+ * Each entry point below names the reference interface it replaces.  Plain pointers and sizes only; no
+ * exceptions cross the ABI; every function returns a ccsm_status and ccsm_last_error() gives the text.
+ *
+ * Threading: a ccsm_model is immutable after creation and may be shared by threads; a ccsm_workspace is
+ * single-owner (one forward in flight per workspace).  Use several workspaces on several HIP streams to keep
+ * more than one batch in flight on a GPU (the reference runs one model instance per worker process,
+ * call_modifications.py:561-578).
+ */
+#ifndef CCSM_H_
+#define CCSM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCSM_SEQ_LEN 21
+#define CCSM_HIDDEN 256
+#define CCSM_LAYERS 3
+#define CCSM_CLASSES 2
+
+typedef enum {
+    CCSM_OK = 0,
+    CCSM_ERR_INVALID_ARG = 1, /* NULL pointer, n_sites out of range, ... */
+    CCSM_ERR_UNSUPPORTED = 2, /* configuration outside what this build implements; mirrors the reference's
+                                 ValueError("--model_type not right!") call_modifications.py:340 */
+    CCSM_ERR_HIP = 3,         /* a HIP runtime call failed; text in ccsm_last_error() */
+    CCSM_ERR_NOMEM = 4,
+    CCSM_ERR_CAPACITY = 5     /* n_sites exceeds the workspace's max_sites */
+} ccsm_status;
+
+/* Arithmetic of the contraction (matmul) work; everything else is fp32.
+ * SPLIT3: every fp32 operand v carried as fp16 pair (hi, lo); products hi*hi + hi*lo + lo*hi accumulate in fp32
+ *         on v_mfma_f32_32x32x16_f16 (fp32-class accuracy; the default, meets the 1e-4 probability bar by >10x).
+ * SPLIT2: fp16-rounded weights, split activations (2 MFMA passes).   FP16: plain fp16 operands (1 pass). */
+typedef enum { CCSM_PRECISION_SPLIT3 = 3, CCSM_PRECISION_SPLIT2 = 2, CCSM_PRECISION_FP16 = 1 } ccsm_precision;
+
+/* Mirrors ModelAttRNN.__init__ (models.py:18-22) as called from call_modifications.py:315-323. */
+typedef struct {
+    int32_t seq_len;     /* 21 (odd; call_modifications.py:500-501 rejects even values) */
+    int32_t num_layers;  /* 3 */
+    int32_t num_classes; /* 2 */
+    int32_t hidden_size; /* 256 */
+    int32_t is_npass;    /* 1 */
+    int32_t is_sn;       /* 0 */
+    int32_t is_map;      /* 0 */
+    int32_t is_stds;     /* 0 */
+    const char* model_type; /* "attbigru2s" */
+    int32_t precision;   /* ccsm_precision; 0 = default (SPLIT3) */
+} ccsm_config;
+
+/* Host fp32 parameter tensors in the reference state_dict layout (models.py:32-61).
+ * Index [layer][dir]: dir 0 = "", dir 1 = "_reverse".  Row order of the 768 = [r; z; n]. */
+typedef struct {
+    const float* embed_weight;                 /* embed.weight (5, 8) */
+    const float* weight_ih[CCSM_LAYERS][2];    /* rnn.weight_ih_l{l}{sfx} (768, 11 | 512) */
+    const float* weight_hh[CCSM_LAYERS][2];    /* rnn.weight_hh_l{l}{sfx} (768, 256) */
+    const float* bias_ih[CCSM_LAYERS][2];      /* rnn.bias_ih_l{l}{sfx} (768) */
+    const float* bias_hh[CCSM_LAYERS][2];      /* rnn.bias_hh_l{l}{sfx} (768) */
+    const float* att_wa;                       /* _att3.Wa.weight (256, 512) */
+    const float* att_ua;                       /* _att3.Ua.weight (256, 512) */
+    const float* att_va;                       /* _att3.va.weight (1, 256) */
+    const float* fc1_weight;                   /* fc1.weight (2, 1024) */
+    const float* fc1_bias;                     /* fc1.bias (2) */
+} ccsm_weights;
+
+/* One strand's per-site 21-mer features = the tensors `kmer, kpass, ipd_means, pw_means` of
+ * ModelAttRNN.forward (models.py:89-90); the unused placeholders (ipd_stds, pw_stds, sns, maps) are not passed. */
+typedef struct {
+    const void* kmer;   /* (N,21) base codes A0 C1 G2 T3 other4 (process_utils.py:26-29): uint8, or float32 when
+                           ccsm_batch.kmer_is_f32 (the reference hands FloatTensors, truncated by .int(), models.py:91) */
+    const float* ipd;   /* (N,21) normalised IPD */
+    const float* pw;    /* (N,21) normalised PW */
+    const float* npass; /* (N) subread passes, or (N,21) when ccsm_batch.npass_per_base (call_modifications.py:96) */
+} ccsm_strand;
+
+typedef struct {
+    ccsm_strand strand[2]; /* [0] = forward-strand features, [1] = reverse-strand ("2"-suffixed arguments) */
+    int32_t kmer_is_f32;
+    int32_t npass_per_base;
+} ccsm_batch;
+
+/* Initial hidden state.  The reference draws torch.randn(6, N, 256) twice per forward, strand 1 first
+ * (models.py:77-87, 125-130), unseeded in its worker processes, so its outputs are only reproducible when h0 is
+ * pinned: EXPLICIT takes both tensors (index 2l = layer-l forward, 2l+1 = backward), DEVICE_RNG draws N(0,1) on
+ * the GPU (Philox4x32-10 keyed by seed, counter = offset + site index), ZERO is for tests. */
+typedef enum { CCSM_H0_EXPLICIT = 0, CCSM_H0_ZERO = 1, CCSM_H0_DEVICE_RNG = 2 } ccsm_h0_mode;
+typedef struct {
+    int32_t mode;
+    const float* h0[2]; /* EXPLICIT: (6, N, 256) fp32 for strand 1 and strand 2 */
+    uint64_t seed;
+    uint64_t offset;
+} ccsm_h0;
+
+typedef struct ccsm_model ccsm_model;
+typedef struct ccsm_workspace ccsm_workspace;
+
+/* Replaces: ModelAttRNN(...) + torch.load + load_state_dict + .cuda(device) + .eval()
+ * (call_modifications.py:315-369).  Packs the weights into MFMA fragments and uploads them to `device`. */
+ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int device, ccsm_model** out);
+void ccsm_destroy(ccsm_model* m);
+
+/* Device buffers (activations, h0, staging) + pinned host staging for batches of up to max_sites sites. */
+ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_workspace** out);
+void ccsm_workspace_destroy(ccsm_workspace* ws);
+
+/* Replaces: model(FloatTensor(...) x16) + .cpu()  (call_modifications.py:201-211) for a batch in HOST memory.
+ * Copies the features into the workspace's pinned staging buffers, enqueues H2D (hipMemcpyAsync), the forward
+ * kernels and D2H on `stream`, waits, and writes logits/probs (N,2 fp32, row-major) to the caller's buffers.
+ * batch / h0 pointers are host pointers.  stream = hipStream_t (NULL = default stream). */
+ccsm_status ccsm_forward_host(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* batch,
+                              const ccsm_h0* h0, float* logits, float* probs, void* stream);
+
+/* Pipelined form of the same call: submit returns once the work is enqueued (inputs already copied out of the
+ * caller's buffers); wait blocks until the batch is done and copies the results out.  With two workspaces this is
+ * the pinned double-buffered hipMemcpyAsync stream the reference's per-tensor pageable copies
+ * (utils/constants_torch.py:9-12) are replaced by. */
+ccsm_status ccsm_submit_host(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* batch,
+                             const ccsm_h0* h0, void* stream);
+ccsm_status ccsm_wait_host(ccsm_workspace* ws, float* logits, float* probs);
+
+/* Same forward with every pointer (batch, h0, logits, probs) already in DEVICE memory; asynchronous on `stream`
+ * (replaces model(...) for callers that keep features resident in HBM). */
+ccsm_status ccsm_forward_device(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* batch,
+                                const ccsm_h0* h0, float* logits, float* probs, void* stream);
+
+/* Diagnostics */
+const char* ccsm_last_error(void);
+const char* ccsm_version(void);
+int ccsm_model_precision(const ccsm_model* m);
+size_t ccsm_workspace_bytes(const ccsm_workspace* ws);
+/* Times (ms, HIP events on `stream`) of the kernels of the LAST forward issued on this workspace with timing
+ * enabled: out[0..2] = GRU layers 0..2, out[3] = attention+FC, out[4] = pack+h0 prep+finalize.  Blocks. */
+ccsm_status ccsm_workspace_set_timing(ccsm_workspace* ws, int enable);
+ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]);
+/* Test hook: copy an internal device buffer to the host after a device sync.  which: 0 = layer-0 input fragments,
+ * 1/2 = activation fragment buffers A/B (layer 0 and 2 write A, layer 1 writes B), 3 = h0 buffer, 4 = logit halves.
+ * NOTE: buffers are laid out for the padded row count of the workspace's max_sites only when n_sites == max_sites;
+ * in general tile/row strides follow the padded row count of the LAST forward's n_sites. */
+ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_t bytes);
+/* Runs one 32x32x16 MFMA tile with this library's fragment conventions against a host reference. */
+ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCSM_H_ */
