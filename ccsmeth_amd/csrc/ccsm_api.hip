@@ -329,7 +329,7 @@ ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_works
     const size_t h0_b = (size_t)2 * kLayers * ws->rows_p * kHidden * sizeof(float);
     const size_t part_b = (size_t)ws->rows_p * 2 * sizeof(float);
     // host-path staging: per strand kmer f32|u8 (N,21) + ipd + pw (N,21) f32 + npass (N,21) f32 worst case
-    ws->in_bytes = (size_t)2 * max_sites * kSeqLen * 4 * sizeof(float);
+    ws->in_bytes = (size_t)2 * ((size_t)max_sites * kSeqLen * 4 * sizeof(float) + 64);  // + alignment padding
     const size_t out_b = (size_t)max_sites * 4 * sizeof(float);
     ccsm_status st = CCSM_OK;
     auto dmalloc = [&](void** p, size_t b) -> ccsm_status {

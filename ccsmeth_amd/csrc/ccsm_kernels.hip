@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
     constexpr int TG = 3;                      // timesteps per Ua pass (21 = 7 * 3)
     constexpr int ROWS = 32 * NB;
     __shared__ float s_epart[kWaves][kSeqLen][ROWS];
-    __shared__ float s_pfc[kSeqLen][ROWS][4];  // [t][row][strand*2 + class]
+    __shared__ float s_pfc[kWaves][kSeqLen][ROWS][2];  // per-wave fc partials [wave][t][row][class] (fixed-order sum: deterministic)
     __shared__ float s_fcw[kClasses * 4 * kHidden];
 
     const int lane = threadIdx.x & 63;
@@ -393,7 +393,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
     const int tile0 = blockIdx.x * NB;
     const int n = lane & 31, hh = lane >> 5;
 
-    for (int i = threadIdx.x; i < kSeqLen * ROWS * 4; i += blockDim.x) (&s_pfc[0][0][0])[i] = 0.f;
     for (int i = threadIdx.x; i < kClasses * 4 * kHidden; i += blockDim.x) s_fcw[i] = fcw[i];
     __syncthreads();
 
@@ -433,25 +432,29 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
             for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) kacc[tt][bt][r] = 0.f;
-        float pf[TG][NB][4];
+        float pf[TG][NB][2];
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt)
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) pf[tt][bt][c] = 0.f;
+                for (int c = 0; c < 2; ++c) pf[tt][bt][c] = 0.f;
 
 #pragma unroll 2
         for (int kb = 0; kb < kKB12; ++kb) {
             const uint4 w[2] = {uap[(kb * 2 + 0) * kFragU4], uap[(kb * 2 + 1) * kFragU4]};
             const bool fc_owner = (kb & (kWaves - 1)) == wave;   // wave-uniform: each k-block's fc partial taken once
-            float fw[4][8];
+            float fw[NB][2][8];   // fc1.weight[class][strand(row)*512 + k] for this lane's row of each batch tile
             if (fc_owner) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)  // c = strand*2 + class -> fc1.weight[class][strand*512 + k]
+                for (int bt = 0; bt < NB; ++bt) {
+                    const int strand = ((tile0 + bt) * 32 + n) >= n_sites;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        fw[c][j] = s_fcw[(c & 1) * 4 * kHidden + (c >> 1) * 2 * kHidden + kb * 16 + hh * 8 + j];
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            fw[bt][c][j] = s_fcw[c * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8 + j];
+                }
             }
 #pragma unroll
             for (int tt = 0; tt < TG; ++tt)
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
                         for (int j = 0; j < 8; ++j) {
                             const float xv = (float)xh[j] + (float)xl[j];
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) pf[tt][bt][c] += fw[c][j] * xv;
+                            for (int c = 0; c < 2; ++c) pf[tt][bt][c] += fw[bt][c][j] * xv;
                         }
                     }
                 }
@@ -480,10 +483,10 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
                 e += __shfl_xor(e, 32);
                 if (hh == 0) s_epart[wave][t0 + tt][bt * 32 + n] = e;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
+                for (int c = 0; c < 2; ++c) {
                     float v = pf[tt][bt][c];
                     v += __shfl_xor(v, 32);
-                    if (hh == 0) atomicAdd(&s_pfc[t0 + tt][bt * 32 + n][c], v);
+                    if (hh == 0) s_pfc[wave][t0 + tt][bt * 32 + n][c] = v;
                 }
             }
     }
@@ -507,13 +510,15 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
 #pragma unroll
         for (int t = 0; t < kSeqLen; ++t) { e[t] = __expf(e[t] - m); den += e[t]; }
         const float inv = 1.0f / den;
-        const int strand = row >= n_sites;
         float l0 = 0.f, l1 = 0.f;
 #pragma unroll
         for (int t = 0; t < kSeqLen; ++t) {
             const float a = e[t] * inv;
-            l0 += a * s_pfc[t][rl][strand * 2 + 0];
-            l1 += a * s_pfc[t][rl][strand * 2 + 1];
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) { p0 += s_pfc[w][t][rl][0]; p1 += s_pfc[w][t][rl][1]; }
+            l0 += a * p0;
+            l1 += a * p1;
         }
         part[(size_t)row * 2 + 0] = l0;
         part[(size_t)row * 2 + 1] = l1;
