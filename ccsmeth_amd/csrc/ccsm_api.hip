@@ -30,8 +30,9 @@ ccsm_status fail(ccsm_status st, const std::string& msg) {
     } while (0)
 
 constexpr int kNBGru = 2;   // batch tiles (of 32 rows) per GRU workgroup
-constexpr int kNBAtt = 2;   // batch tiles per attention workgroup
-constexpr int kRowPad = 64; // rows are padded to a multiple of 32 * max(kNBGru, kNBAtt)
+constexpr int kRowPad = 32 * kNBGru;  // rows are padded to a multiple of the GRU workgroup's row count
+// attention kernel dynamic LDS: 2 staging buffers x 28 KiB + e partials + fc partials + fc1.weight
+constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kWaves * kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4;
 
 inline int rows_padded(int n_sites) { return ((2 * n_sites + kRowPad - 1) / kRowPad) * kRowPad; }
 
@@ -188,8 +189,8 @@ ccsm_status launch_forward(const ccsm_model* m, ccsm_workspace* ws, int n_sites,
     hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[1], ws->act[0], m->wst[2],
                        m->bias[2], ws->h0buf + 2 * slab, rows_p);
     if (tm) HIP_TRY(hipEventRecord(ws->ev[4], st));
-    hipLaunchKernelGGL((attn_fc_kernel<kNBAtt, NPASS>), dim3(tiles / kNBAtt), dim3(512), 0, st, ws->act[0], m->wa, m->ua, m->va,
-                       m->fcw, ws->part, n_sites);
+    hipLaunchKernelGGL((attn_fc_kernel<NPASS>), dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
+                       ws->part, n_sites);
     if (tm) HIP_TRY(hipEventRecord(ws->ev[5], st));
     hipLaunchKernelGGL(finalize_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, st, ws->part, m->fcb, logits, probs, n_sites);
     if (tm) {
@@ -291,6 +292,11 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (prec == 3) { CCSM_SET_LDS(3) } else if (prec == 2) { CCSM_SET_LDS(2) } else { CCSM_SET_LDS(1) }
 #undef CCSM_SET_LDS
+#define CCSM_SET_ALDS(NP)                                                                                   \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fc_kernel<NP>),         \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kAttLds);
+        if (prec == 3) { CCSM_SET_ALDS(3) } else if (prec == 2) { CCSM_SET_ALDS(2) } else { CCSM_SET_ALDS(1) }
+#undef CCSM_SET_ALDS
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }
     if (st != CCSM_OK) {

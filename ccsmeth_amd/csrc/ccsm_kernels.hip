@@ -372,137 +372,143 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const uint4* __restri
 // Attention pool + FC partials (utils/attention.py:48-70, models.py:135-148), one strand-row at a time.
 //   q = Wa h_n ; K_t = Ua out_t ; e_t = va . tanh(q + K_t) ; a = softmax_t(e) ; c = sum_t a_t out_t
 //   logits = fc1 [c_strand1 | c_strand2] + b.  Since fc1 is linear, fc1_s . c = sum_t a_t (fc1_s . out_t): the
-//   2x512 dot products p[t][row][class] are taken while the out_t fragments are in registers for the Ua GEMM, so
+//   2x512 dot products p[t][row][class] are taken while the out_t fragments pass through LDS for the Ua GEMM, so
 //   out is read once and c is never materialised.  Output: part[row][2] = strand-half of the logits.
-// grid = rows_p / (32*NB); block 512; wave w owns attention units [32w, 32w+32).
+// grid = rows_p / 32 (one batch tile per workgroup); block 512; wave w owns attention units [32w, 32w+32) and keeps
+// q + K_t for 7 timesteps in 7 accumulators (init = q), so Ua streams from L2 three times per workgroup.  The
+// activation fragments (shared by all 8 waves) are staged once per workgroup into LDS with global_load_lds
+// (2 k-blocks x 7 timesteps x hi/lo = 28 KiB per chunk, double-buffered).
 //   wa / ua : [wave][kb 32][hl][64] uint4 ; va : [wave][hh][16] floats (C-row order) ; fcw : fc1.weight (2,1024) fp32
 // ---------------------------------------------------------------------------------------------------------
-template <int NB, int NPASS>
+template <int NPASS>
 __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
                                                           const uint4* __restrict__ ua, const float* __restrict__ va,
                                                           const float* __restrict__ fcw, float* __restrict__ part,
                                                           int n_sites) {
-    constexpr int TG = 3;                      // timesteps per Ua pass (21 = 7 * 3)
-    constexpr int ROWS = 32 * NB;
-    __shared__ float s_epart[kWaves][kSeqLen][ROWS];
-    __shared__ float s_pfc[kWaves][kSeqLen][ROWS][2];  // per-wave fc partials [wave][t][row][class] (fixed-order sum: deterministic)
-    __shared__ float s_fcw[kClasses * 4 * kHidden];
+    constexpr int TG = 7;                      // timesteps per Ua pass (21 = 3 * 7)
+    constexpr int CK = 2;                      // k-blocks per staged chunk
+    constexpr int NCHUNK = kKB12 / CK;
+    constexpr int CHUNK_FRAGS = CK * TG * 2;   // 28 fragments of 1 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_stage = smem;                                                     // [2][CK][TG][hl] fragments
+    float* s_epart = reinterpret_cast<float*>(smem + 2 * CHUNK_FRAGS * 1024);  // [wave][t][32]
+    float* s_pfc = s_epart + kWaves * kSeqLen * 32;                            // [wave][t][32][2]
+    float* s_fcw = s_pfc + kWaves * kSeqLen * 32 * 2;                          // [2][1024]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile0 = blockIdx.x * NB;
+    const int tile = blockIdx.x;
     const int n = lane & 31, hh = lane >> 5;
 
     for (int i = threadIdx.x; i < kClasses * 4 * kHidden; i += blockDim.x) s_fcw[i] = fcw[i];
-    __syncthreads();
 
     const uint4* wap = wa + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
     const uint4* uap = ua + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
-    auto ofrag = [&](int bt, int t, int kb, int hl) -> const uint4* {
-        return out2 + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + kb) * 2 * kFragU4 + hl * kFragU4 + lane;
-    };
+    const uint4* otile = out2 + (size_t)tile * kSeqLen * kKB12 * 2 * kFragU4;   // [t][kb][hl][64]
 
     // ---- q = Wa h_n, h_n = [fwd final state = out[t=L-1][0:256] | bwd final state = out[t=0][256:512]] (models.py:135-137)
-    f32x16 qacc[NB];
+    f32x16 qacc;
 #pragma unroll
-    for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) qacc[bt][r] = 0.f;
+    for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
 #pragma unroll 4
     for (int kb = 0; kb < kKB12; ++kb) {
         const uint4 w[2] = {wap[(kb * 2 + 0) * kFragU4], wap[(kb * 2 + 1) * kFragU4]};
         const int tq = kb < kKBH ? kSeqLen - 1 : 0;
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt) {
-            const uint4 x[2] = {*ofrag(bt, tq, kb, 0), *ofrag(bt, tq, kb, 1)};
-            qacc[bt] = mma_split<NPASS>(w, x, qacc[bt]);
-        }
+        const uint4* xp = otile + ((size_t)tq * kKB12 + kb) * 2 * kFragU4 + lane;
+        const uint4 x[2] = {xp[0], xp[kFragU4]};
+        qacc = mma_split<NPASS>(w, x, qacc);
     }
     float vav[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) vav[r] = va[(wave * 2 + hh) * 16 + r];
+    const int strand = (tile * 32 + n) >= n_sites;
 
-    // ---- K_t = Ua out_t for 3 timesteps per pass, e partials, fc partials
+    // stage chunk `c` of timestep group t0 into buffer `buf`: fragment f = (kbl * TG + tt) * 2 + hl
+    auto stage = [&](int t0, int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < (CHUNK_FRAGS + kWaves - 1) / kWaves; ++i) {
+            const int f = wave + kWaves * i;
+            if (f < CHUNK_FRAGS) {
+                const int hl = f & 1, tt = (f >> 1) % TG, kbl = (f >> 1) / TG;
+                const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
     for (int tg = 0; tg < kSeqLen / TG; ++tg) {
         const int t0 = tg * TG;
-        f32x16 kacc[TG][NB];
+        f32x16 kacc[TG];
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt)
+        for (int tt = 0; tt < TG; ++tt) kacc[tt] = qacc;     // accumulate K_t on top of q
+        float pf[TG][2];
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) kacc[tt][bt][r] = 0.f;
-        float pf[TG][NB][2];
-#pragma unroll
-        for (int tt = 0; tt < TG; ++tt)
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) pf[tt][bt][c] = 0.f;
+        for (int tt = 0; tt < TG; ++tt) pf[tt][0] = pf[tt][1] = 0.f;
 
-#pragma unroll 2
-        for (int kb = 0; kb < kKB12; ++kb) {
-            const uint4 w[2] = {uap[(kb * 2 + 0) * kFragU4], uap[(kb * 2 + 1) * kFragU4]};
-            const bool fc_owner = (kb & (kWaves - 1)) == wave;   // wave-uniform: each k-block's fc partial taken once
-            float fw[NB][2][8];   // fc1.weight[class][strand(row)*512 + k] for this lane's row of each batch tile
-            if (fc_owner) {
+        stage(t0, 0, 0);
+#pragma unroll 1
+        for (int c = 0; c < NCHUNK; ++c) {
+            __syncthreads();   // chunk c has landed (the compiler drains vmcnt before the barrier); buffer (c+1)&1 is free
+            if (c + 1 < NCHUNK) stage(t0, c + 1, (c + 1) & 1);
+            const char* sb = s_stage + (c & 1) * CHUNK_FRAGS * 1024 + lane * 16;
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) {
-                    const int strand = ((tile0 + bt) * 32 + n) >= n_sites;
+            for (int kbl = 0; kbl < CK; ++kbl) {
+                const int kb = c * CK + kbl;
+                const uint4 w[2] = {uap[(kb * 2 + 0) * kFragU4], uap[(kb * 2 + 1) * kFragU4]};
+                const bool fc_owner = (kb & (kWaves - 1)) == wave;   // wave-uniform: each k-block's fc partial taken once
+                float fw[2][8];
+                if (fc_owner) {
 #pragma unroll
-                    for (int c = 0; c < 2; ++c)
+                    for (int cl = 0; cl < 2; ++cl)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            fw[bt][c][j] = s_fcw[c * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8 + j];
+                        for (int j = 0; j < 8; ++j) fw[cl][j] = s_fcw[cl * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8 + j];
                 }
-            }
 #pragma unroll
-            for (int tt = 0; tt < TG; ++tt)
-#pragma unroll
-                for (int bt = 0; bt < NB; ++bt) {
-                    const uint4 x[2] = {*ofrag(bt, t0 + tt, kb, 0), *ofrag(bt, t0 + tt, kb, 1)};
-                    kacc[tt][bt] = mma_split<NPASS>(w, x, kacc[tt][bt]);
+                for (int tt = 0; tt < TG; ++tt) {
+                    const uint4 x[2] = {*reinterpret_cast<const uint4*>(sb + ((kbl * TG + tt) * 2 + 0) * 1024),
+                                        *reinterpret_cast<const uint4*>(sb + ((kbl * TG + tt) * 2 + 1) * 1024)};
+                    kacc[tt] = mma_split<NPASS>(w, x, kacc[tt]);
                     if (fc_owner) {
                         const half8 xh = as_half8(x[0]), xl = as_half8(x[1]);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float xv = (float)xh[j] + (float)xl[j];
-#pragma unroll
-                            for (int c = 0; c < 2; ++c) pf[tt][bt][c] += fw[bt][c][j] * xv;
+                            pf[tt][0] += fw[0][j] * xv;
+                            pf[tt][1] += fw[1][j] * xv;
                         }
                     }
                 }
+            }
         }
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt)
+        for (int tt = 0; tt < TG; ++tt) {
+            float e = 0.f;
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                float e = 0.f;
+            for (int r = 0; r < 16; ++r) e += vav[r] * tanh_f(kacc[tt][r]);
+            e += __shfl_xor(e, 32);
+            if (hh == 0) s_epart[(wave * kSeqLen + t0 + tt) * 32 + n] = e;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e += vav[r] * tanh_f(qacc[bt][r] + kacc[tt][bt][r]);
-                e += __shfl_xor(e, 32);
-                if (hh == 0) s_epart[wave][t0 + tt][bt * 32 + n] = e;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float v = pf[tt][bt][c];
-                    v += __shfl_xor(v, 32);
-                    if (hh == 0) s_pfc[wave][t0 + tt][bt * 32 + n][c] = v;
-                }
+            for (int cl = 0; cl < 2; ++cl) {
+                float v = pf[tt][cl];
+                v += __shfl_xor(v, 32);
+                if (hh == 0) s_pfc[((wave * kSeqLen + t0 + tt) * 32 + n) * 2 + cl] = v;
             }
+        }
+        __syncthreads();   // all waves are done with both staging buffers before the next group restages buffer 0
     }
-    __syncthreads();
 
-    // ---- softmax over t and the strand-half of the logits
-    if (threadIdx.x < ROWS) {
+    // ---- softmax over t and the strand-half of the logits (fixed summation order: deterministic)
+    if (threadIdx.x < 32) {
         const int rl = threadIdx.x;
-        const int row = tile0 * 32 + rl;
+        const int row = tile * 32 + rl;
         float e[kSeqLen];
         float m = -3.0e38f;
 #pragma unroll
         for (int t = 0; t < kSeqLen; ++t) {
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) v += s_epart[w][t][rl];
+            for (int w = 0; w < kWaves; ++w) v += s_epart[(w * kSeqLen + t) * 32 + rl];
             e[t] = v;
             m = fmaxf(m, v);
         }
@@ -516,7 +522,10 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
             const float a = e[t] * inv;
             float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) { p0 += s_pfc[w][t][rl][0]; p1 += s_pfc[w][t][rl][1]; }
+            for (int w = 0; w < kWaves; ++w) {
+                p0 += s_pfc[((w * kSeqLen + t) * 32 + rl) * 2 + 0];
+                p1 += s_pfc[((w * kSeqLen + t) * 32 + rl) * 2 + 1];
+            }
             l0 += a * p0;
             l1 += a * p1;
         }
