@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--streams", type=int, default=4)
+    ap.add_argument("--streams", type=int, default=2)
     ap.add_argument("--precision", type=int, default=3, choices=(1, 2, 3),
                     help="3 = split-fp16 x3 (default, fp32-class, meets the 1e-4 bar); 2/1 = faster, reported as such")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg (0 = skip)")
