@@ -51,7 +51,7 @@ _lib = None
 EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspace_destroy", "ccsm_forward_host",
            "ccsm_submit_host", "ccsm_wait_host", "ccsm_forward_device", "ccsm_last_error", "ccsm_version",
            "ccsm_model_precision", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
-           "ccsm_selftest_mfma", "ccsm_debug_read")
+           "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded")
 
 
 def load():
@@ -87,6 +87,7 @@ def load():
     lib.ccsm_workspace_last_timing.argtypes = [vp, _FP]
     lib.ccsm_selftest_mfma.argtypes = [ci, _FP]
     lib.ccsm_debug_read.argtypes = [vp, ci, vp, C.c_size_t]
+    lib.ccsm_debug_rows_padded.argtypes = [ci]
     _lib = lib
     return lib
 

@@ -29,8 +29,10 @@ ccsm_status fail(ccsm_status st, const std::string& msg) {
             return fail(CCSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                       \
     } while (0)
 
-constexpr int kNBGru = 2;   // batch tiles (of 32 rows) per GRU workgroup
-constexpr int kRowPad = 32 * kNBGru;  // rows are padded to a multiple of the GRU workgroup's row count
+constexpr int kNBGru = 2;    // batch tiles (of 32 rows) per workgroup of the version-1 GRU kernel (A/B testing only)
+constexpr int kNBGru2 = 3;   // ... of the version-2 GRU kernel (default)
+constexpr int kRowPad = 32 * kNBGru * kNBGru2;  // rows are padded so that either kernel tiles them exactly
+constexpr int gru2_lds(int kx) { return (kKBH * kNBGru2 * 2 + 2 * (kx >= 4 ? 4 : kx) * kNBGru2 * 2) * 1024; }
 // attention kernel dynamic LDS: 2 staging buffers x 28 KiB + e partials + fc partials + fc1.weight
 constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kWaves * kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4;
 
@@ -52,7 +54,9 @@ inline int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }  // M
 struct ccsm_model {
     int device = 0;
     int precision = 3;
-    uint4* wst[kLayers] = {nullptr, nullptr, nullptr};  // [dir][wave][KX+16][gate][hl][64]
+    int gru_version = 2;
+    uint4* wst[kLayers] = {nullptr, nullptr, nullptr};  // v1: [dir][wave][KX+16][gate][hl][64]
+    uint4* wst2[kLayers] = {nullptr, nullptr, nullptr}; // v2: [dir][wave][A: KX x (r,z) | B: 16 x (r,z,n) | C: KX x (n)][hl][64]
     float* bias[kLayers] = {nullptr, nullptr, nullptr};  // [dir][wave][4][hh][16]
     uint4* wa = nullptr;                                 // [wave][32][hl][64]
     uint4* ua = nullptr;
@@ -119,6 +123,35 @@ void pack_wstream(int layer, const float* const wih[2], const float* const whh[2
                     }
 }
 
+// Version-2 weight stream: per (dir, wave) the fragments in the order the three phases consume them.
+void pack_wstream_v2(int layer, const float* const wih[2], const float* const whh[2], std::vector<_Float16>& out) {
+    const int kx = layer_kx(layer);
+    const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
+    const int nfrag = kx * 4 + kKBH * 6 + kx * 2;   // (gate, hl) fragments per wave
+    out.assign((size_t)2 * kWaves * nfrag * 512, (_Float16)0.f);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave) {
+            size_t f = (size_t)(dir * kWaves + wave) * nfrag;
+            auto emit = [&](bool xpart, int kb, int g) {
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int i = lane & 31, q = lane >> 5;
+                    const int row = g * kHidden + kUnitTile * wave + i;
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 16 * kb + 8 * q + j;
+                        const float v = xpart ? (k < k_in ? wih[dir][(size_t)row * k_in + k] : 0.f) : whh[dir][(size_t)row * kHidden + k];
+                        const HalfPair p = split_host(v);
+                        out[f * 512 + lane * 8 + j] = p.hi;
+                        out[(f + 1) * 512 + lane * 8 + j] = p.lo;
+                    }
+                }
+                f += 2;
+            };
+            for (int kb = 0; kb < kx; ++kb) { emit(true, kb, 0); emit(true, kb, 1); }
+            for (int kb = 0; kb < kKBH; ++kb) { emit(false, kb, 0); emit(false, kb, 1); emit(false, kb, 2); }
+            for (int kb = 0; kb < kx; ++kb) emit(true, kb, 2);
+        }
+}
+
 void pack_bias(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
     out.assign((size_t)2 * kWaves * 4 * 32, 0.f);
     for (int dir = 0; dir < 2; ++dir)
@@ -177,17 +210,29 @@ ccsm_status launch_forward(const ccsm_model* m, ccsm_workspace* ws, int n_sites,
                            rows_p, kmer_is_f32, npass_per_base);
     }
     if (tm) HIP_TRY(hipEventRecord(ws->ev[1], st));
-    const size_t lds = (size_t)kKBH * kNBGru * 2 * 1024;
-    const dim3 ggrid(2 * (tiles / kNBGru));
     const size_t slab = (size_t)2 * rows_p * kHidden;  // floats per layer (two directions)
-    hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB0, NPASS>), ggrid, dim3(512), lds, st, ws->x0, ws->act[0], m->wst[0],
-                       m->bias[0], ws->h0buf, rows_p);
-    if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
-    hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[0], ws->act[1], m->wst[1],
-                       m->bias[1], ws->h0buf + slab, rows_p);
-    if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-    hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[1], ws->act[0], m->wst[2],
-                       m->bias[2], ws->h0buf + 2 * slab, rows_p);
+    if (m->gru_version == 1) {
+        const size_t lds = (size_t)kKBH * kNBGru * 2 * 1024;
+        const dim3 ggrid(2 * (tiles / kNBGru));
+        hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB0, NPASS>), ggrid, dim3(512), lds, st, ws->x0, ws->act[0], m->wst[0],
+                           m->bias[0], ws->h0buf, rows_p);
+        if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
+        hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[0], ws->act[1],
+                           m->wst[1], m->bias[1], ws->h0buf + slab, rows_p);
+        if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
+        hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[1], ws->act[0],
+                           m->wst[2], m->bias[2], ws->h0buf + 2 * slab, rows_p);
+    } else {
+        const dim3 ggrid(2 * (tiles / kNBGru2));
+        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0, NPASS>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
+                           m->wst2[0], m->bias[0], ws->h0buf, rows_p);
+        if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
+        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12, NPASS>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
+                           m->wst2[1], m->bias[1], ws->h0buf + slab, rows_p);
+        if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
+        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12, NPASS>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
+                           m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, rows_p);
+    }
     if (tm) HIP_TRY(hipEventRecord(ws->ev[4], st));
     hipLaunchKernelGGL((attn_fc_kernel<NPASS>), dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
                        ws->part, n_sites);
@@ -262,9 +307,13 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     ccsm_status st = CCSM_OK;
     std::vector<_Float16> hbuf;
     std::vector<float> fbuf;
+    if (const char* e = std::getenv("CCSM_GRU_VERSION")) m->gru_version = std::atoi(e) == 1 ? 1 : 2;
     for (int l = 0; l < kLayers && st == CCSM_OK; ++l) {
         pack_wstream(l, w->weight_ih[l], w->weight_hh[l], hbuf);
         st = upload(&m->wst[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
+        if (st != CCSM_OK) break;
+        pack_wstream_v2(l, w->weight_ih[l], w->weight_hh[l], hbuf);
+        st = upload(&m->wst2[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
         if (st != CCSM_OK) break;
         pack_bias(w->bias_ih[l], w->bias_hh[l], fbuf);
         st = upload(&m->bias[l], fbuf.data(), fbuf.size() * sizeof(float));
@@ -292,6 +341,13 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (prec == 3) { CCSM_SET_LDS(3) } else if (prec == 2) { CCSM_SET_LDS(2) } else { CCSM_SET_LDS(1) }
 #undef CCSM_SET_LDS
+#define CCSM_SET_LDS2(NP)                                                                                                \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB0, NP>),           \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB0));              \
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB12, NP>),          \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
+        if (prec == 3) { CCSM_SET_LDS2(3) } else if (prec == 2) { CCSM_SET_LDS2(2) } else { CCSM_SET_LDS2(1) }
+#undef CCSM_SET_LDS2
 #define CCSM_SET_ALDS(NP)                                                                                   \
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fc_kernel<NP>),         \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kAttLds);
@@ -312,6 +368,7 @@ void ccsm_destroy(ccsm_model* m) {
     (void)hipSetDevice(m->device);
     for (int l = 0; l < kLayers; ++l) {
         (void)hipFree(m->wst[l]);
+        (void)hipFree(m->wst2[l]);
         (void)hipFree(m->bias[l]);
     }
     (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);
@@ -496,6 +553,8 @@ ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]) {
     out_ms[4] = prep + fin;
     return CCSM_OK;
 }
+
+int ccsm_debug_rows_padded(int n_sites) { return n_sites > 0 ? rows_padded(n_sites) : 0; }
 
 ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_t bytes) {
     if (!ws || !host_dst) return fail(CCSM_ERR_INVALID_ARG, "workspace and dst must be non-NULL");

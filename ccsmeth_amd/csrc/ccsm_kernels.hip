@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ccsm_layout.h"
 
 namespace ccsm {
@@ -347,6 +349,306 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const uint4* __restri
 #pragma unroll
             for (int kbl = 0; kbl < 2; ++kbl) {
                 // regs 8kbl..8kbl+3 ("a": q even) and 8kbl+4..8kbl+7 ("b": q odd); packed index base 4*kbl
+                uint4 v[2];
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    const uint32_t* p = hl ? plo : phi;
+                    const uint32_t a0 = p[4 * kbl + 0], a1 = p[4 * kbl + 1], b0 = p[4 * kbl + 2], b1 = p[4 * kbl + 3];
+                    const uint32_t own0 = hh ? b0 : a0, own1 = hh ? b1 : a1;
+                    const uint32_t snd0 = hh ? a0 : b0, snd1 = hh ? a1 : b1;
+                    const uint32_t rcv0 = __shfl_xor(snd0, 32), rcv1 = __shfl_xor(snd1, 32);
+                    v[hl] = hh ? make_uint4(rcv0, rcv1, own0, own1) : make_uint4(own0, own1, rcv0, rcv1);
+                }
+                const int kb = 2 * wave + kbl;
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) = v[0];
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) = v[1];
+                uint4* o = out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4 + lane;
+                o[0] = v[0];
+                o[kFragU4] = v[1];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GRU layer, version 2: 96 batch rows per workgroup (NB = 3 tiles), three accumulator sets, x staged through LDS.
+//
+// Why: version 1 streams the whole (layer, direction) weight set (2.36 MB of fragments) from L2 every timestep for
+// only 64 rows, which is load-path bound (~30 B/clk/CU measured) at ~49 % MFMA utilisation.  96 rows amortise the same
+// weight stream over 1.5x the MFMA work.  The accumulators for 96 rows x 4 quantities (r, z, n_x, n_h) do not fit in
+// 256 VGPRs next to double-buffered weight fragments, so each step runs in three phases over three sets:
+//   A  x-part of r and z            (K = 16*KX)   sets R, Z
+//   B  h-part of r, z and n         (K = 256)     sets R, Z, N(= W_hn h + b_hn)
+//      r = sigmoid(R);  N = b_in + r * N
+//   C  x-part of n                  (K = 16*KX)   set N
+//   epilogue: z = sigmoid(Z), n = tanh(N), h' = (h - n) * z + n
+// x_t is read twice (A and C).  It is staged once per pass into LDS in chunks of 4 k-blocks (24 KiB, two buffers) by
+// plain global loads issued one chunk ahead and written to LDS at the end of the previous chunk, so every wave reads
+// each x fragment from LDS instead of 8 waves pulling it through L1/L2.  The 16 chunk barriers of a step also order
+// the hidden-state fragments (no extra barriers).
+//   wst : [dir][wave][ A: KX x (r,z) x hl | B: 16 x (r,z,n) x hl | C: KX x (n) x hl ][64] uint4
+// ---------------------------------------------------------------------------------------------------------
+template <int KX, int NPASS>
+__global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
+                                                               const uint4* __restrict__ wst, const float* __restrict__ bias,
+                                                               const float* __restrict__ h0, int rows_p) {
+    constexpr int NB = 3;
+    constexpr int CK = KX >= 4 ? 4 : KX;       // k-blocks per staged chunk
+    constexpr int NCH = KX / CK;               // chunks per pass over x_t
+    constexpr int CHF = CK * NB * 2;           // fragments per chunk
+    constexpr int SPW = (CHF + kWaves - 1) / kWaves;  // fragments staged per wave per chunk
+    constexpr int FA = 4, FB = 6, FC = 2;      // fragments per k-block in phases A, B, C
+    constexpr int OFF_B = KX * FA, OFF_C = OFF_B + kKBH * FB, WFRAGS = OFF_C + KX * FC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_h = smem;                               // h fragments  [kb 16][bt 3][hl 2] x 1 KiB = 96 KiB
+    char* s_x = smem + kKBH * NB * 2 * 1024;        // x chunk ring [buf 2][kbl CK][bt 3][hl 2] x 1 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dir = blockIdx.x & 1;
+    const int tile0 = (blockIdx.x >> 1) * NB;
+    const int n = lane & 31, hh = lane >> 5;
+
+    auto hfrag = [&](int kb, int bt, int hl) -> char* { return s_h + (((kb * NB + bt) * 2 + hl) << 10); };
+    auto xfrag = [&](int buf, int kbl, int bt, int hl) -> char* { return s_x + ((((buf * CK + kbl) * NB + bt) * 2 + hl) << 10); };
+
+    // ---- h0 -> LDS fragments (this wave's own two k-blocks, every batch tile)
+    {
+        const float* h0d = h0 + (size_t)dir * rows_p * kHidden;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            const float* src = h0d + ((size_t)(tile0 + bt) * 32 + n) * kHidden;
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                const int kb = 2 * wave + kbl;
+                const float4 a = *reinterpret_cast<const float4*>(src + kb * 16 + hh * 8);
+                const float4 b = *reinterpret_cast<const float4*>(src + kb * 16 + hh * 8 + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                _Float16 hi[8], lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split16(v[j], hi[j], lo[j]);
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) =
+                    make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) =
+                    make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
+            }
+        }
+    }
+
+    // ---- x staging: fragment f = (kbl*NB + bt)*2 + hl of chunk c of timestep t; this wave moves f = wave + 8*i
+    // (three named registers rather than an array: the array form is demoted to scratch memory by hipcc)
+    static_assert(SPW <= 3, "staging registers");
+    uint4 sreg0, sreg1, sreg2;
+    auto stage_src = [&](int t, int c, int i) -> const uint4* {
+        // branch-free: a wave with nothing left to move re-stages the last fragment (same bytes, same place)
+        const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
+        const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
+        return xin + ((((size_t)(tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
+    };
+    auto stage_dst = [&](int buf, int i) -> uint4* {
+        const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
+        return reinterpret_cast<uint4*>(s_x + ((buf * CHF + f) << 10) + lane * 16);
+    };
+    auto stage_load = [&](int t, int c) {
+        sreg0 = *stage_src(t, c, 0);
+        if constexpr (SPW > 1) sreg1 = *stage_src(t, c, 1);
+        if constexpr (SPW > 2) sreg2 = *stage_src(t, c, 2);
+    };
+    auto stage_store = [&](int buf) {
+        *stage_dst(buf, 0) = sreg0;
+        if constexpr (SPW > 1) *stage_dst(buf, 1) = sreg1;
+        if constexpr (SPW > 2) *stage_dst(buf, 2) = sreg2;
+    };
+
+    const uint4* wp = wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4 + lane;
+    const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
+
+    stage_load(dir ? kSeqLen - 1 : 0, 0);
+    stage_store(0);
+
+    for (int s = 0; s < kSeqLen; ++s) {
+        const int t = dir ? (kSeqLen - 1 - s) : s;
+        const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;   // next step's timestep (last step: harmless reload)
+        f32x16 acc[3][NB];                            // R, Z, N
+        const float* bps = bp;
+        asm volatile("" : "+v"(bps));                 // keep the bias table out of permanently live registers
+        auto bias_set = [&](int set) {
+            f32x16 b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(bps + set * 32 + q * 4);
+                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+            return b;
+        };
+        {
+            const f32x16 b0 = bias_set(0), b1 = bias_set(1);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) { acc[0][bt] = b0; acc[1][bt] = b1; }
+        }
+
+        uint4 wA[3][2], wB[3][2];
+        auto ldA = [&](uint4 (&w)[3][2], int kb) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) w[g][hl] = wp[(kb * FA + g * 2 + hl) * kFragU4];
+        };
+        auto ldB = [&](uint4 (&w)[3][2], int kb) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) w[g][hl] = wp[(OFF_B + kb * FB + g * 2 + hl) * kFragU4];
+        };
+        auto ldC = [&](uint4 (&w)[3][2], int kb) {
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) w[0][hl] = wp[(OFF_C + kb * FC + hl) * kFragU4];
+        };
+        // one k-block of MFMAs; G gate fragments w[0..G-1] into accumulator sets SET0.. ; pass-major issue order
+        auto mul_x = [&](const uint4 (&w)[3][2], int buf, int kbl, auto gates, auto set0) {
+            constexpr int G = decltype(gates)::value, S0 = decltype(set0)::value;
+            uint4 x[NB][2];
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) x[bt][hl] = *reinterpret_cast<const uint4*>(xfrag(buf, kbl, bt, hl) + lane * 16);
+#define CCSM_P(P)                                                                                             \
+    _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)           \
+        acc[S0 + g][bt] = mma_pass<P>(w[g], x[bt], acc[S0 + g][bt]);
+            CCSM_P(0)
+            if constexpr (NPASS >= 2) { CCSM_P(1) }
+            if constexpr (NPASS >= 3) { CCSM_P(2) }
+#undef CCSM_P
+        };
+        auto mul_h = [&](const uint4 (&w)[3][2], int kb) {
+            uint4 x[NB][2];
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) x[bt][hl] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, hl) + lane * 16);
+#define CCSM_P(P)                                                                                             \
+    _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < 3; ++g)           \
+        acc[g][bt] = mma_pass<P>(w[g], x[bt], acc[g][bt]);
+            CCSM_P(0)
+            if constexpr (NPASS >= 2) { CCSM_P(1) }
+            if constexpr (NPASS >= 3) { CCSM_P(2) }
+#undef CCSM_P
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+
+        // ---------------- phase A: R, Z += W_i{r,z} x_t ------------------------------------------------------
+        ldA(wA, 0);
+#pragma unroll 1
+        for (int c = 0; c < NCH; ++c) {
+            __syncthreads();                       // chunk c (buffer c&1) is in LDS; the other buffer is free
+            // next chunk of this pass; after the last one: chunk 0 again for phase C (KX > 1) or the next step's chunk (KX == 1)
+            stage_load((c + 1 < NCH || KX > 1) ? t : tn, c + 1 < NCH ? c + 1 : 0);
+            const int buf = (KX > 1) ? (c & 1) : (s & 1);
+            if constexpr (CK == 4) {
+                ldA(wB, c * 4 + 1);
+                mul_x(wA, buf, 0, I2{}, I0{});
+                ldA(wA, c * 4 + 2);
+                mul_x(wB, buf, 1, I2{}, I0{});
+                ldA(wB, c * 4 + 3);
+                mul_x(wA, buf, 2, I2{}, I0{});
+                if (c + 1 < NCH) ldA(wA, c * 4 + 4); else ldB(wA, 0);
+                mul_x(wB, buf, 3, I2{}, I0{});
+            } else {
+                ldB(wB, 0);
+                mul_x(wA, buf, 0, I2{}, I0{});
+            }
+            stage_store((KX > 1) ? ((c + 1) & 1) : ((s + 1) & 1));   // next A chunk / C chunk 0 (buffer NCH&1 == 0) / next step
+        }
+
+        // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------
+        {
+            const f32x16 b3 = bias_set(3);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
+        }
+        if constexpr (CK == 4) {
+#pragma unroll 1
+            for (int kb = 0; kb < kKBH; kb += 2) {
+                ldB(wB, kb + 1);
+                mul_h(wA, kb);
+                if (kb + 2 < kKBH) ldB(wA, kb + 2); else ldC(wA, 0);
+                mul_h(wB, kb + 1);
+            }
+        } else {
+#pragma unroll 1
+            for (int kb = 0; kb < kKBH; kb += 2) {
+                ldB(wA, kb + 1);
+                mul_h(wB, kb);
+                if (kb + 2 < kKBH) ldB(wB, kb + 2); else ldC(wB, 0);
+                mul_h(wA, kb + 1);
+            }
+        }
+        // r = sigmoid(R) ; N = b_in + r * N
+        {
+            const f32x16 b2 = bias_set(2);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
+        }
+
+        // ---------------- phase C: N += W_in x_t ---------------------------------------------------------------
+        if constexpr (CK == 4) {
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                __syncthreads();
+                stage_load(c + 1 < NCH ? t : tn, c + 1 < NCH ? c + 1 : 0);   // next C chunk, then the next step's first A chunk
+                const int buf = c & 1;
+                ldC(wB, c * 4 + 1);
+                mul_x(wA, buf, 0, I1{}, I2{});
+                ldC(wA, c * 4 + 2);
+                mul_x(wB, buf, 1, I1{}, I2{});
+                ldC(wB, c * 4 + 3);
+                mul_x(wA, buf, 2, I1{}, I2{});
+                if (c + 1 < NCH) ldC(wA, c * 4 + 4);
+                mul_x(wB, buf, 3, I1{}, I2{});
+                stage_store((c + 1) & 1);
+            }
+        } else {
+            mul_x(wB, s & 1, 0, I1{}, I2{});      // x chunk of this step is still in its buffer
+        }
+
+        // ---------------- h_{t-1} of this wave's own units (C layout), then the gate epilogue -------------------
+        float hprev[NB][16];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kb = 2 * wave + (q >> 1);
+                const int src_lane = n + 32 * (q & 1);
+                const half4 hi = as_half4(*reinterpret_cast<const uint2*>(hfrag(kb, bt, 0) + src_lane * 16 + hh * 8));
+                const half4 lo = as_half4(*reinterpret_cast<const uint2*>(hfrag(kb, bt, 1) + src_lane * 16 + hh * 8));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hprev[bt][4 * q + e] = (float)hi[e] + (float)lo[e];
+            }
+        if constexpr (CK != 4) __syncthreads();   // KX == 1: no phase-C barriers, so order the h_{t-1} reads explicitly
+
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            uint32_t phi[8], plo[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float hn2[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float zz = sigmoid_f(acc[1][bt][r + e]);
+                    const float nn = tanh_f(acc[2][bt][r + e]);
+                    hn2[e] = (hprev[bt][r + e] - nn) * zz + nn;
+                }
+                _Float16 h0a, l0a, h1a, l1a;
+                split16(hn2[0], h0a, l0a);
+                split16(hn2[1], h1a, l1a);
+                phi[r >> 1] = pack2(h0a, h1a);
+                plo[r >> 1] = pack2(l0a, l1a);
+            }
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
                 uint4 v[2];
 #pragma unroll
                 for (int hl = 0; hl < 2; ++hl) {

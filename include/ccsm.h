@@ -146,6 +146,8 @@ ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]);
  * NOTE: buffers are laid out for the padded row count of the workspace's max_sites only when n_sites == max_sites;
  * in general tile/row strides follow the padded row count of the LAST forward's n_sites. */
 ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_t bytes);
+/* Padded strand-row count (2 * n_sites rounded up to the kernels' row tile) that lays out those buffers. */
+int ccsm_debug_rows_padded(int n_sites);
 /* Runs one 32x32x16 MFMA tile with this library's fragment conventions against a host reference. */
 ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err);
 

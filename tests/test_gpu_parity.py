@@ -171,7 +171,7 @@ def test_h0_modes(model7):
     from ccsmeth_amd import _lib
     ws2 = dm.workspace(n)
     _fwd(ws2, s, None, seed=9)
-    rows_p = ((2 * n + 63) // 64) * 64
+    rows_p = _lib.load().ccsm_debug_rows_padded(n)
     buf = np.empty(6 * rows_p * 256, np.float32)
     _lib.check(dm._lib.ccsm_debug_read(ws2.handle, 3, buf.ctypes.data, buf.nbytes))
     ws2.close()

@@ -43,7 +43,7 @@ def main():
     ws = dm.workspace(n)
     logits, probs = ws.forward_host(s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"],
                                     s["npass2"], h0=(h1, h2))
-    rows_p = ((2 * n + 63) // 64) * 64
+    rows_p = _lib.load().ccsm_debug_rows_padded(n)
     tiles = rows_p // 32
     # oracle, layer by layer, rows strand-major
     w64 = {k: v.astype(np.float64) for k, v in w.items()}
