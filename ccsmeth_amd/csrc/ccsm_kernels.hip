@@ -27,6 +27,14 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// non-temporal 16-byte accesses for streaming data (keeps the re-used weight fragments resident in the XCD's L2)
+__device__ __forceinline__ uint4 nt_load(const uint4* p) {
+    return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+}
+__device__ __forceinline__ void nt_store(uint4 v, uint4* p) {
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
+}
 __device__ __forceinline__ half8 as_half8(uint4 v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ half4 as_half4(uint2 v) { return __builtin_bit_cast(half4, v); }
 
@@ -442,7 +450,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
         // branch-free: a wave with nothing left to move re-stages the last fragment (same bytes, same place)
         const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
         const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
-        return xin + ((((size_t)(tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
+        // uniform fragment base (SGPRs) + lane: lets the compiler use the scalar-base addressing form
+        const uint4* fb = xin + ((((size_t)(tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) * kFragU4;
+        return fb + lane;
     };
     auto stage_dst = [&](int buf, int i) -> uint4* {
         const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
         if constexpr (SPW > 2) *stage_dst(buf, 2) = sreg2;
     };
 
-    const uint4* wp = wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4 + lane;
+    const uint4* wbase = wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4;   // wave-uniform
     const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
 
     stage_load(dir ? kSeqLen - 1 : 0, 0);
@@ -486,103 +496,115 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
             for (int bt = 0; bt < NB; ++bt) { acc[0][bt] = b0; acc[1][bt] = b1; }
         }
 
-        uint4 wA[3][2], wB[3][2];
-        auto ldA = [&](uint4 (&w)[3][2], int kb) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int hl = 0; hl < 2; ++hl) w[g][hl] = wp[(kb * FA + g * 2 + hl) * kFragU4];
-        };
-        auto ldB = [&](uint4 (&w)[3][2], int kb) {
+        // Operand movers and one-k-block MFMA groups.  The schedule is explicit (compiler-level memory fences around every
+        // MFMA group) because, left alone under this register pressure, hipcc sinks the weight loads next to their uses
+        // and the L2 latency (~700+ cycles) is exposed on every k-block.  Register plan per k-block:
+        //   weight fragments (hi and lo) : double-buffered, fetched from L2 one k-block ahead
+        //   x / h fragments  (hi and lo) : single buffer, read from LDS at the start of the k-block (short latency,
+        //                                  covered by the SIMD's other wave)
+        uint4 wq[2][3][2], xq[NB][2];
+        auto w_at = [&](int frag) -> uint4 { return wbase[frag * kFragU4 + lane]; };
+        auto ldw = [&](uint4 (&dst)[3][2], int base_frag, int gates) {   // fragment index = base + g*2 + hl
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int hl = 0; hl < 2; ++hl) w[g][hl] = wp[(OFF_B + kb * FB + g * 2 + hl) * kFragU4];
+                for (int hl = 0; hl < 2; ++hl)
+                    if (g < gates && (hl == 0 || NPASS >= 3)) dst[g][hl] = w_at(base_frag + g * 2 + hl);
         };
-        auto ldC = [&](uint4 (&w)[3][2], int kb) {
+        auto rdx = [&](int buf, int kbl) {
 #pragma unroll
-            for (int hl = 0; hl < 2; ++hl) w[0][hl] = wp[(OFF_C + kb * FC + hl) * kFragU4];
+            for (int hl = 0; hl < (NPASS >= 2 ? 2 : 1); ++hl)
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) xq[bt][hl] = *reinterpret_cast<const uint4*>(xfrag(buf, kbl, bt, hl) + lane * 16);
         };
-        // one k-block of MFMAs; G gate fragments w[0..G-1] into accumulator sets SET0.. ; pass-major issue order
-        auto mul_x = [&](const uint4 (&w)[3][2], int buf, int kbl, auto gates, auto set0) {
+        auto rdh = [&](int kb) {
+#pragma unroll
+            for (int hl = 0; hl < (NPASS >= 2 ? 2 : 1); ++hl)
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) xq[bt][hl] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, hl) + lane * 16);
+        };
+        // A compiler-level memory barrier: the operand loads issued before it may not sink below it (MFMAs are free to
+        // move).  (__builtin_amdgcn_sched_barrier(0) here produced NaNs on ROCm 7.2 / gfx950 — do not use it.)
+#define CCSM_FENCE asm volatile("" ::: "memory")
+        // G gates into accumulator sets S0.. ; pass-major issue order (consecutive MFMAs hit different accumulators)
+        auto mm = [&](const uint4 (&w)[3][2], auto gates, auto set0) {
             constexpr int G = decltype(gates)::value, S0 = decltype(set0)::value;
-            uint4 x[NB][2];
+            CCSM_FENCE;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                for (int hl = 0; hl < 2; ++hl) x[bt][hl] = *reinterpret_cast<const uint4*>(xfrag(buf, kbl, bt, hl) + lane * 16);
-#define CCSM_P(P)                                                                                             \
-    _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)           \
-        acc[S0 + g][bt] = mma_pass<P>(w[g], x[bt], acc[S0 + g][bt]);
-            CCSM_P(0)
-            if constexpr (NPASS >= 2) { CCSM_P(1) }
-            if constexpr (NPASS >= 3) { CCSM_P(2) }
-#undef CCSM_P
-        };
-        auto mul_h = [&](const uint4 (&w)[3][2], int kb) {
-            uint4 x[NB][2];
+                for (int g = 0; g < G; ++g) acc[S0 + g][bt] = mfma16(w[g][0], xq[bt][0], acc[S0 + g][bt]);
+            if constexpr (NPASS >= 2) {
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt)
+                for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                for (int hl = 0; hl < 2; ++hl) x[bt][hl] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, hl) + lane * 16);
-#define CCSM_P(P)                                                                                             \
-    _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < 3; ++g)           \
-        acc[g][bt] = mma_pass<P>(w[g], x[bt], acc[g][bt]);
-            CCSM_P(0)
-            if constexpr (NPASS >= 2) { CCSM_P(1) }
-            if constexpr (NPASS >= 3) { CCSM_P(2) }
-#undef CCSM_P
+                    for (int g = 0; g < G; ++g) acc[S0 + g][bt] = mfma16(w[g][0], xq[bt][1], acc[S0 + g][bt]);
+            }
+            if constexpr (NPASS >= 3) {
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[S0 + g][bt] = mfma16(w[g][1], xq[bt][0], acc[S0 + g][bt]);
+            }
+            CCSM_FENCE;
         };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>;
 
-        // ---------------- phase A: R, Z += W_i{r,z} x_t ------------------------------------------------------
-        ldA(wA, 0);
+        // ---------------- phase A: R, Z += W_i{r,z} x_t  (fragment index of k-block kb: kb*FA + g*2 + hl) ----------
+        ldw(wq[0], 0, 2);
 #pragma unroll 1
         for (int c = 0; c < NCH; ++c) {
             __syncthreads();                       // chunk c (buffer c&1) is in LDS; the other buffer is free
-            // next chunk of this pass; after the last one: chunk 0 again for phase C (KX > 1) or the next step's chunk (KX == 1)
-            stage_load((c + 1 < NCH || KX > 1) ? t : tn, c + 1 < NCH ? c + 1 : 0);
             const int buf = (KX > 1) ? (c & 1) : (s & 1);
             if constexpr (CK == 4) {
-                ldA(wB, c * 4 + 1);
-                mul_x(wA, buf, 0, I2{}, I0{});
-                ldA(wA, c * 4 + 2);
-                mul_x(wB, buf, 1, I2{}, I0{});
-                ldA(wB, c * 4 + 3);
-                mul_x(wA, buf, 2, I2{}, I0{});
-                if (c + 1 < NCH) ldA(wA, c * 4 + 4); else ldB(wA, 0);
-                mul_x(wB, buf, 3, I2{}, I0{});
+#define CCSM_KA(J, CUR, NXT)                                                                       \
+    if (J < 3 || c + 1 < NCH) ldw(wq[NXT], (c * 4 + J + 1) * FA, 2);                                \
+    else ldw(wq[NXT], OFF_B, 3);                                                                   \
+    if (J == 0) stage_load(t, c + 1 < NCH ? c + 1 : 0);                                            \
+    rdx(buf, J);                                                                                   \
+    mm(wq[CUR], I2{}, I0{});
+                // (the staging loads go AFTER the weight prefetch of k-block 0: younger in the in-order vmcnt queue)
+                CCSM_KA(0, 0, 1)
+                CCSM_KA(1, 1, 0)
+                CCSM_KA(2, 0, 1)
+                CCSM_KA(3, 1, 0)
+#undef CCSM_KA
+                stage_store((c + 1) & 1);              // next A chunk, or C chunk 0 into buffer NCH & 1 == 0
             } else {
-                ldB(wB, 0);
-                mul_x(wA, buf, 0, I2{}, I0{});
+                ldw(wq[1], OFF_B, 3);
+                stage_load(tn, 0);                     // KX == 1: the next step's only chunk
+                rdx(buf, 0);
+                mm(wq[0], I2{}, I0{});
+                stage_store((s + 1) & 1);
             }
-            stage_store((KX > 1) ? ((c + 1) & 1) : ((s + 1) & 1));   // next A chunk / C chunk 0 (buffer NCH&1 == 0) / next step
         }
 
         // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------
+        // entering: the fragments of recurrent k-block 0 are in wq[0] (KX > 1) or wq[1] (KX == 1)
         {
             const f32x16 b3 = bias_set(3);
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
         }
-        if constexpr (CK == 4) {
+        constexpr int B0 = (CK == 4) ? 0 : 1;     // buffer parity of recurrent k-block 0
+        uint4 chi[4], clo[2];                     // phase-C weight rings (see below)
 #pragma unroll 1
-            for (int kb = 0; kb < kKBH; kb += 2) {
-                ldB(wB, kb + 1);
-                mul_h(wA, kb);
-                if (kb + 2 < kKBH) ldB(wA, kb + 2); else ldC(wA, 0);
-                mul_h(wB, kb + 1);
+        for (int kb = 0; kb < kKBH; kb += 2) {
+            ldw(wq[B0 ^ 1], OFF_B + (kb + 1) * FB, 3);
+            rdh(kb);
+            mm(wq[B0], I3{}, I0{});
+            if (kb + 2 < kKBH) {
+                ldw(wq[B0], OFF_B + (kb + 2) * FB, 3);
+            } else {   // first n-gate fragments of phase C
+                chi[0] = w_at(OFF_C + 0);
+                if (NPASS >= 3) clo[0] = w_at(OFF_C + 1);
+                if (KX > 1) chi[1] = w_at(OFF_C + FC);
             }
-        } else {
-#pragma unroll 1
-            for (int kb = 0; kb < kKBH; kb += 2) {
-                ldB(wA, kb + 1);
-                mul_h(wB, kb);
-                if (kb + 2 < kKBH) ldB(wB, kb + 2); else ldC(wB, 0);
-                mul_h(wA, kb + 1);
-            }
+            rdh(kb + 1);
+            mm(wq[B0 ^ 1], I3{}, I0{});
         }
         // r = sigmoid(R) ; N = b_in + r * N
         {
@@ -593,26 +615,35 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
                 for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
         }
 
-        // ---------------- phase C: N += W_in x_t ---------------------------------------------------------------
+        // ---------------- phase C: N += W_in x_t.  Only 9 MFMAs per k-block, so the n-gate weights run further ahead:
+        // hi fragments in a ring of 4 fetched two k-blocks ahead, lo fragments in a ring of 2 fetched one ahead.
+        auto mm_c = [&](const uint4& wh, const uint4& wl) {
+            const uint4 w1[3][2] = {{wh, wl}, {wh, wl}, {wh, wl}};
+            mm(w1, I1{}, I2{});
+        };
         if constexpr (CK == 4) {
 #pragma unroll 1
             for (int c = 0; c < NCH; ++c) {
                 __syncthreads();
-                stage_load(c + 1 < NCH ? t : tn, c + 1 < NCH ? c + 1 : 0);   // next C chunk, then the next step's first A chunk
                 const int buf = c & 1;
-                ldC(wB, c * 4 + 1);
-                mul_x(wA, buf, 0, I1{}, I2{});
-                ldC(wA, c * 4 + 2);
-                mul_x(wB, buf, 1, I1{}, I2{});
-                ldC(wB, c * 4 + 3);
-                mul_x(wA, buf, 2, I1{}, I2{});
-                if (c + 1 < NCH) ldC(wA, c * 4 + 4);
-                mul_x(wB, buf, 3, I1{}, I2{});
-                stage_store((c + 1) & 1);
+#define CCSM_KC(J)                                                                                 \
+    if (NPASS >= 3 && (J < 3 || c + 1 < NCH)) clo[(J + 1) & 1] = w_at(OFF_C + (c * 4 + J + 1) * FC + 1); \
+    if (J < 2 || c + 1 < NCH) chi[(J + 2) & 3] = w_at(OFF_C + (c * 4 + J + 2) * FC);               \
+    if (J == 0) stage_load(c + 1 < NCH ? t : tn, c + 1 < NCH ? c + 1 : 0);                         \
+    rdx(buf, J);                                                                                   \
+    mm_c(chi[J], clo[J & 1]);
+                CCSM_KC(0)
+                CCSM_KC(1)
+                CCSM_KC(2)
+                CCSM_KC(3)
+#undef CCSM_KC
+                stage_store((c + 1) & 1);     // next C chunk, or the next step's first A chunk into buffer 0
             }
         } else {
-            mul_x(wB, s & 1, 0, I1{}, I2{});      // x chunk of this step is still in its buffer
+            rdx(s & 1, 0);                        // x chunk of this step is still in its buffer
+            mm_c(chi[0], clo[0]);
         }
+#undef CCSM_FENCE
 
         // ---------------- h_{t-1} of this wave's own units (C layout), then the gate epilogue -------------------
         float hprev[NB][16];
@@ -662,9 +693,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
                 const int kb = 2 * wave + kbl;
                 *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) = v[0];
                 *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) = v[1];
-                uint4* o = out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4 + lane;
-                o[0] = v[0];
-                o[kFragU4] = v[1];
+                uint4* o = out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4;
+                o[lane] = v[0];
+                o[kFragU4 + lane] = v[1];
             }
         }
     }
