@@ -51,7 +51,8 @@ _lib = None
 EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspace_destroy", "ccsm_forward_host",
            "ccsm_submit_host", "ccsm_wait_host", "ccsm_forward_device", "ccsm_last_error", "ccsm_version",
            "ccsm_model_precision", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
-           "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded")
+           "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded", "ccsm_debug_rows_capacity",
+           "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending")
 
 
 def load():
@@ -88,6 +89,10 @@ def load():
     lib.ccsm_selftest_mfma.argtypes = [ci, _FP]
     lib.ccsm_debug_read.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ccsm_debug_rows_padded.argtypes = [ci]
+    lib.ccsm_debug_rows_capacity.argtypes = [vp]
+    lib.ccsm_group_add_device.argtypes = [vp, vp, ci, C.POINTER(Batch), C.POINTER(H0), vp, vp, vp]
+    lib.ccsm_group_run.argtypes = [vp, vp, vp]
+    lib.ccsm_group_pending.argtypes = [vp]
     _lib = lib
     return lib
 

@@ -85,6 +85,13 @@ struct ccsm_workspace {
     size_t in_bytes = 0;
     int pending_sites = 0;
     hipStream_t pending_stream = nullptr;
+    // slices added since the last run (ccsm_group_add_device / ccsm_group_run)
+    int n_slices = 0;
+    int rows_used = 0;
+    int slice_row[kMaxSlices] = {};
+    int slice_n[kMaxSlices] = {};
+    float* slice_logits[kMaxSlices] = {};
+    float* slice_probs[kMaxSlices] = {};
     bool timing = false;
     hipEvent_t ev[8] = {};
     bool ev_ok = false;
@@ -192,69 +199,109 @@ ccsm_status upload(T** dst, const void* src, size_t bytes) {
     return CCSM_OK;
 }
 
+// Cheap per-slice kernels: initial states and layer-0 input fragments of rows [row_base, row_base + 2 n_sites).
+ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, int row_base, const StrandDev& s1,
+                        const StrandDev& s2, int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a,
+                        const float* h0b, uint64_t seed, uint64_t offset, hipStream_t st) {
+    const size_t total4 = (size_t)2 * kLayers * 2 * n_sites * (kHidden / 4);
+    const int grid = (int)std::min<size_t>((total4 + 255) / 256, 4096);
+    hipLaunchKernelGGL(prep_h0_kernel, dim3(grid), dim3(256), 0, st, ws->h0buf, h0a, h0b, n_sites, row_base, ws->rows_p, h0_mode,
+                       seed, offset);
+    const int total = 2 * n_sites * kSeqLen * 2;
+    hipLaunchKernelGGL(pack_x0_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws->x0, s1, s2, m->embed, n_sites, row_base,
+                       kmer_is_f32, npass_per_base);
+    HIP_TRY(hipGetLastError());
+    return CCSM_OK;
+}
+
+// Heavy kernels, once over every row used by the current slices, then the per-slice logits/softmax.
 template <int NPASS>
-ccsm_status launch_forward(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const StrandDev& s1, const StrandDev& s2,
-                           int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a, const float* h0b,
-                           uint64_t seed, uint64_t offset, float* logits, float* probs, hipStream_t st) {
-    const int rows_p = rows_padded(n_sites);
-    const int tiles = rows_p / 32;
+ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
+    const int rows_run = ((ws->rows_used + kRowPad - 1) / kRowPad) * kRowPad;
+    const int tiles = rows_run / 32;
     const bool tm = ws->timing && ws->ev_ok;
-    if (tm) HIP_TRY(hipEventRecord(ws->ev[0], st));
-    {
-        const size_t total4 = (size_t)2 * kLayers * rows_p * (kHidden / 4);
-        const int grid = (int)std::min<size_t>((total4 + 255) / 256, 4096);
-        hipLaunchKernelGGL(prep_h0_kernel, dim3(grid), dim3(256), 0, st, ws->h0buf, h0a, h0b, n_sites, rows_p, h0_mode, seed,
-                           offset);
-        const int total = tiles * kSeqLen * 64;
-        hipLaunchKernelGGL(pack_x0_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws->x0, s1, s2, m->embed, n_sites,
-                           rows_p, kmer_is_f32, npass_per_base);
-    }
     if (tm) HIP_TRY(hipEventRecord(ws->ev[1], st));
-    const size_t slab = (size_t)2 * rows_p * kHidden;  // floats per layer (two directions)
+    const size_t slab = (size_t)2 * ws->rows_p * kHidden;  // floats per layer (two directions)
     if (m->gru_version == 1) {
         const size_t lds = (size_t)kKBH * kNBGru * 2 * 1024;
         const dim3 ggrid(2 * (tiles / kNBGru));
         hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB0, NPASS>), ggrid, dim3(512), lds, st, ws->x0, ws->act[0], m->wst[0],
-                           m->bias[0], ws->h0buf, rows_p);
+                           m->bias[0], ws->h0buf, ws->rows_p);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
         hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[0], ws->act[1],
-                           m->wst[1], m->bias[1], ws->h0buf + slab, rows_p);
+                           m->wst[1], m->bias[1], ws->h0buf + slab, ws->rows_p);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
         hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[1], ws->act[0],
-                           m->wst[2], m->bias[2], ws->h0buf + 2 * slab, rows_p);
+                           m->wst[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p);
     } else {
         const dim3 ggrid(2 * (tiles / kNBGru2));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0, NPASS>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
-                           m->wst2[0], m->bias[0], ws->h0buf, rows_p);
+                           m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12, NPASS>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
-                           m->wst2[1], m->bias[1], ws->h0buf + slab, rows_p);
+                           m->wst2[1], m->bias[1], ws->h0buf + slab, ws->rows_p);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12, NPASS>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
-                           m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, rows_p);
+                           m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p);
     }
     if (tm) HIP_TRY(hipEventRecord(ws->ev[4], st));
+    SliceTable tab;
+    tab.count = ws->n_slices;
+    for (int i = 0; i < kMaxSlices; ++i) {
+        tab.row_base[i] = i < ws->n_slices ? ws->slice_row[i] : 0;
+        tab.n_sites[i] = i < ws->n_slices ? ws->slice_n[i] : 0;
+    }
     hipLaunchKernelGGL((attn_fc_kernel<NPASS>), dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
-                       ws->part, n_sites);
+                       ws->part, tab);
     if (tm) HIP_TRY(hipEventRecord(ws->ev[5], st));
-    hipLaunchKernelGGL(finalize_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, st, ws->part, m->fcb, logits, probs, n_sites);
+    for (int i = 0; i < ws->n_slices; ++i)
+        hipLaunchKernelGGL(finalize_kernel, dim3((ws->slice_n[i] + 255) / 256), dim3(256), 0, st, ws->part, m->fcb,
+                           ws->slice_logits[i], ws->slice_probs[i], ws->slice_n[i], ws->slice_row[i]);
     if (tm) {
         HIP_TRY(hipEventRecord(ws->ev[6], st));
         ws->timed = true;
     }
+    ws->n_slices = 0;
+    ws->rows_used = 0;
     HIP_TRY(hipGetLastError());
+    return CCSM_OK;
+}
+
+ccsm_status dispatch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
+    switch (m->precision) {
+        case 3: return launch_run<3>(m, ws, st);
+        case 2: return launch_run<2>(m, ws, st);
+        case 1: return launch_run<1>(m, ws, st);
+    }
+    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 1, 2 or 3");
+}
+
+// add one slice (device pointers) to the workspace
+ccsm_status add_slice(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const StrandDev& s1, const StrandDev& s2,
+                      int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a, const float* h0b, uint64_t seed,
+                      uint64_t offset, float* logits, float* probs, hipStream_t st) {
+    if (ws->n_slices >= kMaxSlices) return fail(CCSM_ERR_CAPACITY, "too many slices in one group (max 16)");
+    if (ws->rows_used + 2 * n_sites > 2 * ws->max_sites) return fail(CCSM_ERR_CAPACITY, "group exceeds the workspace's max_sites");
+    const int row_base = ws->rows_used;
+    ccsm_status rc = launch_prep(m, ws, n_sites, row_base, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, st);
+    if (rc != CCSM_OK) return rc;
+    const int i = ws->n_slices++;
+    ws->slice_row[i] = row_base;
+    ws->slice_n[i] = n_sites;
+    ws->slice_logits[i] = logits;
+    ws->slice_probs[i] = probs;
+    ws->rows_used += 2 * n_sites;
     return CCSM_OK;
 }
 
 ccsm_status dispatch_forward(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const StrandDev& s1, const StrandDev& s2,
                              int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a, const float* h0b,
                              uint64_t seed, uint64_t offset, float* logits, float* probs, hipStream_t st) {
-    switch (m->precision) {
-        case 3: return launch_forward<3>(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st);
-        case 2: return launch_forward<2>(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st);
-        case 1: return launch_forward<1>(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st);
-    }
-    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 1, 2 or 3");
+    ws->n_slices = 0;
+    ws->rows_used = 0;
+    ccsm_status rc = add_slice(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st);
+    if (rc != CCSM_OK) return rc;
+    return dispatch_run(m, ws, st);
 }
 
 ccsm_status check_call(const ccsm_model* m, const ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0) {
@@ -407,6 +454,11 @@ ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_works
     if (st == CCSM_OK) st = dmalloc((void**)&ws->part, part_b);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->d_in, ws->in_bytes);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->d_out, out_b);
+    if (st == CCSM_OK) {   // padding rows are computed (and ignored): give them finite contents once
+        hipError_t e = hipMemset(ws->x0, 0, x0_b);
+        if (e == hipSuccess) e = hipMemset(ws->h0buf, 0, h0_b);
+        if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    }
     if (st == CCSM_OK) {
         hipError_t e = hipHostMalloc((void**)&ws->p_in, ws->in_bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void**)&ws->p_out, out_b, hipHostMallocDefault);
@@ -453,6 +505,31 @@ ccsm_status ccsm_forward_device(const ccsm_model* m, ccsm_workspace* ws, int n_s
                             h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
                             static_cast<hipStream_t>(stream));
 }
+
+ccsm_status ccsm_group_add_device(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0,
+                                  float* logits, float* probs, void* stream) {
+    if (!m || !ws || !b) return fail(CCSM_ERR_INVALID_ARG, "model, workspace and batch must be non-NULL");
+    if (n_sites <= 0) return fail(CCSM_ERR_INVALID_ARG, "n_sites must be > 0");
+    ccsm_status st = check_call(m, ws, std::min(n_sites, ws->max_sites), b, h0);
+    if (st != CCSM_OK) return st;
+    if (!logits || !probs) return fail(CCSM_ERR_INVALID_ARG, "logits and probs must be non-NULL");
+    HIP_TRY(hipSetDevice(m->device));
+    StrandDev s1{b->strand[0].kmer, b->strand[0].ipd, b->strand[0].pw, b->strand[0].npass};
+    StrandDev s2{b->strand[1].kmer, b->strand[1].ipd, b->strand[1].pw, b->strand[1].npass};
+    const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
+    return add_slice(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
+                     h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
+                     static_cast<hipStream_t>(stream));
+}
+
+ccsm_status ccsm_group_run(const ccsm_model* m, ccsm_workspace* ws, void* stream) {
+    if (!m || !ws) return fail(CCSM_ERR_INVALID_ARG, "model and workspace must be non-NULL");
+    if (ws->n_slices == 0) return CCSM_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    return dispatch_run(m, ws, static_cast<hipStream_t>(stream));
+}
+
+int ccsm_group_pending(const ccsm_workspace* ws) { return ws ? ws->n_slices : 0; }
 
 ccsm_status ccsm_submit_host(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0,
                              void* stream) {
@@ -543,18 +620,18 @@ ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]) {
     if (!ws->timed) return fail(CCSM_ERR_INVALID_ARG, "no timed forward on this workspace");
     HIP_TRY(hipSetDevice(ws->device));
     HIP_TRY(hipEventSynchronize(ws->ev[6]));
-    float prep = 0.f, fin = 0.f;
-    HIP_TRY(hipEventElapsedTime(&prep, ws->ev[0], ws->ev[1]));
+    float fin = 0.f;
     HIP_TRY(hipEventElapsedTime(&out_ms[0], ws->ev[1], ws->ev[2]));
     HIP_TRY(hipEventElapsedTime(&out_ms[1], ws->ev[2], ws->ev[3]));
     HIP_TRY(hipEventElapsedTime(&out_ms[2], ws->ev[3], ws->ev[4]));
     HIP_TRY(hipEventElapsedTime(&out_ms[3], ws->ev[4], ws->ev[5]));
     HIP_TRY(hipEventElapsedTime(&fin, ws->ev[5], ws->ev[6]));
-    out_ms[4] = prep + fin;
+    out_ms[4] = fin;
     return CCSM_OK;
 }
 
 int ccsm_debug_rows_padded(int n_sites) { return n_sites > 0 ? rows_padded(n_sites) : 0; }
+int ccsm_debug_rows_capacity(const ccsm_workspace* ws) { return ws ? ws->rows_p : 0; }
 
 ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_t bytes) {
     if (!ws || !host_dst) return fail(CCSM_ERR_INVALID_ARG, "workspace and dst must be non-NULL");

@@ -87,20 +87,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// h0buf[ld][row][256] fp32, ld = 2*layer + dir, rows = strand-major (row < n_sites: strand 1, else strand 2).
+// A "slice" is one caller batch of n_sites CpG sites occupying strand rows [row_base, row_base + 2*n_sites) of a
+// workspace: rows [row_base, row_base + n_sites) are strand 1, the next n_sites are strand 2.  Several slices packed
+// back to back are run by ONE launch of each heavy kernel (micro-batch coalescing, ccsm_group_*).
+//
+// h0buf[ld][row][256] fp32, ld = 2*layer + dir, row stride = rows_cap (the workspace's padded row capacity).
 // mode 0: explicit (src1/src2 = (6, n_sites, 256) per strand, reference init_hidden layout); 1: zeros; 2: Philox N(0,1).
 __global__ void prep_h0_kernel(float* __restrict__ h0buf, const float* __restrict__ src1, const float* __restrict__ src2,
-                               int n_sites, int rows_p, int mode, uint64_t seed, uint64_t offset) {
-    const size_t total4 = (size_t)2 * kLayers * rows_p * (kHidden / 4);
+                               int n_sites, int row_base, int rows_cap, int mode, uint64_t seed, uint64_t offset) {
+    const size_t total4 = (size_t)2 * kLayers * 2 * n_sites * (kHidden / 4);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int u4 = (int)(i % (kHidden / 4));
         const size_t rr = i / (kHidden / 4);
-        const int row = (int)(rr % rows_p);
-        const int ld = (int)(rr / rows_p);
+        const int rl = (int)(rr % (2 * n_sites));
+        const int ld = (int)(rr / (2 * n_sites));
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < 2 * n_sites && mode != 1) {
-            const int strand = row >= n_sites;
-            const int site = row - strand * n_sites;
+        if (mode != 1) {
+            const int strand = rl >= n_sites;
+            const int site = rl - strand * n_sites;
             if (mode == 0) {
                 const float* src = strand ? src2 : src1;
                 v = *reinterpret_cast<const float4*>(src + ((size_t)ld * n_sites + site) * kHidden + u4 * 4);
@@ -117,7 +121,7 @@ __global__ void prep_h0_kernel(float* __restrict__ h0buf, const float* __restric
                 v = make_float4(ra * __cosf(k2pi * u1), ra * __sinf(k2pi * u1), rb * __cosf(k2pi * u3), rb * __sinf(k2pi * u3));
             }
         }
-        *reinterpret_cast<float4*>(h0buf + i * 4) = v;
+        *reinterpret_cast<float4*>(h0buf + ((size_t)ld * rows_cap + row_base + rl) * kHidden + u4 * 4) = v;
     }
 }
 
@@ -125,6 +129,13 @@ __global__ void prep_h0_kernel(float* __restrict__ h0buf, const float* __restric
 // Layer-0 input fragments: x = cat(embed[kmer.int()], ipd, pw, npass) (models.py:91-106), 11 features padded to
 // one k-block of 16.  x0[tile][t][0][hl][lane] with lane (n,g): g=0 -> embedding dims 0..7, g=1 -> ipd,pw,npass,0...
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxSlices = 16;
+struct SliceTable {          // strand rows of slice i: [row_base[i], row_base[i] + 2 * n_sites[i])
+    int count;
+    int row_base[kMaxSlices];
+    int n_sites[kMaxSlices];
+};
+
 struct StrandDev {
     const void* kmer;   // (N,21) u8 codes, or f32 if kmer_is_f32
     const float* ipd;   // (N,21)
@@ -133,32 +144,29 @@ struct StrandDev {
 };
 
 __global__ void pack_x0_kernel(uint4* __restrict__ x0, StrandDev s1, StrandDev s2, const float* __restrict__ embed,
-                               int n_sites, int rows_p, int kmer_is_f32, int npass_per_base) {
-    const int total = (rows_p / 32) * kSeqLen * 64;
+                               int n_sites, int row_base, int kmer_is_f32, int npass_per_base) {
+    const int total = 2 * n_sites * kSeqLen * 2;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int lane = i & 63;
-        const int tt = i >> 6;
-        const int t = tt % kSeqLen;
-        const int tile = tt / kSeqLen;
-        const int n = lane & 31, g = lane >> 5;
-        const int row = tile * 32 + n;
+        const int g = i & 1;
+        const int t = (i >> 1) % kSeqLen;
+        const int rl = (i >> 1) / kSeqLen;
+        const int row = row_base + rl;
+        const int tile = row >> 5, lane = (row & 31) + 32 * g;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (row < 2 * n_sites) {
-            const int strand = row >= n_sites;
-            const int site = row - strand * n_sites;
-            const StrandDev& s = strand ? s2 : s1;
-            const size_t e = (size_t)site * kSeqLen + t;
-            if (g == 0) {
-                int code = kmer_is_f32 ? (int)reinterpret_cast<const float*>(s.kmer)[e]
-                                       : (int)reinterpret_cast<const uint8_t*>(s.kmer)[e];
-                code = code < 0 ? 0 : (code >= kVocab ? kVocab - 1 : code);
+        const int strand = rl >= n_sites;
+        const int site = rl - strand * n_sites;
+        const StrandDev& s = strand ? s2 : s1;
+        const size_t e = (size_t)site * kSeqLen + t;
+        if (g == 0) {
+            int code = kmer_is_f32 ? (int)reinterpret_cast<const float*>(s.kmer)[e]
+                                   : (int)reinterpret_cast<const uint8_t*>(s.kmer)[e];
+            code = code < 0 ? 0 : (code >= kVocab ? kVocab - 1 : code);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = embed[code * kEmbed + j];
-            } else {
-                v[0] = s.ipd[e];
-                v[1] = s.pw[e];
-                v[2] = npass_per_base ? s.npass[e] : s.npass[site];
-            }
+            for (int j = 0; j < 8; ++j) v[j] = embed[code * kEmbed + j];
+        } else {
+            v[0] = s.ipd[e];
+            v[1] = s.pw[e];
+            v[2] = npass_per_base ? s.npass[e] : s.npass[site];
         }
         _Float16 hi[8], lo[8];
 #pragma unroll
@@ -717,7 +725,7 @@ template <int NPASS>
 __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
                                                           const uint4* __restrict__ ua, const float* __restrict__ va,
                                                           const float* __restrict__ fcw, float* __restrict__ part,
-                                                          int n_sites) {
+                                                          SliceTable slices) {
     constexpr int TG = 7;                      // timesteps per Ua pass (21 = 3 * 7)
     constexpr int CK = 2;                      // k-blocks per staged chunk
     constexpr int NCHUNK = kKB12 / CK;
@@ -754,7 +762,13 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
     float vav[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) vav[r] = va[(wave * 2 + hh) * 16 + r];
-    const int strand = (tile * 32 + n) >= n_sites;
+    int strand = 0;   // which half of fc1.weight this lane's row multiplies: strand 2 rows are the upper half of a slice
+    {
+        const int row = tile * 32 + n;
+        for (int i = 0; i < slices.count; ++i)
+            if (row >= slices.row_base[i] && row < slices.row_base[i] + 2 * slices.n_sites[i])
+                strand = (row - slices.row_base[i]) >= slices.n_sites[i];
+    }
 
     // stage chunk `c` of timestep group t0 into buffer `buf`: fragment f = (kbl * TG + tt) * 2 + hl
     auto stage = [&](int t0, int c, int buf) {
@@ -869,11 +883,13 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
 
 // logits = strand-1 half + strand-2 half + fc1.bias ; probs = softmax(logits)   (models.py:145-150)
 __global__ void finalize_kernel(const float* __restrict__ part, const float* __restrict__ fcb, float* __restrict__ logits,
-                                float* __restrict__ probs, int n_sites) {
+                                float* __restrict__ probs, int n_sites, int row_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_sites) return;
-    const float l0 = part[(size_t)i * 2 + 0] + part[((size_t)n_sites + i) * 2 + 0] + fcb[0];
-    const float l1 = part[(size_t)i * 2 + 1] + part[((size_t)n_sites + i) * 2 + 1] + fcb[1];
+    const float* p1 = part + ((size_t)row_base + i) * 2;
+    const float* p2 = part + ((size_t)row_base + n_sites + i) * 2;
+    const float l0 = p1[0] + p2[0] + fcb[0];
+    const float l1 = p1[1] + p2[1] + fcb[1];
     const float m = fmaxf(l0, l1);
     const float e0 = expf(l0 - m), e1 = expf(l1 - m);
     const float inv = 1.0f / (e0 + e1);

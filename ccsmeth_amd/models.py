@@ -174,6 +174,41 @@ class Workspace:
         self._keep = (keep, keep2)   # inputs must outlive the asynchronous kernels
         return logits, probs
 
+    def group_add_torch(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None,
+                        out=None):
+        """Bind one device-resident batch to the next free rows of this workspace (ccsm_group_add_device)."""
+        import torch
+        dev = torch.device("cuda", self.model.device)
+
+        def ptr_of(a, kmer=False):
+            if not isinstance(a, torch.Tensor):
+                a = torch.as_tensor(a)
+            if kmer and a.dtype == torch.uint8:
+                a = a.to(dev).contiguous()
+                return (a.data_ptr(), tuple(a.shape), a), False
+            a = a.to(device=dev, dtype=torch.float32).contiguous()
+            return (a.data_ptr(), tuple(a.shape), a), True
+        b, n, keep = self._batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of)
+        h, keep2 = self._h0(h0, n, ptr_of, seed, offset)
+        if out is None:
+            out = (torch.empty((n, 2), dtype=torch.float32, device=dev), torch.empty((n, 2), dtype=torch.float32, device=dev))
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(self.model._lib.ccsm_group_add_device(self.model.handle, self.handle, n, C.byref(b), C.byref(h),
+                                                         out[0].data_ptr(), out[1].data_ptr(), stream))
+        if self._keep is None or not isinstance(self._keep, list):
+            self._keep = []
+        self._keep.append((keep, keep2, out))
+        return out
+
+    def group_run(self, stream=None):
+        """Run the heavy kernels once over every batch added since the last run (ccsm_group_run)."""
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream(torch.device("cuda", self.model.device)).cuda_stream
+        _lib.check(self.model._lib.ccsm_group_run(self.model.handle, self.handle, stream))
+        self._keep = list(self._keep[-16:]) if isinstance(self._keep, list) else self._keep
+
     def set_timing(self, enable=True):
         _lib.check(self.model._lib.ccsm_workspace_set_timing(self.handle, int(enable)))
 

@@ -132,13 +132,25 @@ ccsm_status ccsm_wait_host(ccsm_workspace* ws, float* logits, float* probs);
 ccsm_status ccsm_forward_device(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* batch,
                                 const ccsm_h0* h0, float* logits, float* probs, void* stream);
 
+/* Micro-batch coalescing: several independent caller batches ("slices", each with its own outputs and initial
+ * states) are packed back to back into one workspace and run by ONE launch of each heavy kernel, so that a launch
+ * fills the GPU (one 2048-site batch is only 86 workgroups of 96 strand rows; three are exactly 256 = one per CU)
+ * and every CU streams the SAME layer's weights from L2.  ccsm_group_add_device binds a device-resident batch to the
+ * next free rows (runs the cheap per-batch kernels); ccsm_group_run runs the BiGRU / attention kernels over every
+ * slice added since the last run and writes each slice's logits/probs.  Total sites per group <= the workspace's
+ * max_sites; at most 16 slices.  ccsm_forward_device == add one slice + run.  Everything is asynchronous on `stream`. */
+ccsm_status ccsm_group_add_device(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* batch,
+                                  const ccsm_h0* h0, float* logits, float* probs, void* stream);
+ccsm_status ccsm_group_run(const ccsm_model* m, ccsm_workspace* ws, void* stream);
+int ccsm_group_pending(const ccsm_workspace* ws);
+
 /* Diagnostics */
 const char* ccsm_last_error(void);
 const char* ccsm_version(void);
 int ccsm_model_precision(const ccsm_model* m);
 size_t ccsm_workspace_bytes(const ccsm_workspace* ws);
 /* Times (ms, HIP events on `stream`) of the kernels of the LAST forward issued on this workspace with timing
- * enabled: out[0..2] = GRU layers 0..2, out[3] = attention+FC, out[4] = pack+h0 prep+finalize.  Blocks. */
+ * enabled: out[0..2] = GRU layers 0..2, out[3] = attention+FC, out[4] = logits/softmax finalize.  Blocks. */
 ccsm_status ccsm_workspace_set_timing(ccsm_workspace* ws, int enable);
 ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]);
 /* Test hook: copy an internal device buffer to the host after a device sync.  which: 0 = layer-0 input fragments,
@@ -148,6 +160,8 @@ ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]);
 ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_t bytes);
 /* Padded strand-row count (2 * n_sites rounded up to the kernels' row tile) that lays out those buffers. */
 int ccsm_debug_rows_padded(int n_sites);
+/* Row stride of the h0 buffer (= padded row capacity of the workspace). */
+int ccsm_debug_rows_capacity(const ccsm_workspace* ws);
 /* Runs one 32x32x16 MFMA tile with this library's fragment conventions against a host reference. */
 ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err);
 

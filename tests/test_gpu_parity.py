@@ -227,3 +227,42 @@ def test_model_mirror_checkpoint_contract():
     _, rp = _oracle(w, s, h1, h2)
     assert np.abs(probs.cpu().numpy() - rp).max() < PROB_TOL
     assert set(model.state_dict()) == set(w)
+
+
+def test_group_coalescing_matches_single_batches(model7):
+    """ccsm_group_*: batches packed back to back (ragged sizes, slices starting mid-tile) and run by one launch per
+    kernel give each batch exactly the result of running it alone."""
+    import torch
+    w, dm = model7
+    sizes = [100, 33, 257, 1]
+    data = []
+    for i, n in enumerate(sizes):
+        s = synth.synth_sites(n, 300 + i)
+        h = synth.synth_h0(n, 400 + i)
+        data.append((s, h))
+    ws1 = dm.workspace(max(sizes))
+    singles = [_fwd(ws1, s, h)[1] for s, h in data]
+    ws1.close()
+    wsg = dm.workspace(sum(sizes))
+    dev = torch.device("cuda:0")
+    outs = []
+    for s, h in data:
+        t = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+        outs.append(wsg.group_add_torch(t["kmer1"], t["ipd1"], t["pw1"], t["npass1"], t["kmer2"], t["ipd2"], t["pw2"], t["npass2"],
+                                        h0=(torch.from_numpy(h[0]).to(dev), torch.from_numpy(h[1]).to(dev))))
+    wsg.group_run()
+    torch.cuda.synchronize()
+    for single, (logits, probs) in zip(singles, outs):
+        assert np.abs(probs.cpu().numpy() - single).max() < 1e-6
+    # capacity errors
+    from ccsmeth_amd import _lib
+    s, h = data[0]
+    t = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+    for _ in range(3):
+        wsg.group_add_torch(t["kmer1"], t["ipd1"], t["pw1"], t["npass1"], t["kmer2"], t["ipd2"], t["pw2"], t["npass2"], h0="zero")
+    with pytest.raises(_lib.CcsmError) as e:
+        wsg.group_add_torch(t["kmer1"], t["ipd1"], t["pw1"], t["npass1"], t["kmer2"], t["ipd2"], t["pw2"], t["npass2"], h0="zero")
+    assert e.value.status == _lib.ERR_CAPACITY
+    wsg.group_run()
+    torch.cuda.synchronize()
+    wsg.close()
