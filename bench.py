@@ -142,6 +142,8 @@ def main():
     for i in range(a.warmup):
         step(i, last=(i == a.warmup - 1))
     fence()
+    for w in wss:
+        w.set_timing(True)       # re-arm: average only the timed region's launches
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, last=(i == a.steps - 1))
@@ -152,11 +154,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-kernel launch durations of the last step issued on each stream (HIP events recorded in the timed region)
-    kt = np.array([w.last_timing() for w in wss[:min(nst, max(1, a.steps // grp))]])   # ms: gru0, gru1, gru2, attn, finalize
-    last_full = (a.steps % grp == 0) or a.steps < grp
-    sites_per_launch = BATCH * (grp if last_full else a.steps % grp)
-    dom_ms = float(kt[:, 1:3].mean())
+    # ---- per-kernel launch durations: mean over every run of the timed region (HIP events recorded on the stream each
+    # kernel was launched on; the warm-up runs were dropped by re-arming the timers after the warm-up fence)
+    tms = [w.timing_mean() for w in wss]
+    nruns = sum(n for _, n in tms)
+    kt = np.sum([np.array(t) * n for t, n in tms], axis=0) / max(nruns, 1)     # ms: gru0, gru1, gru2, attn, finalize
+    dom_ms = float(kt[1:3].mean())
+    sites_per_launch = a.steps * BATCH / max(nruns, 1)      # = BATCH * coalesce when steps is a multiple of it
     assert bool(torch.isfinite(outs[0][0][1]).all())
 
     if rank == 0:
@@ -182,11 +186,11 @@ def main():
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,
                          "note": "achieved = algorithmic flops of one launch (%d sites x 99.09 MFLOP) / its HIP-event "
                                  "duration; one launch = %d workgroups of 96 strand rows on 256 CUs; launches of %d streams "
-                                 "may overlap" % (sites_per_launch, 2 * ((2 * sites_per_launch + 191) // 192) * 2, nst),
+                                 "may overlap" % (sites_per_launch, 2 * ((2 * int(sites_per_launch) + 95) // 96), nst),
                          "hbm_algorithmic_GBps": value / n_gpus * BYTES_PER_SITE / 1e9,
                          "hbm_frac": value / n_gpus * BYTES_PER_SITE / PEAK_HBM},
-            "kernel_ms": {"gru0": float(kt[:, 0].mean()), "gru1": float(kt[:, 1].mean()), "gru2": float(kt[:, 2].mean()),
-                          "attn_fc": float(kt[:, 3].mean()), "finalize": float(kt[:, 4].mean())},
+            "kernel_ms": {"gru0": float(kt[0]), "gru1": float(kt[1]), "gru2": float(kt[2]), "attn_fc": float(kt[3]),
+                          "finalize": float(kt[4]), "launches_averaged": int(nruns)},
             "whole_path_TFLOPs": value / n_gpus * FLOP_PER_SITE / 1e12,
         }
         if n_gpus == 1 and a.cpu_seconds > 0:

@@ -52,7 +52,7 @@ EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspa
            "ccsm_submit_host", "ccsm_wait_host", "ccsm_forward_device", "ccsm_last_error", "ccsm_version",
            "ccsm_model_precision", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
            "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded", "ccsm_debug_rows_capacity",
-           "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending")
+           "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean")
 
 
 def load():
@@ -93,6 +93,7 @@ def load():
     lib.ccsm_group_add_device.argtypes = [vp, vp, ci, C.POINTER(Batch), C.POINTER(H0), vp, vp, vp]
     lib.ccsm_group_run.argtypes = [vp, vp, vp]
     lib.ccsm_group_pending.argtypes = [vp]
+    lib.ccsm_workspace_timing_mean.argtypes = [vp, _FP, C.POINTER(C.c_int)]
     _lib = lib
     return lib
 

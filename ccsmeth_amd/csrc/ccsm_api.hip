@@ -93,7 +93,10 @@ struct ccsm_workspace {
     float* slice_logits[kMaxSlices] = {};
     float* slice_probs[kMaxSlices] = {};
     bool timing = false;
-    hipEvent_t ev[8] = {};
+    static constexpr int kEvSets = 128;      // ring of event sets: one per run while timing is enabled
+    hipEvent_t evs[kEvSets][8] = {};
+    hipEvent_t* ev = evs[0];                 // the set of the current / last run
+    int ev_runs = 0;                         // timed runs since timing was enabled
     bool ev_ok = false;
     bool timed = false;
 };
@@ -220,6 +223,7 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     const int rows_run = ((ws->rows_used + kRowPad - 1) / kRowPad) * kRowPad;
     const int tiles = rows_run / 32;
     const bool tm = ws->timing && ws->ev_ok;
+    if (tm) ws->ev = ws->evs[ws->ev_runs % ccsm_workspace::kEvSets];
     if (tm) HIP_TRY(hipEventRecord(ws->ev[1], st));
     const size_t slab = (size_t)2 * ws->rows_p * kHidden;  // floats per layer (two directions)
     if (m->gru_version == 1) {
@@ -260,6 +264,7 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     if (tm) {
         HIP_TRY(hipEventRecord(ws->ev[6], st));
         ws->timed = true;
+        ws->ev_runs++;
     }
     ws->n_slices = 0;
     ws->rows_used = 0;
@@ -466,8 +471,9 @@ ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_works
     }
     if (st == CCSM_OK) {
         ws->ev_ok = true;
-        for (int i = 0; i < 8; ++i)
-            if (hipEventCreate(&ws->ev[i]) != hipSuccess) ws->ev_ok = false;
+        for (int k = 0; k < ccsm_workspace::kEvSets; ++k)
+            for (int i = 0; i < 8; ++i)
+                if (hipEventCreate(&ws->evs[k][i]) != hipSuccess) ws->ev_ok = false;
     }
     if (st != CCSM_OK) {
         ccsm_workspace_destroy(ws);
@@ -487,8 +493,9 @@ void ccsm_workspace_destroy(ccsm_workspace* ws) {
     if (ws->p_in) (void)hipHostFree(ws->p_in);
     if (ws->p_h0) (void)hipHostFree(ws->p_h0);
     if (ws->p_out) (void)hipHostFree(ws->p_out);
-    if (ws->ev_ok)
-        for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ws->ev[i]);
+    for (int k = 0; k < ccsm_workspace::kEvSets; ++k)
+        for (int i = 0; i < 8; ++i)
+            if (ws->evs[k][i]) (void)hipEventDestroy(ws->evs[k][i]);
     delete ws;
 }
 
@@ -612,6 +619,7 @@ ccsm_status ccsm_workspace_set_timing(ccsm_workspace* ws, int enable) {
     if (!ws) return fail(CCSM_ERR_INVALID_ARG, "workspace must be non-NULL");
     ws->timing = enable != 0;
     ws->timed = false;
+    ws->ev_runs = 0;
     return CCSM_OK;
 }
 
@@ -632,6 +640,24 @@ ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]) {
 
 int ccsm_debug_rows_padded(int n_sites) { return n_sites > 0 ? rows_padded(n_sites) : 0; }
 int ccsm_debug_rows_capacity(const ccsm_workspace* ws) { return ws ? ws->rows_p : 0; }
+
+ccsm_status ccsm_workspace_timing_mean(ccsm_workspace* ws, float out_ms[5], int* n_runs) {
+    if (!ws || !out_ms || !n_runs) return fail(CCSM_ERR_INVALID_ARG, "workspace, out and n_runs must be non-NULL");
+    HIP_TRY(hipSetDevice(ws->device));
+    const int n = std::min(ws->ev_runs, (int)ccsm_workspace::kEvSets);
+    *n_runs = n;
+    for (int j = 0; j < 5; ++j) out_ms[j] = 0.f;
+    for (int k = 0; k < n; ++k) {
+        hipEvent_t* e = ws->evs[k];
+        HIP_TRY(hipEventSynchronize(e[6]));
+        for (int j = 0; j < 5; ++j) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e[1 + j], e[2 + j]));
+            out_ms[j] += ms / n;
+        }
+    }
+    return CCSM_OK;
+}
 
 ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_t bytes) {
     if (!ws || !host_dst) return fail(CCSM_ERR_INVALID_ARG, "workspace and dst must be non-NULL");

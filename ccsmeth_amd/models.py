@@ -212,6 +212,13 @@ class Workspace:
     def set_timing(self, enable=True):
         _lib.check(self.model._lib.ccsm_workspace_set_timing(self.handle, int(enable)))
 
+    def timing_mean(self):
+        """(mean ms [gru0, gru1, gru2, attn_fc, finalize], runs averaged) since set_timing(True)."""
+        out = (C.c_float * 5)()
+        n = C.c_int(0)
+        _lib.check(self.model._lib.ccsm_workspace_timing_mean(self.handle, out, C.byref(n)))
+        return list(out), n.value
+
     def last_timing(self):
         out = (C.c_float * 5)()
         _lib.check(self.model._lib.ccsm_workspace_last_timing(self.handle, out))

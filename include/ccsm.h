@@ -153,6 +153,9 @@ size_t ccsm_workspace_bytes(const ccsm_workspace* ws);
  * enabled: out[0..2] = GRU layers 0..2, out[3] = attention+FC, out[4] = logits/softmax finalize.  Blocks. */
 ccsm_status ccsm_workspace_set_timing(ccsm_workspace* ws, int enable);
 ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]);
+/* Mean of the same five durations over every run issued on this workspace since timing was enabled (up to the last
+ * 128 runs; *n_runs = how many were averaged).  Blocks until those runs have finished. */
+ccsm_status ccsm_workspace_timing_mean(ccsm_workspace* ws, float out_ms[5], int* n_runs);
 /* Test hook: copy an internal device buffer to the host after a device sync.  which: 0 = layer-0 input fragments,
  * 1/2 = activation fragment buffers A/B (layer 0 and 2 write A, layer 1 writes B), 3 = h0 buffer, 4 = logit halves.
  * NOTE: buffers are laid out for the padded row count of the workspace's max_sites only when n_sites == max_sites;

@@ -1,0 +1,44 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/ccsm.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    path = os.path.join(ROOT, "ccsmeth_amd", "lib", "libccsm.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["python", "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT)
+    return path
+
+
+def test_exports_match_header(libpath):
+    header = open(os.path.join(ROOT, "include", "ccsm.h")).read()
+    declared = set(re.findall(r"\b(ccsm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ccsm_status"}
+    lib = ctypes.CDLL(libpath)
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
+    from ccsmeth_amd import _lib
+    assert set(_lib.EXPORTS) == declared
+
+
+def test_errors_without_touching_the_gpu(libpath):
+    lib = ctypes.CDLL(libpath)
+    lib.ccsm_last_error.restype = ctypes.c_char_p
+    lib.ccsm_version.restype = ctypes.c_char_p
+    assert b"libccsm" in lib.ccsm_version()
+    out = ctypes.c_void_p()
+    assert lib.ccsm_create(None, None, 0, ctypes.byref(out)) == 1          # CCSM_ERR_INVALID_ARG
+    assert b"non-NULL" in lib.ccsm_last_error()
+    from ccsmeth_amd import _lib
+    cfg = _lib.Config(21, 3, 2, 256, 1, 0, 0, 0, b"transencoder2s", 0)
+    w = _lib.Weights()
+    assert lib.ccsm_create(ctypes.byref(cfg), ctypes.byref(w), 0, ctypes.byref(out)) == 2   # CCSM_ERR_UNSUPPORTED
+    assert b"model_type" in lib.ccsm_last_error()
+    assert lib.ccsm_group_pending(None) == 0 and lib.ccsm_debug_rows_padded(2048) == 4224

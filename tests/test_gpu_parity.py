@@ -266,3 +266,38 @@ def test_group_coalescing_matches_single_batches(model7):
     wsg.group_run()
     torch.cuda.synchronize()
     wsg.close()
+
+
+def test_call_mods2s_pipeline_vs_reference_golden():
+    """extract -> _batch_feature_list2s -> _call_mods2s (HIP model, pinned h0) -> MM/ML, against the reference's own
+    outputs for the same reads (tests/golden/pipeline_golden.*): integer fields exact, probabilities within 1e-4."""
+    from ccsmeth_amd import _bam2modbam as mmod
+    from ccsmeth_amd import call_modifications as cm
+    from ccsmeth_amd import extract_features as ef
+    from ccsmeth_amd.models import ModelAttRNN
+    pipe = np.load(os.path.join(GOLDEN, "pipeline_golden.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "pipeline_golden.json")))
+    rows = []
+    for read in meta["reads"]:
+        nm = read["name"]
+        rows += ef.extract_features_from_double_strand_read(nm, read["seq"], pipe[nm + "_fi"], pipe[nm + "_ri"], pipe[nm + "_fp"],
+                                                            pipe[nm + "_rp"], read["fn"], read["rn"])
+    fb = cm._batch_feature_list2s(rows)
+    c = meta["call_mods"]
+    model = ModelAttRNN(21, 3, 2, 0, 256, model_type="attbigru2s", device=0)
+    model.load_state_dict(synth.synth_weights(c["weight_seed"]))
+    model.cuda(0).eval()
+    pred, nb = cm._call_mods2s(fb, model, c["batch_size"], 0,
+                               h0_provider=lambda b, n: synth.synth_h0(n, c["h0_seed_base"] + b))
+    assert nb == c["batch_num"]
+    assert [p[0] for p in pred] == meta["pred_holeid"] and [p[1] for p in pred] == pipe["pred_loc"].tolist()
+    got = np.array([p[2] for p in pred], np.float32)
+    assert np.abs(got - pipe["pred_prob"]).max() < PROB_TOL
+    # ML bytes: quantised probabilities, equal except at bucket edges (SURVEY.md 7: +-1 there)
+    reads = {r["name"]: r for r in meta["reads"]}
+    for name, exp in meta["mmml"].items():
+        lp = sorted((p[1], p[2]) for p in pred if p[0] == name)
+        locs, probs = zip(*lp)
+        assert mmod._convert_locs_to_mmtag(locs, reads[name]["seq"]) == exp["mm"]
+        ml = mmod._convert_probs_to_mltag(probs)
+        assert max(abs(a - b) for a, b in zip(ml, exp["ml"])) <= 1

@@ -1,0 +1,93 @@
+"""Host-side mirrors (feature extraction, batching, MM/ML) against fixtures produced by the reference itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from ccsmeth_amd import _bam2modbam as mm
+from ccsmeth_amd import call_modifications as cm
+from ccsmeth_amd import extract_features as ef
+from ccsmeth_amd.utils import process_utils as pu
+
+PIPE = np.load(os.path.join(GOLDEN, "pipeline_golden.npz"))
+META = json.load(open(os.path.join(GOLDEN, "pipeline_golden.json")))
+
+
+def test_tables():
+    assert pu.codecv1_to_frame2() == PIPE["codecv1"].tolist()
+    assert pu.base2code_dna == META["base2code_dna"]
+    for s, rc in META["complement"].items():
+        assert pu.complement_seq(s) == rc
+
+
+@pytest.mark.parametrize("read", META["reads"], ids=lambda r: r["name"])
+def test_extract_read_arrays_bit_exact(read):
+    nm = read["name"]
+    arr = ef.extract_read_arrays(read["seq"], PIPE[nm + "_fi"], PIPE[nm + "_ri"], PIPE[nm + "_fp"], PIPE[nm + "_rp"])
+    assert arr is not None and len(arr["loc"]) == read["n_sites"]
+    if read["n_sites"] == 0:
+        return
+    assert np.array_equal(arr["loc"], PIPE[nm + "_loc"])
+    assert np.array_equal(arr["fkmer_ascii"], PIPE[nm + "_fkmer"]) and np.array_equal(arr["rkmer_ascii"], PIPE[nm + "_rkmer"])
+    for k in ("fipd", "fpw", "ripd", "rpw"):
+        assert arr[k].dtype == np.float64 and np.array_equal(arr[k], PIPE[nm + "_" + k]), k   # bit-exact float64
+    rows = ef.extract_features_from_double_strand_read(nm, read["seq"], PIPE[nm + "_fi"], PIPE[nm + "_ri"], PIPE[nm + "_fp"],
+                                                       PIPE[nm + "_rp"], read["fn"], read["rn"])
+    assert len(rows) == read["n_sites"] and all(len(r) == 22 for r in rows)
+    r0 = rows[0]
+    assert r0[:5] == [".", -1, ".", nm, int(PIPE[nm + "_loc"][0])] and r0[6] == read["fn"] and r0[14] == read["rn"]
+    assert r0[8] == "." and r0[12] == "." and r0[21] == 1 and r0[5][10:12] == "CG" and r0[13][10:12] == "CG"
+
+
+def test_mismatched_kinetics_length_skips_read():
+    assert ef.extract_read_arrays("ACGTACGTACGTACGTACGTACGTACGT", [1] * 5, [1] * 28, [1] * 28, [1] * 28) is None
+    assert ef.extract_features_from_double_strand_read("x", "ACGT" * 7, [1] * 5, [1] * 28, [1] * 28, [1] * 28, 3, 3) == []
+
+
+def _all_rows():
+    rows = []
+    for read in META["reads"]:
+        nm = read["name"]
+        rows += ef.extract_features_from_double_strand_read(nm, read["seq"], PIPE[nm + "_fi"], PIPE[nm + "_ri"],
+                                                            PIPE[nm + "_fp"], PIPE[nm + "_rp"], read["fn"], read["rn"])
+    return rows
+
+
+def test_batch_feature_list2s_matches_reference():
+    fb = cm._batch_feature_list2s(_all_rows())
+    assert len(fb) == 18
+    assert list(fb[0]) == META["sampleinfo"]
+    assert np.array_equal(np.array(fb[1]), PIPE["batch_fkmers"]) and np.array_equal(np.array(fb[9]), PIPE["batch_rkmers"])
+    assert np.array_equal(np.array(fb[2]), PIPE["batch_fpasss"]) and np.array_equal(np.array(fb[10]), PIPE["batch_rpasss"])
+    assert fb[4][0] == 0 and fb[7][0] == 0 and fb[8][0] == 0     # "." placeholders become scalar 0
+    assert np.array(fb[3]).dtype == np.float64
+
+
+def test_mm_ml_and_refill():
+    for case in META["mm_extra"]:
+        if case["mm"] == "AssertionError":
+            with pytest.raises(AssertionError):
+                mm._convert_locs_to_mmtag(case["locs"], case["seq"])
+        else:
+            assert mm._convert_locs_to_mmtag(case["locs"], case["seq"]) == case["mm"]
+    assert mm._convert_probs_to_mltag(META["ml_extra"]["probs"]) == META["ml_extra"]["ml"]
+    reads = {r["name"]: r for r in META["reads"]}
+    for name, exp in META["mmml"].items():
+        lp = sorted((int(l), p) for l, p, h in zip(PIPE["pred_loc"], PIPE["pred_prob"], META["pred_holeid"]) if h == name)
+        locs, probs = zip(*lp)
+        assert mm._convert_locs_to_mmtag(locs, reads[name]["seq"]) == exp["mm"]
+        assert mm._convert_probs_to_mltag(probs) == exp["ml"]
+    tags = [("fi", [1, 2]), ("MM", "C+m,1;"), ("ML", [3]), ("np", 12), ("rp", [4]), ("sn", [1.0, 2.0])]
+    j = lambda t: [list(x) for x in t]  # noqa: E731
+    assert j(mm._refill_tags(tags, [3, 0], [10, 200], True)) == META["refill"]["rm"]
+    assert j(mm._refill_tags(tags, [3, 0], [10, 200], False)) == META["refill"]["keep"]
+    assert j(mm._refill_tags(tags, None, None, True)) == META["refill"]["none"]
+
+
+def test_prob1_norm_round6_is_float32_rounding():
+    p = np.array([[0.25, 0.75], [0.3333333, 0.6666667], [0.9999999, 1e-7]], np.float32)
+    got = cm.prob1_norm_round6(p)
+    exp = np.array([round(b / (a + b), 6) for a, b in p], np.float32)     # NumPy float32 scalar __round__, as the reference
+    assert got.dtype == np.float32 and np.array_equal(got, exp)
