@@ -1,0 +1,145 @@
+"""Per-read call_mods pipeline on one GPU: reads -> 21-mer features (host, vectorised) -> libccsm forward through the
+pinned double-buffered staging ring (ccsm_submit_host / ccsm_wait_host on two workspaces and two HIP streams) ->
+per-site round(p1/(p0+p1), 6) -> MM / ML tags per read.
+
+Mirrors what reference call_modifications.py does between its reader and writer processes
+(process_one_holebatch :extract_features.py:409-431, _call_mods2s :170-227, _add_modinfo2alignedseg :230-263) for
+denovo mode, without pysam: a read is (name, forward_seq, fi, ri, fp, rp, fn, rn, is_reverse).  BAM parsing/writing
+(a-1, a-10) is outside this round."""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._bam2modbam import _convert_locs_to_mmtag, _convert_probs_to_mltag
+from .call_modifications import prob1_norm_round6
+from .extract_features import extract_read_arrays
+
+Read = namedtuple("Read", "name seq fi ri fp rp fn rn is_reverse")
+ReadCalls = namedtuple("ReadCalls", "name n_sites locs probs mm ml mm_flag")
+
+
+class _Slot:
+    """One workspace + its pending host-side bookkeeping."""
+
+    def __init__(self, dm, max_sites, stream):
+        self.ws = dm.workspace(max_sites)
+        self.stream = stream
+        self.pending = None
+
+
+class CallModsPipeline:
+    def __init__(self, device_model, batch_size=2048, seed=1234):
+        import torch
+        self.dm = device_model
+        self.batch_size = int(batch_size)
+        self.seed = seed
+        dev = torch.device("cuda", device_model.device)
+        self._streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+        self._slots = [_Slot(device_model, self.batch_size, s.cuda_stream) for s in self._streams]
+        self._site_counter = 0
+
+    def close(self):
+        for s in self._slots:
+            s.ws.close()
+
+    # ---- device side ---------------------------------------------------------------------------------------------
+    def _submit(self, slot, feats, meta):
+        n = feats["kmer1"].shape[0]
+        lib = self.dm._lib
+        b = _lib.Batch()
+        keep = []
+        for s, sfx in enumerate(("1", "2")):
+            arrs = [np.ascontiguousarray(feats["kmer" + sfx], np.uint8), np.ascontiguousarray(feats["ipd" + sfx], np.float32),
+                    np.ascontiguousarray(feats["pw" + sfx], np.float32), np.ascontiguousarray(feats["npass" + sfx], np.float32)]
+            keep += arrs
+            b.strand[s].kmer, b.strand[s].ipd, b.strand[s].pw, b.strand[s].npass = (a.ctypes.data for a in arrs)
+        b.kmer_is_f32, b.npass_per_base = 0, 0
+        h = _lib.H0()
+        h.mode, h.seed, h.offset = _lib.H0_DEVICE_RNG, self.seed, self._site_counter
+        self._site_counter += n
+        _lib.check(lib.ccsm_submit_host(self.dm.handle, slot.ws.handle, n, C.byref(b), C.byref(h), slot.stream))
+        slot.pending = (n, meta)
+
+    def _collect(self, slot, acc):
+        if slot.pending is None:
+            return
+        n, meta = slot.pending
+        slot.pending = None
+        logits = np.empty((n, 2), np.float32)
+        probs = np.empty((n, 2), np.float32)
+        _lib.check(self.dm._lib.ccsm_wait_host(slot.ws.handle, logits.ctypes.data, probs.ctypes.data))
+        p1 = prob1_norm_round6(probs)
+        pos = 0
+        for ridx, locs in meta:
+            k = len(locs)
+            acc[ridx].append((locs, p1[pos:pos + k]))
+            pos += k
+
+    # ---- host side ------------------------------------------------------------------------------------------------
+    def run(self, reads):
+        """reads: sequence of Read (e.g. one or many hole-batches).  Returns ([ReadCalls per read, input order], n_failed).
+        Sites are packed into device batches of `batch_size` regardless of read boundaries; batch i+1 is extracted and
+        staged while batch i runs (two workspaces, two streams)."""
+        reads = list(reads)
+        acc = [[] for _ in reads]
+        failed = 0
+        keys = ("kmer1", "ipd1", "pw1", "npass1", "kmer2", "ipd2", "pw2", "npass2")
+        cur = {k: [] for k in keys}
+        meta, nsites, turn = [], 0, 0
+
+        def flush():
+            nonlocal cur, meta, nsites, turn
+            if nsites == 0:
+                return
+            feats = {k: np.concatenate(v) for k, v in cur.items()}
+            slot = self._slots[turn & 1]
+            self._collect(slot, acc)                 # the batch submitted two turns ago on this slot
+            self._submit(slot, feats, meta)
+            turn += 1
+            cur = {k: [] for k in keys}
+            meta, nsites = [], 0
+
+        for ridx, read in enumerate(reads):
+            arr = extract_read_arrays(read.seq, read.fi, read.ri, read.fp, read.rp)
+            if arr is None or len(arr["loc"]) == 0:
+                failed += 1                            # reference counts reads without features as failed (:416-429)
+                continue
+            k = len(arr["loc"])
+            start = 0
+            while start < k:                          # a read may straddle device batches
+                take = min(k - start, self.batch_size - nsites)
+                sl = slice(start, start + take)
+                cur["kmer1"].append(arr["fkmer"][sl]); cur["ipd1"].append(arr["fipd"][sl]); cur["pw1"].append(arr["fpw"][sl])
+                cur["npass1"].append(np.full(take, read.fn, np.float32))
+                cur["kmer2"].append(arr["rkmer"][sl]); cur["ipd2"].append(arr["ripd"][sl]); cur["pw2"].append(arr["rpw"][sl])
+                cur["npass2"].append(np.full(take, read.rn, np.float32))
+                meta.append((ridx, arr["loc"][sl]))
+                nsites += take
+                start += take
+                if nsites == self.batch_size:
+                    flush()
+        flush()
+        for slot in (self._slots[turn & 1], self._slots[(turn + 1) & 1]):
+            self._collect(slot, acc)
+        out = []
+        for read, parts in zip(reads, acc):
+            if parts:
+                out.append(_tags_for_read(read, np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])))
+            else:
+                out.append(ReadCalls(read.name, 0, np.empty(0, np.int64), np.empty(0, np.float32), None, None, 0))
+        return out, failed
+
+
+def _tags_for_read(read, locs, probs):
+    """call_modifications.py:230-263: sort by loc, MM over the forward sequence, ML = floor(p*256); a failed assertion
+    leaves the read untagged (mm_flag 0)."""
+    order = np.argsort(locs, kind="stable")
+    locs, probs = locs[order], probs[order]
+    try:
+        mm = _convert_locs_to_mmtag(locs.tolist(), read.seq)     # read.seq is already the forward sequence
+        ml = _convert_probs_to_mltag(list(probs))
+        return ReadCalls(read.name, len(locs), locs, probs, mm, ml, 1)
+    except AssertionError:
+        return ReadCalls(read.name, len(locs), locs, probs, None, None, 0)

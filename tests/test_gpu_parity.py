@@ -301,3 +301,41 @@ def test_call_mods2s_pipeline_vs_reference_golden():
         assert mmod._convert_locs_to_mmtag(locs, reads[name]["seq"]) == exp["mm"]
         ml = mmod._convert_probs_to_mltag(probs)
         assert max(abs(a - b) for a, b in zip(ml, exp["ml"])) <= 1
+
+
+def test_read_pipeline_double_buffered(model7):
+    """reads -> features -> pinned double-buffered submit/wait -> MM/ML (ccsmeth_amd/pipeline.py): integer fields equal a
+    straight per-read computation; device RNG h0 makes the probabilities a pure function of (seed, running site index)."""
+    from ccsmeth_amd import _bam2modbam as mmod
+    from ccsmeth_amd import extract_features as ef
+    from ccsmeth_amd.pipeline import CallModsPipeline, Read
+    w, dm = model7
+    rng = np.random.default_rng(99)
+    reads = []
+    for i, length in enumerate([900, 40, 20, 3000, 1500, 25]):
+        seq = rng.choice(list("ACGT"), size=length)
+        for j in range(7, length - 1, 13):
+            seq[j], seq[j + 1] = "C", "G"
+        codes = lambda: np.clip(rng.gamma(2.0, 14.0, size=length), 0, 255).astype(np.uint8)  # noqa: E731
+        reads.append(Read("read%d" % i, "".join(seq), codes(), codes(), codes(), codes(), int(rng.integers(3, 31)),
+                          int(rng.integers(3, 31)), False))
+    reads.append(Read("short_kin", "ACGTACGTACGTACGTACGTACGTACGTACGT", np.zeros(5, np.uint8), np.zeros(32, np.uint8),
+                      np.zeros(32, np.uint8), np.zeros(32, np.uint8), 5, 5, False))
+    pipe = CallModsPipeline(dm, batch_size=128, seed=77)      # small batches: reads straddle device batches
+    calls, failed = pipe.run(reads)
+    calls2, _ = CallModsPipeline(dm, batch_size=128, seed=77).run(reads)
+    pipe.close()
+    assert len(calls) == len(reads)
+    n_expected_failed = 0
+    for read, c, c2 in zip(reads, calls, calls2):
+        arr = ef.extract_read_arrays(read.seq, read.fi, read.ri, read.fp, read.rp)
+        if arr is None or len(arr["loc"]) == 0:
+            n_expected_failed += 1
+            assert c.mm_flag == 0 and c.n_sites == 0
+            continue
+        assert np.array_equal(c.locs, arr["loc"]) and c.mm_flag == 1
+        assert c.mm == mmod._convert_locs_to_mmtag(arr["loc"].tolist(), read.seq)
+        assert len(c.ml) == c.n_sites and all(0 <= v <= 255 for v in c.ml)
+        assert np.all((c.probs >= 0) & (c.probs <= 1))
+        assert np.array_equal(c.probs, c2.probs)             # reproducible run to run
+    assert failed == n_expected_failed
