@@ -75,6 +75,7 @@ struct ccsm_workspace {
     uint4* act[2] = {nullptr, nullptr};
     float* h0buf = nullptr;
     float* part = nullptr;
+    unsigned long long* dbg = nullptr;   // phase timestamps of GRU layer 1, workgroup 0 (CCSM_PHASE_DEBUG=1)
     // device staging for the host-pointer path
     uint8_t* d_in = nullptr;   // features of both strands
     float* d_h0 = nullptr;     // explicit h0 (2 x 6 x max_sites x 256), allocated on first explicit use
@@ -240,13 +241,13 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     } else {
         const dim3 ggrid(2 * (tiles / kNBGru2));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0, NPASS>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
-                           m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p);
+                           m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p, nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12, NPASS>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
-                           m->wst2[1], m->bias[1], ws->h0buf + slab, ws->rows_p);
+                           m->wst2[1], m->bias[1], ws->h0buf + slab, ws->rows_p, ws->dbg);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12, NPASS>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
-                           m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p);
+                           m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, nullptr);
     }
     if (tm) HIP_TRY(hipEventRecord(ws->ev[4], st));
     SliceTable tab;
@@ -457,6 +458,7 @@ ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_works
     if (st == CCSM_OK) st = dmalloc((void**)&ws->act[1], act_b);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->h0buf, h0_b);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->part, part_b);
+    if (st == CCSM_OK && std::getenv("CCSM_PHASE_DEBUG")) st = dmalloc((void**)&ws->dbg, (kSeqLen * kWaves * 5 + 2 * kSeqLen * kWaves * 8 * 6) * 8);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->d_in, ws->in_bytes);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->d_out, out_b);
     if (st == CCSM_OK) {   // padding rows are computed (and ignored): give them finite contents once
@@ -488,7 +490,7 @@ void ccsm_workspace_destroy(ccsm_workspace* ws) {
     (void)hipSetDevice(ws->device);
     if (ws->pending_sites) (void)hipStreamSynchronize(ws->pending_stream);
     (void)hipFree(ws->x0); (void)hipFree(ws->act[0]); (void)hipFree(ws->act[1]);
-    (void)hipFree(ws->h0buf); (void)hipFree(ws->part); (void)hipFree(ws->d_in); (void)hipFree(ws->d_h0);
+    (void)hipFree(ws->h0buf); (void)hipFree(ws->part); (void)hipFree(ws->dbg); (void)hipFree(ws->d_in); (void)hipFree(ws->d_h0);
     (void)hipFree(ws->d_out);
     if (ws->p_in) (void)hipHostFree(ws->p_in);
     if (ws->p_h0) (void)hipHostFree(ws->p_h0);
@@ -671,6 +673,7 @@ ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_
         case 2: src = ws->act[1]; cap = tiles * kSeqLen * kKB12 * 2 * 1024; break;
         case 3: src = ws->h0buf; cap = (size_t)2 * kLayers * ws->rows_p * kHidden * sizeof(float); break;
         case 4: src = ws->part; cap = (size_t)ws->rows_p * 2 * sizeof(float); break;
+        case 5: src = ws->dbg; cap = ws->dbg ? (kSeqLen * kWaves * 5 + 2 * kSeqLen * kWaves * 8 * 6) * 8 : 0; break;
         default: return fail(CCSM_ERR_INVALID_ARG, "unknown buffer id");
     }
     if (bytes > cap) return fail(CCSM_ERR_CAPACITY, "debug read larger than the buffer");

@@ -407,7 +407,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const uint4* __restri
 template <int KX, int NPASS>
 __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                const uint4* __restrict__ wst, const float* __restrict__ bias,
-                                                               const float* __restrict__ h0, int rows_p) {
+                                                               const float* __restrict__ h0, int rows_p,
+                                                               unsigned long long* __restrict__ dbg) {
+    // dbg (normally NULL): workgroup 0 records s_memtime at the phase boundaries of every step, [step][wave][5]
     constexpr int NB = 3;
     constexpr int CK = KX >= 4 ? 4 : KX;       // k-blocks per staged chunk
     constexpr int NCH = KX / CK;               // chunks per pass over x_t
@@ -485,6 +487,14 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
 
     for (int s = 0; s < kSeqLen; ++s) {
         const int t = dir ? (kSeqLen - 1 - s) : s;
+        auto stamp = [&](int k) {
+            if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
+        };
+        auto fstamp = [&](int phase, int c, int k) {
+            if (dbg != nullptr && blockIdx.x == 0 && lane == 0)
+                dbg[kSeqLen * kWaves * 5 + ((((phase * kSeqLen + s) * kWaves + wave) * 8 + c) * 6 + k)] = __builtin_readcyclecounter();
+        };
+        stamp(0);
         const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;   // next step's timestep (last step: harmless reload)
         f32x16 acc[3][NB];                            // R, Z, N
         const float* bps = bp;
@@ -506,114 +516,123 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
 
         // Operand movers and one-k-block MFMA groups.  The schedule is explicit (compiler-level memory fences around every
         // MFMA group) because, left alone under this register pressure, hipcc sinks the weight loads next to their uses
-        // and the L2 latency (~700+ cycles) is exposed on every k-block.  Register plan per k-block:
-        //   weight fragments (hi and lo) : double-buffered, fetched from L2 one k-block ahead
-        //   x / h fragments  (hi and lo) : single buffer, read from LDS at the start of the k-block (short latency,
-        //                                  covered by the SIMD's other wave)
-        uint4 wq[2][3][2], xq[NB][2];
+        // and the L2 latency is exposed on every k-block.  Measured with s_memtime (tools/gpu_phases.py): a weight
+        // prefetch needs ~1700 cycles of MFMA cover (both waves of the SIMD) to be free, i.e. one k-block ahead in
+        // phase B (27 MFMAs per k-block) but two ahead in phase A (18) and four ahead in phase C (9).  Register plan:
+        //   phase A : accumulators R,Z (96)   + weight ring of 4 k-blocks (64)            + x (24) + staging (12)
+        //   phase B : accumulators R,Z,N (144) + weights double-buffered (48)              + h (24)
+        //   phase C : accumulators Z,N (96)   + weights of two whole chunks (2 x 32 = 64) + x (24) + staging (12)
+        // x / h fragments are read from LDS at the start of their k-block (short latency, covered by the other wave).
+        uint4 wa[4][2][2];        // phase A ring: [slot][gate r,z][hl]
+        uint4 wq[2][3][2];        // phase B double buffer: [buf][gate r,z,n][hl]
+        uint4 wc[2][4][2];        // phase C: [chunk parity][k-block in chunk][hl]   (KX == 1: wc[0][0] only)
+        uint4 xq[2][NB][2];       // x / h fragments; phases A and C read the next k-block's while the current one multiplies
         auto w_at = [&](int frag) -> uint4 { return wbase[frag * kFragU4 + lane]; };
-        auto ldw = [&](uint4 (&dst)[3][2], int base_frag, int gates) {   // fragment index = base + g*2 + hl
+        auto ldA = [&](uint4 (&dst)[2][2], int kb) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int hl = 0; hl < (NPASS >= 3 ? 2 : 1); ++hl) dst[g][hl] = w_at(kb * FA + g * 2 + hl);
+        };
+        auto ldB = [&](uint4 (&dst)[3][2], int kb) {
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int hl = 0; hl < 2; ++hl)
-                    if (g < gates && (hl == 0 || NPASS >= 3)) dst[g][hl] = w_at(base_frag + g * 2 + hl);
+                for (int hl = 0; hl < (NPASS >= 3 ? 2 : 1); ++hl) dst[g][hl] = w_at(OFF_B + kb * FB + g * 2 + hl);
         };
-        auto rdx = [&](int buf, int kbl) {
+        auto ldC = [&](uint4 (&dst)[4][2], int c) {     // the n-gate fragments of a whole chunk
+#pragma unroll
+            for (int j = 0; j < CK; ++j)
+#pragma unroll
+                for (int hl = 0; hl < (NPASS >= 3 ? 2 : 1); ++hl) dst[j][hl] = w_at(OFF_C + (c * CK + j) * FC + hl);
+        };
+        auto rdx = [&](uint4 (&x)[NB][2], int buf, int kbl) {
 #pragma unroll
             for (int hl = 0; hl < (NPASS >= 2 ? 2 : 1); ++hl)
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) xq[bt][hl] = *reinterpret_cast<const uint4*>(xfrag(buf, kbl, bt, hl) + lane * 16);
+                for (int bt = 0; bt < NB; ++bt) x[bt][hl] = *reinterpret_cast<const uint4*>(xfrag(buf, kbl, bt, hl) + lane * 16);
         };
-        auto rdh = [&](int kb) {
+        auto rdh = [&](uint4 (&x)[NB][2], int kb) {
 #pragma unroll
             for (int hl = 0; hl < (NPASS >= 2 ? 2 : 1); ++hl)
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) xq[bt][hl] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, hl) + lane * 16);
+                for (int bt = 0; bt < NB; ++bt) x[bt][hl] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, hl) + lane * 16);
         };
         // A compiler-level memory barrier: the operand loads issued before it may not sink below it (MFMAs are free to
         // move).  (__builtin_amdgcn_sched_barrier(0) here produced NaNs on ROCm 7.2 / gfx950 — do not use it.)
 #define CCSM_FENCE asm volatile("" ::: "memory")
-        // G gates into accumulator sets S0.. ; pass-major issue order (consecutive MFMAs hit different accumulators)
-        auto mm = [&](const uint4 (&w)[3][2], auto gates, auto set0) {
-            constexpr int G = decltype(gates)::value, S0 = decltype(set0)::value;
-            CCSM_FENCE;
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                for (int g = 0; g < G; ++g) acc[S0 + g][bt] = mfma16(w[g][0], xq[bt][0], acc[S0 + g][bt]);
-            if constexpr (NPASS >= 2) {
-#pragma unroll
-                for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                    for (int g = 0; g < G; ++g) acc[S0 + g][bt] = mfma16(w[g][0], xq[bt][1], acc[S0 + g][bt]);
-            }
-            if constexpr (NPASS >= 3) {
-#pragma unroll
-                for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                    for (int g = 0; g < G; ++g) acc[S0 + g][bt] = mfma16(w[g][1], xq[bt][0], acc[S0 + g][bt]);
-            }
-            CCSM_FENCE;
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        using I3 = std::integral_constant<int, 3>;
+        // one k-block: gate g of `w` (g < G) into accumulator set S0 + g; pass-major issue order
+#define CCSM_MM(W, X, G, S0)                                                                                        \
+    do {                                                                                                            \
+        CCSM_FENCE;                                                                                                 \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)             \
+            acc[S0 + g][bt] = mfma16(W[g][0], X[bt][0], acc[S0 + g][bt]);                                           \
+        if constexpr (NPASS >= 2) {                                                                                 \
+            _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)         \
+                acc[S0 + g][bt] = mfma16(W[g][0], X[bt][1], acc[S0 + g][bt]);                                       \
+        }                                                                                                           \
+        if constexpr (NPASS >= 3) {                                                                                 \
+            _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)         \
+                acc[S0 + g][bt] = mfma16(W[g][1], X[bt][0], acc[S0 + g][bt]);                                       \
+        }                                                                                                           \
+        CCSM_FENCE;                                                                                                 \
+    } while (0)
 
         // ---------------- phase A: R, Z += W_i{r,z} x_t  (fragment index of k-block kb: kb*FA + g*2 + hl) ----------
-        ldw(wq[0], 0, 2);
+        // Every register slot is (re)loaded unconditionally — clamped indices, redundant reloads at the ends — because a
+        // conditional load would keep the slot's old value live across the whole step loop and spill the accumulators.
+        ldA(wa[0], 0);
+        if constexpr (CK == 4) ldA(wa[1], 1);
+        if constexpr (CK == 4) {
 #pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            __syncthreads();                       // chunk c (buffer c&1) is in LDS; the other buffer is free
-            const int buf = (KX > 1) ? (c & 1) : (s & 1);
-            if constexpr (CK == 4) {
-#define CCSM_KA(J, CUR, NXT)                                                                       \
-    if (J < 3 || c + 1 < NCH) ldw(wq[NXT], (c * 4 + J + 1) * FA, 2);                                \
-    else ldw(wq[NXT], OFF_B, 3);                                                                   \
-    if (J == 0) stage_load(t, c + 1 < NCH ? c + 1 : 0);                                            \
-    rdx(buf, J);                                                                                   \
-    mm(wq[CUR], I2{}, I0{});
-                // (the staging loads go AFTER the weight prefetch of k-block 0: younger in the in-order vmcnt queue)
-                CCSM_KA(0, 0, 1)
-                CCSM_KA(1, 1, 0)
-                CCSM_KA(2, 0, 1)
-                CCSM_KA(3, 1, 0)
+            for (int c = 0; c < NCH; ++c) {
+                __syncthreads();                       // chunk c (buffer c&1) is in LDS; the other buffer is free
+                const int buf = c & 1;
+                const bool more = c + 1 < NCH;
+                fstamp(0, c, 0);
+                rdx(xq[0], buf, 0);
+#define CCSM_KA(J)                                                                                 \
+    ldA(wa[(J + 2) & 3], min(c * 4 + J + 2, KX - 1));   /* two k-blocks ahead */                   \
+    if (J == 0) stage_load(t, more ? c + 1 : 0); /* after the weight prefetch: younger in vmcnt */ \
+    if (J < 3) rdx(xq[(J + 1) & 1], buf, J + 1);        /* next k-block's x fragments */           \
+    CCSM_MM(wa[J], xq[J & 1], 2, 0);                                                              \
+    fstamp(0, c, J + 1);
+                CCSM_KA(0);
+                CCSM_KA(1);
+                CCSM_KA(2);
+                CCSM_KA(3);
 #undef CCSM_KA
                 stage_store((c + 1) & 1);              // next A chunk, or C chunk 0 into buffer NCH & 1 == 0
-            } else {
-                ldw(wq[1], OFF_B, 3);
-                stage_load(tn, 0);                     // KX == 1: the next step's only chunk
-                rdx(buf, 0);
-                mm(wq[0], I2{}, I0{});
-                stage_store((s + 1) & 1);
+                fstamp(0, c, 5);
             }
+            ldB(wq[0], 0);                             // first recurrent k-block
+        } else {
+            __syncthreads();
+            ldB(wq[0], 0);
+            stage_load(tn, 0);                         // KX == 1: the next step's only chunk
+            rdx(xq[0], s & 1, 0);
+            CCSM_MM(wa[0], xq[0], 2, 0);
+            stage_store((s + 1) & 1);
         }
 
+        stamp(1);
         // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------
-        // entering: the fragments of recurrent k-block 0 are in wq[0] (KX > 1) or wq[1] (KX == 1)
+        // entering: recurrent k-block 0 is in wq[0]
         {
             const f32x16 b3 = bias_set(3);
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
         }
-        constexpr int B0 = (CK == 4) ? 0 : 1;     // buffer parity of recurrent k-block 0
-        uint4 chi[4], clo[2];                     // phase-C weight rings (see below)
 #pragma unroll 1
         for (int kb = 0; kb < kKBH; kb += 2) {
-            ldw(wq[B0 ^ 1], OFF_B + (kb + 1) * FB, 3);
-            rdh(kb);
-            mm(wq[B0], I3{}, I0{});
-            if (kb + 2 < kKBH) {
-                ldw(wq[B0], OFF_B + (kb + 2) * FB, 3);
-            } else {   // first n-gate fragments of phase C
-                chi[0] = w_at(OFF_C + 0);
-                if (NPASS >= 3) clo[0] = w_at(OFF_C + 1);
-                if (KX > 1) chi[1] = w_at(OFF_C + FC);
-            }
-            rdh(kb + 1);
-            mm(wq[B0 ^ 1], I3{}, I0{});
+            ldB(wq[1], kb + 1);
+            rdh(xq[0], kb);
+            CCSM_MM(wq[0], xq[0], 3, 0);
+            ldB(wq[0], min(kb + 2, kKBH - 1));
+            rdh(xq[0], kb + 1);
+            CCSM_MM(wq[1], xq[0], 3, 0);
         }
+        ldC(wc[0], 0);                                 // n-gate weights of phase C's first chunk: covered by the VALU work below
         // r = sigmoid(R) ; N = b_in + r * N
         {
             const f32x16 b2 = bias_set(2);
@@ -623,36 +642,52 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
                 for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
         }
 
-        // ---------------- phase C: N += W_in x_t.  Only 9 MFMAs per k-block, so the n-gate weights run further ahead:
-        // hi fragments in a ring of 4 fetched two k-blocks ahead, lo fragments in a ring of 2 fetched one ahead.
-        auto mm_c = [&](const uint4& wh, const uint4& wl) {
-            const uint4 w1[3][2] = {{wh, wl}, {wh, wl}, {wh, wl}};
-            mm(w1, I1{}, I2{});
-        };
+        stamp(2);
+        // ---------------- phase C: N += W_in x_t.  Only 9 MFMAs per k-block: the n-gate weights of a whole chunk are
+        // fetched one chunk (four k-blocks) ahead.
+#define CCSM_MMC(WKB, X)                                                                                             \
+    do {                                                                                                            \
+        CCSM_FENCE;                                                                                                 \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(WKB[0], X[bt][0], acc[2][bt]);        \
+        if constexpr (NPASS >= 2) {                                                                                 \
+            _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(WKB[0], X[bt][1], acc[2][bt]);    \
+        }                                                                                                           \
+        if constexpr (NPASS >= 3) {                                                                                 \
+            _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(WKB[1], X[bt][0], acc[2][bt]);    \
+        }                                                                                                           \
+        CCSM_FENCE;                                                                                                 \
+    } while (0)
         if constexpr (CK == 4) {
 #pragma unroll 1
-            for (int c = 0; c < NCH; ++c) {
-                __syncthreads();
-                const int buf = c & 1;
-#define CCSM_KC(J)                                                                                 \
-    if (NPASS >= 3 && (J < 3 || c + 1 < NCH)) clo[(J + 1) & 1] = w_at(OFF_C + (c * 4 + J + 1) * FC + 1); \
-    if (J < 2 || c + 1 < NCH) chi[(J + 2) & 3] = w_at(OFF_C + (c * 4 + J + 2) * FC);               \
-    if (J == 0) stage_load(c + 1 < NCH ? t : tn, c + 1 < NCH ? c + 1 : 0);                         \
-    rdx(buf, J);                                                                                   \
-    mm_c(chi[J], clo[J & 1]);
-                CCSM_KC(0)
-                CCSM_KC(1)
-                CCSM_KC(2)
-                CCSM_KC(3)
-#undef CCSM_KC
-                stage_store((c + 1) & 1);     // next C chunk, or the next step's first A chunk into buffer 0
+            for (int c2 = 0; c2 < NCH; c2 += 2) {
+#define CCSM_CHUNK_C(C, CUR, NXT)                                                                  \
+    {                                                                                              \
+        __syncthreads();                                                                           \
+        const int buf = (C) & 1;                                                                   \
+        const bool more = (C) + 1 < NCH;                                                           \
+        ldC(wc[NXT], min((C) + 1, NCH - 1));             /* a whole chunk ahead */                \
+        fstamp(1, (C), 0);                                                                         \
+        stage_load(more ? t : tn, more ? (C) + 1 : 0); /* next C chunk / next step's first A chunk */ \
+        rdx(xq[0], buf, 0);                                                                        \
+        rdx(xq[1], buf, 1); CCSM_MMC(wc[CUR][0], xq[0]); fstamp(1, (C), 1);               \
+        rdx(xq[0], buf, 2); CCSM_MMC(wc[CUR][1], xq[1]); fstamp(1, (C), 2);               \
+        rdx(xq[1], buf, 3); CCSM_MMC(wc[CUR][2], xq[0]); fstamp(1, (C), 3);               \
+        CCSM_MMC(wc[CUR][3], xq[1]); fstamp(1, (C), 4);                                   \
+        stage_store(((C) + 1) & 1); fstamp(1, (C), 5);                                             \
+    }
+                CCSM_CHUNK_C(c2, 0, 1)
+                CCSM_CHUNK_C(c2 + 1, 1, 0)
+#undef CCSM_CHUNK_C
             }
         } else {
-            rdx(s & 1, 0);                        // x chunk of this step is still in its buffer
-            mm_c(chi[0], clo[0]);
+            rdx(xq[0], s & 1, 0);                 // x chunk of this step is still in its buffer
+            CCSM_MMC(wc[0][0], xq[0]);
         }
+#undef CCSM_MMC
+#undef CCSM_MM
 #undef CCSM_FENCE
 
+        stamp(3);
         // ---------------- h_{t-1} of this wave's own units (C layout), then the gate epilogue -------------------
         float hprev[NB][16];
 #pragma unroll
@@ -706,6 +741,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
                 o[kFragU4 + lane] = v[1];
             }
         }
+        stamp(4);
     }
 }
 

@@ -1,0 +1,40 @@
+"""Phase timeline of GRU layer 1 (workgroup 0, all 8 waves): s_memtime at step start / after phase A / B / C / epilogue."""
+import os, sys
+os.environ["CCSM_PHASE_DEBUG"] = "1"
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from ccsmeth_amd import _lib
+from ccsmeth_amd.models import DeviceModel
+from ccsmeth_amd.utils import synth
+n = int(os.environ.get("NSITES", "6144")); dev = torch.device("cuda:0")
+dm = DeviceModel(synth.synth_weights(7), 0, precision=int(os.environ.get("PREC", "3")))
+s = synth.synth_sites(n, 8); t = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+args = (t["kmer1"], t["ipd1"], t["pw1"], t["npass1"], t["kmer2"], t["ipd2"], t["pw2"], t["npass2"])
+ws = dm.workspace(n)
+for _ in range(3):
+    ws.forward_torch(*args)
+torch.cuda.synchronize()
+buf = np.empty(21 * 8 * 5 + 2 * 21 * 8 * 8 * 6, np.uint64)
+_lib.check(dm._lib.ccsm_debug_read(ws.handle, 5, buf.ctypes.data, buf.nbytes))
+d = buf[:21 * 8 * 5].reshape(21, 8, 5).astype(np.int64)
+f = buf[21 * 8 * 5:].reshape(2, 21, 8, 8, 6).astype(np.int64)
+ph = np.diff(d, axis=2)                       # [step][wave][A, B, C, epilogue]
+gap = d[1:, :, 0] - d[:-1, :, 4]
+print("cycles per phase (mean over steps 1..19, per wave):")
+print("  A   ", np.round(ph[1:20, :, 0].mean(0)))
+print("  B   ", np.round(ph[1:20, :, 1].mean(0)))
+print("  C   ", np.round(ph[1:20, :, 2].mean(0)))
+print("  epi ", np.round(ph[1:20, :, 3].mean(0)))
+print("  step", np.round((d[2:20, :, 0] - d[1:19, :, 0]).mean(0)))
+print("ideal MFMA cycles per wave: A 18432, B 13824, C 9216 (x2 waves per SIMD)")
+
+for ph, name in ((0, "A"), (1, "C")):
+    x = f[ph, 1:20]                                   # [step, wave, chunk, 6]
+    seg = np.diff(x, axis=3)                          # barrier->kb0 done, kb1, kb2, kb3, stage_store
+    wait = x[:, :, 1:, 0] - x[:, :, :-1, 5]           # end of chunk c -> after barrier of chunk c+1
+    print("phase %s per-chunk segments (mean cycles) wave0: kb0 %.0f kb1 %.0f kb2 %.0f kb3 %.0f store %.0f | barrier wait %.0f" %
+          ((name,) + tuple(seg[:, 0].mean((0, 1))) + (wait[:, 0].mean(),)))
+    print("phase %s per-chunk segments (mean cycles) wave4: kb0 %.0f kb1 %.0f kb2 %.0f kb3 %.0f store %.0f | barrier wait %.0f" %
+          ((name,) + tuple(seg[:, 4].mean((0, 1))) + (wait[:, 4].mean(),)))
