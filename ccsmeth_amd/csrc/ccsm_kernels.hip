@@ -35,6 +35,18 @@ __device__ __forceinline__ uint4 nt_load(const uint4* p) {
 __device__ __forceinline__ void nt_store(uint4 v, uint4* p) {
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
 }
+// Buffer-descriptor addressing: a wave-uniform base (4 SGPRs) + a wave-uniform byte offset (1 SGPR) + lane*16 (ONE VGPR
+// shared by every access) instead of a 64-bit per-lane pointer per stream.  In the GRU kernel this removes the address
+// VGPR pairs whose spills forced `s_waitcnt vmcnt(0)` (a full drain of the weight prefetch) in front of every reload.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store(uint4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
 __device__ __forceinline__ half8 as_half8(uint4 v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ half4 as_half4(uint2 v) { return __builtin_bit_cast(half4, v); }
 
@@ -456,22 +468,22 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
     // (three named registers rather than an array: the array form is demoted to scratch memory by hipcc)
     static_assert(SPW <= 3, "staging registers");
     uint4 sreg0, sreg1, sreg2;
-    auto stage_src = [&](int t, int c, int i) -> const uint4* {
+    const int lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xin);
+    auto stage_off = [&](int t, int c, int i) -> int {      // wave-uniform byte offset of the fragment this wave stages
         // branch-free: a wave with nothing left to move re-stages the last fragment (same bytes, same place)
         const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
         const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
-        // uniform fragment base (SGPRs) + lane: lets the compiler use the scalar-base addressing form
-        const uint4* fb = xin + ((((size_t)(tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) * kFragU4;
-        return fb + lane;
+        return (((((tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) << 10);
     };
     auto stage_dst = [&](int buf, int i) -> uint4* {
         const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
         return reinterpret_cast<uint4*>(s_x + ((buf * CHF + f) << 10) + lane * 16);
     };
     auto stage_load = [&](int t, int c) {
-        sreg0 = *stage_src(t, c, 0);
-        if constexpr (SPW > 1) sreg1 = *stage_src(t, c, 1);
-        if constexpr (SPW > 2) sreg2 = *stage_src(t, c, 2);
+        sreg0 = buf_load(xrs, lane16, stage_off(t, c, 0));
+        if constexpr (SPW > 1) sreg1 = buf_load(xrs, lane16, stage_off(t, c, 1));
+        if constexpr (SPW > 2) sreg2 = buf_load(xrs, lane16, stage_off(t, c, 2));
     };
     auto stage_store = [&](int buf) {
         *stage_dst(buf, 0) = sreg0;
@@ -479,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
         if constexpr (SPW > 2) *stage_dst(buf, 2) = sreg2;
     };
 
-    const uint4* wbase = wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4;   // wave-uniform
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4);   // wave-uniform
     const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
 
     stage_load(dir ? kSeqLen - 1 : 0, 0);
@@ -489,10 +501,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
         const int t = dir ? (kSeqLen - 1 - s) : s;
         auto stamp = [&](int k) {
             if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
-        };
-        auto fstamp = [&](int phase, int c, int k) {
-            if (dbg != nullptr && blockIdx.x == 0 && lane == 0)
-                dbg[kSeqLen * kWaves * 5 + ((((phase * kSeqLen + s) * kWaves + wave) * 8 + c) * 6 + k)] = __builtin_readcyclecounter();
         };
         stamp(0);
         const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;   // next step's timestep (last step: harmless reload)
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
         uint4 wq[2][3][2];        // phase B double buffer: [buf][gate r,z,n][hl]
         uint4 wc[2][4][2];        // phase C: [chunk parity][k-block in chunk][hl]   (KX == 1: wc[0][0] only)
         uint4 xq[2][NB][2];       // x / h fragments; phases A and C read the next k-block's while the current one multiplies
-        auto w_at = [&](int frag) -> uint4 { return wbase[frag * kFragU4 + lane]; };
+        auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, frag << 10); };
         auto ldA = [&](uint4 (&dst)[2][2], int kb) {
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -589,21 +597,18 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
                 __syncthreads();                       // chunk c (buffer c&1) is in LDS; the other buffer is free
                 const int buf = c & 1;
                 const bool more = c + 1 < NCH;
-                fstamp(0, c, 0);
                 rdx(xq[0], buf, 0);
 #define CCSM_KA(J)                                                                                 \
     ldA(wa[(J + 2) & 3], min(c * 4 + J + 2, KX - 1));   /* two k-blocks ahead */                   \
     if (J == 0) stage_load(t, more ? c + 1 : 0); /* after the weight prefetch: younger in vmcnt */ \
     if (J < 3) rdx(xq[(J + 1) & 1], buf, J + 1);        /* next k-block's x fragments */           \
-    CCSM_MM(wa[J], xq[J & 1], 2, 0);                                                              \
-    fstamp(0, c, J + 1);
+    CCSM_MM(wa[J], xq[J & 1], 2, 0);
                 CCSM_KA(0);
                 CCSM_KA(1);
                 CCSM_KA(2);
                 CCSM_KA(3);
 #undef CCSM_KA
                 stage_store((c + 1) & 1);              // next A chunk, or C chunk 0 into buffer NCH & 1 == 0
-                fstamp(0, c, 5);
             }
             ldB(wq[0], 0);                             // first recurrent k-block
         } else {
@@ -666,14 +671,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
         const int buf = (C) & 1;                                                                   \
         const bool more = (C) + 1 < NCH;                                                           \
         ldC(wc[NXT], min((C) + 1, NCH - 1));             /* a whole chunk ahead */                \
-        fstamp(1, (C), 0);                                                                         \
         stage_load(more ? t : tn, more ? (C) + 1 : 0); /* next C chunk / next step's first A chunk */ \
         rdx(xq[0], buf, 0);                                                                        \
-        rdx(xq[1], buf, 1); CCSM_MMC(wc[CUR][0], xq[0]); fstamp(1, (C), 1);               \
-        rdx(xq[0], buf, 2); CCSM_MMC(wc[CUR][1], xq[1]); fstamp(1, (C), 2);               \
-        rdx(xq[1], buf, 3); CCSM_MMC(wc[CUR][2], xq[0]); fstamp(1, (C), 3);               \
-        CCSM_MMC(wc[CUR][3], xq[1]); fstamp(1, (C), 4);                                   \
-        stage_store(((C) + 1) & 1); fstamp(1, (C), 5);                                             \
+        rdx(xq[1], buf, 1); CCSM_MMC(wc[CUR][0], xq[0]);               \
+        rdx(xq[0], buf, 2); CCSM_MMC(wc[CUR][1], xq[1]);               \
+        rdx(xq[1], buf, 3); CCSM_MMC(wc[CUR][2], xq[0]);               \
+        CCSM_MMC(wc[CUR][3], xq[1]);                                   \
+        stage_store(((C) + 1) & 1);                                             \
     }
                 CCSM_CHUNK_C(c2, 0, 1)
                 CCSM_CHUNK_C(c2 + 1, 1, 0)
@@ -736,6 +740,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
                 const int kb = 2 * wave + kbl;
                 *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) = v[0];
                 *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) = v[1];
+                // plain 64-bit-address stores: the raw_buffer_store_b128 form of these two stores corrupted a few output
+                // elements at random on ROCm 7.2 / gfx950 (data registers reused too early); loads are unaffected.
                 uint4* o = out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4;
                 o[lane] = v[0];
                 o[kFragU4 + lane] = v[1];

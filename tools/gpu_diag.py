@@ -68,6 +68,11 @@ def main():
     a = decode_act(read(ws, 1, tiles * 21 * 32 * 2 * 1024), tiles, 32)[:2 * n]
     b = decode_act(read(ws, 2, tiles * 21 * 32 * 2 * 1024), tiles, 32)[:2 * n]
     for name, got, ref in (("layer1 (act B)", b, outs[1]), ("layer2 (act A)", a, outs[2])):
+        nanmask = np.isnan(got)
+        if nanmask.any():
+            print(name, "NaN count", int(nanmask.sum()), "rows with NaN:", np.flatnonzero(nanmask.any(axis=(1, 2)))[:40],
+                  "t with NaN:", np.flatnonzero(nanmask.any(axis=(0, 2))), "k-blocks with NaN:",
+                  np.flatnonzero(nanmask.reshape(got.shape[0], 21, 32, 16).any(axis=(0, 1, 3))))
         e = np.abs(got - ref)
         print(name, "max err: %.3e  fwd-half %.3e  bwd-half %.3e  t0 %.3e  tL %.3e" %
               (e.max(), e[:, :, :256].max(), e[:, :, 256:].max(), e[:, 0].max(), e[:, -1].max()))

@@ -16,10 +16,9 @@ ws = dm.workspace(n)
 for _ in range(3):
     ws.forward_torch(*args)
 torch.cuda.synchronize()
-buf = np.empty(21 * 8 * 5 + 2 * 21 * 8 * 8 * 6, np.uint64)
+buf = np.empty(21 * 8 * 5, np.uint64)
 _lib.check(dm._lib.ccsm_debug_read(ws.handle, 5, buf.ctypes.data, buf.nbytes))
 d = buf[:21 * 8 * 5].reshape(21, 8, 5).astype(np.int64)
-f = buf[21 * 8 * 5:].reshape(2, 21, 8, 8, 6).astype(np.int64)
 ph = np.diff(d, axis=2)                       # [step][wave][A, B, C, epilogue]
 gap = d[1:, :, 0] - d[:-1, :, 4]
 print("cycles per phase (mean over steps 1..19, per wave):")
@@ -30,11 +29,3 @@ print("  epi ", np.round(ph[1:20, :, 3].mean(0)))
 print("  step", np.round((d[2:20, :, 0] - d[1:19, :, 0]).mean(0)))
 print("ideal MFMA cycles per wave: A 18432, B 13824, C 9216 (x2 waves per SIMD)")
 
-for ph, name in ((0, "A"), (1, "C")):
-    x = f[ph, 1:20]                                   # [step, wave, chunk, 6]
-    seg = np.diff(x, axis=3)                          # barrier->kb0 done, kb1, kb2, kb3, stage_store
-    wait = x[:, :, 1:, 0] - x[:, :, :-1, 5]           # end of chunk c -> after barrier of chunk c+1
-    print("phase %s per-chunk segments (mean cycles) wave0: kb0 %.0f kb1 %.0f kb2 %.0f kb3 %.0f store %.0f | barrier wait %.0f" %
-          ((name,) + tuple(seg[:, 0].mean((0, 1))) + (wait[:, 0].mean(),)))
-    print("phase %s per-chunk segments (mean cycles) wave4: kb0 %.0f kb1 %.0f kb2 %.0f kb3 %.0f store %.0f | barrier wait %.0f" %
-          ((name,) + tuple(seg[:, 4].mean((0, 1))) + (wait[:, 4].mean(),)))
