@@ -39,6 +39,12 @@ class H0(C.Structure):
     _fields_ = [("mode", C.c_int32), ("h0", C.c_void_p * 2), ("seed", C.c_uint64), ("offset", C.c_uint64)]
 
 
+class AggrWeights(C.Structure):
+    _fields_ = [("weight_ih", C.c_void_p * 2), ("weight_hh", C.c_void_p * 2), ("bias_ih", C.c_void_p * 2),
+                ("bias_hh", C.c_void_p * 2), ("att_wa", C.c_void_p), ("att_ua", C.c_void_p), ("att_va", C.c_void_p),
+                ("fc1_weight", C.c_void_p), ("fc1_bias", C.c_void_p)]
+
+
 class CcsmError(RuntimeError):
     def __init__(self, status, text):
         super().__init__("libccsm status %d: %s" % (status, text))
@@ -52,7 +58,8 @@ EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspa
            "ccsm_submit_host", "ccsm_wait_host", "ccsm_forward_device", "ccsm_last_error", "ccsm_version",
            "ccsm_model_precision", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
            "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded", "ccsm_debug_rows_capacity",
-           "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean")
+           "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean",
+           "ccsm_aggr_create", "ccsm_aggr_destroy", "ccsm_aggr_forward_host", "ccsm_aggr_forward_device")
 
 
 def load():
@@ -94,6 +101,11 @@ def load():
     lib.ccsm_group_run.argtypes = [vp, vp, vp]
     lib.ccsm_group_pending.argtypes = [vp]
     lib.ccsm_workspace_timing_mean.argtypes = [vp, _FP, C.POINTER(C.c_int)]
+    lib.ccsm_aggr_create.argtypes = [C.POINTER(AggrWeights), ci, C.c_uint64, C.c_int64, C.POINTER(vp)]
+    lib.ccsm_aggr_destroy.argtypes = [vp]
+    lib.ccsm_aggr_destroy.restype = None
+    lib.ccsm_aggr_forward_host.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, vp, vp]
+    lib.ccsm_aggr_forward_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, vp, vp]
     _lib = lib
     return lib
 

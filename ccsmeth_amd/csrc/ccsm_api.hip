@@ -10,6 +10,10 @@
 
 #include "../../include/ccsm.h"
 #include "ccsm_kernels.hip"
+#include "ccsm_aggr.hip"
+
+#include <cmath>
+#include <random>
 
 using namespace ccsm;
 
@@ -707,6 +711,135 @@ ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err) {
     float me = 0.f;
     for (int i = 0; i < 32 * 32; ++i) me = std::max(me, std::abs(c[i] - ref[i]));
     *max_abs_err = me;
+    return CCSM_OK;
+}
+
+}  // extern "C"
+
+
+// =========================================================================================================
+// Aggregate mode (config 5)
+// =========================================================================================================
+struct ccsm_aggr_model {
+    int device = 0;
+    float *w_ih = nullptr, *w_hh = nullptr, *b_ih = nullptr, *b_hh = nullptr, *wa_t = nullptr, *ua_t = nullptr, *va = nullptr,
+          *fcw = nullptr, *fcb = nullptr;
+    float* normals = nullptr;      // seeded torch.randn stream replica
+    int64_t n_normals = 0;
+    // staging for the host-pointer path
+    int64_t cap_sites = 0;
+    long long* d_pos = nullptr;
+    float *d_hist = nullptr, *d_out = nullptr;
+};
+
+namespace {
+// torch CPU randn after manual_seed(seed) + `skip` 32-bit draws: mt19937 -> 24-bit uniforms -> Box-Muller in blocks of 16
+// (ATen/native/cpu/DistributionTemplates.h:140-149, 208-229; ATen/core/TransformationHelper.h:85-88).
+void torch_randn_stream(uint64_t seed, int64_t skip, int64_t n, std::vector<float>& out) {
+    std::mt19937 gen(static_cast<uint32_t>(seed));       // init_genrand(seed & 0xffffffff)
+    gen.discard(static_cast<unsigned long long>(skip));
+    const int64_t blocks = (n + 15) / 16;
+    out.resize(static_cast<size_t>(blocks) * 16);
+    for (int64_t b = 0; b < blocks; ++b) {
+        float u[16];
+        for (int j = 0; j < 16; ++j) u[j] = static_cast<float>(gen() & ((1u << 24) - 1)) * (1.0f / 16777216.0f);
+        for (int j = 0; j < 8; ++j) {
+            const float u1 = 1.0f - u[j], u2 = u[j + 8];
+            const float radius = std::sqrt(-2.0f * std::log(u1));
+            const float theta = 6.283185307179586f * u2;
+            out[b * 16 + j] = radius * std::cos(theta);
+            out[b * 16 + j + 8] = radius * std::sin(theta);
+        }
+    }
+}
+}  // namespace
+
+extern "C" {
+
+ccsm_status ccsm_aggr_create(const ccsm_aggr_weights* w, int device, uint64_t seed, int64_t stream_sites, ccsm_aggr_model** out) {
+    if (!w || !out) return fail(CCSM_ERR_INVALID_ARG, "weights and out must be non-NULL");
+    *out = nullptr;
+    for (int d = 0; d < 2; ++d)
+        if (!w->weight_ih[d] || !w->weight_hh[d] || !w->bias_ih[d] || !w->bias_hh[d]) return fail(CCSM_ERR_INVALID_ARG, "NULL rnn tensor");
+    if (!w->att_wa || !w->att_ua || !w->att_va || !w->fc1_weight || !w->fc1_bias) return fail(CCSM_ERR_INVALID_ARG, "NULL tensor");
+    if (stream_sites <= 0 || stream_sites > (int64_t)1 << 27) return fail(CCSM_ERR_INVALID_ARG, "stream_sites must be in [1, 2^27]");
+    HIP_TRY(hipSetDevice(device));
+    ccsm_aggr_model* m = new (std::nothrow) ccsm_aggr_model();
+    if (!m) return fail(CCSM_ERR_NOMEM, "out of host memory");
+    m->device = device;
+    using namespace ccsm_aggr;
+    std::vector<float> buf;
+    ccsm_status st = CCSM_OK;
+    buf.resize(2 * 96 * F);
+    for (int d = 0; d < 2; ++d) std::memcpy(&buf[d * 96 * F], w->weight_ih[d], sizeof(float) * 96 * F);
+    st = upload(&m->w_ih, buf.data(), buf.size() * 4);
+    if (st == CCSM_OK) { buf.resize(2 * 96 * H); for (int d = 0; d < 2; ++d) std::memcpy(&buf[d * 96 * H], w->weight_hh[d], sizeof(float) * 96 * H); st = upload(&m->w_hh, buf.data(), buf.size() * 4); }
+    if (st == CCSM_OK) { buf.resize(2 * 96); for (int d = 0; d < 2; ++d) std::memcpy(&buf[d * 96], w->bias_ih[d], sizeof(float) * 96); st = upload(&m->b_ih, buf.data(), buf.size() * 4); }
+    if (st == CCSM_OK) { buf.resize(2 * 96); for (int d = 0; d < 2; ++d) std::memcpy(&buf[d * 96], w->bias_hh[d], sizeof(float) * 96); st = upload(&m->b_hh, buf.data(), buf.size() * 4); }
+    if (st == CCSM_OK) { buf.resize(64 * H); for (int k = 0; k < 64; ++k) for (int a = 0; a < H; ++a) buf[k * H + a] = w->att_wa[a * 64 + k]; st = upload(&m->wa_t, buf.data(), buf.size() * 4); }
+    if (st == CCSM_OK) { buf.resize(64 * H); for (int k = 0; k < 64; ++k) for (int a = 0; a < H; ++a) buf[k * H + a] = w->att_ua[a * 64 + k]; st = upload(&m->ua_t, buf.data(), buf.size() * 4); }
+    if (st == CCSM_OK) st = upload(&m->va, w->att_va, sizeof(float) * H);
+    if (st == CCSM_OK) st = upload(&m->fcw, w->fc1_weight, sizeof(float) * 64);
+    if (st == CCSM_OK) st = upload(&m->fcb, w->fc1_bias, sizeof(float));
+    if (st == CCSM_OK) {
+        // the reference seeds, THEN constructs AggrAttRNN (call_mods_freq_bam.py:313-322): its parameter initialisation
+        // consumes one 32-bit draw per parameter (14 753) before the first h0 is drawn
+        const int64_t n_params = 2 * (96 * F + 96 * H + 96 + 96) + 2 * (H * 64) + H + 64 + 1;
+        std::vector<float> nrm;
+        torch_randn_stream(seed, n_params, stream_sites * 64, nrm);
+        m->n_normals = (int64_t)nrm.size();
+        st = upload(&m->normals, nrm.data(), nrm.size() * sizeof(float));
+    }
+    if (st != CCSM_OK) { ccsm_aggr_destroy(m); return st; }
+    *out = m;
+    return CCSM_OK;
+}
+
+void ccsm_aggr_destroy(ccsm_aggr_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipFree(m->w_ih); (void)hipFree(m->w_hh); (void)hipFree(m->b_ih); (void)hipFree(m->b_hh);
+    (void)hipFree(m->wa_t); (void)hipFree(m->ua_t); (void)hipFree(m->va); (void)hipFree(m->fcw); (void)hipFree(m->fcb);
+    (void)hipFree(m->normals); (void)hipFree(m->d_pos); (void)hipFree(m->d_hist); (void)hipFree(m->d_out);
+    delete m;
+}
+
+ccsm_status ccsm_aggr_forward_device(ccsm_aggr_model* m, int64_t n_sites, const int64_t* refposes, const float* histos,
+                                     int64_t stream_pos, float* out, void* stream) {
+    if (!m || !refposes || !histos || !out) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");
+    if (n_sites <= 0 || n_sites > (int64_t)1 << 30) return fail(CCSM_ERR_INVALID_ARG, "n_sites out of range");
+    if (stream_pos < 0 || stream_pos + n_sites * 64 > m->n_normals)
+        return fail(CCSM_ERR_CAPACITY, "random stream exhausted: create the model with a larger stream_sites");
+    HIP_TRY(hipSetDevice(m->device));
+    ccsm_aggr::Weights w{m->w_ih, m->w_hh, m->b_ih, m->b_hh, m->wa_t, m->ua_t, m->va, m->fcw, m->fcb};
+    const int waves = (int)std::min<int64_t>(n_sites, 256 * 8 * 2);
+    const int grid = (waves + ccsm_aggr::WAVES - 1) / ccsm_aggr::WAVES;
+    hipLaunchKernelGGL(ccsm_aggr::aggr_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       reinterpret_cast<const long long*>(refposes), histos, m->normals, (long long)stream_pos, (int)n_sites, out);
+    HIP_TRY(hipGetLastError());
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_aggr_forward_host(ccsm_aggr_model* m, int64_t n_sites, const int64_t* refposes, const float* histos,
+                                   int64_t stream_pos, float* out, void* stream) {
+    if (!m || !refposes || !histos || !out) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");
+    if (n_sites <= 0) return fail(CCSM_ERR_INVALID_ARG, "n_sites must be > 0");
+    HIP_TRY(hipSetDevice(m->device));
+    if (n_sites > m->cap_sites) {
+        (void)hipFree(m->d_pos); (void)hipFree(m->d_hist); (void)hipFree(m->d_out);
+        m->d_pos = nullptr; m->d_hist = nullptr; m->d_out = nullptr; m->cap_sites = 0;
+        HIP_TRY(hipMalloc((void**)&m->d_pos, n_sites * sizeof(long long)));
+        HIP_TRY(hipMalloc((void**)&m->d_hist, n_sites * 20 * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&m->d_out, n_sites * sizeof(float)));
+        m->cap_sites = n_sites;
+    }
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(m->d_pos, refposes, n_sites * sizeof(long long), hipMemcpyHostToDevice, hs));
+    HIP_TRY(hipMemcpyAsync(m->d_hist, histos, n_sites * 20 * sizeof(float), hipMemcpyHostToDevice, hs));
+    ccsm_status st = ccsm_aggr_forward_device(m, n_sites, reinterpret_cast<const int64_t*>(m->d_pos), m->d_hist, stream_pos, m->d_out, stream);
+    if (st != CCSM_OK) return st;
+    HIP_TRY(hipMemcpyAsync(out, m->d_out, n_sites * sizeof(float), hipMemcpyDeviceToHost, hs));
+    HIP_TRY(hipStreamSynchronize(hs));
     return CCSM_OK;
 }
 

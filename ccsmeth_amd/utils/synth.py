@@ -92,3 +92,14 @@ def synth_h0(n, seed, num_layers=3, hidden=256):
     h1 = rng.standard_normal((2 * num_layers, n, hidden), dtype=np.float32)
     h2 = rng.standard_normal((2 * num_layers, n, hidden), dtype=np.float32)
     return h1, h2
+
+
+def synth_pileup(n_sites, seed, cov_lo=2, cov_hi=60):
+    """Synthetic CpG pile-up for the aggregate model: reference positions with gaps ~ U[2,400],
+    per-site coverage ~ U[cov_lo, cov_hi], per-read methylation probabilities ~ Beta(0.3, 0.3) quantised to ML bytes
+    (floor(p * 256), what a modbam carries).  Returns dict(pos int64 (n,), ml list of uint8 arrays)."""
+    rng = np.random.default_rng(seed)
+    pos = np.cumsum(rng.integers(2, 401, size=n_sites)).astype(np.int64) + 10000
+    cov = rng.integers(cov_lo, cov_hi + 1, size=n_sites)
+    ml = [np.minimum(np.floor(rng.beta(0.3, 0.3, size=c) * 256), 255).astype(np.uint8) for c in cov]
+    return dict(pos=pos, ml=ml)

@@ -168,6 +168,39 @@ int ccsm_debug_rows_capacity(const ccsm_workspace* ws);
 /* Runs one 32x32x16 MFMA tile with this library's fragment conventions against a host reference. */
 ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Aggregate mode (`ccsmeth call_freqb --call_mode aggregate`, BASELINE config 5).
+ * Replaces: AggrAttRNN(...) + load_state_dict (call_mods_freq_bam.py:316-342, models.py:625-694) and the model loop of
+ * _cal_modfreq_in_aggregate_mode (call_mods_freq_bam.py:295-304).  The 11-site windows are built on the device from the
+ * per-site histogram table (the reference materialises an (M,11,21) tensor on the host).
+ * h0: the reference re-seeds per region (torch.manual_seed(tseed), :313) and draws torch.randn(2, B, 32) per batch of
+ * 1024, so results ARE deterministic; the library carries a replica of that stream (mt19937 -> 24-bit uniforms ->
+ * Box-Muller in blocks of 16, after the 14 753 draws the reference's model construction consumes) for `stream_sites`
+ * site evaluations.  `stream_pos` = number of values consumed so far in the region (64 per site; the reference calls
+ * all -> hp1 -> hp2 on one stream, :394-414). */
+typedef struct {
+    const float* weight_ih[2];  /* rnn.weight_ih_l0[_reverse] (96, 21) */
+    const float* weight_hh[2];  /* rnn.weight_hh_l0[_reverse] (96, 32) */
+    const float* bias_ih[2];    /* (96) */
+    const float* bias_hh[2];    /* (96) */
+    const float* att_wa;        /* _att3.Wa.weight (32, 64) */
+    const float* att_ua;        /* _att3.Ua.weight (32, 64) */
+    const float* att_va;        /* _att3.va.weight (1, 32) */
+    const float* fc1_weight;    /* fc1.weight (1, 64) */
+    const float* fc1_bias;      /* fc1.bias (1) */
+} ccsm_aggr_weights;
+typedef struct ccsm_aggr_model ccsm_aggr_model;
+
+ccsm_status ccsm_aggr_create(const ccsm_aggr_weights* w, int device, uint64_t seed, int64_t stream_sites, ccsm_aggr_model** out);
+void ccsm_aggr_destroy(ccsm_aggr_model* m);
+/* refposes (M) int64 sorted positions, histos (M,20) fp32 normalised histograms (_get_normalized_histo), out (M) fp32 raw
+ * fc1 outputs (the caller applies round(clip(y,0,1),6), call_mods_freq_bam.py:302).  Host pointers, synchronous. */
+ccsm_status ccsm_aggr_forward_host(ccsm_aggr_model* m, int64_t n_sites, const int64_t* refposes, const float* histos,
+                                   int64_t stream_pos, float* out, void* stream);
+/* Same with device pointers, asynchronous on `stream`. */
+ccsm_status ccsm_aggr_forward_device(ccsm_aggr_model* m, int64_t n_sites, const int64_t* refposes, const float* histos,
+                                     int64_t stream_pos, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

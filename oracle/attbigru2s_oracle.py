@@ -222,3 +222,59 @@ def convert_locs_to_mmtag(locs, seq_fwd, base="C"):
 def convert_probs_to_mltag(probs):
     """_bam2modbam.py:206-208: floor(p*256), 255 if p >= 1."""
     return [math.floor(p * 256) if p < 1 else 255 for p in probs]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Aggregate model (SURVEY.md 8 a-11, BASELINE config 5): per-site methylation frequency from pile-up histograms.
+# ---------------------------------------------------------------------------------------------------------
+
+def cal_mod_prob(ml_value):
+    """call_mods_freq_bam.py:102-107: ML byte -> probability, round(ml/256 + 1e-6, 6), 0 for ml == 0."""
+    return round(ml_value / float(256) + 0.000001, 6) if ml_value > 0 else 0
+
+
+def normalized_histo(probs, cov_cf=4, binsize=20):
+    """call_mods_freq_bam.py:221-237: 20-bin histogram over [0,1], divided by its L2 norm, rounded to 6 dp."""
+    assert len(probs) >= cov_cf
+    hist = np.histogram(probs, bins=binsize, range=[0, 1])[0]
+    return np.round(hist / np.linalg.norm(hist), 6)
+
+
+def aggregate_windows(refposes, histos, seq_len=11):
+    """call_mods_freq_bam.py:270-284 (only_close False): zero-padded histogram windows (M,L,20) and |pos - centre|
+    offsets (M,L) with pad positions first-1000 / last+1000."""
+    refposes = np.asarray(refposes, dtype=np.int64)
+    histos = np.asarray(histos, dtype=np.float64)
+    m, pad = len(refposes), seq_len // 2
+    hp = np.zeros((m + 2 * pad, histos.shape[1]), dtype=np.float64)
+    hp[pad:pad + m] = histos
+    pp = np.concatenate([np.full(pad, refposes[0] - 1000), refposes, np.full(pad, refposes[-1] + 1000)])
+    idx = np.arange(m)[:, None] + np.arange(seq_len)[None, :]
+    return hp[idx], np.abs(pp[idx] - refposes[:, None])
+
+
+def aggr_attbigru_forward(weights, offsets, histos, h0, dtype=np.float64):
+    """AggrAttRNN.forward, models.py:673-694: x = cat(histos, offsets) (histogram first, offset last), 1-layer BiGRU(H=32),
+    attention with query = final states, fc1 (64 -> 1), no softmax.  h0 (2, M, 32)."""
+    w = {k: np.asarray(v, dtype=dtype) for k, v in weights.items()}
+    x = np.concatenate([np.asarray(histos, dtype), np.asarray(offsets, dtype)[..., None]], axis=2)
+    out, h_n = bigru(x, np.asarray(h0, dtype), w, 1)
+    q = np.concatenate([h_n[0], h_n[1]], axis=1)
+    ctx, _ = attention(q, out, w["_att3.Wa.weight"], w["_att3.Ua.weight"], w["_att3.va.weight"])
+    return ctx @ w["fc1.weight"].T + w["fc1.bias"]
+
+
+def cal_modfreq_in_aggregate_mode(refposes, histos, weights, h0_normals, stream_pos=0, seq_len=11, batch_size=1024):
+    """call_mods_freq_bam.py:265-305: batches of 1024, h0 = the next 64*B values of the seeded randn stream reshaped
+    (2,B,32), output round(clip(y,0,1),6) as float32.  Returns (probs float32 (M,), new stream position)."""
+    histos_mat, pos_mat = aggregate_windows(refposes, histos, seq_len)
+    probs = []
+    for s in range(0, len(histos_mat), batch_size):
+        b_h = histos_mat[s:s + batch_size].astype(np.float32)
+        b_p = pos_mat[s:s + batch_size].astype(np.float32)
+        n = len(b_h)
+        h0 = np.asarray(h0_normals[stream_pos:stream_pos + 64 * n], np.float32).reshape(2, n, 32)
+        stream_pos += 64 * n
+        y = aggr_attbigru_forward(weights, b_p, b_h, h0, dtype=np.float64).astype(np.float32)
+        probs.append(np.round(np.clip(y, 0, 1), 6)[:, 0])
+    return np.concatenate(probs).astype(np.float32), stream_pos

@@ -339,3 +339,37 @@ def test_read_pipeline_double_buffered(model7):
         assert np.all((c.probs >= 0) & (c.probs <= 1))
         assert np.array_equal(c.probs, c2.probs)             # reproducible run to run
     assert failed == n_expected_failed
+
+
+def test_aggregate_mode_vs_reference_golden():
+    """Config 5 kernel (attbigru_b11, the only real checkpoint): HIP path vs the reference's own outputs, including the
+    replicated per-region torch.randn stream (all -> hp1 call order), and vs the NumPy oracle."""
+    from ccsmeth_amd.call_mods_freq_bam import AggrModel, _cal_modfreq_in_aggregate_mode, _cal_mod_prob, _get_normalized_histo
+    g = np.load(os.path.join(GOLDEN, "aggr_golden.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "aggr_golden.json")))
+    w = dict(np.load(os.path.join(GOLDEN, "aggr_ckpt_weights.npz")))
+    model = AggrModel({"module." + k: v for k, v in w.items()}, device=0, tseed=meta["seed"], stream_sites=1 << 14)
+    pile = synth.synth_pileup(meta["n_pile"], meta["pileup_seed"])
+    pos, hist = [], []
+    for p, mls in zip(pile["pos"], pile["ml"]):
+        probs = [_cal_mod_prob(int(m)) for m in mls]
+        if len(probs) >= 4:
+            pos.append(int(p)); hist.append(_get_normalized_histo(probs))
+    model.new_region()
+    out_all = np.array(_cal_modfreq_in_aggregate_mode(pos, hist, model), np.float32)
+    a, b = meta["sub"]
+    out_hp1 = np.array(_cal_modfreq_in_aggregate_mode(pos[a:b], hist[a:b], model), np.float32)
+    assert np.abs(out_all - g["out_all"]).max() < 1e-4 and np.abs(out_hp1 - g["out_hp1"]).max() < 1e-4
+    assert np.mean(out_all == g["out_all"]) > 0.9            # 6-dp rounded: the bulk is bit-identical
+    # stream exhaustion is an error, not silent reuse
+    from ccsmeth_amd import _lib
+    model.stream_pos = (1 << 14) * 64 - 64
+    with pytest.raises(_lib.CcsmError) as e:
+        model.forward_raw(pos[:2], np.stack(hist[:2]))
+    assert e.value.status == _lib.ERR_CAPACITY
+    assert _cal_modfreq_in_aggregate_mode([], [], model) is None
+    # single site / tiny regions (all-padding windows)
+    model.new_region()
+    one = _cal_modfreq_in_aggregate_mode(pos[:1], hist[:1], model)
+    assert len(one) == 1 and 0.0 <= one[0] <= 1.0
+    model.close()
