@@ -30,6 +30,10 @@ FLOP_PER_SITE = 2.0 * (MAC_GRU0 + 2 * MAC_GRU12 + MAC_ATT + 2048)   # = 244.23e6
 BYTES_PER_SITE = 680.0
 PEAK_F16_MFMA = 2.5e15       # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
+# HBM/fabric bytes of ONE launch of the dominant kernel over 3 x 2048 sites, from rocprofv3 PMC passes on the same launch
+# shape (profiles/r01_c_pmc_coalesced.md: 2 x FETCH_SIZE + WRITE_SIZE, KiB, gfx950 read correction per MI355X_MICROARCH.md).
+# PMC counters cannot be read from inside this process; the figure is per-launch like `achieved` and scales with sites.
+TRAFFIC_BYTES_PER_SITE_GRU12 = (2 * 1241546 + 516096) * 1024 / 6144.0
 
 
 def parse():
@@ -181,7 +185,9 @@ def main():
             "prob_max_abs_err_vs_oracle": prob_err,
             "roofline": {"bound": "mfma", "kernel": "gru_layer_v2_kernel<KX=32> (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F16_MFMA, "traffic": None,
+                         "frac": achieved / PEAK_F16_MFMA,
+                         "traffic": TRAFFIC_BYTES_PER_SITE_GRU12 * sites_per_launch if passes == 3 else None,
+                         "traffic_source": "profiles/r01_c_pmc_coalesced.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                          "launch_ms": dom_ms, "mfma_passes_per_flop": passes,
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,
                          "note": "achieved = algorithmic flops of one launch (%d sites x 99.09 MFLOP) / its HIP-event "
