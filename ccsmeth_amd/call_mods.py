@@ -1,0 +1,128 @@
+"""`call_mods` driver: HiFi BAM with kinetics -> modbam, one GPU, no pysam.
+
+Mirrors reference call_modifications.py:474-613 (argument checks, `<output>.modbam.bam`, @PG line, "bad read => written
+untagged", end-of-run counters) with one process instead of the reference's reader/extract/call/writer process pool:
+bamio.BamReader -> hole-batches of `--holes_batch` reads -> pipeline.CallModsPipeline (features, pinned double-buffered
+forward, MM/ML) -> bamio.BamWriter.  Output order = input order (the reference's `--no_sort`)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import __version__
+from ._bam2modbam import _refill_tags
+from .bamio import BamReader, BamWriter, add_pg_line
+from .pipeline import CallModsPipeline, Read
+
+REF_VERSION = "0.5.0"     # VN the reference writes (ccsmeth/_version.py)
+
+
+def build_parser():
+    p = argparse.ArgumentParser("ccsmeth_amd call_mods", description="call 5mCpG from a HiFi BAM with kinetics (MI355X)")
+    p.add_argument("--input", "-i", required=True, help="input BAM (fi/ri/fp/rp/fn/rn tags)")
+    p.add_argument("--model_file", "-m", required=True, help=".ckpt (torch state_dict) of attbigru2s")
+    p.add_argument("--output", "-o", required=True, help="output prefix; writes <output>.modbam.bam")
+    p.add_argument("--model_type", default="attbigru2s")
+    p.add_argument("--seq_len", type=int, default=21)
+    p.add_argument("--layer_rnn", type=int, default=3)
+    p.add_argument("--hid_rnn", type=int, default=256)
+    p.add_argument("--class_num", type=int, default=2)
+    p.add_argument("--dropout_rate", type=float, default=0)
+    p.add_argument("--batch_size", "-b", type=int, default=512)
+    p.add_argument("--holes_batch", type=int, default=50)
+    p.add_argument("--tseed", type=int, default=1234)
+    p.add_argument("--keep_pulse", action="store_true", default=False)
+    p.add_argument("--device", type=int, default=0)
+    p.add_argument("--mode", default="denovo", choices=["denovo"])
+    p.add_argument("--norm", default="zscore", choices=["zscore"])
+    p.add_argument("--motifs", default="CG")
+    p.add_argument("--mod_loc", type=int, default=0)
+    return p
+
+
+def _load_state_dict(path):
+    import torch
+    sd = torch.load(path, map_location="cpu")
+    return sd
+
+
+def _read_of(rec):
+    def tag(name, default):
+        try:
+            return rec.get_tag(name)
+        except KeyError:
+            return default
+    fwd = rec.get_forward_sequence()
+    return Read(rec.query_name, fwd, np.asarray(tag("fi", [])), np.asarray(tag("ri", [])), np.asarray(tag("fp", [])),
+                np.asarray(tag("rp", [])), tag("fn", 0), tag("rn", 0), rec.is_reverse)
+
+
+def call_mods(args, log=sys.stderr):
+    t0 = time.time()
+    if not os.path.exists(args.model_file):
+        raise ValueError("--model_file is not set right!")            # call_modifications.py:484-485
+    if not os.path.exists(args.input):
+        raise ValueError("--input_file does not exist!")              # :486-488
+    if args.seq_len % 2 == 0:
+        raise ValueError("--seq_len must be odd")                      # :500-501
+    if args.motifs.upper() != "CG" or args.mod_loc != 0:
+        raise ValueError("this build implements --motifs CG --mod_loc 0")
+    from collections import OrderedDict
+    from .models import ModelAttRNN
+    model = ModelAttRNN(args.seq_len, args.layer_rnn, args.class_num, args.dropout_rate, args.hid_rnn, is_npass=True,
+                        model_type=args.model_type, device=args.device, seed=args.tseed, max_batch=args.batch_size)
+    para = _load_state_dict(args.model_file)
+    try:
+        model.load_state_dict(para)
+    except RuntimeError:                                               # DDP checkpoints: strip "module." (:350-358)
+        model.load_state_dict(OrderedDict((k[7:], v) for k, v in para.items()))
+    model.cuda(args.device).eval()
+    pipe = CallModsPipeline(model._dev, batch_size=args.batch_size, seed=args.tseed)
+    out_path = args.output + ".modbam.bam"                             # :494
+    cnt_w = cnt_mm = cnt_failed = 0
+    rm_pulse = not args.keep_pulse
+    with BamReader(args.input) as rd:
+        header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
+        with BamWriter(out_path, header, rd.references) as wr:
+            batch = []
+
+            def flush():
+                nonlocal cnt_w, cnt_mm, cnt_failed
+                if not batch:
+                    return
+                calls, failed = pipe.run([_read_of(r) for r in batch])
+                cnt_failed += failed
+                for rec, c in zip(batch, calls):
+                    old = [(t, v) for t, _, v in rec.tags]
+                    mm_vals = c.mm if c.mm_flag else None
+                    kept = {t for t, _ in _refill_tags(old, None, None, rm_pulse)}
+                    rec.tags = [tv for tv in rec.tags if tv[0] in kept]
+                    if mm_vals is not None:
+                        rec.tags.append(("MM", "Z", "C+m?," + ",".join(map(str, mm_vals)) + ";"))
+                        rec.tags.append(("ML", "BC", np.asarray(c.ml, np.uint8)))
+                    wr.write(rec)
+                    cnt_w += 1
+                    cnt_mm += c.mm_flag
+                batch.clear()
+
+            for rec in rd:
+                batch.append(rec)
+                if len(batch) == args.holes_batch:
+                    flush()
+            flush()
+    pipe.close()
+    print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
+    print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; ccsmeth_amd %s)" %
+          (time.time() - t0, cnt_failed, __version__), file=log)
+    return dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, output=out_path)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    return call_mods(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -373,3 +373,66 @@ def test_aggregate_mode_vs_reference_golden():
     one = _cal_modfreq_in_aggregate_mode(pos[:1], hist[:1], model)
     assert len(one) == 1 and 0.0 <= one[0] <= 1.0
     model.close()
+
+
+def test_call_mods_bam_to_modbam(tmp_path):
+    """`python -m ccsmeth_amd call_mods` end to end on a synthetic HiFi BAM: DDP-prefixed .ckpt, @PG line, MM/ML added,
+    pulse tags dropped, reads without usable kinetics written untagged, reverse-strand record handled."""
+    import torch
+    from collections import OrderedDict
+    from ccsmeth_amd import bamio
+    from ccsmeth_amd import extract_features as ef
+    from ccsmeth_amd import _bam2modbam as mmod
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    rng = np.random.default_rng(2024)
+    inp = str(tmp_path / "in.bam")
+    recs = []
+    with bamio.BamWriter(inp, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
+        for i, L in enumerate([800, 30, 2500, 1200, 15, 600]):
+            seq = rng.choice(list("ACGT"), size=L)
+            for j in range(9, L - 1, 17):
+                seq[j], seq[j + 1] = "C", "G"
+            seq = "".join(seq)
+            kin = lambda: rng.integers(0, 256, L).astype(np.uint8)  # noqa: E731
+            tags = [("fi", "BC", kin()), ("fp", "BC", kin()), ("ri", "BC", kin()), ("rp", "BC", kin()),
+                    ("fn", "C", int(rng.integers(3, 30))), ("rn", "C", int(rng.integers(3, 30))), ("np", "C", 12),
+                    ("MM", "Z", "C+m,1;"), ("ML", "BC", np.array([7], np.uint8))]
+            if i == 3:
+                tags[0] = ("fi", "BC", kin()[:10])          # broken kinetics -> read skipped, written untagged
+            flag = 16 if i == 5 else 4                       # one reverse-strand record
+            stored = bamio.BamRecord("q", flag=16, seq=seq).get_forward_sequence() if i == 5 else seq
+            r = bamio.BamRecord("hole%d" % i, flag=flag, ref_id=-1, seq=stored, tags=tags)
+            recs.append((r, seq))
+            w.write(r)
+    wts = synth.synth_weights(5)
+    ckpt = str(tmp_path / "m.ckpt")
+    torch.save(OrderedDict(("module." + k, torch.from_numpy(v)) for k, v in wts.items()), ckpt)
+    args = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "out"), "--batch_size", "256", "--holes_batch", "4"])
+    res = call_mods(args)
+    assert res["reads"] == 6 and res["output"].endswith("out.modbam.bam")
+    with bamio.BamReader(res["output"]) as rd:
+        assert "@PG\tID:ccsmeth\tPN:ccsmeth\tVN:0.5.0" in rd.header_text
+        out = list(rd)
+    assert [o.query_name for o in out] == ["hole%d" % i for i in range(6)]
+    tagged = 0
+    for (rin, fwd), o in zip(recs, out):
+        names = [t[0] for t in o.tags]
+        assert not ({"fi", "fp", "ri", "rp"} & set(names)) and names.count("MM") <= 1 and "np" in names
+        assert o.seq == rin.seq and o.flag == rin.flag
+        arr = None if len(rin.get_tag("fi")) != len(fwd) else ef.extract_read_arrays(fwd, rin.get_tag("fi"), rin.get_tag("ri"),
+                                                                                   rin.get_tag("fp"), rin.get_tag("rp"))
+        if arr is None or len(arr["loc"]) == 0:
+            assert "MM" not in names and "ML" not in names
+            continue
+        tagged += 1
+        exp_mm = mmod._convert_locs_to_mmtag(arr["loc"].tolist(), fwd)
+        assert o.get_tag("MM") == "C+m?," + ",".join(map(str, exp_mm)) + ";"
+        ml = o.get_tag("ML")
+        assert ml.dtype == np.uint8 and len(ml) == len(arr["loc"])
+    assert tagged == res["tagged"] and res["failed"] == 6 - tagged
+    # argument checks of the reference
+    bad = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "o2"), "--seq_len", "20"])
+    with pytest.raises(ValueError):
+        call_mods(bad)
+    with pytest.raises(ValueError):
+        call_mods(build_parser().parse_args(["-i", str(tmp_path / "nope.bam"), "-m", ckpt, "-o", "x"]))
