@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the coalesced groups alternate over (2 overlaps launch tails: +3 % value, but the overlapped\n"
+                         "launches then report inflated per-kernel durations; 1 keeps roofline.achieved = a solo launch)")
     ap.add_argument("--coalesce", type=int, default=3, help="batches run per launch of the heavy kernels (micro-batching)")
     ap.add_argument("--precision", type=int, default=3, choices=(1, 2, 3),
                     help="3 = split-fp16 x3 (default, fp32-class, meets the 1e-4 bar); 2/1 = faster, reported as such")
@@ -49,8 +51,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(weights, target_s):
-    """oracle/attbigru2s_oracle.c on the host cores, bounded sample of the same synthetic workload."""
+def cpu_baseline(weights, target_s, device_model):
+    """The one leg that touches oracle/: oracle/attbigru2s_oracle.c on the host cores over a bounded sample of the same
+    synthetic workload, plus (same leg, same probe inputs, h0 pinned) the max |delta prob| of the HIP path against it —
+    the "prob delta vs ref" half of BASELINE.json's metric."""
     from ccsmeth_amd.utils import synth
     from oracle import c_oracle
     threads = c_oracle.max_threads()
@@ -60,8 +64,13 @@ def cpu_baseline(weights, target_s):
     args = (s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2)
     c_oracle.forward(weights, *args)            # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
-    c_oracle.forward(weights, *args)
+    _, ref_probs = c_oracle.forward(weights, *args)
     rate = probe_n / (time.perf_counter() - t0)
+    ws = device_model.workspace(probe_n)
+    _, gpu_probs = ws.forward_host(s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"],
+                                   h0=(h1, h2))
+    ws.close()
+    prob_err = float(np.abs(gpu_probs - ref_probs).max())
     n = int(min(max(rate * target_s, probe_n), 65536))
     n = (n // (8 * threads)) * 8 * threads or probe_n
     s = synth.synth_sites(n, 779)
@@ -71,7 +80,8 @@ def cpu_baseline(weights, target_s):
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "sites/s", "cores": threads, "kind": "port",
             "sample": "%d synthetic sites (same generator as the GPU run), explicit h0, oracle/attbigru2s_oracle.c fp32 "
-                      "AVX2+OpenMP, %.1f s" % (n, dt)}
+                      "AVX2+OpenMP, %.1f s" % (n, dt),
+            "gpu_prob_max_abs_err": prob_err, "gpu_prob_err_sites": probe_n}
 
 
 def main():
@@ -127,22 +137,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- parity subset (first 64 sites of batch 0, explicit h0) against the C oracle: the metric's "prob delta"
-    prob_err = None
-    if rank == 0:
-        try:
-            from oracle import c_oracle
-            m = 64
-            h1, h2 = synth.synth_h0(m, 4242)
-            sub = {k: sites[k][:m] for k in sites}
-            _, gp = wss[0].forward_host(sub["kmer1"], sub["ipd1"], sub["pw1"], sub["npass1"], sub["kmer2"], sub["ipd2"],
-                                        sub["pw2"], sub["npass2"], h0=(h1, h2))
-            _, rp = c_oracle.forward(weights, sub["kmer1"], sub["ipd1"], sub["pw1"], sub["npass1"], sub["kmer2"],
-                                     sub["ipd2"], sub["pw2"], sub["npass2"], h1, h2)
-            prob_err = float(np.abs(gp - rp).max())
-        except ImportError:
-            prob_err = None
-
     for i in range(a.warmup):
         step(i, last=(i == a.warmup - 1))
     fence()
@@ -182,7 +176,6 @@ def main():
                                       2: "fp16 weights x split-fp16 activations (2 MFMA passes), fp32 accumulate",
                                       1: "fp16 operands (1 MFMA pass), fp32 accumulate"}[passes],
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
-            "prob_max_abs_err_vs_oracle": prob_err,
             "roofline": {"bound": "mfma", "kernel": "gru_layer_v2_kernel<KX=32> (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
@@ -201,7 +194,7 @@ def main():
         }
         if n_gpus == 1 and a.cpu_seconds > 0:
             try:
-                line["cpu_baseline"] = cpu_baseline(weights, a.cpu_seconds)
+                line["cpu_baseline"] = cpu_baseline(weights, a.cpu_seconds, dm)
             except ImportError as e:
                 line["cpu_baseline"] = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
         print(json.dumps(line), flush=True)
