@@ -39,6 +39,12 @@ class H0(C.Structure):
     _fields_ = [("mode", C.c_int32), ("h0", C.c_void_p * 2), ("seed", C.c_uint64), ("offset", C.c_uint64)]
 
 
+class Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("offset", C.c_void_p), ("length", C.c_void_p), ("seq", C.c_void_p),
+                ("fi", C.c_void_p), ("ri", C.c_void_p), ("fp", C.c_void_p), ("rp", C.c_void_p), ("fn", C.c_void_p),
+                ("rn", C.c_void_p)]
+
+
 class AggrWeights(C.Structure):
     _fields_ = [("weight_ih", C.c_void_p * 2), ("weight_hh", C.c_void_p * 2), ("bias_ih", C.c_void_p * 2),
                 ("bias_hh", C.c_void_p * 2), ("att_wa", C.c_void_p), ("att_ua", C.c_void_p), ("att_va", C.c_void_p),
@@ -59,6 +65,7 @@ EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspa
            "ccsm_model_precision", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
            "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded", "ccsm_debug_rows_capacity",
            "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean",
+           "ccsm_forward_reads_host",
            "ccsm_aggr_create", "ccsm_aggr_destroy", "ccsm_aggr_forward_host", "ccsm_aggr_forward_device")
 
 
@@ -100,6 +107,7 @@ def load():
     lib.ccsm_group_add_device.argtypes = [vp, vp, ci, C.POINTER(Batch), C.POINTER(H0), vp, vp, vp]
     lib.ccsm_group_run.argtypes = [vp, vp, vp]
     lib.ccsm_group_pending.argtypes = [vp]
+    lib.ccsm_forward_reads_host.argtypes = [vp, vp, C.POINTER(Reads), C.POINTER(H0), vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
     lib.ccsm_workspace_timing_mean.argtypes = [vp, _FP, C.POINTER(C.c_int)]
     lib.ccsm_aggr_create.argtypes = [C.POINTER(AggrWeights), ci, C.c_uint64, C.c_int64, C.POINTER(vp)]
     lib.ccsm_aggr_destroy.argtypes = [vp]

@@ -39,6 +39,8 @@ def build_parser():
     p.add_argument("--norm", default="zscore", choices=["zscore"])
     p.add_argument("--motifs", default="CG")
     p.add_argument("--mod_loc", type=int, default=0)
+    p.add_argument("--extract", default="device", choices=["device", "host"],
+                   help="where the 21-mer features are built: on the GPU from the raw read arrays (default) or NumPy on the host")
     return p
 
 
@@ -79,7 +81,7 @@ def call_mods(args, log=sys.stderr):
     except RuntimeError:                                               # DDP checkpoints: strip "module." (:350-358)
         model.load_state_dict(OrderedDict((k[7:], v) for k, v in para.items()))
     model.cuda(args.device).eval()
-    pipe = CallModsPipeline(model._dev, batch_size=args.batch_size, seed=args.tseed)
+    pipe = CallModsPipeline(model._dev, batch_size=args.batch_size, seed=args.tseed, extract=args.extract)
     out_path = args.output + ".modbam.bam"                             # :494
     cnt_w = cnt_mm = cnt_failed = 0
     rm_pulse = not args.keep_pulse

@@ -11,6 +11,7 @@
 #include "../../include/ccsm.h"
 #include "ccsm_kernels.hip"
 #include "ccsm_aggr.hip"
+#include "ccsm_extract.hip"
 
 #include <cmath>
 #include <random>
@@ -97,6 +98,12 @@ struct ccsm_workspace {
     int slice_n[kMaxSlices] = {};
     float* slice_logits[kMaxSlices] = {};
     float* slice_probs[kMaxSlices] = {};
+    // read-level path (ccsm_forward_reads_host): raw per-read byte arrays and per-read tables, grown on demand
+    uint8_t* r_bytes = nullptr;      // seq | fi | ri | fp | rp, each r_cap_bases long
+    size_t r_cap_bases = 0;
+    uint8_t* r_table = nullptr;      // offset i64 | stats f64 x8 | length i32 | fn | rn | nsites | first_site
+    int r_cap_reads = 0;
+    int* r_locs = nullptr;           // (max_sites)
     bool timing = false;
     static constexpr int kEvSets = 128;      // ring of event sets: one per run while timing is enabled
     hipEvent_t evs[kEvSets][8] = {};
@@ -496,6 +503,7 @@ void ccsm_workspace_destroy(ccsm_workspace* ws) {
     (void)hipFree(ws->x0); (void)hipFree(ws->act[0]); (void)hipFree(ws->act[1]);
     (void)hipFree(ws->h0buf); (void)hipFree(ws->part); (void)hipFree(ws->dbg); (void)hipFree(ws->d_in); (void)hipFree(ws->d_h0);
     (void)hipFree(ws->d_out);
+    (void)hipFree(ws->r_bytes); (void)hipFree(ws->r_table); (void)hipFree(ws->r_locs);
     if (ws->p_in) (void)hipHostFree(ws->p_in);
     if (ws->p_h0) (void)hipHostFree(ws->p_h0);
     if (ws->p_out) (void)hipHostFree(ws->p_out);
@@ -619,6 +627,120 @@ ccsm_status ccsm_forward_host(const ccsm_model* m, ccsm_workspace* ws, int n_sit
     ccsm_status st = ccsm_submit_host(m, ws, n_sites, b, h0, stream);
     if (st != CCSM_OK) return st;
     return ccsm_wait_host(ws, logits, probs);
+}
+
+// ---- read-level entry: raw CCS read arrays in, per-site calls out (feature extraction on the GPU) -----------------------
+ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, const ccsm_reads* rd, const ccsm_h0* h0,
+                                    int32_t* first_site, int32_t* locs, float* logits, float* probs, int32_t* n_sites_out,
+                                    void* stream) {
+    if (!m || !ws || !rd || !first_site || !locs || !logits || !probs || !n_sites_out)
+        return fail(CCSM_ERR_INVALID_ARG, "model, workspace, reads and every output must be non-NULL");
+    *n_sites_out = 0;
+    if (rd->n_reads <= 0) return fail(CCSM_ERR_INVALID_ARG, "n_reads must be > 0");
+    if (!rd->offset || !rd->length || !rd->seq || !rd->fi || !rd->ri || !rd->fp || !rd->rp || !rd->fn || !rd->rn)
+        return fail(CCSM_ERR_INVALID_ARG, "read arrays must be non-NULL");
+    if (ws->device != m->device) return fail(CCSM_ERR_INVALID_ARG, "workspace and model live on different devices");
+    if (ws->pending_sites || ws->n_slices) return fail(CCSM_ERR_INVALID_ARG, "workspace has work in flight");
+    if (h0 && (h0->mode < 0 || h0->mode > 2)) return fail(CCSM_ERR_INVALID_ARG, "unknown h0 mode");
+    const int nr = rd->n_reads;
+    size_t total = 0;
+    for (int r = 0; r < nr; ++r) {
+        if (rd->length[r] <= 0 || rd->offset[r] < 0) return fail(CCSM_ERR_INVALID_ARG, "read lengths must be > 0 and offsets >= 0");
+        total = std::max(total, (size_t)rd->offset[r] + (size_t)rd->length[r]);
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (total > ws->r_cap_bases) {
+        (void)hipFree(ws->r_bytes);
+        ws->r_bytes = nullptr;
+        ws->r_cap_bases = 0;
+        const size_t cap = ((total * 5 / 4 + 4095) / 4096) * 4096;
+        HIP_TRY(hipMalloc((void**)&ws->r_bytes, cap * 5));
+        ws->r_cap_bases = cap;
+    }
+    if (nr > ws->r_cap_reads) {
+        (void)hipFree(ws->r_table);
+        ws->r_table = nullptr;
+        ws->r_cap_reads = 0;
+        const int cap = ((nr * 5 / 4 + 63) / 64) * 64;
+        HIP_TRY(hipMalloc((void**)&ws->r_table, (size_t)cap * (8 + 64 + 4 * 5)));
+        ws->r_cap_reads = cap;
+    }
+    if (!ws->r_locs) HIP_TRY(hipMalloc((void**)&ws->r_locs, (size_t)ws->max_sites * sizeof(int)));
+    const size_t cb = ws->r_cap_bases;
+    uint8_t* d_arr[5];
+    const uint8_t* h_arr[5] = {rd->seq, rd->fi, rd->ri, rd->fp, rd->rp};
+    for (int a = 0; a < 5; ++a) {
+        d_arr[a] = ws->r_bytes + a * cb;
+        HIP_TRY(hipMemcpyAsync(d_arr[a], h_arr[a], total, hipMemcpyHostToDevice, hs));
+    }
+    const size_t cr = (size_t)ws->r_cap_reads;
+    long long* d_off = reinterpret_cast<long long*>(ws->r_table);
+    double* d_stats = reinterpret_cast<double*>(ws->r_table + cr * 8);
+    int* d_len = reinterpret_cast<int*>(ws->r_table + cr * 72);
+    float* d_fn = reinterpret_cast<float*>(ws->r_table + cr * 76);
+    float* d_rn = reinterpret_cast<float*>(ws->r_table + cr * 80);
+    int* d_ns = reinterpret_cast<int*>(ws->r_table + cr * 84);
+    int* d_first = reinterpret_cast<int*>(ws->r_table + cr * 88);
+    HIP_TRY(hipMemcpyAsync(d_off, rd->offset, (size_t)nr * 8, hipMemcpyHostToDevice, hs));
+    HIP_TRY(hipMemcpyAsync(d_len, rd->length, (size_t)nr * 4, hipMemcpyHostToDevice, hs));
+    HIP_TRY(hipMemcpyAsync(d_fn, rd->fn, (size_t)nr * 4, hipMemcpyHostToDevice, hs));
+    HIP_TRY(hipMemcpyAsync(d_rn, rd->rn, (size_t)nr * 4, hipMemcpyHostToDevice, hs));
+    ccsm_extract::ReadTable rt{d_off, d_len, d_fn, d_rn};
+    hipLaunchKernelGGL(ccsm_extract::extract_stats_kernel, dim3(nr), dim3(256), 0, hs, rt, d_arr[0], d_arr[1], d_arr[2], d_arr[3],
+                       d_arr[4], d_stats, d_ns);
+    HIP_TRY(hipGetLastError());
+    // the number of rows is data dependent: one round trip for the per-read site counts
+    HIP_TRY(hipMemcpyAsync(first_site + 1, d_ns, (size_t)nr * 4, hipMemcpyDeviceToHost, hs));
+    HIP_TRY(hipStreamSynchronize(hs));
+    first_site[0] = 0;
+    long long acc = 0;
+    for (int r = 0; r < nr; ++r) {
+        acc += first_site[r + 1];
+        if (acc > ws->max_sites) return fail(CCSM_ERR_CAPACITY, "reads hold more sites than the workspace's max_sites");
+        first_site[r + 1] = (int32_t)acc;
+    }
+    const int n_sites = (int)acc;
+    *n_sites_out = n_sites;
+    if (n_sites == 0) return CCSM_OK;
+    HIP_TRY(hipMemcpyAsync(d_first, first_site, (size_t)nr * 4, hipMemcpyHostToDevice, hs));
+    const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
+    const float *h0a = nullptr, *h0b = nullptr;
+    if (mode == CCSM_H0_EXPLICIT) {   // host tensors (6, n_sites, 256) per strand: parity/test path only
+        if (!h0->h0[0] || !h0->h0[1]) return fail(CCSM_ERR_INVALID_ARG, "explicit h0 needs both strand tensors");
+        const size_t cap = (size_t)2 * 2 * kLayers * ws->max_sites * kHidden * sizeof(float);
+        if (!ws->d_h0) {
+            HIP_TRY(hipMalloc((void**)&ws->d_h0, cap));
+            ws->bytes += cap;
+            HIP_TRY(hipHostMalloc((void**)&ws->p_h0, cap, hipHostMallocDefault));
+        }
+        const size_t hb = (size_t)2 * kLayers * n_sites * kHidden * sizeof(float);
+        std::memcpy(ws->p_h0, h0->h0[0], hb);
+        std::memcpy(reinterpret_cast<uint8_t*>(ws->p_h0) + hb, h0->h0[1], hb);
+        HIP_TRY(hipMemcpyAsync(ws->d_h0, ws->p_h0, 2 * hb, hipMemcpyHostToDevice, hs));
+        h0a = ws->d_h0;
+        h0b = ws->d_h0 + hb / sizeof(float);
+    }
+    const size_t total4 = (size_t)2 * kLayers * 2 * n_sites * (kHidden / 4);
+    hipLaunchKernelGGL(prep_h0_kernel, dim3((int)std::min<size_t>((total4 + 255) / 256, 4096)), dim3(256), 0, hs, ws->h0buf, h0a,
+                       h0b, n_sites, 0, ws->rows_p, mode, h0 ? h0->seed : 0, h0 ? h0->offset : 0);
+    hipLaunchKernelGGL(ccsm_extract::extract_pack_kernel, dim3(nr), dim3(256), 0, hs, rt, d_arr[0], d_arr[1], d_arr[2], d_arr[3],
+                       d_arr[4], d_stats, d_first, m->embed, ws->x0, ws->r_locs, n_sites, 0);
+    HIP_TRY(hipGetLastError());
+    ws->n_slices = 1;
+    ws->rows_used = 2 * n_sites;
+    ws->slice_row[0] = 0;
+    ws->slice_n[0] = n_sites;
+    ws->slice_logits[0] = ws->d_out;
+    ws->slice_probs[0] = ws->d_out + (size_t)n_sites * 2;
+    ccsm_status st = dispatch_run(m, ws, hs);
+    if (st != CCSM_OK) return st;
+    HIP_TRY(hipMemcpyAsync(ws->p_out, ws->d_out, (size_t)n_sites * 4 * sizeof(float), hipMemcpyDeviceToHost, hs));
+    HIP_TRY(hipMemcpyAsync(locs, ws->r_locs, (size_t)n_sites * sizeof(int), hipMemcpyDeviceToHost, hs));
+    HIP_TRY(hipStreamSynchronize(hs));
+    std::memcpy(logits, ws->p_out, (size_t)n_sites * 2 * sizeof(float));
+    std::memcpy(probs, ws->p_out + (size_t)n_sites * 2, (size_t)n_sites * 2 * sizeof(float));
+    return CCSM_OK;
 }
 
 ccsm_status ccsm_workspace_set_timing(ccsm_workspace* ws, int enable) {

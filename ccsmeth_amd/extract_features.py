@@ -32,6 +32,14 @@ def motif_locs_cg(seq_bytes):
     return np.flatnonzero((seq_bytes[:-1] == _ASCII_C) & (seq_bytes[1:] == _ASCII_G)) if len(seq_bytes) > 1 else np.empty(0, np.int64)
 
 
+def count_kept_sites(seq_bytes, seq_len=21):
+    """Number of CG sites of one read that pass the window test of extract_features.py:343-350."""
+    n, nb = len(seq_bytes), (seq_len - 1) // 2
+    locs = motif_locs_cg(np.asarray(seq_bytes))
+    rl = n - 1 - (locs + 1)
+    return int(np.count_nonzero((locs >= nb) & (locs < n - nb) & (rl >= nb) & (rl < n - nb)))
+
+
 def extract_read_arrays(seq, fi, ri, fp, rp, seq_len=21, no_decode=False, norm="zscore"):
     """One double-strand HiFi read -> per-site arrays (n_sites may be 0), or None when the kinetics arrays do not match
     the sequence length (extract_features.py:320-325 -> read skipped).

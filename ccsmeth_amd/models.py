@@ -146,6 +146,64 @@ class Workspace:
                                                      logits.ctypes.data, probs.ctypes.data, stream))
         return logits, probs
 
+    def forward_reads(self, reads, h0=None, seed=0, offset=0, stream=None):
+        """Read-level call (ccsm_forward_reads_host): feature extraction and the model on the GPU.
+
+        reads: list of (seq str|bytes, fi, ri, fp, rp uint8 arrays of len(seq), fn, rn).  Returns (first_site int32
+        (n_reads+1), locs int32 (n_sites), logits, probs float32 (n_sites, 2))."""
+        nr = len(reads)
+        lens = np.array([len(r[0]) for r in reads], np.int32)
+        offs = np.zeros(nr, np.int64)
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.int64)
+        cat = []
+        for k in range(5):
+            parts = []
+            for r in reads:
+                a = r[k]
+                if k == 0:
+                    a = np.frombuffer(a.encode("ascii") if isinstance(a, str) else bytes(a), np.uint8)
+                else:
+                    a = np.asarray(a)
+                    if a.shape != (len(r[0]),):
+                        raise ValueError("kinetics arrays must match the sequence length")
+                    a = a.astype(np.uint8, copy=False)
+                parts.append(a)
+            cat.append(np.ascontiguousarray(np.concatenate(parts)))
+        fn = np.array([r[5] for r in reads], np.float32)
+        rn = np.array([r[6] for r in reads], np.float32)
+        rd = _lib.Reads()
+        rd.n_reads = nr
+        rd.offset, rd.length = offs.ctypes.data, lens.ctypes.data
+        rd.seq, rd.fi, rd.ri, rd.fp, rd.rp = (a.ctypes.data for a in cat)
+        rd.fn, rd.rn = fn.ctypes.data, rn.ctypes.data
+        h = _lib.H0()
+        keep = []
+        if h0 is None:
+            h.mode = _lib.H0_DEVICE_RNG
+        elif isinstance(h0, str) and h0 == "zero":
+            h.mode = _lib.H0_ZERO
+        else:
+            from .extract_features import count_kept_sites
+            n_exp = sum(count_kept_sites(cat[0][o:o + l]) for o, l in zip(offs, lens))
+            h.mode = _lib.H0_EXPLICIT
+            for s in range(2):
+                t = _f32c(h0[s])
+                if t.shape != (2 * _lib.LAYERS, n_exp, _lib.HIDDEN):
+                    raise ValueError("h0 tensors must have shape (6, n_sites=%d, 256)" % n_exp)
+                keep.append(t)
+                h.h0[s] = t.ctypes.data
+        h.seed, h.offset = int(seed), int(offset)
+        first = np.zeros(nr + 1, np.int32)
+        locs = np.empty(self.max_sites, np.int32)
+        logits = np.empty((self.max_sites, 2), np.float32)
+        probs = np.empty((self.max_sites, 2), np.float32)
+        n = C.c_int32(0)
+        _lib.check(self.model._lib.ccsm_forward_reads_host(self.model.handle, self.handle, C.byref(rd), C.byref(h),
+                                                           first.ctypes.data, locs.ctypes.data, logits.ctypes.data,
+                                                           probs.ctypes.data, C.byref(n), stream))
+        n = n.value
+        return first, locs[:n].copy(), logits[:n].copy(), probs[:n].copy()
+
     def forward_torch(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None,
                       out=None):
         """torch CUDA tensors in / out, asynchronous on `stream` (default: torch's current stream)."""

@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 from ._bam2modbam import _convert_locs_to_mmtag, _convert_probs_to_mltag
 from .call_modifications import prob1_norm_round6
-from .extract_features import extract_read_arrays
+from .extract_features import count_kept_sites, extract_read_arrays
 
 Read = namedtuple("Read", "name seq fi ri fp rp fn rn is_reverse")
 ReadCalls = namedtuple("ReadCalls", "name n_sites locs probs mm ml mm_flag")
@@ -30,11 +30,17 @@ class _Slot:
 
 
 class CallModsPipeline:
-    def __init__(self, device_model, batch_size=2048, seed=1234):
+    def __init__(self, device_model, batch_size=2048, seed=1234, extract="host"):
+        """extract="host": NumPy feature extraction + feature-level C-ABI (ccsm_submit_host / ccsm_wait_host);
+        extract="device": raw read arrays go to the GPU, ccsm_forward_reads_host extracts there (include/ccsm.h)."""
         import torch
+        if extract not in ("host", "device"):
+            raise ValueError("extract must be 'host' or 'device'")
         self.dm = device_model
         self.batch_size = int(batch_size)
         self.seed = seed
+        self.extract = extract
+        self._rws = None
         dev = torch.device("cuda", device_model.device)
         self._streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
         self._slots = [_Slot(device_model, self.batch_size, s.cuda_stream) for s in self._streams]
@@ -43,6 +49,51 @@ class CallModsPipeline:
     def close(self):
         for s in self._slots:
             s.ws.close()
+        if self._rws is not None:
+            self._rws.close()
+
+    # ---- device-side extraction -----------------------------------------------------------------------------------
+    def _run_device(self, reads):
+        """Chunks of whole reads holding <= batch_size sites (one larger read alone if it exceeds that) go through
+        ccsm_forward_reads_host.  The Philox h0 counter is the running site index, as in the host path, so both paths give
+        the same probabilities for the same seed."""
+        out = [None] * len(reads)
+        failed = 0
+        cnts = []
+        for r in reads:
+            ok = all(len(a) == len(r.seq) for a in (r.fi, r.ri, r.fp, r.rp))          # extract_features.py:320-325
+            cnts.append(count_kept_sites(np.frombuffer(r.seq.encode("ascii"), np.uint8)) if ok else 0)
+        chunk, csites = [], 0
+
+        def flush():
+            nonlocal chunk, csites
+            if not chunk:
+                return
+            if self._rws is None or self._rws.max_sites < csites:
+                if self._rws is not None:
+                    self._rws.close()
+                self._rws = self.dm.workspace(max(csites, self.batch_size))
+            rd = [(reads[i].seq, reads[i].fi, reads[i].ri, reads[i].fp, reads[i].rp, reads[i].fn, reads[i].rn) for i in chunk]
+            first, locs, _, probs = self._rws.forward_reads(rd, seed=self.seed, offset=self._site_counter,
+                                                           stream=self._slots[0].stream)
+            self._site_counter += len(locs)
+            p1 = prob1_norm_round6(probs)
+            for j, i in enumerate(chunk):
+                a, b = int(first[j]), int(first[j + 1])
+                out[i] = _tags_for_read(reads[i], locs[a:b].astype(np.int64), p1[a:b])
+            chunk, csites = [], 0
+
+        for i, (r, c) in enumerate(zip(reads, cnts)):
+            if c == 0:
+                failed += 1
+                out[i] = ReadCalls(r.name, 0, np.empty(0, np.int64), np.empty(0, np.float32), None, None, 0)
+                continue
+            if csites + c > self.batch_size:
+                flush()
+            chunk.append(i)
+            csites += c
+        flush()
+        return out, failed
 
     # ---- device side ---------------------------------------------------------------------------------------------
     def _submit(self, slot, feats, meta):
@@ -83,6 +134,8 @@ class CallModsPipeline:
         Sites are packed into device batches of `batch_size` regardless of read boundaries; batch i+1 is extracted and
         staged while batch i runs (two workspaces, two streams)."""
         reads = list(reads)
+        if self.extract == "device":
+            return self._run_device(reads)
         acc = [[] for _ in reads]
         failed = 0
         keys = ("kmer1", "ipd1", "pw1", "npass1", "kmer2", "ipd2", "pw2", "npass2")

@@ -144,6 +144,34 @@ ccsm_status ccsm_group_add_device(const ccsm_model* m, ccsm_workspace* ws, int n
 ccsm_status ccsm_group_run(const ccsm_model* m, ccsm_workspace* ws, void* stream);
 int ccsm_group_pending(const ccsm_workspace* ws);
 
+/* Read-level entry (SURVEY.md 8 a-2/a-3 + the model): replaces, for a chunk of CCS reads, the host work of
+ * extract_features.py:297-405 (CodecV1 decode, per-read float64 z-score rounded to 6 decimals, CG scan, forward and
+ * reverse-complement 21-mer windows), the batching of call_modifications.py:95-142 and the forward of :201-211.
+ * All arrays are HOST pointers; the per-base arrays are the reads' values concatenated, read r occupying
+ * [offset[r], offset[r] + length[r]).  seq = the read's forward sequence, upper-case ASCII (fwd_seq, extract_features.py:288-289);
+ * fi/ri/fp/rp = the tags' raw CodecV1 bytes exactly as stored (the reference does not flip ri/rp, :314-319; --no_decode is
+ * not offered); fn/rn = subread passes.  Reads whose tag lengths differ from the sequence length are the caller's to skip
+ * (:320-325). */
+typedef struct ccsm_reads {
+    int32_t n_reads;
+    const int64_t* offset;   /* (n_reads) */
+    const int32_t* length;   /* (n_reads) */
+    const uint8_t* seq;
+    const uint8_t* fi;
+    const uint8_t* ri;
+    const uint8_t* fp;
+    const uint8_t* rp;
+    const float* fn;         /* (n_reads) */
+    const float* rn;         /* (n_reads) */
+} ccsm_reads;
+/* Outputs (host): first_site (n_reads + 1) prefix of kept CG sites per read; locs (capacity max_sites) position of
+ * each site's C in its read, in read order then ascending; logits / probs (capacity max_sites x 2); *n_sites.
+ * h0 explicit tensors, if given, are HOST (6, n_sites, 256) per strand.  CCSM_ERR_CAPACITY when the reads hold more
+ * than the workspace's max_sites sites (nothing is computed; *n_sites is not set).  Blocks until done. */
+ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, const ccsm_reads* reads, const ccsm_h0* h0,
+                                    int32_t* first_site, int32_t* locs, float* logits, float* probs, int32_t* n_sites,
+                                    void* stream);
+
 /* Diagnostics */
 const char* ccsm_last_error(void);
 const char* ccsm_version(void);

@@ -339,6 +339,15 @@ def test_read_pipeline_double_buffered(model7):
         assert np.all((c.probs >= 0) & (c.probs <= 1))
         assert np.array_equal(c.probs, c2.probs)             # reproducible run to run
     assert failed == n_expected_failed
+    # GPU-side extraction: same sites, same Philox counters -> same calls
+    pipe_d = CallModsPipeline(dm, batch_size=128, seed=77, extract="device")
+    calls_d, failed_d = pipe_d.run(reads)
+    pipe_d.close()
+    assert failed_d == failed
+    for c, cd in zip(calls, calls_d):
+        assert c.mm_flag == cd.mm_flag and c.mm == cd.mm and np.array_equal(c.locs, cd.locs)
+        if c.n_sites:
+            assert np.abs(c.probs - cd.probs).max() < 2e-6
 
 
 def test_aggregate_mode_vs_reference_golden():
@@ -430,9 +439,123 @@ def test_call_mods_bam_to_modbam(tmp_path):
         ml = o.get_tag("ML")
         assert ml.dtype == np.uint8 and len(ml) == len(arr["loc"])
     assert tagged == res["tagged"] and res["failed"] == 6 - tagged
+    # default is GPU-side extraction; the host-extraction path must write the same records (ML within one bucket)
+    res_h = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "outh"), "--batch_size", "256",
+                                                 "--holes_batch", "4", "--extract", "host"]))
+    assert res_h["tagged"] == res["tagged"]
+    with bamio.BamReader(res_h["output"]) as rd:
+        for o, oh in zip(out, rd):
+            assert [t[0] for t in o.tags] == [t[0] for t in oh.tags]
+            if "MM" in [t[0] for t in o.tags]:
+                assert o.get_tag("MM") == oh.get_tag("MM")
+                assert np.abs(o.get_tag("ML").astype(int) - oh.get_tag("ML").astype(int)).max() <= 1
     # argument checks of the reference
     bad = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "o2"), "--seq_len", "20"])
     with pytest.raises(ValueError):
         call_mods(bad)
     with pytest.raises(ValueError):
         call_mods(build_parser().parse_args(["-i", str(tmp_path / "nope.bam"), "-m", ckpt, "-o", "x"]))
+
+
+def _x0_bytes(dm, ws):
+    from ccsmeth_amd import _lib
+    cap = dm._lib.ccsm_debug_rows_capacity(ws.handle)
+    buf = np.empty((cap // 32) * 21 * 2 * 1024, np.uint8)
+    _lib.check(dm._lib.ccsm_debug_read(ws.handle, 0, buf.ctypes.data, buf.nbytes))
+    return buf
+
+
+def _mirror_batch(reads):
+    """Host-mirror features of a list of reads, concatenated in read order (what _batch_feature_list2s would hand over)."""
+    from ccsmeth_amd import extract_features as ef
+    parts, counts = [], []
+    for r in reads:
+        arr = ef.extract_read_arrays(r[0], r[1], r[2], r[3], r[4])
+        counts.append(len(arr["loc"]))
+        if counts[-1]:
+            parts.append((arr, r[5], r[6]))
+    cat = lambda key: np.concatenate([a[key] for a, _, _ in parts])  # noqa: E731
+    s = dict(kmer1=cat("fkmer"), ipd1=cat("fipd").astype(np.float32), pw1=cat("fpw").astype(np.float32),
+             kmer2=cat("rkmer"), ipd2=cat("ripd").astype(np.float32), pw2=cat("rpw").astype(np.float32),
+             npass1=np.concatenate([np.full(len(a["loc"]), fn, np.float32) for a, fn, _ in parts]),
+             npass2=np.concatenate([np.full(len(a["loc"]), rn, np.float32) for a, _, rn in parts]))
+    return s, np.concatenate([a["loc"] for a, _, _ in parts]), np.array(counts)
+
+
+def test_read_level_extraction_vs_reference_golden(model7):
+    """ccsm_forward_reads_host: raw read arrays in, GPU extraction + model.  The layer-0 fragments it builds must be
+    byte-identical to those packed from the REFERENCE's own extracted features (tests/golden/pipeline_golden.*), the site
+    lists equal, and the probabilities therefore equal to the feature-level call's."""
+    from ccsmeth_amd.utils.process_utils import seq_to_codes
+    w, dm = model7
+    pipe = np.load(os.path.join(GOLDEN, "pipeline_golden.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "pipeline_golden.json")))
+    reads, exp_loc, exp_cnt, feats = [], [], [], {k: [] for k in ("kmer1", "ipd1", "pw1", "npass1", "kmer2", "ipd2", "pw2", "npass2")}
+    for r in meta["reads"]:
+        nm = r["name"]
+        reads.append((r["seq"], pipe[nm + "_fi"], pipe[nm + "_ri"], pipe[nm + "_fp"], pipe[nm + "_rp"], r["fn"], r["rn"]))
+        exp_cnt.append(r["n_sites"])
+        if r["n_sites"] == 0:
+            continue
+        exp_loc.append(pipe[nm + "_loc"])
+        feats["kmer1"].append(seq_to_codes(pipe[nm + "_fkmer"])); feats["kmer2"].append(seq_to_codes(pipe[nm + "_rkmer"]))
+        feats["ipd1"].append(pipe[nm + "_fipd"]); feats["pw1"].append(pipe[nm + "_fpw"])
+        feats["ipd2"].append(pipe[nm + "_ripd"]); feats["pw2"].append(pipe[nm + "_rpw"])
+        feats["npass1"].append(np.full(r["n_sites"], r["fn"])); feats["npass2"].append(np.full(r["n_sites"], r["rn"]))
+    s = {k: np.concatenate(v).astype(np.uint8 if k.startswith("kmer") else np.float32) for k, v in feats.items()}
+    n = int(sum(exp_cnt))
+    h1, h2 = synth.synth_h0(n, 4242)
+    ws_r, ws_f = dm.workspace(256), dm.workspace(256)
+    first, locs, logits, probs = ws_r.forward_reads(reads, h0=(h1, h2))
+    lg_f, pr_f = _fwd(ws_f, s, (h1, h2))
+    assert first.tolist() == np.concatenate([[0], np.cumsum(exp_cnt)]).tolist()
+    assert np.array_equal(locs, np.concatenate(exp_loc))
+    assert np.array_equal(_x0_bytes(dm, ws_r), _x0_bytes(dm, ws_f))
+    assert np.array_equal(logits, lg_f) and np.array_equal(probs, pr_f)
+    assert np.abs(probs - _oracle(w, s, h1, h2)[1]).max() < PROB_TOL
+    ws_r.close(); ws_f.close()
+
+
+def test_read_level_extraction_long_reads(model7):
+    """Realistic read lengths (up to 25 kb), ambiguous bases, a constant-kinetics read (std == 0 -> zeros), reads without
+    sites: device extraction vs the NumPy host mirror (itself pinned to the reference by tests/test_host_mirror.py)."""
+    from ccsmeth_amd import _lib
+    w, dm = model7
+    rng = np.random.default_rng(2024)
+    reads = []
+    for i, length in enumerate([25000, 12, 21, 22, 23, 15000, 300, 8000, 64, 257, 511]):
+        seq = rng.choice(list("ACGT"), size=length, p=[0.3, 0.2, 0.2, 0.3])
+        if i == 5:
+            seq[rng.integers(0, length, 40)] = "N"
+        if i == 8:
+            seq[:] = list("CG" * (length // 2))
+        code = lambda: np.clip(rng.gamma(2.0, 20.0, size=length), 0, 255).astype(np.uint8)  # noqa: E731
+        fi, ri, fp, rp = code(), code(), code(), code()
+        if i == 6:
+            fi[:] = 17                                          # std == 0
+        reads.append(("".join(seq), fi, ri, fp, rp, int(rng.integers(3, 40)), int(rng.integers(3, 40))))
+    s, exp_loc, counts = _mirror_batch(reads)
+    n = len(exp_loc)
+    assert n > 2000 and counts[1] == 0 and counts[2] == 0
+    ws_r, ws_f = dm.workspace(n), dm.workspace(n)
+    first, locs, logits, probs = ws_r.forward_reads(reads, h0="zero")
+    lg_f, pr_f = _fwd(ws_f, s, "zero")
+    assert np.array_equal(np.diff(first), counts) and np.array_equal(locs, exp_loc)
+    a, b = _x0_bytes(dm, ws_r), _x0_bytes(dm, ws_f)
+    # float64 variance sums are reduced in a different order than NumPy's pairwise sum: a last-ulp difference in std can
+    # flip the 6th decimal of an isolated value; anything systematic would show up as thousands of differing bytes
+    assert np.count_nonzero(a != b) <= 8
+    assert np.abs(probs - pr_f).max() < 1e-6
+    # device RNG h0: same running-site counter as the feature-level call
+    _, _, _, p_rng = ws_r.forward_reads(reads, seed=5, offset=100)
+    _, p_rng_f = _fwd(ws_f, s, None, seed=5, offset=100)
+    assert np.abs(p_rng - p_rng_f).max() < 1e-6
+    # capacity error: nothing computed, clean status
+    small = dm.workspace(100)
+    with pytest.raises(_lib.CcsmError) as ei:
+        small.forward_reads(reads, h0="zero")
+    assert ei.value.status == 5
+    # a chunk without any site is legal and returns empty outputs
+    f0, l0, _, p0 = small.forward_reads([reads[1], reads[2]], h0="zero")
+    assert f0.tolist() == [0, 0, 0] and len(l0) == 0 and p0.shape == (0, 2)
+    ws_r.close(); ws_f.close(); small.close()
