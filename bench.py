@@ -33,7 +33,7 @@ PEAK_HBM = 8.0e12
 # HBM/fabric bytes of ONE launch of the dominant kernel over 3 x 2048 sites, from rocprofv3 PMC passes on the same launch
 # shape (profiles/r01_c_pmc_coalesced.md: 2 x FETCH_SIZE + WRITE_SIZE, KiB, gfx950 read correction per MI355X_MICROARCH.md).
 # PMC counters cannot be read from inside this process; the figure is per-launch like `achieved` and scales with sites.
-TRAFFIC_BYTES_PER_SITE_GRU12 = (2 * 1241546 + 516096) * 1024 / 6144.0
+TRAFFIC_BYTES_PER_SITE_GRU12 = {3: (2 * 1241546 + 516096) * 1024 / 6144.0}    # by --precision; unmeasured modes report null
 
 
 def parse():
@@ -45,8 +45,9 @@ def parse():
                     help="HIP streams the coalesced groups alternate over (2 overlaps launch tails: +3 % value, but the overlapped\n"
                          "launches then report inflated per-kernel durations; 1 keeps roofline.achieved = a solo launch)")
     ap.add_argument("--coalesce", type=int, default=3, help="batches run per launch of the heavy kernels (micro-batching)")
-    ap.add_argument("--precision", type=int, default=3, choices=(1, 2, 3),
-                    help="3 = split-fp16 x3 (default, fp32-class, meets the 1e-4 bar); 2/1 = faster, reported as such")
+    ap.add_argument("--precision", type=int, default=4, choices=(1, 2, 3, 4),
+                    help="4 = split-f8 (default: fp16 main product + fp8 correction products, max |dprob| ~4e-6); 3 = split-fp16\n"
+                         "x3 (fp32-class, ~2e-7); 2/1 = fewer passes, outside the parity margin, reported as such")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg (0 = skip)")
     return ap.parse_args()
 
@@ -163,23 +164,27 @@ def main():
 
     if rank == 0:
         value = n_gpus * a.steps * BATCH / elapsed
-        passes = a.precision
+        passes = {4: 2, 3: 3, 2: 2, 1: 1}[a.precision]     # MFMA issue cycles per algorithmic flop, in fp16-rate units
         achieved = 2.0 * MAC_GRU12 * sites_per_launch / (dom_ms * 1e-3)
         line = {
             "metric": "CpG sites/sec (call_mods, attbigru2s b21)", "value": value, "unit": "sites/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {4: "f16+f8 split operands, f32 accumulate", 3: "f16x3 split operands, f32 accumulate",
+                      2: "f16 weights x split-f16 activations, f32 accumulate", 1: "f16 operands, f32 accumulate"}[a.precision],
+            "data": "synthetic",
             "config": {"workload": "attbigru2s_b21 forward on synthetic 21-mer CpG batches (BASELINE.json configs[1])",
                        "batch": BATCH, "sites_per_step": BATCH, "streams": nst, "coalesce": grp, "h0": "device Philox N(0,1)",
-                       "arithmetic": {3: "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate",
+                       "arithmetic": {4: "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) with fp8 e4m3 operands on "
+                                         "v_mfma_scale_f32_32x32x64_f8f6f4, one fp32 accumulator (GRU layers); attention pool split-fp16 x3",
+                                      3: "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate",
                                       2: "fp16 weights x split-fp16 activations (2 MFMA passes), fp32 accumulate",
-                                      1: "fp16 operands (1 MFMA pass), fp32 accumulate"}[passes],
+                                      1: "fp16 operands (1 MFMA pass), fp32 accumulate"}[a.precision],
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "gru_layer_v2_kernel<KX=32> (BiGRU layers 1-2)",
+            "roofline": {"bound": "mfma", "kernel": ("gru_layer_f8_kernel<KX=32>" if a.precision == 4 else "gru_layer_v2_kernel<KX=32>") + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
-                         "traffic": TRAFFIC_BYTES_PER_SITE_GRU12 * sites_per_launch if passes == 3 else None,
+                         "traffic": TRAFFIC_BYTES_PER_SITE_GRU12.get(a.precision, 0) * sites_per_launch or None,
                          "traffic_source": "profiles/r01_c_pmc_coalesced.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                          "launch_ms": dom_ms, "mfma_passes_per_flop": passes,
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,

@@ -10,6 +10,7 @@
 
 #include "../../include/ccsm.h"
 #include "ccsm_kernels.hip"
+#include "ccsm_gru_f8.hip"
 #include "ccsm_aggr.hip"
 #include "ccsm_extract.hip"
 
@@ -62,6 +63,8 @@ struct ccsm_model {
     int gru_version = 2;
     uint4* wst[kLayers] = {nullptr, nullptr, nullptr};  // v1: [dir][wave][KX+16][gate][hl][64]
     uint4* wst2[kLayers] = {nullptr, nullptr, nullptr}; // v2: [dir][wave][A: KX x (r,z) | B: 16 x (r,z,n) | C: KX x (n)][hl][64]
+    uint4* wst3[kLayers] = {nullptr, nullptr, nullptr}; // split-f8: as wst2 with the second fragment of a k-block = fp8 corr
+    int4 wscale[kLayers] = {};                           // E8M0 scales of the corr weight operands (x-part/h-part per dir)
     float* bias[kLayers] = {nullptr, nullptr, nullptr};  // [dir][wave][4][hh][16]
     uint4* wa = nullptr;                                 // [wave][32][hl][64]
     uint4* ua = nullptr;
@@ -174,6 +177,88 @@ void pack_wstream_v2(int layer, const float* const wih[2], const float* const wh
         }
 }
 
+// OCP fp8 e4m3fn, round to nearest even, saturating at +-448 (what v_mfma_scale_f32_32x32x64_f8f6f4 decodes with FMT 0)
+uint8_t fp8_e4m3_host(float v) {
+    const uint8_t sign = std::signbit(v) ? 0x80 : 0x00;
+    float a = std::fabs(v);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0f) return sign | 0x7e;
+    if (a < std::ldexp(1.0f, -10)) return sign;                       // below half of the smallest subnormal (2^-9)
+    int e;
+    (void)std::frexp(a, &e);                                          // a = m * 2^e, m in [0.5, 1)
+    int ex = e - 1;                                                   // a in [2^ex, 2^(ex+1))
+    if (ex < -6) ex = -6;                                             // subnormal range: step 2^-9
+    const float step = std::ldexp(1.0f, ex - 3);
+    const float q = std::nearbyint(a / step);                         // RNE (default rounding mode)
+    float r = q * step;
+    if (r >= 448.0f) r = 448.0f;
+    if (r < std::ldexp(1.0f, -6)) return sign | (uint8_t)std::lrint(r / std::ldexp(1.0f, -9));
+    int e2;
+    const float m2 = std::frexp(r, &e2);                              // r = m2 * 2^e2, m2 in [0.5, 1)
+    const int ebits = (e2 - 1) + 7;
+    const int mbits = (int)std::lrint((m2 * 2.0f - 1.0f) * 8.0f);
+    return sign | (uint8_t)(ebits << 3) | (uint8_t)mbits;
+}
+
+constexpr int kCorrPerm[16] = {0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15};   // see ccsm_gru_f8.hip
+
+// log2 of the power-of-two pre-scale sw of one weight matrix: the largest with max|W| * sw <= 240 (fp8 e4m3 headroom)
+int corr_scale_log2(const float* w, size_t count) {
+    float mx = 0.f;
+    for (size_t i = 0; i < count; ++i) mx = std::fmax(mx, std::fabs(w[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 0;
+    int e = (int)std::floor(std::log2(240.0f / mx));
+    return std::max(-100, std::min(100, e));
+}
+
+// corr fragment (1 KiB) of one (gate-row block, k-block): lane (i, g), byte j <-> k = 16 kb + kCorrPerm[j];
+// g = 0: fp8(W_lo * 2^11 * sw), g = 1: fp8(W_hi * sw).  `get(row_in_block i, k)` returns the fp32 weight (0 outside).
+template <typename Get>
+void emit_corr_frag(uint8_t* dst, int kb, int log2sw, Get get) {
+    for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 31, g = lane >> 5;
+        for (int j = 0; j < 16; ++j) {
+            const float v = get(i, 16 * kb + kCorrPerm[j]);
+            const float hi = (float)(_Float16)v;
+            const float c = g ? std::ldexp(hi, log2sw) : std::ldexp(v - hi, 11 + log2sw);
+            dst[lane * 16 + j] = fp8_e4m3_host(c);
+        }
+    }
+}
+
+// Split-f8 weight stream: the version-2 order with the second fragment of every k-block replaced by its corr fragment
+// (layer 0 keeps fp16 lo for its x-part).  scales = E8M0 bytes {x-part dir 0, h-part dir 0, x-part dir 1, h-part dir 1}.
+void pack_wstream_v3(int layer, const float* const wih[2], const float* const whh[2], std::vector<_Float16>& out, int4& scales) {
+    const int kx = layer_kx(layer);
+    const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
+    const int nfrag = kx * 4 + kKBH * 6 + kx * 2;
+    pack_wstream_v2(layer, wih, whh, out);               // hi fragments (and layer 0's fp16 lo) are already in place
+    int lg[2][2];
+    for (int dir = 0; dir < 2; ++dir) {
+        lg[dir][0] = corr_scale_log2(wih[dir], (size_t)kGates * kHidden * k_in);
+        lg[dir][1] = corr_scale_log2(whh[dir], (size_t)kGates * kHidden * kHidden);
+    }
+    scales = make_int4(127 - 11 - lg[0][0], 127 - 11 - lg[0][1], 127 - 11 - lg[1][0], 127 - 11 - lg[1][1]);
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(out.data());
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave) {
+            size_t f = (size_t)(dir * kWaves + wave) * nfrag;
+            auto emit = [&](bool xpart, int kb, int g) {
+                if (!(xpart && layer == 0)) {
+                    auto get = [&](int i, int k) -> float {
+                        const int row = g * kHidden + kUnitTile * wave + i;
+                        return xpart ? (k < k_in ? wih[dir][(size_t)row * k_in + k] : 0.f) : whh[dir][(size_t)row * kHidden + k];
+                    };
+                    emit_corr_frag(bytes + (f + 1) * 1024, kb, lg[dir][xpart ? 0 : 1], get);
+                }
+                f += 2;
+            };
+            for (int kb = 0; kb < kx; ++kb) { emit(true, kb, 0); emit(true, kb, 1); }
+            for (int kb = 0; kb < kKBH; ++kb) { emit(false, kb, 0); emit(false, kb, 1); emit(false, kb, 2); }
+            for (int kb = 0; kb < kx; ++kb) emit(true, kb, 2);
+        }
+}
+
 void pack_bias(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
     out.assign((size_t)2 * kWaves * 4 * 32, 0.f);
     for (int dir = 0; dir < 2; ++dir)
@@ -230,7 +315,7 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
 }
 
 // Heavy kernels, once over every row used by the current slices, then the per-slice logits/softmax.
-template <int NPASS>
+template <int NPASS, bool F8 = false>
 ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
     const int rows_run = ((ws->rows_used + kRowPad - 1) / kRowPad) * kRowPad;
     const int tiles = rows_run / 32;
@@ -238,7 +323,17 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     if (tm) ws->ev = ws->evs[ws->ev_runs % ccsm_workspace::kEvSets];
     if (tm) HIP_TRY(hipEventRecord(ws->ev[1], st));
     const size_t slab = (size_t)2 * ws->rows_p * kHidden;  // floats per layer (two directions)
-    if (m->gru_version == 1) {
+    if constexpr (F8) {
+        const dim3 ggrid(2 * (tiles / kNBGru2));
+        hipLaunchKernelGGL((gru_layer_f8_kernel<kKB0, false>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
+                           m->wst3[0], m->bias[0], ws->h0buf, ws->rows_p, m->wscale[0], nullptr);
+        if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
+        hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, false>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
+                           m->wst3[1], m->bias[1], ws->h0buf + slab, ws->rows_p, m->wscale[1], ws->dbg);
+        if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
+        hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, true>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
+                           m->wst3[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, m->wscale[2], nullptr);
+    } else if (m->gru_version == 1) {
         const size_t lds = (size_t)kKBH * kNBGru * 2 * 1024;
         const dim3 ggrid(2 * (tiles / kNBGru));
         hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB0, NPASS>), ggrid, dim3(512), lds, st, ws->x0, ws->act[0], m->wst[0],
@@ -286,11 +381,12 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
 
 ccsm_status dispatch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
     switch (m->precision) {
+        case 4: return launch_run<3, true>(m, ws, st);
         case 3: return launch_run<3>(m, ws, st);
         case 2: return launch_run<2>(m, ws, st);
         case 1: return launch_run<1>(m, ws, st);
     }
-    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 1, 2 or 3");
+    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 1, 2, 3 or 4");
 }
 
 // add one slice (device pointers) to the workspace
@@ -355,8 +451,8 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         return fail(CCSM_ERR_UNSUPPORTED, "this build implements seq_len 21, layer_rnn 3, class_num 2, hid_rnn 256");
     if (!cfg->is_npass || cfg->is_sn || cfg->is_map || cfg->is_stds)
         return fail(CCSM_ERR_UNSUPPORTED, "this build implements is_npass=yes, is_sn=no, is_map=no, is_stds=no");
-    const int prec = cfg->precision == 0 ? 3 : cfg->precision;
-    if (prec < 1 || prec > 3) return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default), 1, 2 or 3");
+    const int prec = cfg->precision == 0 ? 4 : cfg->precision;
+    if (prec < 1 || prec > 4) return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default), 1, 2, 3 or 4");
     if (!w->embed_weight || !w->att_wa || !w->att_ua || !w->att_va || !w->fc1_weight || !w->fc1_bias)
         return fail(CCSM_ERR_INVALID_ARG, "weights: NULL tensor");
     for (int l = 0; l < kLayers; ++l)
@@ -379,6 +475,11 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         pack_wstream_v2(l, w->weight_ih[l], w->weight_hh[l], hbuf);
         st = upload(&m->wst2[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
         if (st != CCSM_OK) break;
+        if (prec == 4) {
+            pack_wstream_v3(l, w->weight_ih[l], w->weight_hh[l], hbuf, m->wscale[l]);
+            st = upload(&m->wst3[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
+            if (st != CCSM_OK) break;
+        }
         pack_bias(w->bias_ih[l], w->bias_hh[l], fbuf);
         st = upload(&m->bias[l], fbuf.data(), fbuf.size() * sizeof(float));
     }
@@ -403,19 +504,27 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);                         \
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_kernel<kNBGru, kKB12, NP>),    \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (prec == 3) { CCSM_SET_LDS(3) } else if (prec == 2) { CCSM_SET_LDS(2) } else { CCSM_SET_LDS(1) }
+        if (prec >= 3) { CCSM_SET_LDS(3) } else if (prec == 2) { CCSM_SET_LDS(2) } else { CCSM_SET_LDS(1) }
 #undef CCSM_SET_LDS
 #define CCSM_SET_LDS2(NP)                                                                                                \
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB0, NP>),           \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB0));              \
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB12, NP>),          \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
-        if (prec == 3) { CCSM_SET_LDS2(3) } else if (prec == 2) { CCSM_SET_LDS2(2) } else { CCSM_SET_LDS2(1) }
+        if (prec >= 3) { CCSM_SET_LDS2(3) } else if (prec == 2) { CCSM_SET_LDS2(2) } else { CCSM_SET_LDS2(1) }
 #undef CCSM_SET_LDS2
+        if (prec == 4) {
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB0, false>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB0));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, false>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
+        }
 #define CCSM_SET_ALDS(NP)                                                                                   \
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fc_kernel<NP>),         \
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, kAttLds);
-        if (prec == 3) { CCSM_SET_ALDS(3) } else if (prec == 2) { CCSM_SET_ALDS(2) } else { CCSM_SET_ALDS(1) }
+        if (prec >= 3) { CCSM_SET_ALDS(3) } else if (prec == 2) { CCSM_SET_ALDS(2) } else { CCSM_SET_ALDS(1) }
 #undef CCSM_SET_ALDS
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }
@@ -433,6 +542,7 @@ void ccsm_destroy(ccsm_model* m) {
     for (int l = 0; l < kLayers; ++l) {
         (void)hipFree(m->wst[l]);
         (void)hipFree(m->wst2[l]);
+        (void)hipFree(m->wst3[l]);
         (void)hipFree(m->bias[l]);
     }
     (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);
@@ -766,6 +876,7 @@ ccsm_status ccsm_workspace_last_timing(ccsm_workspace* ws, float out_ms[5]) {
     return CCSM_OK;
 }
 
+int ccsm_debug_fp8_e4m3(float v) { return fp8_e4m3_host(v); }
 int ccsm_debug_rows_padded(int n_sites) { return n_sites > 0 ? rows_padded(n_sites) : 0; }
 int ccsm_debug_rows_capacity(const ccsm_workspace* ws) { return ws ? ws->rows_p : 0; }
 
@@ -805,6 +916,49 @@ ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_
     if (bytes > cap) return fail(CCSM_ERR_CAPACITY, "debug read larger than the buffer");
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(host_dst, src, bytes, hipMemcpyDeviceToHost));
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_selftest_split_f8(int device, float* err_corr, float* err_main_only) {
+    if (!err_corr || !err_main_only) return fail(CCSM_ERR_INVALID_ARG, "outputs must be non-NULL");
+    HIP_TRY(hipSetDevice(device));
+    // W: 32 units x 32 k, X: 32 rows x 32 k, deterministic, non-symmetric, weights ~ U(-0.07, 0.07), activations in (-1, 1)
+    std::vector<float> w(32 * 32), x(32 * 32);
+    uint32_t sd = 12345u;
+    auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return (float)(sd >> 8) * (1.0f / 16777216.0f); };
+    for (auto& v : w) v = (rnd() - 0.5f) * 0.14f;
+    for (auto& v : x) v = (rnd() - 0.5f) * 1.9f;
+    const int lg = corr_scale_log2(w.data(), w.size());
+    std::vector<_Float16> frag(2 * 2 * 512, (_Float16)0.f);
+    for (int kb = 0; kb < 2; ++kb) {
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) frag[(kb * 2) * 512 + lane * 8 + j] = (_Float16)w[(lane & 31) * 32 + 16 * kb + 8 * (lane >> 5) + j];
+        emit_corr_frag(reinterpret_cast<uint8_t*>(frag.data()) + (kb * 2 + 1) * 1024, kb, lg,
+                       [&](int i, int k) { return w[i * 32 + k]; });
+    }
+    uint4* dw = nullptr;
+    float *dx = nullptr, *dc = nullptr;
+    HIP_TRY(hipMalloc((void**)&dw, 4096));
+    HIP_TRY(hipMalloc((void**)&dx, 4096));
+    HIP_TRY(hipMalloc((void**)&dc, 4096));
+    HIP_TRY(hipMemcpy(dw, frag.data(), 4096, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dx, x.data(), 4096, hipMemcpyHostToDevice));
+    float* outs[2] = {err_corr, err_main_only};
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(corr_selftest_kernel, dim3(1), dim3(64), 0, 0, dw, dx, dc, 127 - 11 - lg, pass == 0 ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        std::vector<float> c(1024);
+        HIP_TRY(hipMemcpy(c.data(), dc, 4096, hipMemcpyDeviceToHost));
+        double err = 0.0;
+        for (int u = 0; u < 32; ++u)
+            for (int r = 0; r < 32; ++r) {
+                double ref = 0.0;
+                for (int k = 0; k < 32; ++k) ref += (double)w[u * 32 + k] * (double)x[r * 32 + k];
+                err = std::fmax(err, std::fabs(ref - (double)c[u * 32 + r]));
+            }
+        *outs[pass] = (float)err;
+    }
+    (void)hipFree(dw); (void)hipFree(dx); (void)hipFree(dc);
     return CCSM_OK;
 }
 

@@ -1,0 +1,493 @@
+// libccsm GRU layer, version 3 ("split-f8"): f16 main product + fp8 error-compensation products on the gfx950 block-scaled
+// MFMA (v_mfma_scale_f32_32x32x64_f8f6f4).  Included by ccsm_api.hip after ccsm_kernels.hip.
+//
+// Arithmetic.  Every fp32 operand v is carried as hi = fp16(v) plus the residual lo = v - hi.  The product
+//     W x  =  W_hi x_hi  +  W_lo x_hi  +  W_hi x_lo  (+ W_lo x_lo, dropped: 2^-22 relative)
+// is issued as
+//     main : v_mfma_f32_32x32x16_f16 on (W_hi, x_hi)                      32 cycles per 16 k
+//     corr : v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 e4m3 x fp8 e4m3), K = 64 = [32 k of W_lo x_hi | 32 k of W_hi x_lo]
+//                                                                         64 cycles per 32 k
+// i.e. 128 MFMA cycles per 32 k instead of the 192 of three f16 passes (CCSM_PRECISION_SPLIT3).  The two correction terms
+// are 2^-11 of the main term, so their fp8 operands (4 significant bits) leave a relative error of ~2^-15 per product,
+// 16x below plain fp16 operands; measured on the parity suite max |dprob| is ~3e-6 (bar: 1e-4, SPLIT3: 2e-7).
+// All sums are fp32 in the same accumulators; the 2^-11 and the operand pre-scales are folded into the instruction's
+// E8M0 block scales, so there is no separate accumulator set and no post-scaling.
+//
+// Fragments.  Per k-block (16 k) there are still two 1 KiB fragments, [hi | corr]:
+//   hi   : lane (n, g) holds fp16 M_hi[n][16kb + 8g + j], j < 8                                  (unchanged)
+//   corr : lane (n, g) holds 16 fp8 bytes, byte j <-> k = 16kb + kCorrPerm[j];
+//          weights     : g = 0 -> fp8(W_lo * 2^11 * sw),  g = 1 -> fp8(W_hi * sw)      (sw: per-matrix power of two)
+//          activations : g = 0 -> fp8(x_hi * 64),         g = 1 -> fp8(x_lo * 2^11 * 64)
+//   The K = 64 operand of one corr MFMA is the corr fragments of two consecutive k-blocks (8 dwords per lane): lanes
+//   g = 0 multiply W_lo by x_hi, lanes g = 1 multiply W_hi by x_lo (A and B share the lane/byte -> k mapping).
+//   kCorrPerm = [0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15] is what two v_permlane32_swap per k-block produce from the MFMA
+//   C layout in the step epilogue; the host packs the weights with the same permutation.
+// The recurrent state is carried as hi + fp8(lo) too (h_{t-1} is re-read from these fragments): 2^-16 relative per step.
+//
+// Layer 0 (KX == 1, K = 11 padded to 16, inputs up to hundreds in magnitude) keeps three f16 passes for its x-part.
+// The last layer writes [hi | lo] fp16 fragments for the attention kernel (OUT_F16LO).
+#include <hip/hip_runtime.h>
+
+namespace ccsm {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+constexpr float kCorrActHi = 64.0f;                // fp8 copy of x_hi carries x_hi * 2^6
+constexpr float kCorrActLo = 2048.0f * 64.0f;      // fp8 copy of x_lo carries x_lo * 2^17
+constexpr int kCorrScaleB = 127 - 6;               // E8M0 block scale of the activation operand: 2^-6
+constexpr float kF8Clamp = 448.0f;                 // e4m3 finite maximum (v_cvt_pk_fp8_f32 does not saturate)
+
+__device__ __forceinline__ f32x16 mfma_corr(uint4 w0, uint4 w1, uint4 x0, uint4 x1, f32x16 c, int scale_a) {
+    const i32x8 a = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
+    const i32x8 b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, kCorrScaleB);
+}
+
+__device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d) {
+    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+    return (uint32_t)r;
+}
+__device__ __forceinline__ void swap32(uint32_t& x, uint32_t& y) {   // lanes 32-63 of x <-> lanes 0-31 of y
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+
+// Eight MFMA-C-layout values of one k-block held by lane (n, hh): v[0..3] = units e + 4hh, v[4..7] = units 8 + e + 4hh of
+// batch row n.  Produces this lane's 16 bytes of the k-block's hi fragment, corr fragment and (WITH_LO) fp16 lo fragment.
+template <bool WITH_LO>
+__device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint4& co_out, uint4& lo_out) {
+    _Float16 h[8];
+    float hf[8], lf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = (_Float16)v[j];
+        hf[j] = (float)h[j];
+        lf[j] = v[j] - hf[j];
+    }
+    uint32_t a0 = pack2(h[0], h[1]), a1 = pack2(h[2], h[3]), b0 = pack2(h[4], h[5]), b1 = pack2(h[6], h[7]);
+    swap32(a0, b0);
+    swap32(a1, b1);
+    hi_out = make_uint4(a0, a1, b0, b1);
+    uint32_t h0 = cvt4_fp8(hf[0] * kCorrActHi, hf[1] * kCorrActHi, hf[2] * kCorrActHi, hf[3] * kCorrActHi);
+    uint32_t h1 = cvt4_fp8(hf[4] * kCorrActHi, hf[5] * kCorrActHi, hf[6] * kCorrActHi, hf[7] * kCorrActHi);
+    uint32_t l0 = cvt4_fp8(lf[0] * kCorrActLo, lf[1] * kCorrActLo, lf[2] * kCorrActLo, lf[3] * kCorrActLo);
+    uint32_t l1 = cvt4_fp8(lf[4] * kCorrActLo, lf[5] * kCorrActLo, lf[6] * kCorrActLo, lf[7] * kCorrActLo);
+    swap32(h0, l0);   // lower lanes: (own hi, partner's hi) ; upper lanes: (partner's lo, own lo)
+    swap32(h1, l1);
+    co_out = make_uint4(h0, h1, l0, l1);
+    if constexpr (WITH_LO) {
+        uint32_t c0 = pack2((_Float16)lf[0], (_Float16)lf[1]), c1 = pack2((_Float16)lf[2], (_Float16)lf[3]);
+        uint32_t d0 = pack2((_Float16)lf[4], (_Float16)lf[5]), d1 = pack2((_Float16)lf[6], (_Float16)lf[7]);
+        swap32(c0, d0);
+        swap32(c1, d1);
+        lo_out = make_uint4(c0, c1, d0, d1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// One bidirectional GRU layer, 96 batch rows per workgroup, phases A (x-part of r, z), B (h-part of r, z, n), C (x-part
+// of n) as in gru_layer_v2_kernel; the unit of work inside a phase is a PAIR of k-blocks:
+//   G1: main MFMAs of k-block 2p      G2: main MFMAs of k-block 2p+1      G3: corr MFMAs of the pair
+// Weight registers are reloaded immediately after the group that used them, two pairs ahead in phase A (ring of two
+// pairs), one pair ahead in phase B (one pair resident) and one chunk (two pairs) ahead in phase C.
+//   xin  : [tile][t][KX][hi|corr][64] uint4 (KX == 1: [hi|lo] fp16)       out : [tile][t][32][hi|corr or hi|lo][64]
+//   wst  : [dir][wave][ A: KX x (r,z) x 2 | B: 16 x (r,z,n) x 2 | C: KX x (n) x 2 ][64] uint4, second fragment = corr
+//          (KX == 1: A and C second fragment = fp16 lo)
+//   sc   : E8M0 weight-operand scales: x = x-part dir 0, y = h-part dir 0, z = x-part dir 1, w = h-part dir 1
+// ---------------------------------------------------------------------------------------------------------
+template <int KX, bool OUT_F16LO>
+__global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
+                                                               const uint4* __restrict__ wst, const float* __restrict__ bias,
+                                                               const float* __restrict__ h0, int rows_p, int4 sc,
+                                                               unsigned long long* __restrict__ dbg) {
+    constexpr int NB = 3;
+    constexpr int CK = KX >= 4 ? 4 : KX;
+    constexpr int NCH = KX / CK;
+    constexpr int CHF = CK * NB * 2;
+    constexpr int SPW = (CHF + kWaves - 1) / kWaves;
+    constexpr int FA = 4, FB = 6, FC = 2;
+    constexpr int OFF_B = KX * FA, OFF_C = OFF_B + kKBH * FB, WFRAGS = OFF_C + KX * FC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_h = smem;                               // h fragments  [kb 16][bt 3][hi|corr] x 1 KiB = 96 KiB
+    char* s_x = smem + kKBH * NB * 2 * 1024;        // x chunk ring [buf 2][kbl CK][bt 3][2] x 1 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dir = blockIdx.x & 1;
+    const int tile0 = (blockIdx.x >> 1) * NB;
+    const int n = lane & 31, hh = lane >> 5;
+    const int sa_x = dir ? sc.z : sc.x, sa_h = dir ? sc.w : sc.y;
+
+    auto hfrag = [&](int kb, int bt, int f) -> char* { return s_h + (((kb * NB + bt) * 2 + f) << 10); };
+    auto xfrag = [&](int buf, int kbl, int bt, int f) -> char* { return s_x + ((((buf * CK + kbl) * NB + bt) * 2 + f) << 10); };
+
+    // ---- h0 -> LDS fragments (this wave's own two k-blocks, every batch tile)
+    {
+        const float* h0d = h0 + (size_t)dir * rows_p * kHidden;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            const float* src = h0d + ((size_t)(tile0 + bt) * 32 + n) * kHidden;
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                const int kb = 2 * wave + kbl;
+                const float4 q0 = *reinterpret_cast<const float4*>(src + kb * 16 + 0);
+                const float4 q1 = *reinterpret_cast<const float4*>(src + kb * 16 + 4);
+                const float4 q2 = *reinterpret_cast<const float4*>(src + kb * 16 + 8);
+                const float4 q3 = *reinterpret_cast<const float4*>(src + kb * 16 + 12);
+                const float u[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                _Float16 hi[16];
+                float cv[16];                        // this lane's corr values in natural k order
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    hi[j] = (_Float16)u[j];
+                    const float hf = (float)hi[j];
+                    const float c = hh ? (u[j] - hf) * kCorrActLo : hf * kCorrActHi;
+                    cv[j] = fminf(fmaxf(c, -kF8Clamp), kF8Clamp);
+                }
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) =
+                    hh ? make_uint4(pack2(hi[8], hi[9]), pack2(hi[10], hi[11]), pack2(hi[12], hi[13]), pack2(hi[14], hi[15]))
+                       : make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
+                // kCorrPerm order: k = 0..3, 8..11, 4..7, 12..15
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) =
+                    make_uint4(cvt4_fp8(cv[0], cv[1], cv[2], cv[3]), cvt4_fp8(cv[8], cv[9], cv[10], cv[11]),
+                               cvt4_fp8(cv[4], cv[5], cv[6], cv[7]), cvt4_fp8(cv[12], cv[13], cv[14], cv[15]));
+            }
+        }
+    }
+
+    // ---- x staging (as gru_layer_v2_kernel): fragment f = (kbl*NB + bt)*2 + hl of chunk c of timestep t
+    static_assert(SPW <= 3, "staging registers");
+    uint4 sreg0, sreg1, sreg2;
+    const int lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xin);
+    auto stage_off = [&](int t, int c, int i) -> int {
+        const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
+        const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
+        return (((((tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) << 10);
+    };
+    auto stage_dst = [&](int buf, int i) -> uint4* {
+        const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
+        return reinterpret_cast<uint4*>(s_x + ((buf * CHF + f) << 10) + lane * 16);
+    };
+    auto stage_load = [&](int t, int c) {
+        sreg0 = buf_load(xrs, lane16, stage_off(t, c, 0));
+        if constexpr (SPW > 1) sreg1 = buf_load(xrs, lane16, stage_off(t, c, 1));
+        if constexpr (SPW > 2) sreg2 = buf_load(xrs, lane16, stage_off(t, c, 2));
+    };
+    auto stage_store = [&](int buf) {
+        *stage_dst(buf, 0) = sreg0;
+        if constexpr (SPW > 1) *stage_dst(buf, 1) = sreg1;
+        if constexpr (SPW > 2) *stage_dst(buf, 2) = sreg2;
+    };
+
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4);
+    const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
+
+    stage_load(dir ? kSeqLen - 1 : 0, 0);
+    stage_store(0);
+
+    for (int s = 0; s < kSeqLen; ++s) {
+        const int t = dir ? (kSeqLen - 1 - s) : s;
+        auto stamp = [&](int k) {
+            if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
+        };
+        stamp(0);
+        const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;
+        f32x16 acc[3][NB];                            // R, Z, N
+        const float* bps = bp;
+        asm volatile("" : "+v"(bps));
+        auto bias_set = [&](int set) {
+            f32x16 b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(bps + set * 32 + q * 4);
+                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+            return b;
+        };
+        {
+            const f32x16 b0 = bias_set(0), b1 = bias_set(1);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) { acc[0][bt] = b0; acc[1][bt] = b1; }
+        }
+
+        auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, frag << 10); };
+        uint4 xh[NB], xc[2][NB];                      // main fragments of one k-block, corr fragments of a pair
+        auto rdx = [&](uint4 (&x)[NB], int buf, int kbl, int f) {
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(xfrag(buf, kbl, bt, f) + lane * 16);
+        };
+        auto rdh = [&](uint4 (&x)[NB], int kb, int f) {
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, f) + lane * 16);
+        };
+#define CCSM_FENCE asm volatile("" ::: "memory")
+        // G gates of one k-block, main product: W[g] (hi) x X[bt] (hi) into accumulator set S0 + g
+#define CCSM_MAIN(W, X, G, S0)                                                                                \
+    do {                                                                                                      \
+        CCSM_FENCE;                                                                                           \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)       \
+            acc[S0 + g][bt] = mfma16(W[g], X[bt], acc[S0 + g][bt]);                                           \
+        CCSM_FENCE;                                                                                           \
+    } while (0)
+        // correction product of a pair of k-blocks: corr fragments W0[g], W1[g] x X[0][bt], X[1][bt]
+#define CCSM_CORR(W0, W1, X, G, S0, SA)                                                                       \
+    do {                                                                                                      \
+        CCSM_FENCE;                                                                                           \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)       \
+            acc[S0 + g][bt] = mfma_corr(W0[g], W1[g], X[0][bt], X[1][bt], acc[S0 + g][bt], SA);               \
+        CCSM_FENCE;                                                                                           \
+    } while (0)
+
+        uint4 wbh[2][3], wbc[2][3];                   // phase B: main / corr fragments of the resident pair [kb in pair][gate]
+        auto ldBh = [&](uint4 (&d)[3], int kb) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) d[g] = w_at(OFF_B + kb * FB + g * 2);
+        };
+        auto ldBc = [&](uint4 (&d)[3], int kb) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) d[g] = w_at(OFF_B + kb * FB + g * 2 + 1);
+        };
+
+        // ---------------- phase A: R, Z += W_i{r,z} x_t -------------------------------------------------------------
+        if constexpr (CK == 4) {
+            uint4 wah[2][2][2], wac[2][2][2];         // ring of two pairs: [pair slot][kb in pair][gate]
+            auto ldAh = [&](uint4 (&d)[2], int kb) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) d[g] = w_at(kb * FA + g * 2);
+            };
+            auto ldAc = [&](uint4 (&d)[2], int kb) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) d[g] = w_at(kb * FA + g * 2 + 1);
+            };
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                ldAh(wah[p][0], 2 * p); ldAh(wah[p][1], 2 * p + 1);
+                ldAc(wac[p][0], 2 * p); ldAc(wac[p][1], 2 * p + 1);
+            }
+#pragma unroll 1
+            for (int c = 0; c < NCH; ++c) {
+                __syncthreads();                       // chunk c (buffer c&1) is in LDS; the other buffer is free
+                const int buf = c & 1;
+                const bool more = c + 1 < NCH;
+#define CCSM_PAIR_A(P)                                                                                         \
+    {                                                                                                          \
+        const int k0 = min(4 * c + 2 * (P) + 4, KX - 2);      /* first k-block of the pair two pairs ahead */  \
+        rdx(xh, buf, 2 * (P), 0);                                                                              \
+        rdx(xc[0], buf, 2 * (P), 1);                                                                           \
+        rdx(xc[1], buf, 2 * (P) + 1, 1);                                                                       \
+        CCSM_MAIN(wah[P][0], xh, 2, 0);                                                                        \
+        ldAh(wah[P][0], k0);                                                                                   \
+        if ((P) == 0) stage_load(t, more ? c + 1 : 0);        /* after the weight prefetch: younger in vmcnt */ \
+        rdx(xh, buf, 2 * (P) + 1, 0);                                                                          \
+        CCSM_MAIN(wah[P][1], xh, 2, 0);                                                                        \
+        ldAh(wah[P][1], k0 + 1);                                                                               \
+        CCSM_CORR(wac[P][0], wac[P][1], xc, 2, 0, sa_x);                                                       \
+        ldAc(wac[P][0], k0);                                                                                   \
+        ldAc(wac[P][1], k0 + 1);                                                                               \
+    }
+                CCSM_PAIR_A(0)
+                CCSM_PAIR_A(1)
+#undef CCSM_PAIR_A
+                stage_store((c + 1) & 1);              // next A chunk, or C chunk 0 into buffer NCH & 1 == 0
+            }
+            ldBh(wbh[0], 0); ldBh(wbh[1], 1);
+            ldBc(wbc[0], 0); ldBc(wbc[1], 1);
+        } else {
+            // layer 0: one k-block (11 features padded to 16), three fp16 passes, [hi|lo] fragments on both sides
+            uint4 w0[2][2], x0[NB][2];
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { w0[g][0] = w_at(g * 2); w0[g][1] = w_at(g * 2 + 1); }
+            ldBh(wbh[0], 0); ldBh(wbh[1], 1);
+            ldBc(wbc[0], 0); ldBc(wbc[1], 1);
+            stage_load(tn, 0);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + lane * 16);
+                x0[bt][1] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 1) + lane * 16);
+            }
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    acc[g][bt] = mfma16(w0[g][0], x0[bt][0], acc[g][bt]);
+                    acc[g][bt] = mfma16(w0[g][0], x0[bt][1], acc[g][bt]);
+                    acc[g][bt] = mfma16(w0[g][1], x0[bt][0], acc[g][bt]);
+                }
+            CCSM_FENCE;
+            stage_store((s + 1) & 1);
+        }
+
+        stamp(1);
+        // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------------
+        {
+            const f32x16 b3 = bias_set(3);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
+        }
+#pragma unroll 1
+        for (int kb = 0; kb < kKBH; kb += 2) {
+            const int kn = min(kb + 2, kKBH - 2);
+            rdh(xh, kb, 0);
+            rdh(xc[0], kb, 1);
+            rdh(xc[1], kb + 1, 1);
+            CCSM_MAIN(wbh[0], xh, 3, 0);
+            ldBh(wbh[0], kn);
+            rdh(xh, kb + 1, 0);
+            CCSM_MAIN(wbh[1], xh, 3, 0);
+            ldBh(wbh[1], kn + 1);
+            CCSM_CORR(wbc[0], wbc[1], xc, 3, 0, sa_h);
+            ldBc(wbc[0], kn);
+            ldBc(wbc[1], kn + 1);
+        }
+        // r = sigmoid(R) ; N = b_in + r * N
+        uint4 wch[2][4], wcc[2][4];                   // phase C: n-gate fragments of two chunks [chunk parity][kb in chunk]
+        auto ldC = [&](int par, int c) {
+#pragma unroll
+            for (int j = 0; j < CK; ++j) {
+                wch[par][j] = w_at(OFF_C + (c * CK + j) * FC);
+                wcc[par][j] = w_at(OFF_C + (c * CK + j) * FC + 1);
+            }
+        };
+        ldC(0, 0);
+        {
+            const f32x16 b2 = bias_set(2);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
+        }
+
+        stamp(2);
+        // ---------------- phase C: N += W_in x_t ----------------------------------------------------------------------
+        if constexpr (CK == 4) {
+#pragma unroll 1
+            for (int c2 = 0; c2 < NCH; c2 += 2) {
+#define CCSM_PAIR_C(CUR, P)                                                                                    \
+    {                                                                                                          \
+        rdx(xh, buf, 2 * (P), 0);                                                                              \
+        rdx(xc[0], buf, 2 * (P), 1);                                                                           \
+        rdx(xc[1], buf, 2 * (P) + 1, 1);                                                                       \
+        CCSM_FENCE;                                                                                            \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[CUR][2 * (P)], xh[bt], acc[2][bt]); \
+        CCSM_FENCE;                                                                                            \
+        rdx(xh, buf, 2 * (P) + 1, 0);                                                                          \
+        CCSM_FENCE;                                                                                            \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[CUR][2 * (P) + 1], xh[bt], acc[2][bt]); \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt)                                                      \
+            acc[2][bt] = mfma_corr(wcc[CUR][2 * (P)], wcc[CUR][2 * (P) + 1], xc[0][bt], xc[1][bt], acc[2][bt], sa_x); \
+        CCSM_FENCE;                                                                                            \
+    }
+#define CCSM_CHUNK_C(C, CUR, NXT)                                                                              \
+    {                                                                                                          \
+        __syncthreads();                                                                                       \
+        const int buf = (C) & 1;                                                                               \
+        const bool more = (C) + 1 < NCH;                                                                       \
+        ldC(NXT, min((C) + 1, NCH - 1));                 /* a whole chunk ahead */                             \
+        stage_load(more ? t : tn, more ? (C) + 1 : 0);   /* next C chunk / next step's first A chunk */        \
+        CCSM_PAIR_C(CUR, 0)                                                                                    \
+        CCSM_PAIR_C(CUR, 1)                                                                                    \
+        stage_store(((C) + 1) & 1);                                                                            \
+    }
+                CCSM_CHUNK_C(c2, 0, 1)
+                CCSM_CHUNK_C(c2 + 1, 1, 0)
+#undef CCSM_CHUNK_C
+#undef CCSM_PAIR_C
+            }
+        } else {
+            uint4 x0[NB][2];
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + lane * 16);
+                x0[bt][1] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 1) + lane * 16);
+            }
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                acc[2][bt] = mfma16(wch[0][0], x0[bt][0], acc[2][bt]);
+                acc[2][bt] = mfma16(wch[0][0], x0[bt][1], acc[2][bt]);
+                acc[2][bt] = mfma16(wcc[0][0], x0[bt][0], acc[2][bt]);      // layer 0: second fragment = fp16 lo
+            }
+            CCSM_FENCE;
+        }
+#undef CCSM_CORR
+#undef CCSM_MAIN
+#undef CCSM_FENCE
+
+        stamp(3);
+        // ---------------- h_{t-1} of this wave's own units (C layout): hi fragment + fp8 residual of the corr fragment
+        float hprev[NB][16];
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kb = 2 * wave + (q >> 1);
+                const int src_lane = n + 32 * (q & 1);
+                const half4 hi = as_half4(*reinterpret_cast<const uint2*>(hfrag(kb, bt, 0) + src_lane * 16 + hh * 8));
+                // residuals: lane (n, g = 1) of the corr fragment, bytes 4*(q&1) + 8*hh .. +3  (kCorrPerm order)
+                const int lo4 = *reinterpret_cast<const int*>(hfrag(kb, bt, 1) + (n + 32) * 16 + 4 * (q & 1) + 8 * hh);
+                hprev[bt][4 * q + 0] = (float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo4, 0) * (1.0f / kCorrActLo);
+                hprev[bt][4 * q + 1] = (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo4, 1) * (1.0f / kCorrActLo);
+                hprev[bt][4 * q + 2] = (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo4, 2) * (1.0f / kCorrActLo);
+                hprev[bt][4 * q + 3] = (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo4, 3) * (1.0f / kCorrActLo);
+            }
+        if constexpr (CK != 4) __syncthreads();   // KX == 1: no phase-C barriers, so order the h_{t-1} reads explicitly
+
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            float hn[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float zz = sigmoid_f(acc[1][bt][r]);
+                const float nn = tanh_f(acc[2][bt][r]);
+                hn[r] = (hprev[bt][r] - nn) * zz + nn;
+            }
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                const float v[8] = {hn[8 * kbl + 0], hn[8 * kbl + 1], hn[8 * kbl + 2], hn[8 * kbl + 3],
+                                    hn[8 * kbl + 4], hn[8 * kbl + 5], hn[8 * kbl + 6], hn[8 * kbl + 7]};
+                uint4 fh, fc, fl;
+                pack_kb<OUT_F16LO>(v, fh, fc, fl);
+                const int kb = 2 * wave + kbl;
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) = fh;
+                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) = fc;
+                uint4* o = out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4;
+                o[lane] = fh;
+                if constexpr (OUT_F16LO) o[kFragU4 + lane] = fl; else o[kFragU4 + lane] = fc;
+            }
+        }
+        stamp(4);
+    }
+}
+
+// Self-test of the split-f8 product: C[unit][row] = sum_k W[unit][k] X[row][k] over 32 k, W fragments packed by the host
+// (hi, corr of two k-blocks), X given in fp32 and packed on the device with pack_kb from an MFMA-C-layout register image.
+__global__ void corr_selftest_kernel(const uint4* __restrict__ wfrag /* [kb 2][hi|corr][64] */, const float* __restrict__ x /* [row 32][k 32] */,
+                                     float* __restrict__ c /* [unit 32][row 32] */, int scale_a, int with_corr) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 31, hh = lane >> 5;
+    uint4 xh[2], xc[2], dummy;
+#pragma unroll
+    for (int kbl = 0; kbl < 2; ++kbl) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = x[n * 32 + 16 * kbl + e + 4 * hh];
+            v[4 + e] = x[n * 32 + 16 * kbl + 8 + e + 4 * hh];
+        }
+        pack_kb<false>(v, xh[kbl], xc[kbl], dummy);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = mfma16(wfrag[(0 * 2 + 0) * 64 + lane], xh[0], acc);
+    acc = mfma16(wfrag[(1 * 2 + 0) * 64 + lane], xh[1], acc);
+    if (with_corr) acc = mfma_corr(wfrag[(0 * 2 + 1) * 64 + lane], wfrag[(1 * 2 + 1) * 64 + lane], xc[0], xc[1], acc, scale_a);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + n] = acc[r];
+}
+
+}  // namespace ccsm

@@ -39,9 +39,13 @@ typedef enum {
 
 /* Arithmetic of the contraction (matmul) work; everything else is fp32.
  * SPLIT3: every fp32 operand v carried as fp16 pair (hi, lo); products hi*hi + hi*lo + lo*hi accumulate in fp32
- *         on v_mfma_f32_32x32x16_f16 (fp32-class accuracy; the default, meets the 1e-4 probability bar by >10x).
- * SPLIT2: fp16-rounded weights, split activations (2 MFMA passes).   FP16: plain fp16 operands (1 pass). */
-typedef enum { CCSM_PRECISION_SPLIT3 = 3, CCSM_PRECISION_SPLIT2 = 2, CCSM_PRECISION_FP16 = 1 } ccsm_precision;
+ *         on v_mfma_f32_32x32x16_f16 (fp32-class accuracy: max |dprob| ~2e-7).
+ * SPLIT2: fp16-rounded weights, split activations (2 MFMA passes).   FP16: plain fp16 operands (1 pass).
+ * SPLIT_F8: hi*hi on the fp16 MFMA, the two correction products hi*lo + lo*hi with fp8 (e4m3) operands on the gfx950
+ *         block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) into the same fp32 accumulators: 2/3 of SPLIT3's MFMA
+ *         cycles, max |dprob| ~4e-6 on the parity suite, 25x inside the 1e-4 bar (GRU layers; the attention pool
+ *         stays SPLIT3).  The default. */
+typedef enum { CCSM_PRECISION_SPLIT_F8 = 4, CCSM_PRECISION_SPLIT3 = 3, CCSM_PRECISION_SPLIT2 = 2, CCSM_PRECISION_FP16 = 1 } ccsm_precision;
 
 /* Mirrors ModelAttRNN.__init__ (models.py:18-22) as called from call_modifications.py:315-323. */
 typedef struct {
@@ -54,7 +58,7 @@ typedef struct {
     int32_t is_map;      /* 0 */
     int32_t is_stds;     /* 0 */
     const char* model_type; /* "attbigru2s" */
-    int32_t precision;   /* ccsm_precision; 0 = default (SPLIT3) */
+    int32_t precision;   /* ccsm_precision; 0 = default (SPLIT_F8) */
 } ccsm_config;
 
 /* Host fp32 parameter tensors in the reference state_dict layout (models.py:32-61).
@@ -191,10 +195,15 @@ ccsm_status ccsm_workspace_timing_mean(ccsm_workspace* ws, float out_ms[5], int*
 ccsm_status ccsm_debug_read(ccsm_workspace* ws, int which, void* host_dst, size_t bytes);
 /* Padded strand-row count (2 * n_sites rounded up to the kernels' row tile) that lays out those buffers. */
 int ccsm_debug_rows_padded(int n_sites);
+/* Host-side OCP fp8 e4m3fn encoder used to pack the SPLIT_F8 weight fragments (round to nearest even, saturating). */
+int ccsm_debug_fp8_e4m3(float v);
 /* Row stride of the h0 buffer (= padded row capacity of the workspace). */
 int ccsm_debug_rows_capacity(const ccsm_workspace* ws);
 /* Runs one 32x32x16 MFMA tile with this library's fragment conventions against a host reference. */
 ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err);
+/* One 32x32x32 product in SPLIT_F8 arithmetic (host-packed weight fragments, device-packed activation fragments) against
+ * a float64 host reference: *err_corr with the fp8 correction MFMA, *err_main_only without it (fp16 operands only). */
+ccsm_status ccsm_selftest_split_f8(int device, float* err_corr, float* err_main_only);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Aggregate mode (`ccsmeth call_freqb --call_mode aggregate`, BASELINE config 5).

@@ -42,3 +42,33 @@ def test_errors_without_touching_the_gpu(libpath):
     assert lib.ccsm_create(ctypes.byref(cfg), ctypes.byref(w), 0, ctypes.byref(out)) == 2   # CCSM_ERR_UNSUPPORTED
     assert b"model_type" in lib.ccsm_last_error()
     assert lib.ccsm_group_pending(None) == 0 and lib.ccsm_debug_rows_padded(2048) == 4224
+
+
+def test_fp8_e4m3_host_encoder():
+    """The weight packer's fp8 (OCP e4m3fn) encoder: every finite code round-trips, halfway cases round to even, values
+    beyond the format saturate at +-448 (no NaN codes), tiny values flush to zero.  Host arithmetic only."""
+    import numpy as np
+    from ccsmeth_amd import _lib
+    lib = _lib.load()
+
+    def dec(c):
+        s, e, m = c >> 7, (c >> 3) & 15, c & 7
+        v = m * 2.0 ** -9 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 7)
+        return -v if s else v
+    vals = {}
+    for c in range(256):
+        if (c & 0x7f) == 0x7f:
+            continue                                        # NaN codes
+        v = dec(c)
+        got = lib.ccsm_debug_fp8_e4m3(v)
+        assert dec(got) == v and (got == c or v == 0.0)
+        vals[v] = c
+    pos = sorted(v for v in vals if v >= 0)
+    for lo, hi in zip(pos[:-1], pos[1:]):
+        mid = 0.5 * (lo + hi)
+        c = lib.ccsm_debug_fp8_e4m3(mid)
+        assert dec(c) in (lo, hi) and (c & 1) == 0          # ties to even mantissa
+        assert dec(lib.ccsm_debug_fp8_e4m3(np.nextafter(np.float32(mid), np.float32(hi)))) == hi
+        assert dec(lib.ccsm_debug_fp8_e4m3(np.nextafter(np.float32(mid), np.float32(lo)))) == lo
+    assert dec(lib.ccsm_debug_fp8_e4m3(1e9)) == 448.0 and dec(lib.ccsm_debug_fp8_e4m3(-500.0)) == -448.0
+    assert dec(lib.ccsm_debug_fp8_e4m3(1e-6)) == 0.0

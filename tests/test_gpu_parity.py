@@ -22,11 +22,13 @@ def lib():
     return _lib
 
 
-@pytest.fixture(scope="module")
-def model7():
+@pytest.fixture(scope="module", params=[0, 3], ids=["default-split-f8", "split3"])
+def model7(request):
+    """Every test on this fixture runs in the default arithmetic (CCSM_PRECISION_SPLIT_F8) and in the three-pass fp16 split."""
     from ccsmeth_amd.models import DeviceModel
     w = synth.synth_weights(7)
-    dm = DeviceModel(w, device=0)
+    dm = DeviceModel(w, device=0, precision=request.param)
+    assert dm.precision == (4 if request.param == 0 else 3)
     yield w, dm
     dm.close()
 
@@ -46,6 +48,13 @@ def test_mfma_fragment_convention(lib):
     err = C.c_float(1.0)
     lib.check(lib.load().ccsm_selftest_mfma(0, C.byref(err)))
     assert err.value < 1e-3
+
+
+def test_split_f8_product_selftest(lib):
+    """One 32x32x32 product in SPLIT_F8 arithmetic: the fp8 correction MFMA must remove most of the fp16 operand error."""
+    a, b = C.c_float(1.0), C.c_float(0.0)
+    lib.check(lib.load().ccsm_selftest_split_f8(0, C.byref(a), C.byref(b)))
+    assert a.value < 2e-5 and a.value < b.value / 8
 
 
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 100, 513])
@@ -72,12 +81,13 @@ def test_forward_vs_reference_goldens():
         w = synth.synth_weights(m["weight_seed"])
         s = synth.synth_sites(m["n"], m["site_seed"])
         h1, h2 = synth.synth_h0(m["n"], m["h0_seed"])
-        dm = DeviceModel(w, device=0)
-        ws = dm.workspace(m["n"])
-        logits, probs = _fwd(ws, s, (h1, h2))
-        dm.close()
-        assert np.abs(probs - fwd[name + "_probs"]).max() < PROB_TOL, name
-        assert np.abs(logits - fwd[name + "_logits"]).max() < LOGIT_TOL, name
+        for prec in (0, 3):
+            dm = DeviceModel(w, device=0, precision=prec)
+            ws = dm.workspace(m["n"])
+            logits, probs = _fwd(ws, s, (h1, h2))
+            dm.close()
+            assert np.abs(probs - fwd[name + "_probs"]).max() < PROB_TOL, (name, prec)
+            assert np.abs(logits - fwd[name + "_logits"]).max() < LOGIT_TOL, (name, prec)
 
 
 def test_input_layout_variants_agree(model7):
