@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libccsm.so")
+LIB_PATH = os.environ.get("CCSM_LIB_PATH") or os.path.join(_HERE, "lib", "libccsm.so")   # override: kernel experiments
 
 SEQ_LEN, HIDDEN, LAYERS, CLASSES = 21, 256, 3, 2
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = range(6)
