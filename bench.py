@@ -33,7 +33,8 @@ PEAK_HBM = 8.0e12
 # HBM/fabric bytes of ONE launch of the dominant kernel over 3 x 2048 sites, from rocprofv3 PMC passes on the same launch
 # shape (profiles/r01_c_pmc_coalesced.md: 2 x FETCH_SIZE + WRITE_SIZE, KiB, gfx950 read correction per MI355X_MICROARCH.md).
 # PMC counters cannot be read from inside this process; the figure is per-launch like `achieved` and scales with sites.
-TRAFFIC_BYTES_PER_SITE_GRU12 = {3: (2 * 1241546 + 516096) * 1024 / 6144.0}    # by --precision; unmeasured modes report null
+TRAFFIC_BYTES_PER_SITE_GRU12 = {3: (2 * 1241546 + 516096) * 1024 / 6144.0,      # profiles/r01_c_pmc_coalesced.md
+                                4: (2 * 1241600 + 516100) * 1024 / 6144.0}      # profiles/r01_e_pmc_coalesced.md; other modes: null
 
 
 def parse():
@@ -185,7 +186,7 @@ def main():
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
                          "traffic": TRAFFIC_BYTES_PER_SITE_GRU12.get(a.precision, 0) * sites_per_launch or None,
-                         "traffic_source": "profiles/r01_c_pmc_coalesced.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                         "traffic_source": "profiles/r01_%s_pmc_coalesced.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % ("e" if a.precision == 4 else "c"),
                          "launch_ms": dom_ms, "mfma_passes_per_flop": passes,
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,
                          "note": "achieved = algorithmic flops of one launch (%d sites x 99.09 MFLOP) / its HIP-event "

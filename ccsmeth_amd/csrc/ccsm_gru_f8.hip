@@ -190,20 +190,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         if constexpr (SPW > 2) *stage_dst(buf, 2) = sreg2;
     };
 
-    // L2 warm-up of the x chunk two chunks ahead: the staged loads run only one chunk (~3-5k cycles) ahead of their use,
-    // less than an HBM round trip under load; waves 0..2 each touch one dword per 128-B line of one batch tile's 8 KiB of
-    // that chunk, so the real staging loads one chunk later hit in L2.  Measured: -10 % step time (tools/gpu_phases.py).
-    uint32_t touch_v = 0, touch_sink = 0;
-    auto touch = [&](int t, int c) {
-        if constexpr (CK == 4) {
-            if (wave < NB) {
-                touch_sink += touch_v;                // consumes the previous touch (one chunk old: no stall)
-                const int soff = ((((tile0 + wave) * kSeqLen + t) * KX + c * CK) * 2) << 10;
-                touch_v = __builtin_amdgcn_raw_buffer_load_b32(xrs, lane * 128, soff, 0);
-            }
-        }
-    };
-
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4);
     const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
 
@@ -295,7 +281,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
             }
 #pragma unroll 1
             for (int c = 0; c < NCH; ++c) {
-                __syncthreads();                       // chunk c (buffer c&1) is in LDS; the other buffer is free
+                // chunk c (buffer c&1) is in LDS and the other buffer is free.  Chunk 0 was staged by the previous step's
+                // last phase-C chunk and is ordered by the barrier that follows phase C (before the tail), so a wave leaving
+                // the tail early starts its chunk-0 MFMAs while its SIMD partner is still in the vector-ALU-only tail.
+                if (c > 0 || s == 0) __syncthreads();
                 const int buf = c & 1;
                 const bool more = c + 1 < NCH;
 #define CCSM_PAIR_A(P)                                                                                         \
@@ -425,7 +414,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         const bool more = (C) + 1 < NCH;                                                                       \
         ldC(NXT, min((C) + 1, NCH - 1));                 /* a whole chunk ahead */                             \
         stage_load(more ? t : tn, more ? (C) + 1 : 0);   /* next C chunk / next step's first A chunk */        \
-        touch((C) + 2 < NCH ? t : tn, ((C) + 2) % NCH);                                                        \
         rdx(xh, buf, 0, 0);                                                                                    \
         CCSM_PAIR_C(CUR, 0)                                                                                    \
         CCSM_PAIR_C(CUR, 1)                                                                                    \
@@ -457,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
 #undef CCSM_MAIN
 #undef CCSM_FENCE
 
+        if constexpr (CK == 4) __syncthreads();       // next step's x chunk 0 is staged; every wave is done with this step's x
         stamp(3);
         if constexpr (CK != 4) {
 #pragma unroll
@@ -485,6 +474,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                     hn[4 * q + e] = (hp[e] - nn) * acc[1][bt][4 * q + e] + nn;
                 }
             }
+#if defined(CCSM_EXP) && CCSM_EXP == 5
+            if (bt == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(1); }   /* tail timing: blend of tile 0 done */
+#endif
 #pragma unroll
             for (int kbl = 0; kbl < 2; ++kbl) {
                 const float v[8] = {hn[8 * kbl + 0], hn[8 * kbl + 1], hn[8 * kbl + 2], hn[8 * kbl + 3],
@@ -498,10 +490,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                 o[lane] = fh;
                 if constexpr (OUT_F16LO) o[kFragU4 + lane] = fl; else o[kFragU4 + lane] = fc;
             }
+#if defined(CCSM_EXP) && CCSM_EXP == 5
+            if (bt == 0) stamp(2);                                                            /* pack + stores of tile 0 issued */
+#endif
         }
         stamp(4);
     }
-    if (touch_sink + touch_v == 0x9e3779b9u && dbg != nullptr) dbg[0] = touch_sink;   // keeps the touch loads alive
 }
 
 // Self-test of the split-f8 product: C[unit][row] = sum_k W[unit][k] X[row][k] over 32 k, W fragments packed by the host

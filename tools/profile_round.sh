@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round profile on the GPU box: bench.py plain and under rocprofv3 --kernel-trace --stats, then four --pmc passes over the
+# launch shape bench.py times (tools/gpu_group.py).  usage: tools/profile_round.sh <tag>   (outputs under gpurun_out/<tag>/)
+set -u
+TAG=${1:-r01_x}
+R=${GRAFT_REPO_ROOT:-$PWD}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py > $O/bench_under_rocprof.json 2> $O/rocprof.err
+cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  name=${pass%%:*}; ctrs=${pass#*:}
+  PREC=${PREC:-4} REPS=6 rocprofv3 --kernel-trace --output-format csv --pmc $ctrs -d /tmp/pmc/$name -- python $R/tools/gpu_group.py > /dev/null 2>> $O/pmc.err
+done
+python $R/tools/pmc_summary.py /tmp/pmc $O/pmc.md "$TAG PMC - coalesced launch (3 x 2048 sites = 256 workgroups), precision ${PREC:-4}"
+tail -1 $O/bench_plain.json
+head -8 $O/bench_kernel_stats.csv
