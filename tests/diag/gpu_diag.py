@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """GPU-box diagnostic: MFMA self-test, then a pinned-h0 forward compared with the NumPy oracle layer by layer.
-Prints (does not assert) so that one gpurun call localises a fault.  Usage: python tools/gpu_diag.py [n_sites] [precision]"""
+Prints (does not assert) so that one gpurun call localises a fault.  Usage: python tests/diag/gpu_diag.py [n_sites] [precision]"""
 import ctypes as C
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from ccsmeth_amd import _lib  # noqa: E402

@@ -1,7 +1,7 @@
 """split-f8 bring-up: selftest, parity vs NumPy oracle for a few sizes, per-kernel timing vs SPLIT3."""
 import ctypes as C, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from ccsmeth_amd import _lib
