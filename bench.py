@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the coalesced groups alternate over (2 overlaps launch tails: +3 % value, but the overlapped\n"
                          "launches then report inflated per-kernel durations; 1 keeps roofline.achieved = a solo launch)")
-    ap.add_argument("--coalesce", type=int, default=3, help="batches run per launch of the heavy kernels (micro-batching)")
+    ap.add_argument("--coalesce", type=int, default=6,
+                    help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
+                         "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds); 3 leaves the\n"
+                         "attention kernel a half-empty second round (+20 %% on its per-site time)")
     ap.add_argument("--precision", type=int, default=4, choices=(1, 2, 3, 4),
                     help="4 = split-f8 (default: fp16 main product + fp8 correction products, max |dprob| ~4e-6); 3 = split-fp16\n"
                          "x3 (fp32-class, ~2e-7); 2/1 = fewer passes, outside the parity margin, reported as such")
@@ -117,7 +120,8 @@ def main():
                           ("kmer1", "ipd1", "pw1", "npass1", "kmer2", "ipd2", "pw2", "npass2")))
     # Micro-batch coalescing (ccsm_group_*): every step binds its own 2048-site batch (own outputs, own initial states)
     # to a workspace; after `--coalesce` steps the heavy kernels run ONCE over those batches, so that one launch fills the
-    # chip (3 x 2048 sites = 256 workgroups of 96 strand rows = one per CU).  Workspaces alternate over `--streams` streams.
+    # chip (3 x 2048 sites = 256 workgroups of 96 strand rows = one per CU; the default 6 = two full rounds).  Workspaces
+    # alternate over `--streams` streams.
     nst = max(1, a.streams)
     grp = max(1, a.coalesce)
     wss = [dm.workspace(BATCH * grp) for _ in range(nst)]

@@ -826,6 +826,10 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
         }
     };
 
+    uint4 wu[CK][2];       // Ua fragments of the next chunk, requested one chunk ahead
+#pragma unroll
+    for (int kbl = 0; kbl < CK; ++kbl) { wu[kbl][0] = uap[(kbl * 2 + 0) * kFragU4]; wu[kbl][1] = uap[(kbl * 2 + 1) * kFragU4]; }
+
     for (int tg = 0; tg < kSeqLen / TG; ++tg) {
         const int t0 = tg * TG;
         f32x16 kacc[TG];
@@ -838,13 +842,26 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
         stage(t0, 0, 0);
 #pragma unroll 1
         for (int c = 0; c < NCHUNK; ++c) {
-            __syncthreads();   // chunk c has landed (the compiler drains vmcnt before the barrier); buffer (c+1)&1 is free
+            // Ua fragments of this chunk were requested a whole chunk ago (wu).  The next chunk's are requested right AFTER the
+            // barrier, next to the LDS-DMA staging of the next activation chunk: the compiler drains vmcnt(0) in front of every
+            // barrier (the DMA must have landed), so anything requested before it would be waited for on the spot.
+            uint4 w[CK][2];
+#pragma unroll
+            for (int kbl = 0; kbl < CK; ++kbl) { w[kbl][0] = wu[kbl][0]; w[kbl][1] = wu[kbl][1]; }
+            __syncthreads();   // chunk c has landed; buffer (c+1)&1 is free
             if (c + 1 < NCHUNK) stage(t0, c + 1, (c + 1) & 1);
+            {
+                const int cn = c + 1 < NCHUNK ? c + 1 : 0;       // Ua is re-streamed for every timestep group
+#pragma unroll
+                for (int kbl = 0; kbl < CK; ++kbl) {
+                    wu[kbl][0] = uap[((cn * CK + kbl) * 2 + 0) * kFragU4];
+                    wu[kbl][1] = uap[((cn * CK + kbl) * 2 + 1) * kFragU4];
+                }
+            }
             const char* sb = s_stage + (c & 1) * CHUNK_FRAGS * 1024 + lane * 16;
 #pragma unroll
             for (int kbl = 0; kbl < CK; ++kbl) {
                 const int kb = c * CK + kbl;
-                const uint4 w[2] = {uap[(kb * 2 + 0) * kFragU4], uap[(kb * 2 + 1) * kFragU4]};
                 const bool fc_owner = (kb & (kWaves - 1)) == wave;   // wave-uniform: each k-block's fc partial taken once
                 float fw[2][8];
                 if (fc_owner) {
@@ -857,7 +874,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
                 for (int tt = 0; tt < TG; ++tt) {
                     const uint4 x[2] = {*reinterpret_cast<const uint4*>(sb + ((kbl * TG + tt) * 2 + 0) * 1024),
                                         *reinterpret_cast<const uint4*>(sb + ((kbl * TG + tt) * 2 + 1) * 1024)};
-                    kacc[tt] = mma_split<NPASS>(w, x, kacc[tt]);
+                    kacc[tt] = mma_split<NPASS>(w[kbl], x, kacc[tt]);
                     if (fc_owner) {
                         const half8 xh = as_half8(x[0]), xl = as_half8(x[1]);
 #pragma unroll
