@@ -190,7 +190,8 @@ def main():
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
                          "traffic": TRAFFIC_BYTES_PER_SITE_GRU12.get(a.precision, 0) * sites_per_launch or None,
-                         "traffic_source": "profiles/r01_%s_pmc_coalesced.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" % ("e" if a.precision == 4 else "c"),
+                         "traffic_source": "profiles/r01_%s_pmc_coalesced.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on a 6144-site launch, "
+                                           "scaled per site)" % ("e" if a.precision == 4 else "c"),
                          "launch_ms": dom_ms, "mfma_passes_per_flop": passes,
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,
                          "note": "achieved = algorithmic flops of one launch (%d sites x 99.09 MFLOP) / its HIP-event "
