@@ -53,27 +53,46 @@ __device__ __forceinline__ void swap32(uint32_t& x, uint32_t& y) {   // lanes 32
     x = r[0];
     y = r[1];
 }
+typedef short short2v __attribute__((ext_vector_type(2)));
+// v_cvt_scalef32_pk_fp8_{f16,f32}: dst = fp8(src / scale) (measured, tools/ubench: scale 2^-6 -> x 64), i.e. the operand
+// pre-scale costs no multiply.  `seed` only supplies the register whose other half the first conversion leaves in place.
+__device__ __forceinline__ uint32_t cvt4_fp8_h(uint32_t h01, uint32_t h23) {          // four fp16 (two packed pairs) * 2^6
+    short2v r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(__builtin_bit_cast(short2v, h01), __builtin_bit_cast(half2v, h01),
+                                                         1.0f / kCorrActHi, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(half2v, h23), 1.0f / kCorrActHi, true);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t cvt4_fp8_l(uint32_t seed, float a, float b, float c, float d) {   // four fp32 * 2^17
+    short2v r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(short2v, seed), a, b, 1.0f / kCorrActLo, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, 1.0f / kCorrActLo, true);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float tanh_fold(float x) {    // 1 - 2 / (e^{2x} + 1) with the doubling folded into the exp2 constant
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f);
+}
 
 // Eight MFMA-C-layout values of one k-block held by lane (n, hh): v[0..3] = units e + 4hh, v[4..7] = units 8 + e + 4hh of
 // batch row n.  Produces this lane's 16 bytes of the k-block's hi fragment, corr fragment and (WITH_LO) fp16 lo fragment.
 template <bool WITH_LO>
 __device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint4& co_out, uint4& lo_out) {
-    _Float16 h[8];
-    float hf[8], lf[8];
+    typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+    uint32_t hp[4];
+    float lf[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h[j] = (_Float16)v[j];
-        hf[j] = (float)h[j];
-        lf[j] = v[j] - hf[j];
+    for (int j = 0; j < 8; j += 2) {
+        const half2p h = {(_Float16)v[j], (_Float16)v[j + 1]};
+        hp[j >> 1] = __builtin_bit_cast(uint32_t, h);
+        lf[j] = v[j] - (float)h[0];
+        lf[j + 1] = v[j + 1] - (float)h[1];
     }
-    uint32_t a0 = pack2(h[0], h[1]), a1 = pack2(h[2], h[3]), b0 = pack2(h[4], h[5]), b1 = pack2(h[6], h[7]);
+    uint32_t h0 = cvt4_fp8_h(hp[0], hp[1]);
+    uint32_t h1 = cvt4_fp8_h(hp[2], hp[3]);
+    uint32_t l0 = cvt4_fp8_l(hp[0], lf[0], lf[1], lf[2], lf[3]);
+    uint32_t l1 = cvt4_fp8_l(hp[2], lf[4], lf[5], lf[6], lf[7]);
+    uint32_t a0 = hp[0], a1 = hp[1], b0 = hp[2], b1 = hp[3];
     swap32(a0, b0);
     swap32(a1, b1);
     hi_out = make_uint4(a0, a1, b0, b1);
-    uint32_t h0 = cvt4_fp8(hf[0] * kCorrActHi, hf[1] * kCorrActHi, hf[2] * kCorrActHi, hf[3] * kCorrActHi);
-    uint32_t h1 = cvt4_fp8(hf[4] * kCorrActHi, hf[5] * kCorrActHi, hf[6] * kCorrActHi, hf[7] * kCorrActHi);
-    uint32_t l0 = cvt4_fp8(lf[0] * kCorrActLo, lf[1] * kCorrActLo, lf[2] * kCorrActLo, lf[3] * kCorrActLo);
-    uint32_t l1 = cvt4_fp8(lf[4] * kCorrActLo, lf[5] * kCorrActLo, lf[6] * kCorrActLo, lf[7] * kCorrActLo);
     swap32(h0, l0);   // lower lanes: (own hi, partner's hi) ; upper lanes: (partner's lo, own lo)
     swap32(h1, l1);
     co_out = make_uint4(h0, h1, l0, l1);
@@ -470,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                                      (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo4, 3) * (1.0f / kCorrActLo)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float nn = tanh_f(acc[2][bt][4 * q + e]);
+                    const float nn = tanh_fold(acc[2][bt][4 * q + e]);
                     hn[4 * q + e] = (hp[e] - nn) * acc[1][bt][4 * q + e] + nn;
                 }
             }
