@@ -215,6 +215,64 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
     stage_load(dir ? kSeqLen - 1 : 0, 0);
     stage_store(0);
 
+#if defined(CCSM_EXP) && (CCSM_EXP == 3 || CCSM_EXP == 4)
+    auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, (frag & 3) << 10); };   // timing experiment: L1-resident weights
+#elif defined(CCSM_EXP) && CCSM_EXP == 6
+    auto w_at = [&](int frag) -> uint4 {      // timing experiment: same instruction count and addresses, half the bytes
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(wrs, lane16, frag << 10, 0);
+        return make_uint4(v[0], v[1], v[0], v[1]);
+    };
+#else
+    auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, frag << 10); };
+#endif
+    // Weight registers.  Every phase's FIRST fragments are requested while the previous phase still has MFMAs to issue (in the
+    // slots whose "two ahead" reload would run past the end of that phase), so no phase starts behind an exposed L2 round trip:
+    //   phase A pair 0  <- last chunk of phase C (previous step)      phase A pair 1 <- start of the tail (previous step)
+    //   phase B pair 0  <- last chunk of phase A                      phase C chunk 0 <- last pair of phase B
+    uint4 wah[2][2][2], wac[2][2][2];             // phase A ring of two pairs: [pair slot][kb in pair][gate] main / corr
+    uint4 wbh[2][3], wbc[2][3];                   // phase B resident pair: [kb in pair][gate]
+    uint4 wch[2][4], wcc[2][4];                   // phase C, n gate: [chunk parity][kb in chunk]
+    auto ldAh = [&](uint4 (&d)[2], int kb) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) d[g] = w_at(kb * FA + g * 2);
+    };
+    auto ldAc = [&](uint4 (&d)[2], int kb) {      // KX == 1: the fp16 lo fragments
+#pragma unroll
+        for (int g = 0; g < 2; ++g) d[g] = w_at(kb * FA + g * 2 + 1);
+    };
+    auto ldBh = [&](uint4 (&d)[3], int kb) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) d[g] = w_at(OFF_B + kb * FB + g * 2);
+    };
+    auto ldBc = [&](uint4 (&d)[3], int kb) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) d[g] = w_at(OFF_B + kb * FB + g * 2 + 1);
+    };
+    auto ldC = [&](int par, int c) {              // the n-gate fragments of a whole chunk
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            wch[par][j] = w_at(OFF_C + (c * CK + j) * FC);
+            wcc[par][j] = w_at(OFF_C + (c * CK + j) * FC + 1);
+        }
+    };
+    auto ldA_pair = [&](int p) {
+        ldAh(wah[p][0], 2 * p); ldAh(wah[p][1], 2 * p + 1);
+        ldAc(wac[p][0], 2 * p); ldAc(wac[p][1], 2 * p + 1);
+    };
+    auto ldB_first = [&]() {
+        ldBh(wbh[0], 0); ldBh(wbh[1], 1);
+        ldBc(wbc[0], 0); ldBc(wbc[1], 1);
+    };
+    if constexpr (CK == 4) {
+        ldA_pair(0);
+        ldA_pair(1);
+    } else {
+        ldAh(wah[0][0], 0);
+        ldAc(wac[0][0], 0);
+        ldB_first();
+    }
+
     for (int s = 0; s < kSeqLen; ++s) {
         const int t = dir ? (kSeqLen - 1 - s) : s;
         auto stamp = [&](int k) {
@@ -240,11 +298,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
             for (int bt = 0; bt < NB; ++bt) { acc[0][bt] = b0; acc[1][bt] = b1; }
         }
 
-#if defined(CCSM_EXP) && (CCSM_EXP == 3 || CCSM_EXP == 4)
-        auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, (frag & 3) << 10); };   // timing experiment: L1-resident weights
-#else
-        auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, frag << 10); };
-#endif
         uint4 xh[NB], xh1[NB], xc[2][NB];             // main fragments of two k-blocks, corr fragments of a pair
         auto rdx = [&](uint4 (&x)[NB], int buf, int kbl, int f) {
 #pragma unroll
@@ -272,72 +325,53 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         CCSM_FENCE;                                                                                           \
     } while (0)
 
-        uint4 wbh[2][3], wbc[2][3];                   // phase B: main / corr fragments of the resident pair [kb in pair][gate]
-        auto ldBh = [&](uint4 (&d)[3], int kb) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) d[g] = w_at(OFF_B + kb * FB + g * 2);
-        };
-        auto ldBc = [&](uint4 (&d)[3], int kb) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) d[g] = w_at(OFF_B + kb * FB + g * 2 + 1);
-        };
-
         // ---------------- phase A: R, Z += W_i{r,z} x_t -------------------------------------------------------------
         if constexpr (CK == 4) {
-            uint4 wah[2][2][2], wac[2][2][2];         // ring of two pairs: [pair slot][kb in pair][gate]
-            auto ldAh = [&](uint4 (&d)[2], int kb) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g) d[g] = w_at(kb * FA + g * 2);
-            };
-            auto ldAc = [&](uint4 (&d)[2], int kb) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g) d[g] = w_at(kb * FA + g * 2 + 1);
-            };
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                ldAh(wah[p][0], 2 * p); ldAh(wah[p][1], 2 * p + 1);
-                ldAc(wac[p][0], 2 * p); ldAc(wac[p][1], 2 * p + 1);
-            }
+            // one pair of one chunk; L1 / L2 / L3 = the weight requests issued after the pair's three MFMA groups; every LDS
+            // read is issued one MFMA group ahead of its use (xh / xh1 / xc are three register sets)
+#define CCSM_PAIR_A(P, L1, L2, L3)                                                                             \
+    {                                                                                                          \
+        rdx(xh1, buf, 2 * (P) + 1, 0);                                                                         \
+        CCSM_MAIN(wah[P][0], xh, 2, 0);                                                                        \
+        L1;                                                                                                    \
+        if ((P) == 0) stage_load(t, more ? c + 1 : 0);        /* after the weight prefetch: younger in vmcnt */ \
+        rdx(xc[0], buf, 2 * (P), 1);                                                                           \
+        rdx(xc[1], buf, 2 * (P) + 1, 1);                                                                       \
+        CCSM_MAIN(wah[P][1], xh1, 2, 0);                                                                       \
+        L2;                                                                                                    \
+        if ((P) == 0) rdx(xh, buf, 2, 0);                     /* the chunk's second pair */                    \
+        CCSM_CORR(wac[P][0], wac[P][1], xc, 2, 0, sa_x);                                                       \
+        L3;                                                                                                    \
+    }
 #pragma unroll 1
-            for (int c = 0; c < NCH; ++c) {
+            for (int c = 0; c < NCH - 1; ++c) {
                 // chunk c (buffer c&1) is in LDS and the other buffer is free.  Chunk 0 was staged by the previous step's
                 // last phase-C chunk and is ordered by the barrier that follows phase C (before the tail), so a wave leaving
                 // the tail early starts its chunk-0 MFMAs while its SIMD partner is still in the vector-ALU-only tail.
                 if (c > 0 || s == 0) __syncthreads();
                 const int buf = c & 1;
-                const bool more = c + 1 < NCH;
-#define CCSM_PAIR_A(P)                                                                                         \
-    {   /* every LDS read is issued one MFMA group ahead of its use (xh / xh1 / xc are three register sets) */ \
-        const int k0 = min(4 * c + 2 * (P) + 4, KX - 2);      /* first k-block of the pair two pairs ahead */  \
-        rdx(xh1, buf, 2 * (P) + 1, 0);                                                                         \
-        CCSM_MAIN(wah[P][0], xh, 2, 0);                                                                        \
-        ldAh(wah[P][0], k0);                                                                                   \
-        if ((P) == 0) stage_load(t, more ? c + 1 : 0);        /* after the weight prefetch: younger in vmcnt */ \
-        rdx(xc[0], buf, 2 * (P), 1);                                                                           \
-        rdx(xc[1], buf, 2 * (P) + 1, 1);                                                                       \
-        CCSM_MAIN(wah[P][1], xh1, 2, 0);                                                                       \
-        ldAh(wah[P][1], k0 + 1);                                                                               \
-        if ((P) == 0) rdx(xh, buf, 2, 0);                     /* the chunk's second pair */                    \
-        CCSM_CORR(wac[P][0], wac[P][1], xc, 2, 0, sa_x);                                                       \
-        ldAc(wac[P][0], k0);                                                                                   \
-        ldAc(wac[P][1], k0 + 1);                                                                               \
-    }
+                const bool more = true;
+                const int k0 = 4 * c + 4;                      // first k-block of the pair two pairs ahead of pair 0
                 rdx(xh, buf, 0, 0);
-                CCSM_PAIR_A(0)
-                CCSM_PAIR_A(1)
-#undef CCSM_PAIR_A
-                stage_store((c + 1) & 1);              // next A chunk, or C chunk 0 into buffer NCH & 1 == 0
+                CCSM_PAIR_A(0, ldAh(wah[0][0], k0), ldAh(wah[0][1], k0 + 1), { ldAc(wac[0][0], k0); ldAc(wac[0][1], k0 + 1); })
+                CCSM_PAIR_A(1, ldAh(wah[1][0], k0 + 2), ldAh(wah[1][1], k0 + 3), { ldAc(wac[1][0], k0 + 2); ldAc(wac[1][1], k0 + 3); })
+                stage_store((c + 1) & 1);
             }
-            ldBh(wbh[0], 0); ldBh(wbh[1], 1);
-            ldBc(wbc[0], 0); ldBc(wbc[1], 1);
+            {   // last chunk: its ring slots are refilled with phase B's first pair instead of fragments past the end
+                constexpr int c = NCH - 1;
+                __syncthreads();
+                const int buf = c & 1;
+                const bool more = false;
+                rdx(xh, buf, 0, 0);
+                CCSM_PAIR_A(0, (void)0, (void)0, { ldBh(wbh[0], 0); ldBh(wbh[1], 1); })
+                CCSM_PAIR_A(1, ldBc(wbc[0], 0), ldBc(wbc[1], 1), (void)0)
+                stage_store((c + 1) & 1);                      // C chunk 0 into buffer NCH & 1 == 0
+            }
+#undef CCSM_PAIR_A
         } else {
             // layer 0: one k-block (11 features padded to 16), three fp16 passes, [hi|lo] fragments on both sides
-            uint4 w0[2][2], x0[NB][2];
+            uint4 x0[NB][2];
             __syncthreads();
-#pragma unroll
-            for (int g = 0; g < 2; ++g) { w0[g][0] = w_at(g * 2); w0[g][1] = w_at(g * 2 + 1); }
-            ldBh(wbh[0], 0); ldBh(wbh[1], 1);
-            ldBc(wbc[0], 0); ldBc(wbc[1], 1);
             stage_load(tn, 0);
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
@@ -349,9 +383,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
             for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    acc[g][bt] = mfma16(w0[g][0], x0[bt][0], acc[g][bt]);
-                    acc[g][bt] = mfma16(w0[g][0], x0[bt][1], acc[g][bt]);
-                    acc[g][bt] = mfma16(w0[g][1], x0[bt][0], acc[g][bt]);
+                    acc[g][bt] = mfma16(wah[0][0][g], x0[bt][0], acc[g][bt]);
+                    acc[g][bt] = mfma16(wah[0][0][g], x0[bt][1], acc[g][bt]);
+                    acc[g][bt] = mfma16(wac[0][0][g], x0[bt][0], acc[g][bt]);
                 }
             CCSM_FENCE;
             stage_store((s + 1) & 1);
@@ -364,31 +398,33 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
         }
+#define CCSM_PAIR_B(KB, L1, L2, L3)                                                                            \
+    {                                                                                                          \
+        rdh(xh, KB, 0);                                                                                        \
+        rdh(xc[0], KB, 1);                                                                                     \
+        rdh(xc[1], (KB) + 1, 1);                                                                               \
+        CCSM_MAIN(wbh[0], xh, 3, 0);                                                                           \
+        L1;                                                                                                    \
+        rdh(xh, (KB) + 1, 0);                                                                                  \
+        CCSM_MAIN(wbh[1], xh, 3, 0);                                                                           \
+        L2;                                                                                                    \
+        CCSM_CORR(wbc[0], wbc[1], xc, 3, 0, sa_h);                                                             \
+        L3;                                                                                                    \
+    }
 #pragma unroll 1
-        for (int kb = 0; kb < kKBH; kb += 2) {
-            const int kn = min(kb + 2, kKBH - 2);
-            rdh(xh, kb, 0);
-            rdh(xc[0], kb, 1);
-            rdh(xc[1], kb + 1, 1);
-            CCSM_MAIN(wbh[0], xh, 3, 0);
-            ldBh(wbh[0], kn);
-            rdh(xh, kb + 1, 0);
-            CCSM_MAIN(wbh[1], xh, 3, 0);
-            ldBh(wbh[1], kn + 1);
-            CCSM_CORR(wbc[0], wbc[1], xc, 3, 0, sa_h);
-            ldBc(wbc[0], kn);
-            ldBc(wbc[1], kn + 1);
+        for (int kb = 0; kb < kKBH - 2; kb += 2)
+            CCSM_PAIR_B(kb, ldBh(wbh[0], kb + 2), ldBh(wbh[1], kb + 3), { ldBc(wbc[0], kb + 2); ldBc(wbc[1], kb + 3); })
+        // last pair: its registers are refilled with phase C's first chunk of n-gate fragments
+        if constexpr (CK == 4) {
+            CCSM_PAIR_B(kKBH - 2, { wch[0][0] = w_at(OFF_C + 0 * FC); wch[0][1] = w_at(OFF_C + 1 * FC); },
+                        { wch[0][2] = w_at(OFF_C + 2 * FC); wch[0][3] = w_at(OFF_C + 3 * FC); },
+                        { wcc[0][0] = w_at(OFF_C + 0 * FC + 1); wcc[0][1] = w_at(OFF_C + 1 * FC + 1);
+                          wcc[0][2] = w_at(OFF_C + 2 * FC + 1); wcc[0][3] = w_at(OFF_C + 3 * FC + 1); })
+        } else {
+            CCSM_PAIR_B(kKBH - 2, wch[0][0] = w_at(OFF_C), wcc[0][0] = w_at(OFF_C + 1), (void)0)
         }
+#undef CCSM_PAIR_B
         // r = sigmoid(R) ; N = b_in + r * N
-        uint4 wch[2][4], wcc[2][4];                   // phase C: n-gate fragments of two chunks [chunk parity][kb in chunk]
-        auto ldC = [&](int par, int c) {
-#pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                wch[par][j] = w_at(OFF_C + (c * CK + j) * FC);
-                wcc[par][j] = w_at(OFF_C + (c * CK + j) * FC + 1);
-            }
-        };
-        ldC(0, 0);
         {
             const f32x16 b2 = bias_set(2);
 #pragma unroll
@@ -407,8 +443,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         stamp(2);
         // ---------------- phase C: N += W_in x_t ----------------------------------------------------------------------
         if constexpr (CK == 4) {
-#pragma unroll 1
-            for (int c2 = 0; c2 < NCH; c2 += 2) {
 #define CCSM_PAIR_C(CUR, P)                                                                                    \
     {                                                                                                          \
         rdx(xh1, buf, 2 * (P) + 1, 0);                                                                         \
@@ -426,24 +460,30 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
             acc[2][bt] = mfma_corr(wcc[CUR][2 * (P)], wcc[CUR][2 * (P) + 1], xc[0][bt], xc[1][bt], acc[2][bt], sa_x); \
         CCSM_FENCE;                                                                                            \
     }
-#define CCSM_CHUNK_C(C, CUR, NXT)                                                                              \
+            // one chunk; LNEXT = the weight request for what comes after it (a whole chunk ahead)
+#define CCSM_CHUNK_C(C, CUR, LNEXT)                                                                            \
     {                                                                                                          \
         __syncthreads();                                                                                       \
         const int buf = (C) & 1;                                                                               \
         const bool more = (C) + 1 < NCH;                                                                       \
-        ldC(NXT, min((C) + 1, NCH - 1));                 /* a whole chunk ahead */                             \
+        LNEXT;                                                                                                 \
         stage_load(more ? t : tn, more ? (C) + 1 : 0);   /* next C chunk / next step's first A chunk */        \
         rdx(xh, buf, 0, 0);                                                                                    \
         CCSM_PAIR_C(CUR, 0)                                                                                    \
         CCSM_PAIR_C(CUR, 1)                                                                                    \
         stage_store(((C) + 1) & 1);                                                                            \
     }
-                CCSM_CHUNK_C(c2, 0, 1)
-                if (c2 == 0) zwork(0); else if (c2 == 2) zwork(1); else if (c2 == 4) zwork(2);
-                CCSM_CHUNK_C(c2 + 1, 1, 0)
+#pragma unroll 1
+            for (int c2 = 0; c2 < NCH - 2; c2 += 2) {
+                CCSM_CHUNK_C(c2, 0, ldC(1, c2 + 1))
+                if (c2 == 0) zwork(0); else if (c2 == 2) zwork(1); else zwork(2);
+                CCSM_CHUNK_C(c2 + 1, 1, ldC(0, c2 + 2))
+            }
+            static_assert(NCH == 8 || CK != 4, "zwork schedule assumes three loop iterations");
+            CCSM_CHUNK_C(NCH - 2, 0, ldC(1, NCH - 1))
+            CCSM_CHUNK_C(NCH - 1, 1, ldA_pair(0))            // the next step's first phase-A pair
 #undef CCSM_CHUNK_C
 #undef CCSM_PAIR_C
-            }
         } else {
             uint4 x0[NB][2];
 #pragma unroll
@@ -462,10 +502,19 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         }
 #undef CCSM_CORR
 #undef CCSM_MAIN
-#undef CCSM_FENCE
 
         if constexpr (CK == 4) __syncthreads();       // next step's x chunk 0 is staged; every wave is done with this step's x
         stamp(3);
+        // the rest of the next step's first weight fragments: in flight during the tail
+        if constexpr (CK == 4) {
+            ldA_pair(1);
+        } else {
+            ldAh(wah[0][0], 0);
+            ldAc(wac[0][0], 0);
+            ldB_first();
+        }
+        CCSM_FENCE;
+#undef CCSM_FENCE
         if constexpr (CK != 4) {
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) zwork(bt);
