@@ -65,6 +65,9 @@ struct ccsm_model {
     uint4* wst2[kLayers] = {nullptr, nullptr, nullptr}; // v2: [dir][wave][A: KX x (r,z) | B: 16 x (r,z,n) | C: KX x (n)][hl][64]
     uint4* wst3[kLayers] = {nullptr, nullptr, nullptr}; // split-f8: as wst2 with the second fragment of a k-block = fp8 corr
     int4 wscale[kLayers] = {};                           // E8M0 scales of the corr weight operands (x-part/h-part per dir)
+    uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
+    uint4* ua3 = nullptr;
+    int att_scale[2] = {127, 127};                       // E8M0 scales of the Wa / Ua corr operands
     float* bias[kLayers] = {nullptr, nullptr, nullptr};  // [dir][wave][4][hh][16]
     uint4* wa = nullptr;                                 // [wave][32][hl][64]
     uint4* ua = nullptr;
@@ -292,6 +295,18 @@ void pack_att(const float* w, std::vector<_Float16>& out) {
             }
 }
 
+// Split-f8 attention projection: pack_att's hi fragments with the second fragment of every k-block = its corr fragment
+void pack_att_v3(const float* w, std::vector<_Float16>& out, int& scale) {
+    pack_att(w, out);
+    const int lg = corr_scale_log2(w, (size_t)kAttHidden * 2 * kHidden);
+    scale = 127 - 11 - lg;
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(out.data());
+    for (int wave = 0; wave < kWaves; ++wave)
+        for (int kb = 0; kb < kKB12; ++kb)
+            emit_corr_frag(bytes + (((size_t)wave * kKB12 + kb) * 2 + 1) * 1024, kb, lg,
+                           [&](int i, int k) { return w[(size_t)(kUnitTile * wave + i) * 2 * kHidden + k]; });
+}
+
 template <typename T>
 ccsm_status upload(T** dst, const void* src, size_t bytes) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), bytes));
@@ -325,14 +340,20 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     const size_t slab = (size_t)2 * ws->rows_p * kHidden;  // floats per layer (two directions)
     if constexpr (F8) {
         const dim3 ggrid(2 * (tiles / kNBGru2));
+        static const int dbg_layer = std::getenv("CCSM_PHASE_LAYER") ? std::atoi(std::getenv("CCSM_PHASE_LAYER")) : 1;
         hipLaunchKernelGGL((gru_layer_f8_kernel<kKB0, false>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
-                           m->wst3[0], m->bias[0], ws->h0buf, ws->rows_p, m->wscale[0], nullptr);
+                           m->wst3[0], m->bias[0], ws->h0buf, ws->rows_p, m->wscale[0], dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
         hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, false>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
-                           m->wst3[1], m->bias[1], ws->h0buf + slab, ws->rows_p, m->wscale[1], ws->dbg);
+                           m->wst3[1], m->bias[1], ws->h0buf + slab, ws->rows_p, m->wscale[1], dbg_layer == 1 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-        hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, true>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
-                           m->wst3[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, m->wscale[2], nullptr);
+        static const bool att_f16 = std::getenv("CCSM_ATTN_SPLIT3") != nullptr;   // A/B switch: fp16-split attention pool
+        if (att_f16)
+            hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, true>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
+                               m->wst3[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, m->wscale[2], dbg_layer == 2 ? ws->dbg : nullptr);
+        else
+            hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, false>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
+                               m->wst3[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, m->wscale[2], dbg_layer == 2 ? ws->dbg : nullptr);
     } else if (m->gru_version == 1) {
         const size_t lds = (size_t)kKBH * kNBGru * 2 * 1024;
         const dim3 ggrid(2 * (tiles / kNBGru));
@@ -362,8 +383,12 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         tab.row_base[i] = i < ws->n_slices ? ws->slice_row[i] : 0;
         tab.n_sites[i] = i < ws->n_slices ? ws->slice_n[i] : 0;
     }
-    hipLaunchKernelGGL((attn_fc_kernel<NPASS>), dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
-                       ws->part, tab);
+    if (F8 && std::getenv("CCSM_ATTN_SPLIT3") == nullptr)
+        hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fcw,
+                           ws->part, tab, m->att_scale[0], m->att_scale[1]);
+    else
+        hipLaunchKernelGGL((attn_fc_kernel<NPASS>), dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
+                           ws->part, tab);
     if (tm) HIP_TRY(hipEventRecord(ws->ev[5], st));
     for (int i = 0; i < ws->n_slices; ++i)
         hipLaunchKernelGGL(finalize_kernel, dim3((ws->slice_n[i] + 255) / 256), dim3(256), 0, st, ws->part, m->fcb,
@@ -485,6 +510,8 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     }
     if (st == CCSM_OK) { pack_att(w->att_wa, hbuf); st = upload(&m->wa, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
     if (st == CCSM_OK) { pack_att(w->att_ua, hbuf); st = upload(&m->ua, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
+    if (st == CCSM_OK && prec == 4) { pack_att_v3(w->att_wa, hbuf, m->att_scale[0]); st = upload(&m->wa3, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
+    if (st == CCSM_OK && prec == 4) { pack_att_v3(w->att_ua, hbuf, m->att_scale[1]); st = upload(&m->ua3, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
     if (st == CCSM_OK) {
         fbuf.assign((size_t)kWaves * 2 * 16, 0.f);
         for (int wave = 0; wave < kWaves; ++wave)
@@ -520,6 +547,8 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, true>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fc_f8_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kAttLds);
         }
 #define CCSM_SET_ALDS(NP)                                                                                   \
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fc_kernel<NP>),         \
@@ -546,6 +575,7 @@ void ccsm_destroy(ccsm_model* m) {
         (void)hipFree(m->bias[l]);
     }
     (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);
+    (void)hipFree(m->wa3); (void)hipFree(m->ua3);
     (void)hipFree(m->fcw); (void)hipFree(m->fcb); (void)hipFree(m->embed);
     delete m;
 }

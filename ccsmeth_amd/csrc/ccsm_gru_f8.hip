@@ -566,6 +566,200 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Attention pool + FC partials in split-f8 arithmetic: attn_fc_kernel (ccsm_kernels.hip) with the activation and the
+// Wa / Ua fragments in [hi | corr] form.  One staged chunk (2 k-blocks) is exactly one pair: per timestep two main MFMAs and
+// one K = 64 corr MFMA instead of six fp16 MFMAs.  The fc1 partial dot products need the activations themselves: hi from the
+// main fragment in registers, the fp8 residual from the staged corr fragment (lane (n, 1), kCorrPerm order).
+//   wa / ua : [wave][kb 32][hi|corr][64] uint4 ; sa_wa / sa_ua : E8M0 scales of their corr operands
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
+                                                             const uint4* __restrict__ ua, const float* __restrict__ va,
+                                                             const float* __restrict__ fcw, float* __restrict__ part,
+                                                             SliceTable slices, int sa_wa, int sa_ua) {
+    constexpr int TG = 7;                      // timesteps per Ua pass (21 = 3 * 7)
+    constexpr int CK = 2;                      // k-blocks per staged chunk = one pair
+    constexpr int NCHUNK = kKB12 / CK;
+    constexpr int CHUNK_FRAGS = CK * TG * 2;   // 28 fragments of 1 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_stage = smem;                                                     // [2][CK][TG][hi|corr] fragments
+    float* s_epart = reinterpret_cast<float*>(smem + 2 * CHUNK_FRAGS * 1024);  // [wave][t][32]
+    float* s_pfc = s_epart + kWaves * kSeqLen * 32;                            // [wave][t][32][2]
+    float* s_fcw = s_pfc + kWaves * kSeqLen * 32 * 2;                          // [2][1024]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x;
+    const int n = lane & 31, hh = lane >> 5;
+
+    for (int i = threadIdx.x; i < kClasses * 4 * kHidden; i += blockDim.x) s_fcw[i] = fcw[i];
+
+    const uint4* wap = wa + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
+    const uint4* uap = ua + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
+    const uint4* otile = out2 + (size_t)tile * kSeqLen * kKB12 * 2 * kFragU4;   // [t][kb][hi|corr][64]
+
+    // ---- q = Wa h_n, h_n = [fwd final state = out[t=L-1][0:256] | bwd final state = out[t=0][256:512]] (models.py:135-137)
+    f32x16 qacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
+#pragma unroll 2
+    for (int kb = 0; kb < kKB12; kb += 2) {
+        const int tq = kb < kKBH ? kSeqLen - 1 : 0;
+        const uint4* xp = otile + ((size_t)tq * kKB12 + kb) * 2 * kFragU4 + lane;
+        const uint4 w0h = wap[(kb * 2 + 0) * kFragU4], w0c = wap[(kb * 2 + 1) * kFragU4];
+        const uint4 w1h = wap[(kb * 2 + 2) * kFragU4], w1c = wap[(kb * 2 + 3) * kFragU4];
+        const uint4 x0h = xp[0], x0c = xp[kFragU4], x1h = xp[2 * kFragU4], x1c = xp[3 * kFragU4];
+        qacc = mfma16(w0h, x0h, qacc);
+        qacc = mfma16(w1h, x1h, qacc);
+        qacc = mfma_corr(w0c, w1c, x0c, x1c, qacc, sa_wa);
+    }
+    float vav[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vav[r] = va[(wave * 2 + hh) * 16 + r];
+    int strand = 0;   // which half of fc1.weight this lane's row multiplies: strand 2 rows are the upper half of a slice
+    {
+        const int row = tile * 32 + n;
+        for (int i = 0; i < slices.count; ++i)
+            if (row >= slices.row_base[i] && row < slices.row_base[i] + 2 * slices.n_sites[i])
+                strand = (row - slices.row_base[i]) >= slices.n_sites[i];
+    }
+
+    // stage chunk `c` of timestep group t0 into buffer `buf`: fragment f = (kbl * TG + tt) * 2 + hl
+    auto stage = [&](int t0, int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < (CHUNK_FRAGS + kWaves - 1) / kWaves; ++i) {
+            const int f = wave + kWaves * i;
+            if (f < CHUNK_FRAGS) {
+                const int hl = f & 1, tt = (f >> 1) % TG, kbl = (f >> 1) / TG;
+                const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    uint4 wu[CK][2];       // Ua fragments of the next chunk, requested one chunk ahead
+#pragma unroll
+    for (int kbl = 0; kbl < CK; ++kbl) { wu[kbl][0] = uap[(kbl * 2 + 0) * kFragU4]; wu[kbl][1] = uap[(kbl * 2 + 1) * kFragU4]; }
+
+    for (int tg = 0; tg < kSeqLen / TG; ++tg) {
+        const int t0 = tg * TG;
+        f32x16 kacc[TG];
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) kacc[tt] = qacc;     // accumulate K_t on top of q
+        float pf[TG][2];
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) pf[tt][0] = pf[tt][1] = 0.f;
+
+        stage(t0, 0, 0);
+#pragma unroll 1
+        for (int c = 0; c < NCHUNK; ++c) {
+            uint4 w[CK][2];
+#pragma unroll
+            for (int kbl = 0; kbl < CK; ++kbl) { w[kbl][0] = wu[kbl][0]; w[kbl][1] = wu[kbl][1]; }
+            __syncthreads();   // chunk c has landed; buffer (c+1)&1 is free
+            if (c + 1 < NCHUNK) stage(t0, c + 1, (c + 1) & 1);
+            {
+                const int cn = c + 1 < NCHUNK ? c + 1 : 0;       // Ua is re-streamed for every timestep group
+#pragma unroll
+                for (int kbl = 0; kbl < CK; ++kbl) {
+                    wu[kbl][0] = uap[((cn * CK + kbl) * 2 + 0) * kFragU4];
+                    wu[kbl][1] = uap[((cn * CK + kbl) * 2 + 1) * kFragU4];
+                }
+            }
+            const char* sb0 = s_stage + (c & 1) * CHUNK_FRAGS * 1024;
+            const char* sb = sb0 + lane * 16;
+            // each k-block's fc partial is taken by one wave (wave-uniform): kb = 2c + kbl
+            const int own_kbl = ((2 * c) & (kWaves - 1)) == wave ? 0 : (((2 * c + 1) & (kWaves - 1)) == wave ? 1 : -1);
+            float fw[2][8];
+            if (own_kbl >= 0) {
+                const int kb = c * CK + own_kbl;
+#pragma unroll
+                for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) fw[cl][j] = s_fcw[cl * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8 + j];
+            }
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt) {
+                const uint4 x0h = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 0) * 1024);
+                const uint4 x0c = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 1) * 1024);
+                const uint4 x1h = *reinterpret_cast<const uint4*>(sb + ((1 * TG + tt) * 2 + 0) * 1024);
+                const uint4 x1c = *reinterpret_cast<const uint4*>(sb + ((1 * TG + tt) * 2 + 1) * 1024);
+                kacc[tt] = mfma16(w[0][0], x0h, kacc[tt]);
+                kacc[tt] = mfma16(w[1][0], x1h, kacc[tt]);
+                kacc[tt] = mfma_corr(w[0][1], w[1][1], x0c, x1c, kacc[tt], sa_ua);
+                if (own_kbl >= 0) {
+                    const half8 xh = as_half8(own_kbl ? x1h : x0h);
+                    // residuals of k = 8hh + 0..7: lane (n, 1) of the corr fragment, dwords hh (k = 8hh..8hh+3) and 2 + hh
+                    const char* cf = sb0 + ((own_kbl * TG + tt) * 2 + 1) * 1024 + (n + 32) * 16;
+                    const int la = *reinterpret_cast<const int*>(cf + 4 * hh);
+                    const int lb = *reinterpret_cast<const int*>(cf + 8 + 4 * hh);
+                    const float xl[8] = {__builtin_amdgcn_cvt_f32_fp8(la, 0), __builtin_amdgcn_cvt_f32_fp8(la, 1),
+                                         __builtin_amdgcn_cvt_f32_fp8(la, 2), __builtin_amdgcn_cvt_f32_fp8(la, 3),
+                                         __builtin_amdgcn_cvt_f32_fp8(lb, 0), __builtin_amdgcn_cvt_f32_fp8(lb, 1),
+                                         __builtin_amdgcn_cvt_f32_fp8(lb, 2), __builtin_amdgcn_cvt_f32_fp8(lb, 3)};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xv = (float)xh[j] + xl[j] * (1.0f / kCorrActLo);
+                        pf[tt][0] += fw[0][j] * xv;
+                        pf[tt][1] += fw[1][j] * xv;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) {
+            float e = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e += vav[r] * tanh_f(kacc[tt][r]);
+            e += __shfl_xor(e, 32);
+            if (hh == 0) s_epart[(wave * kSeqLen + t0 + tt) * 32 + n] = e;
+#pragma unroll
+            for (int cl = 0; cl < 2; ++cl) {
+                float v = pf[tt][cl];
+                v += __shfl_xor(v, 32);
+                if (hh == 0) s_pfc[((wave * kSeqLen + t0 + tt) * 32 + n) * 2 + cl] = v;
+            }
+        }
+        __syncthreads();   // all waves are done with both staging buffers before the next group restages buffer 0
+    }
+
+    // ---- softmax over t and the strand-half of the logits (fixed summation order: deterministic)
+    if (threadIdx.x < 32) {
+        const int rl = threadIdx.x;
+        const int row = tile * 32 + rl;
+        float e[kSeqLen];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < kSeqLen; ++t) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) v += s_epart[(w * kSeqLen + t) * 32 + rl];
+            e[t] = v;
+            m = fmaxf(m, v);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t < kSeqLen; ++t) { e[t] = __expf(e[t] - m); den += e[t]; }
+        const float inv = 1.0f / den;
+        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < kSeqLen; ++t) {
+            const float a = e[t] * inv;
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) {
+                p0 += s_pfc[((w * kSeqLen + t) * 32 + rl) * 2 + 0];
+                p1 += s_pfc[((w * kSeqLen + t) * 32 + rl) * 2 + 1];
+            }
+            l0 += a * p0;
+            l1 += a * p1;
+        }
+        part[(size_t)row * 2 + 0] = l0;
+        part[(size_t)row * 2 + 1] = l1;
+    }
+}
+
 // Self-test of the split-f8 product: C[unit][row] = sum_k W[unit][k] X[row][k] over 32 k, W fragments packed by the host
 // (hi, corr of two k-blocks), X given in fp32 and packed on the device with pack_kb from an MFMA-C-layout register image.
 __global__ void corr_selftest_kernel(const uint4* __restrict__ wfrag /* [kb 2][hi|corr][64] */, const float* __restrict__ x /* [row 32][k 32] */,
