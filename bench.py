@@ -181,7 +181,7 @@ def main():
             "config": {"workload": "attbigru2s_b21 forward on synthetic 21-mer CpG batches (BASELINE.json configs[1])",
                        "batch": BATCH, "sites_per_step": BATCH, "streams": nst, "coalesce": grp, "h0": "device Philox N(0,1)",
                        "arithmetic": {4: "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) with fp8 e4m3 operands on "
-                                         "v_mfma_scale_f32_32x32x64_f8f6f4, one fp32 accumulator (GRU layers); attention pool split-fp16 x3",
+                                         "v_mfma_scale_f32_32x32x64_f8f6f4, one fp32 accumulator (GRU layers and attention pool)",
                                       3: "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate",
                                       2: "fp16 weights x split-fp16 activations (2 MFMA passes), fp32 accumulate",
                                       1: "fp16 operands (1 MFMA pass), fp32 accumulate"}[a.precision],

@@ -25,7 +25,8 @@
 // The recurrent state is carried as hi + fp8(lo) too (h_{t-1} is re-read from these fragments): 2^-16 relative per step.
 //
 // Layer 0 (KX == 1, K = 11 padded to 16, inputs up to hundreds in magnitude) keeps three f16 passes for its x-part.
-// The last layer writes [hi | lo] fp16 fragments for the attention kernel (OUT_F16LO).
+// The attention pool (attn_fc_f8_kernel below) consumes the same [hi | corr] fragments; OUT_F16LO makes a layer write
+// [hi | lo] fp16 instead, for the fp16-split attention kernel (CCSM_ATTN_SPLIT3=1 A/B runs).
 #include <hip/hip_runtime.h>
 
 namespace ccsm {
