@@ -1,0 +1,148 @@
+"""ctypes binding of libccsm_bam (include/ccsm_bam.h): threaded BGZF/BAM reader that hands chunks of reads over in the layout
+of ccsm_forward_reads_host, and the modbam writer (tag refill + MM/ML encoding + threaded BGZF).  The pure-Python
+ccsmeth_amd/bamio.py implements the same formats record by record and is what the tests compare this library with."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libccsm_bam.so")
+
+EXPORTS = ("ccsm_bam_last_error", "ccsm_bam_open", "ccsm_bam_header", "ccsm_bam_next", "ccsm_bam_batch_free", "ccsm_bam_close",
+           "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_close")
+
+
+class _Batch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("records", C.c_void_p), ("rec_offset", C.c_void_p), ("flag", C.c_void_p),
+                ("offset", C.c_void_p), ("length", C.c_void_p), ("n_sites", C.c_void_p), ("seq", C.c_void_p), ("fi", C.c_void_p),
+                ("ri", C.c_void_p), ("fp", C.c_void_p), ("rp", C.c_void_p), ("fn", C.c_void_p), ("rn", C.c_void_p),
+                ("total_bases", C.c_int64)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libccsm_bam.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.ccsm_bam_last_error.restype = C.c_char_p
+    lib.ccsm_bam_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.ccsm_bam_header.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.ccsm_bam_next.argtypes = [vp, C.c_int32, C.POINTER(C.POINTER(_Batch))]
+    lib.ccsm_bam_batch_free.argtypes = [C.POINTER(_Batch)]
+    lib.ccsm_bam_batch_free.restype = None
+    lib.ccsm_bam_close.argtypes = [vp]
+    lib.ccsm_bam_close.restype = None
+    lib.ccsm_bam_writer_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, vp, C.c_int64, C.c_int32, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.ccsm_bam_write_batch.argtypes = [vp, C.POINTER(_Batch), vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int32)]
+    lib.ccsm_bam_writer_close.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise IOError(load().ccsm_bam_last_error().decode("utf-8", "replace"))
+
+
+def _view(ptr, dtype, count):
+    if count == 0 or not ptr:
+        return np.empty(0, dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,))
+
+
+class Batch:
+    """NumPy views of one ccsm_bam_batch (valid until close())."""
+
+    def __init__(self, ptr):
+        self._ptr = ptr
+        b = ptr.contents
+        n = self.n_reads = int(b.n_reads)
+        self.total_bases = int(b.total_bases)
+        self.rec_offset = _view(b.rec_offset, np.int64, n + 1)
+        self.records = _view(b.records, np.uint8, int(self.rec_offset[-1]))
+        self.flag = _view(b.flag, np.int32, n)
+        self.offset = _view(b.offset, np.int64, n)
+        self.length = _view(b.length, np.int32, n)
+        self.n_sites = _view(b.n_sites, np.int32, n)
+        self.seq, self.fi, self.ri, self.fp, self.rp = (_view(p, np.uint8, self.total_bases) for p in (b.seq, b.fi, b.ri, b.fp, b.rp))
+        self.fn = _view(b.fn, np.float32, n)
+        self.rn = _view(b.rn, np.float32, n)
+
+    def close(self):
+        if self._ptr is not None:
+            load().ccsm_bam_batch_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        self.close()
+
+
+class NativeBamReader:
+    def __init__(self, path, threads=4):
+        self._h = C.c_void_p()
+        _check(load().ccsm_bam_open(os.fsencode(path), int(threads), C.byref(self._h)))
+        text, refs = C.c_void_p(), C.c_void_p()
+        tl, rl, nref = C.c_int64(), C.c_int64(), C.c_int32()
+        _check(_lib.ccsm_bam_header(self._h, C.byref(text), C.byref(tl), C.byref(refs), C.byref(rl), C.byref(nref)))
+        self.header_text = C.string_at(text, tl.value).decode("utf-8") if tl.value else ""
+        self.raw_refs = C.string_at(refs, rl.value) if rl.value else b""
+        self.n_ref = nref.value
+
+    def next_batch(self, max_reads):
+        """Batch of up to max_reads records, or None at end of file."""
+        p = C.POINTER(_Batch)()
+        _check(_lib.ccsm_bam_next(self._h, int(max_reads), C.byref(p)))
+        return Batch(p) if p else None
+
+    def close(self):
+        if self._h:
+            _lib.ccsm_bam_close(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class NativeBamWriter:
+    def __init__(self, path, header_text, raw_refs=b"", n_ref=0, threads=4, level=6):
+        self._h = C.c_void_p()
+        text = header_text.encode("utf-8")
+        self._refs = raw_refs
+        _check(load().ccsm_bam_writer_open(os.fsencode(path), text, len(text), C.cast(C.c_char_p(raw_refs), C.c_void_p) if raw_refs else None,
+                                           len(raw_refs), int(n_ref), int(threads), int(level), C.byref(self._h)))
+
+    def write_batch(self, batch, first_site=None, locs=None, prob1=None, tagged=None, rm_pulse=True):
+        """Write every record of `batch`; returns the number of reads that received MM/ML."""
+        keep = []
+
+        def ptr(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.ctypes.data
+        n = C.c_int32(0)
+        _check(_lib.ccsm_bam_write_batch(self._h, batch._ptr, ptr(first_site, np.int32), ptr(locs, np.int32), ptr(prob1, np.float32),
+                                         ptr(tagged, np.uint8), int(bool(rm_pulse)), C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, C.c_void_p()
+            _check(_lib.ccsm_bam_writer_close(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -2,8 +2,10 @@
 
 Mirrors reference call_modifications.py:474-613 (argument checks, `<output>.modbam.bam`, @PG line, "bad read => written
 untagged", end-of-run counters) with one process instead of the reference's reader/extract/call/writer process pool:
-bamio.BamReader -> hole-batches of `--holes_batch` reads -> pipeline.CallModsPipeline (features, pinned double-buffered
-forward, MM/ML) -> bamio.BamWriter.  Output order = input order (the reference's `--no_sort`)."""
+default (`--io native`): libccsm_bam (threaded BGZF, include/ccsm_bam.h) -> chunks of `--holes_batch` reads ->
+ccsm_forward_reads_host (feature extraction + model on the GPU) -> libccsm_bam (tag refill, MM/ML, threaded BGZF);
+`--io python`: bamio.BamReader -> pipeline.CallModsPipeline -> bamio.BamWriter, record by record.
+Output order = input order (the reference's `--no_sort`)."""
 import argparse
 import os
 import sys
@@ -39,6 +41,10 @@ def build_parser():
     p.add_argument("--norm", default="zscore", choices=["zscore"])
     p.add_argument("--motifs", default="CG")
     p.add_argument("--mod_loc", type=int, default=0)
+    p.add_argument("--io", default="native", choices=["native", "python"],
+                   help="BAM reader/writer: libccsm_bam (threaded BGZF, whole read chunks straight to the GPU; implies --extract\n"
+                        "device) or the pure-Python record-by-record implementation")
+    p.add_argument("--threads", type=int, default=8, help="BGZF inflate / deflate threads of --io native")
     p.add_argument("--extract", default="device", choices=["device", "host"],
                    help="where the 21-mer features are built: on the GPU from the raw read arrays (default) or NumPy on the host")
     return p
@@ -85,6 +91,40 @@ def call_mods(args, log=sys.stderr):
     out_path = args.output + ".modbam.bam"                             # :494
     cnt_w = cnt_mm = cnt_failed = 0
     rm_pulse = not args.keep_pulse
+    if args.io == "native" and args.extract == "device":
+        # file -> libccsm_bam -> ccsm_forward_reads_host -> libccsm_bam -> file; the next chunk is inflated / parsed and the
+        # previous one deflated / written by two helper threads while the GPU works on the current one
+        from concurrent.futures import ThreadPoolExecutor
+        from .bamnative import NativeBamReader, NativeBamWriter
+        with NativeBamReader(args.input, threads=args.threads) as rd:
+            header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
+            with NativeBamWriter(out_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
+                    ThreadPoolExecutor(1) as rpool, ThreadPoolExecutor(1) as wpool:
+                nxt = rpool.submit(rd.next_batch, args.holes_batch)
+                pending = None
+
+                def write(b, first, locs, prob1, tagged):
+                    n = wr.write_batch(b, first, locs, prob1, tagged, rm_pulse)
+                    b.close()
+                    return n
+                while True:
+                    b = nxt.result()
+                    if b is None:
+                        break
+                    nxt = rpool.submit(rd.next_batch, args.holes_batch)
+                    first, locs, prob1, tagged, failed = pipe.run_native_batch(b)
+                    if pending is not None:
+                        cnt_mm += pending.result()
+                    pending = wpool.submit(write, b, first, locs, prob1, tagged)
+                    cnt_w += b.n_reads
+                    cnt_failed += failed
+                if pending is not None:
+                    cnt_mm += pending.result()
+        pipe.close()
+        print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
+        print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; ccsmeth_amd %s)" %
+              (time.time() - t0, cnt_failed, __version__), file=log)
+        return dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, output=out_path)
     with BamReader(args.input) as rd:
         header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
         with BamWriter(out_path, header, rd.references) as wr:

@@ -1,0 +1,506 @@
+// libccsm_bam: native BGZF / BAM reader and modbam writer of the call_mods path (include/ccsm_bam.h).
+// Host only.  Follows the SAM/BAM specification v1 (BGZF = gzip members with a 'BC' extra subfield, little-endian records);
+// mirrors ccsmeth_amd/bamio.py + ccsmeth_amd/_bam2modbam.py, which the tests compare it with.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ccsm_bam.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& msg) {
+    g_err = msg;
+    return 1;
+}
+
+inline uint16_t rd16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline void wr16(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); }
+inline void wr32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+constexpr size_t kBlockPayload = 0xff00;      // uncompressed bytes per BGZF block written
+constexpr int kBlocksPerRound = 256;          // blocks inflated / deflated per parallel round
+const uint8_t kBgzfEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+template <typename F>
+void parallel_for(int n, int threads, F f) {   // f(i) for i in [0, n), static interleaved partition
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) {
+        for (int i = 0; i < n; ++i) f(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([=]() { for (int i = t; i < n; i += threads) f(i); });
+    for (auto& th : pool) th.join();
+}
+
+struct RawBlock {
+    std::vector<uint8_t> cdata;
+    uint32_t crc = 0, isize = 0;
+    std::vector<uint8_t> data;
+    bool ok = true;
+};
+
+const char kSeqDecode[] = "=ACMGRSVTWYHKDBN";
+
+inline uint8_t comp_fwd(uint8_t b) {   // bamio.py _COMP: A<->T, C<->G, N, everything else unchanged
+    switch (b) {
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+        default: return b;
+    }
+}
+
+// tag walker: calls f(tag0, tag1, type, sub, count, value_ptr, whole_ptr, whole_len) for every tag; false on malformed data
+template <typename F>
+bool walk_tags(const uint8_t* p, const uint8_t* end, F f) {
+    while (p < end) {
+        if (end - p < 3) return false;
+        const uint8_t* start = p;
+        const uint8_t t0 = p[0], t1 = p[1], typ = p[2];
+        p += 3;
+        uint8_t sub = 0;
+        int64_t count = 1;
+        const uint8_t* val = p;
+        size_t sz;
+        switch (typ) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': {
+                const void* z = std::memchr(p, 0, (size_t)(end - p));
+                if (!z) return false;
+                sz = (size_t)((const uint8_t*)z - p) + 1;
+                break;
+            }
+            case 'B': {
+                if (end - p < 5) return false;
+                sub = p[0];
+                count = (int32_t)rd32(p + 1);
+                size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+                if (es == 0 || count < 0) return false;
+                val = p + 5;
+                sz = 5 + es * (size_t)count;
+                break;
+            }
+            default: return false;
+        }
+        if ((size_t)(end - p) < sz) return false;
+        p += sz;
+        f(t0, t1, typ, sub, count, val, start, (size_t)(p - start));
+    }
+    return true;
+}
+
+struct OwnedBatch {
+    ccsm_bam_batch view;          // first member: the public pointer is the object's address
+    std::vector<uint8_t> records;
+    std::vector<int64_t> rec_offset, offset;
+    std::vector<int32_t> flag, length, n_sites;
+    std::vector<uint8_t> seq, fi, ri, fp, rp;
+    std::vector<float> fn, rn;
+};
+
+}  // namespace
+
+struct ccsm_bam_reader {
+    FILE* fh = nullptr;
+    int threads = 1;
+    std::vector<uint8_t> stream;   // inflated bytes not yet consumed: [pos, size)
+    size_t pos = 0;
+    bool file_eof = false;
+    std::string text;
+    std::vector<uint8_t> refs;
+    int32_t n_ref = 0;
+
+    // read one BGZF block's compressed payload; false at clean EOF; throws through `err`
+    bool read_block(RawBlock& b, std::string& err) {
+        uint8_t head[12];
+        const size_t got = std::fread(head, 1, 12, fh);
+        if (got == 0) return false;
+        if (got < 12 || head[0] != 0x1f || head[1] != 0x8b || head[2] != 8 || head[3] != 4) {
+            err = "not a BGZF stream (bad gzip member header)";
+            return false;
+        }
+        const uint32_t xlen = rd16(head + 10);
+        std::vector<uint8_t> extra(xlen);
+        if (std::fread(extra.data(), 1, xlen, fh) != xlen) { err = "truncated BGZF block"; return false; }
+        int bsize = -1;
+        for (size_t off = 0; off + 4 <= xlen;) {
+            const uint32_t slen = rd16(extra.data() + off + 2);
+            if (extra[off] == 66 && extra[off + 1] == 67 && slen == 2) bsize = rd16(extra.data() + off + 4);
+            off += 4 + slen;
+        }
+        if (bsize < 0) { err = "gzip member without the BGZF 'BC' field"; return false; }
+        const long clen = (long)bsize - (long)xlen - 19;
+        if (clen < 0) { err = "corrupt BGZF block size"; return false; }
+        b.cdata.resize((size_t)clen);
+        uint8_t tail[8];
+        if (std::fread(b.cdata.data(), 1, (size_t)clen, fh) != (size_t)clen || std::fread(tail, 1, 8, fh) != 8) {
+            err = "truncated BGZF block";
+            return false;
+        }
+        b.crc = rd32(tail);
+        b.isize = rd32(tail + 4);
+        return true;
+    }
+
+    // make at least `need` unconsumed bytes available (fewer only at end of file)
+    int fill(size_t need) {
+        while (stream.size() - pos < need && !file_eof) {
+            if (pos > 0 && pos >= stream.size() / 2) {
+                stream.erase(stream.begin(), stream.begin() + (long)pos);
+                pos = 0;
+            }
+            std::vector<RawBlock> blocks;
+            blocks.reserve(kBlocksPerRound);
+            std::string err;
+            for (int i = 0; i < kBlocksPerRound; ++i) {
+                RawBlock b;
+                if (!read_block(b, err)) {
+                    if (!err.empty()) return fail(err);
+                    file_eof = true;
+                    break;
+                }
+                blocks.push_back(std::move(b));
+            }
+            parallel_for((int)blocks.size(), threads, [&](int i) {
+                RawBlock& b = blocks[(size_t)i];
+                b.data.resize(b.isize);
+                if (b.isize == 0) return;
+                z_stream zs;
+                std::memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) { b.ok = false; return; }
+                zs.next_in = b.cdata.data();
+                zs.avail_in = (uInt)b.cdata.size();
+                zs.next_out = b.data.data();
+                zs.avail_out = (uInt)b.data.size();
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END || zs.total_out != b.isize || (uint32_t)crc32(0L, b.data.data(), (uInt)b.data.size()) != b.crc)
+                    b.ok = false;
+            });
+            for (auto& b : blocks) {
+                if (!b.ok) return fail("BGZF block failed its CRC / size check");
+                stream.insert(stream.end(), b.data.begin(), b.data.end());
+            }
+        }
+        return 0;
+    }
+    size_t avail() const { return stream.size() - pos; }
+};
+
+struct ccsm_bam_writer {
+    FILE* fh = nullptr;
+    int threads = 1, level = 6;
+    std::vector<uint8_t> buf;      // uncompressed bytes not yet written
+
+    int flush_blocks(bool all) {
+        const size_t nfull = buf.size() / kBlockPayload;
+        const size_t nblk = all ? (buf.size() + kBlockPayload - 1) / kBlockPayload : nfull;
+        if (nblk == 0) return 0;
+        std::vector<std::vector<uint8_t>> out(nblk);
+        std::vector<char> ok(nblk, 1);
+        parallel_for((int)nblk, threads, [&](int i) {
+            const size_t beg = (size_t)i * kBlockPayload, len = std::min(kBlockPayload, buf.size() - beg);
+            std::vector<uint8_t>& o = out[(size_t)i];
+            o.resize(18 + compressBound((uLong)len) + 8);
+            z_stream zs;
+            std::memset(&zs, 0, sizeof(zs));
+            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok[(size_t)i] = 0; return; }
+            zs.next_in = buf.data() + beg;
+            zs.avail_in = (uInt)len;
+            zs.next_out = o.data() + 18;
+            zs.avail_out = (uInt)(o.size() - 26);
+            const int rc = deflate(&zs, Z_FINISH);
+            const size_t clen = zs.total_out;
+            deflateEnd(&zs);
+            if (rc != Z_STREAM_END || clen + 26 > 65536) { ok[(size_t)i] = 0; return; }
+            static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
+            std::memcpy(o.data(), head, 16);
+            wr16(o.data() + 16, (uint32_t)(clen + 25));
+            wr32(o.data() + 18 + clen, (uint32_t)crc32(0L, buf.data() + beg, (uInt)len));
+            wr32(o.data() + 18 + clen + 4, (uint32_t)len);
+            o.resize(18 + clen + 8);
+        });
+        for (size_t i = 0; i < nblk; ++i) {
+            if (!ok[i]) return fail("BGZF deflate failed");
+            if (std::fwrite(out[i].data(), 1, out[i].size(), fh) != out[i].size()) return fail("write failed");
+        }
+        const size_t used = std::min(buf.size(), nblk * kBlockPayload);
+        buf.erase(buf.begin(), buf.begin() + (long)used);
+        return 0;
+    }
+    int put(const uint8_t* p, size_t n) {
+        buf.insert(buf.end(), p, p + n);
+        if (buf.size() >= (size_t)kBlocksPerRound * kBlockPayload) return flush_blocks(false);
+        return 0;
+    }
+};
+
+extern "C" {
+
+const char* ccsm_bam_last_error(void) { return g_err.c_str(); }
+
+int ccsm_bam_open(const char* path, int threads, ccsm_bam_reader** out) {
+    if (!path || !out) return fail("path and out must be non-NULL");
+    *out = nullptr;
+    ccsm_bam_reader* r = new (std::nothrow) ccsm_bam_reader();
+    if (!r) return fail("out of memory");
+    r->threads = std::max(1, threads);
+    r->fh = std::fopen(path, "rb");
+    if (!r->fh) { delete r; return fail(std::string("cannot open ") + path); }
+    auto bail = [&](const std::string& m) { std::fclose(r->fh); delete r; return fail(m); };
+    if (r->fill(12)) return bail(g_err);
+    if (r->avail() < 12 || std::memcmp(r->stream.data() + r->pos, "BAM\1", 4) != 0) return bail(std::string(path) + " is not a BAM file");
+    const uint32_t l_text = rd32(r->stream.data() + r->pos + 4);
+    if (r->fill(12 + (size_t)l_text)) return bail(g_err);
+    if (r->avail() < 12 + (size_t)l_text) return bail("truncated BAM header");
+    const char* tp = reinterpret_cast<const char*>(r->stream.data() + r->pos + 8);
+    r->text.assign(tp, strnlen(tp, l_text));
+    r->n_ref = (int32_t)rd32(r->stream.data() + r->pos + 8 + l_text);
+    r->pos += 12 + l_text;
+    for (int i = 0; i < r->n_ref; ++i) {
+        if (r->fill(4)) return bail(g_err);
+        if (r->avail() < 4) return bail("truncated BAM reference list");
+        const uint32_t l_name = rd32(r->stream.data() + r->pos);
+        if (r->fill(8 + (size_t)l_name)) return bail(g_err);
+        if (r->avail() < 8 + (size_t)l_name) return bail("truncated BAM reference list");
+        r->refs.insert(r->refs.end(), r->stream.begin() + (long)r->pos, r->stream.begin() + (long)(r->pos + 8 + l_name));
+        r->pos += 8 + l_name;
+    }
+    *out = r;
+    return 0;
+}
+
+int ccsm_bam_header(const ccsm_bam_reader* r, const char** text, int64_t* text_len, const uint8_t** refs, int64_t* refs_len,
+                    int32_t* n_ref) {
+    if (!r || !text || !text_len || !refs || !refs_len || !n_ref) return fail("arguments must be non-NULL");
+    *text = r->text.data();
+    *text_len = (int64_t)r->text.size();
+    *refs = r->refs.data();
+    *refs_len = (int64_t)r->refs.size();
+    *n_ref = r->n_ref;
+    return 0;
+}
+
+void ccsm_bam_close(ccsm_bam_reader* r) {
+    if (!r) return;
+    if (r->fh) std::fclose(r->fh);
+    delete r;
+}
+
+void ccsm_bam_batch_free(ccsm_bam_batch* b) { delete reinterpret_cast<OwnedBatch*>(b); }
+
+int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) {
+    if (!r || !out) return fail("reader and out must be non-NULL");
+    *out = nullptr;
+    if (max_reads <= 0) return fail("max_reads must be > 0");
+    OwnedBatch* ob = new (std::nothrow) OwnedBatch();
+    if (!ob) return fail("out of memory");
+    ob->rec_offset.push_back(0);
+    for (int n = 0; n < max_reads; ++n) {
+        if (r->fill(4)) { delete ob; return 1; }
+        if (r->avail() == 0) break;
+        if (r->avail() < 4) { delete ob; return fail("truncated BAM record"); }
+        const uint32_t bs = rd32(r->stream.data() + r->pos);
+        if (bs < 32) { delete ob; return fail("corrupt BAM record (block_size < 32)"); }
+        if (r->fill(4 + (size_t)bs)) { delete ob; return 1; }
+        if (r->avail() < 4 + (size_t)bs) { delete ob; return fail("truncated BAM record"); }
+        const uint8_t* rec = r->stream.data() + r->pos;
+        const uint8_t* body = rec + 4;
+        const uint32_t l_name = body[8], n_cig = rd16(body + 12), flag = rd16(body + 14);
+        const uint32_t l_seq = rd32(body + 16);
+        const size_t fixed = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+        if (fixed > bs) { delete ob; return fail("corrupt BAM record (field lengths exceed block_size)"); }
+        const uint8_t* packed = body + 32 + l_name + 4 * n_cig;
+        const uint8_t* tags = body + fixed;
+        const uint8_t* end = body + bs;
+        const uint8_t *tfi = nullptr, *tri = nullptr, *tfp = nullptr, *trp = nullptr;
+        bool has_fn = false, has_rn = false;
+        float fn = 0.f, rn = 0.f;
+        auto as_num = [](uint8_t typ, const uint8_t* v, float& o) -> bool {
+            switch (typ) {
+                case 'c': o = (float)(int8_t)v[0]; return true;
+                case 'C': o = (float)v[0]; return true;
+                case 's': o = (float)(int16_t)rd16(v); return true;
+                case 'S': o = (float)rd16(v); return true;
+                case 'i': o = (float)(int32_t)rd32(v); return true;
+                case 'I': o = (float)rd32(v); return true;
+                case 'f': { uint32_t u = rd32(v); float f; std::memcpy(&f, &u, 4); o = f; return true; }
+                default: return false;
+            }
+        };
+        const bool tags_ok = walk_tags(tags, end, [&](uint8_t t0, uint8_t t1, uint8_t typ, uint8_t sub, int64_t count, const uint8_t* val,
+                                                     const uint8_t*, size_t) {
+            const bool arr = typ == 'B' && sub == 'C' && count == (int64_t)l_seq;
+            if (t0 == 'f' && t1 == 'i') { if (!tfi && arr) tfi = val; }
+            else if (t0 == 'r' && t1 == 'i') { if (!tri && arr) tri = val; }
+            else if (t0 == 'f' && t1 == 'p') { if (!tfp && arr) tfp = val; }
+            else if (t0 == 'r' && t1 == 'p') { if (!trp && arr) trp = val; }
+            else if (t0 == 'f' && t1 == 'n') { if (!has_fn) has_fn = as_num(typ, val, fn); }
+            else if (t0 == 'r' && t1 == 'n') { if (!has_rn) has_rn = as_num(typ, val, rn); }
+        });
+        if (!tags_ok) { delete ob; return fail("corrupt BAM record (auxiliary data)"); }
+        const bool usable = l_seq > 0 && tfi && tri && tfp && trp;
+        ob->records.insert(ob->records.end(), rec, rec + 4 + bs);
+        ob->rec_offset.push_back((int64_t)ob->records.size());
+        ob->flag.push_back((int32_t)flag);
+        ob->offset.push_back((int64_t)ob->seq.size());
+        ob->fn.push_back(has_fn ? fn : 0.f);
+        ob->rn.push_back(has_rn ? rn : 0.f);
+        int32_t nsites = 0;
+        if (usable) {
+            const size_t o = ob->seq.size(), L = l_seq;
+            ob->seq.resize(o + L);
+            uint8_t* s = ob->seq.data() + o;
+            if (flag & 16) {
+                for (size_t i = 0; i < L; ++i) {
+                    const size_t j = L - 1 - i;
+                    s[i] = comp_fwd((uint8_t)kSeqDecode[(packed[j >> 1] >> ((j & 1) ? 0 : 4)) & 15]);
+                }
+            } else {
+                for (size_t i = 0; i < L; ++i) s[i] = (uint8_t)kSeqDecode[(packed[i >> 1] >> ((i & 1) ? 0 : 4)) & 15];
+            }
+            ob->fi.insert(ob->fi.end(), tfi, tfi + L);
+            ob->ri.insert(ob->ri.end(), tri, tri + L);
+            ob->fp.insert(ob->fp.end(), tfp, tfp + L);
+            ob->rp.insert(ob->rp.end(), trp, trp + L);
+            const long n_ = (long)L;
+            for (long i = 0; i + 1 < n_; ++i)
+                if (s[i] == 'C' && s[i + 1] == 'G') {
+                    const long rl = n_ - 2 - i;
+                    nsites += (i >= 10 && i < n_ - 10 && rl >= 10 && rl < n_ - 10) ? 1 : 0;
+                }
+            ob->length.push_back((int32_t)L);
+        } else {
+            ob->length.push_back(0);
+        }
+        ob->n_sites.push_back(nsites);
+        r->pos += 4 + bs;
+    }
+    const int32_t nr = (int32_t)ob->flag.size();
+    if (nr == 0) { delete ob; return 0; }
+    ob->view.n_reads = nr;
+    ob->view.records = ob->records.data();
+    ob->view.rec_offset = ob->rec_offset.data();
+    ob->view.flag = ob->flag.data();
+    ob->view.offset = ob->offset.data();
+    ob->view.length = ob->length.data();
+    ob->view.n_sites = ob->n_sites.data();
+    ob->view.seq = ob->seq.data();
+    ob->view.fi = ob->fi.data();
+    ob->view.ri = ob->ri.data();
+    ob->view.fp = ob->fp.data();
+    ob->view.rp = ob->rp.data();
+    ob->view.fn = ob->fn.data();
+    ob->view.rn = ob->rn.data();
+    ob->view.total_bases = (int64_t)ob->seq.size();
+    *out = &ob->view;
+    return 0;
+}
+
+int ccsm_bam_writer_open(const char* path, const char* header_text, int64_t text_len, const uint8_t* refs, int64_t refs_len,
+                         int32_t n_ref, int threads, int level, ccsm_bam_writer** out) {
+    if (!path || !out || (text_len > 0 && !header_text) || (refs_len > 0 && !refs)) return fail("bad arguments");
+    *out = nullptr;
+    if (level < 1 || level > 9) return fail("level must be in [1, 9]");
+    ccsm_bam_writer* w = new (std::nothrow) ccsm_bam_writer();
+    if (!w) return fail("out of memory");
+    w->threads = std::max(1, threads);
+    w->level = level;
+    w->fh = std::fopen(path, "wb");
+    if (!w->fh) { delete w; return fail(std::string("cannot create ") + path); }
+    uint8_t h[8] = {'B', 'A', 'M', 1};
+    wr32(h + 4, (uint32_t)text_len);
+    w->put(h, 8);
+    if (text_len > 0) w->put(reinterpret_cast<const uint8_t*>(header_text), (size_t)text_len);
+    uint8_t nr[4];
+    wr32(nr, (uint32_t)n_ref);
+    w->put(nr, 4);
+    if (refs_len > 0) w->put(refs, (size_t)refs_len);
+    *out = w;
+    return 0;
+}
+
+int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int32_t* first_site, const int32_t* locs,
+                         const float* prob1, const uint8_t* tagged, int rm_pulse, int32_t* n_tagged) {
+    if (!w || !b) return fail("writer and batch must be non-NULL");
+    int32_t cnt = 0;
+    std::vector<uint8_t> rec;
+    std::string mm;
+    std::vector<uint8_t> ml;
+    for (int32_t r = 0; r < b->n_reads; ++r) {
+        const uint8_t* src = b->records + b->rec_offset[r];
+        const uint32_t bs = rd32(src);
+        const uint8_t* body = src + 4;
+        const uint32_t l_name = body[8], n_cig = rd16(body + 12), l_seq = rd32(body + 16);
+        const size_t fixed = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+        rec.assign(src, src + 4 + fixed);
+        walk_tags(body + fixed, body + bs, [&](uint8_t t0, uint8_t t1, uint8_t, uint8_t, int64_t, const uint8_t*, const uint8_t* whole, size_t len) {
+            if (t0 == 'M' && (t1 == 'M' || t1 == 'L')) return;
+            if (rm_pulse && ((t0 == 'f' || t0 == 'r') && (t1 == 'i' || t1 == 'p'))) return;
+            rec.insert(rec.end(), whole, whole + len);
+        });
+        bool add = tagged && tagged[r] && first_site && locs && prob1 && b->length[r] > 0 && first_site[r + 1] > first_site[r];
+        if (add) {
+            // _convert_locs_to_mmtag: one forward scan over the C's of the forward sequence; a location that is not the next C
+            // at or after the previous match leaves the read untagged
+            const uint8_t* s = b->seq + b->offset[r];
+            const int32_t L = b->length[r];
+            mm.assign("C+m?");
+            ml.clear();
+            int32_t p = 0, order = -1, prev_order = -1;
+            for (int32_t k = first_site[r]; k < first_site[r + 1] && add; ++k) {
+                const int32_t loc = locs[k];
+                if (loc < p || loc >= L || s[loc] != 'C') { add = false; break; }
+                for (; p < loc; ++p) order += (s[p] == 'C') ? 1 : 0;
+                order += 1;              // the C at loc itself
+                p = loc + 1;
+                mm += ',';
+                mm += std::to_string(prev_order < 0 ? order : order - 1 - prev_order);
+                prev_order = order;
+                const float pr = prob1[k];
+                ml.push_back(pr < 1.0f ? (uint8_t)std::floor(pr * 256.0f) : (uint8_t)255);
+            }
+            mm += ';';
+        }
+        if (add) {
+            rec.push_back('M'); rec.push_back('M'); rec.push_back('Z');
+            rec.insert(rec.end(), mm.begin(), mm.end());
+            rec.push_back(0);
+            rec.push_back('M'); rec.push_back('L'); rec.push_back('B'); rec.push_back('C');
+            uint8_t c4[4];
+            wr32(c4, (uint32_t)ml.size());
+            rec.insert(rec.end(), c4, c4 + 4);
+            rec.insert(rec.end(), ml.begin(), ml.end());
+            ++cnt;
+        }
+        wr32(rec.data(), (uint32_t)(rec.size() - 4));
+        if (w->put(rec.data(), rec.size())) return 1;
+    }
+    if (n_tagged) *n_tagged = cnt;
+    return 0;
+}
+
+int ccsm_bam_writer_close(ccsm_bam_writer* w) {
+    if (!w) return 0;
+    int rc = w->flush_blocks(true);
+    if (rc == 0 && std::fwrite(kBgzfEof, 1, sizeof(kBgzfEof), w->fh) != sizeof(kBgzfEof)) rc = fail("write failed");
+    if (std::fclose(w->fh) != 0 && rc == 0) rc = fail("close failed");
+    delete w;
+    return rc;
+}
+
+}  // extern "C"

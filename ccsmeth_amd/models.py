@@ -204,6 +204,43 @@ class Workspace:
         n = n.value
         return first, locs[:n].copy(), logits[:n].copy(), probs[:n].copy()
 
+    def forward_reads_arrays(self, offset, length, seq, fi, ri, fp, rp, fn, rn, seed=0, offset_counter=0, h0=None, stream=None):
+        """ccsm_forward_reads_host on caller-owned arrays (e.g. the views of a bamnative.Batch): offset int64 / length int32 /
+        fn, rn float32 per read, seq / fi / ri / fp / rp uint8 concatenated.  No copies.  Returns (first_site, locs, logits, probs)."""
+        offset = np.ascontiguousarray(offset, np.int64)
+        length = np.ascontiguousarray(length, np.int32)
+        fn, rn = np.ascontiguousarray(fn, np.float32), np.ascontiguousarray(rn, np.float32)
+        nr = len(offset)
+        if not (len(length) == len(fn) == len(rn) == nr) or nr == 0:
+            raise ValueError("per-read arrays must have the same, non-zero length")
+        arrs = [np.ascontiguousarray(a, np.uint8) for a in (seq, fi, ri, fp, rp)]
+        need = int((offset + length).max())
+        if any(len(a) < need for a in arrs):
+            raise ValueError("byte arrays are shorter than offset + length")
+        rd = _lib.Reads()
+        rd.n_reads = nr
+        rd.offset, rd.length = offset.ctypes.data, length.ctypes.data
+        rd.seq, rd.fi, rd.ri, rd.fp, rd.rp = (a.ctypes.data for a in arrs)
+        rd.fn, rd.rn = fn.ctypes.data, rn.ctypes.data
+        h = _lib.H0()
+        if h0 is None:
+            h.mode = _lib.H0_DEVICE_RNG
+        elif isinstance(h0, str) and h0 == "zero":
+            h.mode = _lib.H0_ZERO
+        else:
+            raise ValueError("forward_reads_arrays takes h0=None (device RNG) or 'zero'")
+        h.seed, h.offset = int(seed), int(offset_counter)
+        first = np.zeros(nr + 1, np.int32)
+        locs = np.empty(self.max_sites, np.int32)
+        logits = np.empty((self.max_sites, 2), np.float32)
+        probs = np.empty((self.max_sites, 2), np.float32)
+        n = C.c_int32(0)
+        _lib.check(self.model._lib.ccsm_forward_reads_host(self.model.handle, self.handle, C.byref(rd), C.byref(h),
+                                                           first.ctypes.data, locs.ctypes.data, logits.ctypes.data,
+                                                           probs.ctypes.data, C.byref(n), stream))
+        n = n.value
+        return first, locs[:n], logits[:n], probs[:n]
+
     def forward_torch(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None,
                       out=None):
         """torch CUDA tensors in / out, asynchronous on `stream` (default: torch's current stream)."""

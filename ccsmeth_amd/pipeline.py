@@ -128,6 +128,42 @@ class CallModsPipeline:
             acc[ridx].append((locs, p1[pos:pos + k]))
             pos += k
 
+    # ---- native BAM batches (ccsmeth_amd/bamnative.py): no per-read Python objects ------------------------------------------
+    def run_native_batch(self, batch):
+        """One bamnative.Batch through ccsm_forward_reads_host, in chunks of whole reads holding <= batch_size sites.
+        Returns (first_site int32 (n_reads+1), locs int32, prob1 float32, tagged uint8 (n_reads), n_failed) in the batch's read
+        order, i.e. exactly the arguments of NativeBamWriter.write_batch."""
+        nr = batch.n_reads
+        cnt = np.where(batch.length > 0, batch.n_sites, 0).astype(np.int64)
+        first = np.zeros(nr + 1, np.int32)
+        np.cumsum(cnt, out=first[1:])
+        total = int(first[-1])
+        locs = np.empty(total, np.int32)
+        prob1 = np.empty(total, np.float32)
+        tagged = (cnt > 0).astype(np.uint8)
+        idx = np.flatnonzero(cnt > 0)
+        start = 0
+        while start < len(idx):
+            csum = np.cumsum(cnt[idx[start:]])
+            take = max(1, int(np.searchsorted(csum, self.batch_size, side="right")))
+            sel = idx[start:start + take]
+            csites = int(cnt[sel].sum())
+            if self._rws is None or self._rws.max_sites < csites:
+                if self._rws is not None:
+                    self._rws.close()
+                self._rws = self.dm.workspace(max(csites, self.batch_size))
+            f, lc, _, pr = self._rws.forward_reads_arrays(batch.offset[sel], batch.length[sel], batch.seq, batch.fi, batch.ri, batch.fp,
+                                                          batch.rp, batch.fn[sel], batch.rn[sel], seed=self.seed,
+                                                          offset_counter=self._site_counter, stream=self._slots[0].stream)
+            if not np.array_equal(np.diff(f), cnt[sel]):
+                raise RuntimeError("device and host site counts disagree")
+            self._site_counter += len(lc)
+            a = int(first[sel[0]])
+            locs[a:a + len(lc)] = lc                      # sel is a run of consecutive usable reads: their spans are adjacent
+            prob1[a:a + len(lc)] = prob1_norm_round6(pr)
+            start += take
+        return first, locs, prob1, tagged, int(nr - len(idx))
+
     # ---- host side ------------------------------------------------------------------------------------------------
     def run(self, reads):
         """reads: sequence of Read (e.g. one or many hole-batches).  Returns ([ReadCalls per read, input order], n_failed).

@@ -1,0 +1,76 @@
+/* libccsm_bam — native BGZF/BAM side of the call_mods path (host only: C++17, zlib, std::thread; no HIP, no htslib).
+ *
+ * What it replaces in the reference (PengNi/ccsmeth v0.5.0, through pysam/htslib):
+ *   reader   extract_features.py:129-177 (worker_read_split_holebatches_to_queue: pysam.AlignmentFile(check_sq=False),
+ *            get_forward_sequence(), tags fi/ri/fp/rp/fn/rn)        -> ccsm_bam_open / ccsm_bam_next
+ *   writer   call_modifications.py:437-462 (_worker_write_modbam) + _bam2modbam.py:187-226 (_convert_locs_to_mmtag,
+ *            _convert_probs_to_mltag, _refill_tags)                  -> ccsm_bam_writer_open / ccsm_bam_write_batch
+ * A batch hands over the reads' arrays in exactly the layout ccsm_forward_reads_host (ccsm.h) takes, so a chunk of reads goes
+ * file -> GPU -> file without a per-record Python object.  BGZF blocks are inflated / deflated by a pool of threads; record
+ * order is preserved (the reference's --no_sort output).  Plain pointers and sizes; int status (0 = ok), text from
+ * ccsm_bam_last_error().
+ */
+#ifndef CCSM_BAM_H_
+#define CCSM_BAM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ccsm_bam_reader ccsm_bam_reader;
+typedef struct ccsm_bam_writer ccsm_bam_writer;
+
+/* One chunk of consecutive records.  Every pointer is owned by the batch (ccsm_bam_batch_free). */
+typedef struct ccsm_bam_batch {
+    int32_t n_reads;
+    const uint8_t* records;     /* the raw BAM records back to back, each with its 4-byte block_size prefix */
+    const int64_t* rec_offset;  /* (n_reads + 1) byte offsets into `records` */
+    const int32_t* flag;        /* (n_reads) BAM FLAG */
+    /* Read-level arrays in the layout of ccsm_reads (ccsm.h).  A read is "usable" when fi, ri, fp and rp are B:C arrays as
+     * long as the sequence (extract_features.py:320-325 skips the others); unusable reads have length 0 here. */
+    const int64_t* offset;      /* (n_reads) start of the read's bases in seq / fi / ri / fp / rp */
+    const int32_t* length;      /* (n_reads) bases, 0 = unusable */
+    const int32_t* n_sites;     /* (n_reads) CG sites that keep a full 21-mer window on both strands (extract_features.py:343-350) */
+    const uint8_t* seq;         /* forward sequence, upper-case ASCII (reverse-complemented back for FLAG 0x10 records) */
+    const uint8_t* fi;
+    const uint8_t* ri;
+    const uint8_t* fp;
+    const uint8_t* rp;
+    const float* fn;            /* (n_reads) */
+    const float* rn;
+    int64_t total_bases;        /* bytes used in seq / fi / ri / fp / rp */
+} ccsm_bam_batch;
+
+const char* ccsm_bam_last_error(void);
+
+/* threads = BGZF inflate workers (>= 1). */
+int ccsm_bam_open(const char* path, int threads, ccsm_bam_reader** out);
+/* SAM header text (not NUL-terminated: *text_len bytes) and the binary reference list exactly as stored (n_ref entries of
+ * l_name, name, l_ref), for copying into the output file. */
+int ccsm_bam_header(const ccsm_bam_reader* r, const char** text, int64_t* text_len, const uint8_t** refs, int64_t* refs_len,
+                    int32_t* n_ref);
+/* Next chunk of up to max_reads records (fewer at end of file; *out = NULL when no record is left). */
+int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out);
+void ccsm_bam_batch_free(ccsm_bam_batch* b);
+void ccsm_bam_close(ccsm_bam_reader* r);
+
+/* level = zlib level of the BGZF blocks (1..9), threads = deflate workers. */
+int ccsm_bam_writer_open(const char* path, const char* header_text, int64_t text_len, const uint8_t* refs, int64_t refs_len,
+                         int32_t n_ref, int threads, int level, ccsm_bam_writer** out);
+/* Writes the batch's records in order.  Old MM / ML tags are dropped, and fi / fp / ri / rp too when rm_pulse
+ * (_bam2modbam.py:211-226).  Read r with tagged[r] != 0 gets  MM:Z:C+m?,<deltas>;  and  ML:B:C  built from its sites
+ * k in [first_site[r], first_site[r+1]):  locs[k] = 0-based position of the called C in the forward sequence (ascending),
+ * prob1[k] = the methylation probability as the reference rounds it (call_modifications.py:223).  A read whose
+ * locations do not all sit on C's is written untagged, as the reference's failed assertion does (_bam2modbam.py:187-203).
+ * *n_tagged = reads that received MM/ML. */
+int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int32_t* first_site, const int32_t* locs,
+                         const float* prob1, const uint8_t* tagged, int rm_pulse, int32_t* n_tagged);
+int ccsm_bam_writer_close(ccsm_bam_writer* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

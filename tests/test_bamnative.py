@@ -1,0 +1,159 @@
+"""libccsm_bam (native threaded BGZF/BAM reader + modbam writer) against the pure-Python bamio / _bam2modbam mirrors, which
+are themselves pinned to the reference's outputs (tests/test_host_mirror.py, tests/test_bamio.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from ccsmeth_amd import _bam2modbam as mmod
+from ccsmeth_amd import bamio, bamnative
+from ccsmeth_amd import extract_features as ef
+
+
+def _make_bam(path, rng, n_reads=40):
+    recs = []
+    with bamio.BamWriter(path, "@HD\tVN:1.5\tSO:unknown\n@RG\tID:x\n", [("chr1", 1000), ("chrUn_2", 77)]) as w:
+        for i in range(n_reads):
+            L = int(rng.choice([0, 1, 19, 21, 22, 23, 64, 257, 1000, 4097, 70001][: 11 if i % 13 == 0 else 9]))
+            seq = "".join(rng.choice(list("ACGTN"), size=L, p=[0.27, 0.22, 0.22, 0.27, 0.02]))
+            kin = lambda: rng.integers(0, 256, L).astype(np.uint8)  # noqa: E731
+            tags = [("np", "C", 12), ("fi", "BC", kin()), ("zm", "i", 100000 + i), ("fp", "BC", kin()), ("ri", "BC", kin()),
+                    ("rp", "BC", kin()), ("fn", ["C", "c", "S", "s", "I", "i"][i % 6], int(rng.integers(3, 100))),
+                    ("rn", "C", int(rng.integers(3, 100))), ("sn", "Bf", rng.random(4).astype(np.float32)), ("RG", "Z", "x"),
+                    ("MM", "Z", "C+m,1;"), ("ML", "BC", np.array([7], np.uint8)), ("rq", "f", 0.999)]
+            if i % 7 == 3:
+                tags[1] = ("fi", "BC", kin()[: max(L - 1, 0)])       # wrong length -> unusable
+            if i % 11 == 5:
+                tags = [t for t in tags if t[0] != "rp"]             # missing tag -> unusable
+            if i % 9 == 4:
+                tags[4] = ("ri", "BS", rng.integers(0, 256, L).astype(np.uint16))   # wrong element type -> unusable
+            flag = [4, 0, 16, 4 | 16][i % 4]
+            r = bamio.BamRecord("m64/%d/ccs" % i, flag=flag, ref_id=0 if not flag & 4 else -1, pos=10 * i if not flag & 4 else -1,
+                                mapq=60, cigar=((0, L),) if L and not flag & 4 else (), seq=seq,
+                                qual=None if i % 5 == 0 else rng.integers(0, 60, L).astype(np.uint8), tags=tags)
+            recs.append(r)
+            w.write(r)
+    return recs
+
+
+def _usable(r):
+    L = len(r.seq)
+    try:
+        arrs = [r.get_tag(t) for t in ("fi", "ri", "fp", "rp")]
+    except KeyError:
+        return False
+    return L > 0 and all(isinstance(a, np.ndarray) and a.dtype == np.uint8 and len(a) == L for a in arrs)
+
+
+@pytest.mark.parametrize("threads,chunk", [(1, 7), (4, 1000), (3, 1)])
+def test_native_reader_matches_python_reader(tmp_path, threads, chunk):
+    rng = np.random.default_rng(11)
+    path = str(tmp_path / "in.bam")
+    recs = _make_bam(path, rng)
+    with bamnative.NativeBamReader(path, threads=threads) as rd:
+        assert rd.header_text == "@HD\tVN:1.5\tSO:unknown\n@RG\tID:x\n" and rd.n_ref == 2
+        i = 0
+        while True:
+            b = rd.next_batch(chunk)
+            if b is None:
+                break
+            assert 0 < b.n_reads <= chunk
+            for k in range(b.n_reads):
+                r = recs[i]
+                assert b.flag[k] == r.flag
+                raw = bytes(b.records[b.rec_offset[k]:b.rec_offset[k + 1]])
+                assert int.from_bytes(raw[:4], "little") == len(raw) - 4
+                if _usable(r):
+                    L = len(r.seq)
+                    o = int(b.offset[k])
+                    assert b.length[k] == L
+                    assert bytes(b.seq[o:o + L]).decode() == r.get_forward_sequence()
+                    for name, arr in (("fi", b.fi), ("ri", b.ri), ("fp", b.fp), ("rp", b.rp)):
+                        assert np.array_equal(arr[o:o + L], r.get_tag(name))
+                    assert b.fn[k] == r.get_tag("fn") and b.rn[k] == r.get_tag("rn")
+                    assert b.n_sites[k] == ef.count_kept_sites(np.frombuffer(r.get_forward_sequence().encode(), np.uint8))
+                else:
+                    assert b.length[k] == 0 and b.n_sites[k] == 0
+                i += 1
+            b.close()
+        assert i == len(recs)
+
+
+def test_native_writer_matches_python_refill(tmp_path):
+    """Records written by the native writer (tag refill + MM/ML) parse back, with the Python reader, to exactly what the
+    Python mirrors of _refill_tags / _convert_locs_to_mmtag / _convert_probs_to_mltag produce."""
+    rng = np.random.default_rng(5)
+    inp, outp = str(tmp_path / "in.bam"), str(tmp_path / "out.bam")
+    recs = _make_bam(inp, rng, n_reads=30)
+    expected = []
+    with bamnative.NativeBamReader(inp, threads=2) as rd, \
+            bamnative.NativeBamWriter(outp, rd.header_text + "@PG\tID:t\n", rd.raw_refs, rd.n_ref, threads=3, level=4) as wr:
+        base = 0
+        n_tagged_total = 0
+        while True:
+            b = rd.next_batch(8)
+            if b is None:
+                break
+            first = np.zeros(b.n_reads + 1, np.int32)
+            locs, probs, tagged = [], [], np.zeros(b.n_reads, np.uint8)
+            for k in range(b.n_reads):
+                r = recs[base + k]
+                lk, pk = [], []
+                if b.length[k] > 0 and b.n_sites[k] > 0:
+                    fwd = r.get_forward_sequence()
+                    cs = [j for j, c in enumerate(fwd) if c == "C"]
+                    lk = sorted(rng.choice(cs, size=min(len(cs), int(rng.integers(1, 9))), replace=False).tolist())
+                    pk = np.round(rng.random(len(lk)), 6).astype(np.float32)
+                    pk[rng.random(len(lk)) < 0.1] = 1.0
+                    tagged[k] = 1
+                    if (base + k) % 5 == 2:
+                        lk[-1] = next(j for j, c in enumerate(fwd) if c != "C")   # not a C -> the read stays untagged
+                        lk = sorted(lk)
+                locs += lk
+                probs += list(pk)
+                first[k + 1] = first[k] + len(lk)
+                old = [(t, v) for t, _, v in r.tags]
+                try:
+                    mm = mmod._convert_locs_to_mmtag(lk, r.get_forward_sequence()) if tagged[k] else None
+                except AssertionError:
+                    mm = None
+                ml = mmod._convert_probs_to_mltag(list(pk)) if mm is not None else None
+                expected.append((r, mmod._refill_tags(old, mm, ml, rm_pulse=(base % 2 == 0)), mm is not None))
+            n_tagged_total += wr.write_batch(b, first, np.array(locs, np.int32), np.array(probs, np.float32), tagged,
+                                             rm_pulse=(base % 2 == 0))
+            base += b.n_reads
+            b.close()
+    assert n_tagged_total == sum(1 for _, _, t in expected if t) and n_tagged_total > 3
+    with bamio.BamReader(outp) as rd:
+        assert rd.header_text.endswith("@PG\tID:t\n") and rd.references == [("chr1", 1000), ("chrUn_2", 77)]
+        out = list(rd)
+    assert len(out) == len(expected)
+    for o, (r, tags, _) in zip(out, expected):
+        assert (o.query_name, o.flag, o.ref_id, o.pos, o.mapq, o.cigar, o.seq) == (r.query_name, r.flag, r.ref_id, r.pos, r.mapq, r.cigar, r.seq)
+        assert (o.qual is None and r.qual is None) or np.array_equal(o.qual, r.qual)
+        assert [t for t, _, _ in o.tags] == [t for t, _ in tags]
+        for (t, typ, v), (_, ev) in zip(o.tags, tags):
+            if isinstance(v, np.ndarray) or isinstance(ev, (list, np.ndarray)):
+                assert np.array_equal(np.asarray(v), np.asarray(ev)), t
+            elif isinstance(v, float):
+                assert abs(v - ev) < 1e-6
+            else:
+                assert v == ev, t
+
+
+def test_native_reader_errors(tmp_path):
+    p = str(tmp_path / "junk.bam")
+    open(p, "wb").write(b"this is not a bam file at all, not even gzip")
+    with pytest.raises(IOError):
+        bamnative.NativeBamReader(p)
+    with pytest.raises(IOError):
+        bamnative.NativeBamReader(str(tmp_path / "missing.bam"))
+    # truncated file: valid header, record cut in the middle of a block stream
+    good = str(tmp_path / "good.bam")
+    _make_bam(good, np.random.default_rng(1), n_reads=6)
+    data = open(good, "rb").read()
+    open(p, "wb").write(data[: len(data) // 2])
+    with pytest.raises(IOError):
+        with bamnative.NativeBamReader(p) as rd:
+            while rd.next_batch(2) is not None:
+                pass

@@ -449,16 +449,20 @@ def test_call_mods_bam_to_modbam(tmp_path):
         ml = o.get_tag("ML")
         assert ml.dtype == np.uint8 and len(ml) == len(arr["loc"])
     assert tagged == res["tagged"] and res["failed"] == 6 - tagged
-    # default is GPU-side extraction; the host-extraction path must write the same records (ML within one bucket)
-    res_h = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "outh"), "--batch_size", "256",
-                                                 "--holes_batch", "4", "--extract", "host"]))
-    assert res_h["tagged"] == res["tagged"]
-    with bamio.BamReader(res_h["output"]) as rd:
-        for o, oh in zip(out, rd):
-            assert [t[0] for t in o.tags] == [t[0] for t in oh.tags]
-            if "MM" in [t[0] for t in o.tags]:
-                assert o.get_tag("MM") == oh.get_tag("MM")
-                assert np.abs(o.get_tag("ML").astype(int) - oh.get_tag("ML").astype(int)).max() <= 1
+    # default = native BAM I/O + GPU-side extraction; the pure-Python I/O path with GPU extraction must write identical
+    # records, and the host-extraction path the same records with ML within one bucket
+    for extra, exact in ((["--io", "python"], True), (["--io", "python", "--extract", "host"], False)):
+        res_h = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / ("o" + str(exact))), "--batch_size",
+                                                     "256", "--holes_batch", "4"] + extra))
+        assert res_h["tagged"] == res["tagged"] and res_h["failed"] == res["failed"]
+        with bamio.BamReader(res_h["output"]) as rd:
+            for o, oh in zip(out, rd):
+                assert [t[0] for t in o.tags] == [t[0] for t in oh.tags]
+                assert (o.query_name, o.flag, o.seq) == (oh.query_name, oh.flag, oh.seq)
+                if "MM" in [t[0] for t in o.tags]:
+                    assert o.get_tag("MM") == oh.get_tag("MM")
+                    d = np.abs(o.get_tag("ML").astype(int) - oh.get_tag("ML").astype(int)).max()
+                    assert d == 0 if exact else d <= 1
     # argument checks of the reference
     bad = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "o2"), "--seq_len", "20"])
     with pytest.raises(ValueError):
