@@ -72,3 +72,17 @@ def test_fp8_e4m3_host_encoder():
         assert dec(lib.ccsm_debug_fp8_e4m3(np.nextafter(np.float32(mid), np.float32(lo)))) == lo
     assert dec(lib.ccsm_debug_fp8_e4m3(1e9)) == 448.0 and dec(lib.ccsm_debug_fp8_e4m3(-500.0)) == -448.0
     assert dec(lib.ccsm_debug_fp8_e4m3(1e-6)) == 0.0
+
+
+def test_bam_header_symbols_exported():
+    """Every function include/ccsm_bam.h declares is exported by libccsm_bam.so (and listed in bamnative.EXPORTS)."""
+    import ctypes
+    import re
+    from conftest import ROOT
+    from ccsmeth_amd import bamnative
+    hdr = open(os.path.join(ROOT, "include", "ccsm_bam.h")).read()
+    declared = set(re.findall(r"\b(ccsm_bam_\w+)\s*\(", hdr))
+    assert declared == set(bamnative.EXPORTS)
+    lib = ctypes.CDLL(bamnative.LIB_PATH)
+    for name in declared:
+        getattr(lib, name)
