@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libccsm_bam.so")
 
 EXPORTS = ("ccsm_bam_last_error", "ccsm_bam_open", "ccsm_bam_header", "ccsm_bam_next", "ccsm_bam_batch_free", "ccsm_bam_close",
-           "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_close")
+           "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_flush", "ccsm_bam_writer_close")
 
 
 class _Batch(C.Structure):
@@ -41,6 +41,7 @@ def load():
     lib.ccsm_bam_close.restype = None
     lib.ccsm_bam_writer_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, vp, C.c_int64, C.c_int32, C.c_int, C.c_int, C.POINTER(vp)]
     lib.ccsm_bam_write_batch.argtypes = [vp, C.POINTER(_Batch), vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int32)]
+    lib.ccsm_bam_writer_flush.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.ccsm_bam_writer_close.argtypes = [vp]
     _lib = lib
     return lib
@@ -136,6 +137,12 @@ class NativeBamWriter:
                                          ptr(tagged, np.uint8), int(bool(rm_pulse)), C.byref(n)))
         return n.value
 
+    def flush(self):
+        """End the current BGZF block; returns the file size so far."""
+        off = C.c_int64(0)
+        _check(_lib.ccsm_bam_writer_flush(self._h, C.byref(off)))
+        return off.value
+
     def close(self):
         if self._h:
             h, self._h = self._h, C.c_void_p()
@@ -146,3 +153,32 @@ class NativeBamWriter:
 
     def __exit__(self, *a):
         self.close()
+
+
+BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def stitch_runs(out_path, header_file, header_end, runs):
+    """Multi-GPU merge: `header_file`[0:header_end] (the block-aligned BAM header), then every (file, start, end) run of BGZF
+    blocks in the given order, then the BGZF end-of-file marker."""
+    with open(out_path, "wb") as out:
+        with open(header_file, "rb") as fh:
+            out.write(fh.read(header_end))
+        handles = {}
+        try:
+            for path, start, end in runs:
+                fh = handles.get(path)
+                if fh is None:
+                    fh = handles[path] = open(path, "rb")
+                fh.seek(start)
+                left = end - start
+                while left > 0:
+                    chunk = fh.read(min(left, 1 << 24))
+                    if not chunk:
+                        raise IOError("short read while stitching %s" % path)
+                    out.write(chunk)
+                    left -= len(chunk)
+        finally:
+            for fh in handles.values():
+                fh.close()
+        out.write(BGZF_EOF)

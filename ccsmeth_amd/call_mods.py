@@ -79,6 +79,9 @@ def call_mods(args, log=sys.stderr):
         raise ValueError("this build implements --motifs CG --mod_loc 0")
     from collections import OrderedDict
     from .models import ModelAttRNN
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        args.device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)    # one process per GPU
     model = ModelAttRNN(args.seq_len, args.layer_rnn, args.class_num, args.dropout_rate, args.hid_rnn, is_npass=True,
                         model_type=args.model_type, device=args.device, seed=args.tseed, max_batch=args.batch_size)
     para = _load_state_dict(args.model_file)
@@ -91,39 +94,82 @@ def call_mods(args, log=sys.stderr):
     out_path = args.output + ".modbam.bam"                             # :494
     cnt_w = cnt_mm = cnt_failed = 0
     rm_pulse = not args.keep_pulse
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1 and not (args.io == "native" and args.extract == "device"):
+        raise ValueError("multi-GPU call_mods needs --io native --extract device")
     if args.io == "native" and args.extract == "device":
         # file -> libccsm_bam -> ccsm_forward_reads_host -> libccsm_bam -> file; the next chunk is inflated / parsed and the
-        # previous one deflated / written by two helper threads while the GPU works on the current one
+        # previous one deflated / written by two helper threads while the GPU works on the current one.
+        # Multi-GPU (torch.distributed.run, one process per GPU): every rank parses the whole stream, takes the
+        # hole-batches with index = rank (mod world) and writes them as block-aligned runs into its own part file; the Philox
+        # counter of a batch is the number of sites in all earlier batches, so every probability equals the single-GPU run's;
+        # rank 0 stitches the runs back into input order.  The only communication is the gather of the run index and counters.
         from concurrent.futures import ThreadPoolExecutor
-        from .bamnative import NativeBamReader, NativeBamWriter
+        from .bamnative import NativeBamReader, NativeBamWriter, stitch_runs
+        dist = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if not dist.is_initialized():
+                dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side bookkeeping only
+        part_path = out_path if world == 1 else "%s.part%d" % (out_path, rank)
+        runs = []
         with NativeBamReader(args.input, threads=args.threads) as rd:
             header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
-            with NativeBamWriter(out_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
+            with NativeBamWriter(part_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
                     ThreadPoolExecutor(1) as rpool, ThreadPoolExecutor(1) as wpool:
+                header_end = wr.flush()
                 nxt = rpool.submit(rd.next_batch, args.holes_batch)
                 pending = None
+                site_base = 0
+                bi = 0
 
-                def write(b, first, locs, prob1, tagged):
+                def write(b, first, locs, prob1, tagged, index):
                     n = wr.write_batch(b, first, locs, prob1, tagged, rm_pulse)
                     b.close()
+                    if world > 1:
+                        runs.append((index, wr.flush()))
                     return n
                 while True:
                     b = nxt.result()
                     if b is None:
                         break
                     nxt = rpool.submit(rd.next_batch, args.holes_batch)
-                    first, locs, prob1, tagged, failed = pipe.run_native_batch(b)
-                    if pending is not None:
-                        cnt_mm += pending.result()
-                    pending = wpool.submit(write, b, first, locs, prob1, tagged)
-                    cnt_w += b.n_reads
-                    cnt_failed += failed
+                    batch_sites = int(np.where(b.length > 0, b.n_sites, 0).sum())
+                    if bi % world == rank:
+                        pipe._site_counter = site_base
+                        first, locs, prob1, tagged, failed = pipe.run_native_batch(b)
+                        if pending is not None:
+                            cnt_mm += pending.result()
+                        pending = wpool.submit(write, b, first, locs, prob1, tagged, bi)
+                        cnt_w += b.n_reads
+                        cnt_failed += failed
+                    else:
+                        b.close()
+                    site_base += batch_sites
+                    bi += 1
                 if pending is not None:
                     cnt_mm += pending.result()
         pipe.close()
-        print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
-        print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; ccsmeth_amd %s)" %
-              (time.time() - t0, cnt_failed, __version__), file=log)
+        if world > 1:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, dict(rank=rank, header_end=header_end, runs=runs, counts=(cnt_w, cnt_mm, cnt_failed)))
+            cnt_w, cnt_mm, cnt_failed = (sum(g["counts"][k] for g in gathered) for k in range(3))
+            if rank == 0:
+                spans = []
+                for g in gathered:
+                    start = g["header_end"]
+                    for index, end in g["runs"]:
+                        spans.append((index, "%s.part%d" % (out_path, g["rank"]), start, end))
+                        start = end
+                spans.sort()
+                stitch_runs(out_path, part_path, header_end, [(p, a, e) for _, p, a, e in spans])
+            dist.barrier()
+            os.remove(part_path)
+        if rank == 0:
+            print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
+            print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d GPU(s); ccsmeth_amd %s)" %
+                  (time.time() - t0, cnt_failed, world, __version__), file=log)
         return dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, output=out_path)
     with BamReader(args.input) as rd:
         header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))

@@ -494,6 +494,14 @@ int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int3
     return 0;
 }
 
+int ccsm_bam_writer_flush(ccsm_bam_writer* w, int64_t* file_offset) {
+    if (!w) return fail("writer must be non-NULL");
+    if (w->flush_blocks(true)) return 1;
+    if (std::fflush(w->fh) != 0) return fail("write failed");
+    if (file_offset) *file_offset = (int64_t)std::ftell(w->fh);
+    return 0;
+}
+
 int ccsm_bam_writer_close(ccsm_bam_writer* w) {
     if (!w) return 0;
     int rc = w->flush_blocks(true);

@@ -68,6 +68,10 @@ int ccsm_bam_writer_open(const char* path, const char* header_text, int64_t text
  * *n_tagged = reads that received MM/ML. */
 int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int32_t* first_site, const int32_t* locs,
                          const float* prob1, const uint8_t* tagged, int rm_pulse, int32_t* n_tagged);
+/* Ends the current BGZF block: everything written so far is compressed and on disk, the next record starts a new block.
+ * *file_offset = size of the file so far, so that [previous offset, *file_offset) is a self-contained run of BGZF blocks
+ * (the multi-GPU call_mods stitches the per-rank files back into input order out of such runs). */
+int ccsm_bam_writer_flush(ccsm_bam_writer* w, int64_t* file_offset);
 int ccsm_bam_writer_close(ccsm_bam_writer* w);
 
 #ifdef __cplusplus

@@ -573,3 +573,49 @@ def test_read_level_extraction_long_reads(model7):
     f0, l0, _, p0 = small.forward_reads([reads[1], reads[2]], h0="zero")
     assert f0.tolist() == [0, 0, 0] and len(l0) == 0 and p0.shape == (0, 2)
     ws_r.close(); ws_f.close(); small.close()
+
+
+def test_call_mods_two_ranks_equal_single_process(tmp_path):
+    """Multi-GPU call_mods (one process per GPU, reads sharded by hole-batch, no data-path collective): two ranks — here both on
+    cuda:0, bookkeeping over gloo — must produce, after stitching, exactly the records of the single-process run, in input
+    order, with the same probabilities (the Philox counter of a site is its global index, whichever rank computes it)."""
+    import subprocess
+    import sys
+    import torch
+    from collections import OrderedDict
+    from ccsmeth_amd import bamio
+    from conftest import ROOT
+    rng = np.random.default_rng(77)
+    inp = str(tmp_path / "in.bam")
+    with bamio.BamWriter(inp, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
+        for i in range(23):
+            L = int(rng.integers(200, 3000))
+            seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=L)
+            pos = rng.integers(0, L - 1, L // 40)
+            seq[pos], seq[pos + 1] = ord("C"), ord("G")
+            kin = lambda: rng.integers(0, 256, L).astype(np.uint8)  # noqa: E731
+            tags = [("fi", "BC", kin()), ("fp", "BC", kin()), ("ri", "BC", kin()), ("rp", "BC", kin()), ("fn", "C", 9), ("rn", "C", 11)]
+            if i == 7:
+                tags = tags[1:]                                     # unusable read in the middle
+            w.write(bamio.BamRecord("z/%d/ccs" % i, flag=16 if i % 5 == 0 else 4, seq=seq.tobytes().decode(), tags=tags))
+    ckpt = str(tmp_path / "m.ckpt")
+    torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
+    base = [sys.executable, "-m", "ccsmeth_amd", "call_mods", "-i", inp, "-m", ckpt, "--batch_size", "300", "--holes_batch", "3"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.run(base + ["-o", str(tmp_path / "single")], check=True, env=env, cwd=ROOT, timeout=600)
+    procs = [subprocess.Popen(base + ["-o", str(tmp_path / "multi")], cwd=ROOT,
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+    def records(path):
+        with bamio.BamReader(path) as rd:
+            hdr = rd.header_text
+            return hdr, [(r.query_name, r.flag, r.seq, [(t, ty, v.tolist() if isinstance(v, np.ndarray) else v) for t, ty, v in r.tags]) for r in rd]
+    h1, r1 = records(str(tmp_path / "single.modbam.bam"))
+    h2, r2 = records(str(tmp_path / "multi.modbam.bam"))
+    assert len(r1) == 23 and r1 == r2
+    assert h1.split("@PG")[0] == h2.split("@PG")[0]
+    assert sum(1 for r in r1 if any(t == "ML" for t, _, _ in r[3])) >= 20
