@@ -65,7 +65,8 @@ EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspa
            "ccsm_model_precision", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
            "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded", "ccsm_debug_rows_capacity",
            "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean",
-           "ccsm_forward_reads_host", "ccsm_selftest_split_f8", "ccsm_debug_fp8_e4m3",
+           "ccsm_forward_reads_host", "ccsm_submit_reads_host", "ccsm_wait_reads_host", "ccsm_selftest_split_f8",
+           "ccsm_debug_fp8_e4m3",
            "ccsm_aggr_create", "ccsm_aggr_destroy", "ccsm_aggr_forward_host", "ccsm_aggr_forward_device")
 
 
@@ -110,6 +111,8 @@ def load():
     lib.ccsm_group_run.argtypes = [vp, vp, vp]
     lib.ccsm_group_pending.argtypes = [vp]
     lib.ccsm_forward_reads_host.argtypes = [vp, vp, C.POINTER(Reads), C.POINTER(H0), vp, vp, vp, vp, C.POINTER(C.c_int32), vp]
+    lib.ccsm_submit_reads_host.argtypes = [vp, vp, C.POINTER(Reads), vp, C.POINTER(H0), vp]
+    lib.ccsm_wait_reads_host.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
     lib.ccsm_workspace_timing_mean.argtypes = [vp, _FP, C.POINTER(C.c_int)]
     lib.ccsm_aggr_create.argtypes = [C.POINTER(AggrWeights), ci, C.c_uint64, C.c_int64, C.POINTER(vp)]
     lib.ccsm_aggr_destroy.argtypes = [vp]

@@ -35,6 +35,7 @@ ccsm_status fail(ccsm_status st, const std::string& msg) {
             return fail(CCSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                       \
     } while (0)
 
+constexpr size_t kReadTableBytes = 8 + 64 + 4 * 5 + 4;   // per read: offset | stats | length, fn, rn, nsites, first_site | spare
 constexpr int kNBGru = 2;    // batch tiles (of 32 rows) per workgroup of the version-1 GRU kernel (A/B testing only)
 constexpr int kNBGru2 = 3;   // ... of the version-2 GRU kernel (default)
 constexpr int kRowPad = 32 * kNBGru * kNBGru2;  // rows are padded so that either kernel tiles them exactly
@@ -110,6 +111,13 @@ struct ccsm_workspace {
     uint8_t* r_table = nullptr;      // offset i64 | stats f64 x8 | length i32 | fn | rn | nsites | first_site
     int r_cap_reads = 0;
     int* r_locs = nullptr;           // (max_sites)
+    uint8_t* rp_bytes = nullptr;     // pinned mirrors of r_bytes / r_table / r_locs
+    uint8_t* rp_table = nullptr;
+    int* rp_locs = nullptr;
+    bool r_pending = false;          // a read chunk is in flight (ccsm_submit_reads_host .. ccsm_wait_reads_host)
+    bool r_checked = false;
+    int r_nreads = 0, r_nsites = 0;
+    hipStream_t r_stream = nullptr;
     bool timing = false;
     static constexpr int kEvSets = 128;      // ring of event sets: one per run while timing is enabled
     hipEvent_t evs[kEvSets][8] = {};
@@ -643,7 +651,11 @@ void ccsm_workspace_destroy(ccsm_workspace* ws) {
     (void)hipFree(ws->x0); (void)hipFree(ws->act[0]); (void)hipFree(ws->act[1]);
     (void)hipFree(ws->h0buf); (void)hipFree(ws->part); (void)hipFree(ws->dbg); (void)hipFree(ws->d_in); (void)hipFree(ws->d_h0);
     (void)hipFree(ws->d_out);
+    if (ws->r_pending) (void)hipStreamSynchronize(ws->r_stream);
     (void)hipFree(ws->r_bytes); (void)hipFree(ws->r_table); (void)hipFree(ws->r_locs);
+    if (ws->rp_bytes) (void)hipHostFree(ws->rp_bytes);
+    if (ws->rp_table) (void)hipHostFree(ws->rp_table);
+    if (ws->rp_locs) (void)hipHostFree(ws->rp_locs);
     if (ws->p_in) (void)hipHostFree(ws->p_in);
     if (ws->p_h0) (void)hipHostFree(ws->p_h0);
     if (ws->p_out) (void)hipHostFree(ws->p_out);
@@ -770,17 +782,17 @@ ccsm_status ccsm_forward_host(const ccsm_model* m, ccsm_workspace* ws, int n_sit
 }
 
 // ---- read-level entry: raw CCS read arrays in, per-site calls out (feature extraction on the GPU) -----------------------
-ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, const ccsm_reads* rd, const ccsm_h0* h0,
-                                    int32_t* first_site, int32_t* locs, float* logits, float* probs, int32_t* n_sites_out,
-                                    void* stream) {
-    if (!m || !ws || !rd || !first_site || !locs || !logits || !probs || !n_sites_out)
-        return fail(CCSM_ERR_INVALID_ARG, "model, workspace, reads and every output must be non-NULL");
-    *n_sites_out = 0;
+// Enqueue everything for a chunk of reads on `stream`: H2D of the raw arrays (through the workspace's pinned block), per-read
+// statistics, h0, fragment packing, the model, D2H of locs / logits / probs.  With site_counts (the caller's per-read kept-site
+// counts, e.g. ccsm_bam_batch.n_sites) nothing waits on the GPU in here; without them one round trip fetches the counts.
+ccsm_status ccsm_submit_reads_host(const ccsm_model* m, ccsm_workspace* ws, const ccsm_reads* rd, const int32_t* site_counts,
+                                   const ccsm_h0* h0, void* stream) {
+    if (!m || !ws || !rd) return fail(CCSM_ERR_INVALID_ARG, "model, workspace and reads must be non-NULL");
     if (rd->n_reads <= 0) return fail(CCSM_ERR_INVALID_ARG, "n_reads must be > 0");
     if (!rd->offset || !rd->length || !rd->seq || !rd->fi || !rd->ri || !rd->fp || !rd->rp || !rd->fn || !rd->rn)
         return fail(CCSM_ERR_INVALID_ARG, "read arrays must be non-NULL");
     if (ws->device != m->device) return fail(CCSM_ERR_INVALID_ARG, "workspace and model live on different devices");
-    if (ws->pending_sites || ws->n_slices) return fail(CCSM_ERR_INVALID_ARG, "workspace has work in flight");
+    if (ws->pending_sites || ws->n_slices || ws->r_pending) return fail(CCSM_ERR_INVALID_ARG, "workspace has work in flight");
     if (h0 && (h0->mode < 0 || h0->mode > 2)) return fail(CCSM_ERR_INVALID_ARG, "unknown h0 mode");
     const int nr = rd->n_reads;
     size_t total = 0;
@@ -792,62 +804,85 @@ ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, con
     hipStream_t hs = static_cast<hipStream_t>(stream);
     if (total > ws->r_cap_bases) {
         (void)hipFree(ws->r_bytes);
-        ws->r_bytes = nullptr;
+        if (ws->rp_bytes) (void)hipHostFree(ws->rp_bytes);
+        ws->r_bytes = ws->rp_bytes = nullptr;
         ws->r_cap_bases = 0;
         const size_t cap = ((total * 5 / 4 + 4095) / 4096) * 4096;
         HIP_TRY(hipMalloc((void**)&ws->r_bytes, cap * 5));
+        HIP_TRY(hipHostMalloc((void**)&ws->rp_bytes, cap * 5, hipHostMallocDefault));
         ws->r_cap_bases = cap;
     }
     if (nr > ws->r_cap_reads) {
         (void)hipFree(ws->r_table);
-        ws->r_table = nullptr;
+        if (ws->rp_table) (void)hipHostFree(ws->rp_table);
+        ws->r_table = ws->rp_table = nullptr;
         ws->r_cap_reads = 0;
         const int cap = ((nr * 5 / 4 + 63) / 64) * 64;
-        HIP_TRY(hipMalloc((void**)&ws->r_table, (size_t)cap * (8 + 64 + 4 * 5)));
+        HIP_TRY(hipMalloc((void**)&ws->r_table, (size_t)cap * kReadTableBytes + 64));
+        HIP_TRY(hipHostMalloc((void**)&ws->rp_table, (size_t)cap * kReadTableBytes + 64, hipHostMallocDefault));
         ws->r_cap_reads = cap;
     }
-    if (!ws->r_locs) HIP_TRY(hipMalloc((void**)&ws->r_locs, (size_t)ws->max_sites * sizeof(int)));
+    if (!ws->r_locs) {
+        HIP_TRY(hipMalloc((void**)&ws->r_locs, (size_t)ws->max_sites * sizeof(int) + 64));
+        HIP_TRY(hipHostMalloc((void**)&ws->rp_locs, (size_t)ws->max_sites * sizeof(int) + 64, hipHostMallocDefault));
+    }
     const size_t cb = ws->r_cap_bases;
     uint8_t* d_arr[5];
     const uint8_t* h_arr[5] = {rd->seq, rd->fi, rd->ri, rd->fp, rd->rp};
     for (int a = 0; a < 5; ++a) {
         d_arr[a] = ws->r_bytes + a * cb;
-        HIP_TRY(hipMemcpyAsync(d_arr[a], h_arr[a], total, hipMemcpyHostToDevice, hs));
+        std::memcpy(ws->rp_bytes + a * cb, h_arr[a], total);
+        HIP_TRY(hipMemcpyAsync(d_arr[a], ws->rp_bytes + a * cb, total, hipMemcpyHostToDevice, hs));
     }
+    // per-read table, device and pinned mirror: offset i64 | stats f64 x8 | length | fn | rn | nsites | first_site (+1) | flag
     const size_t cr = (size_t)ws->r_cap_reads;
-    long long* d_off = reinterpret_cast<long long*>(ws->r_table);
-    double* d_stats = reinterpret_cast<double*>(ws->r_table + cr * 8);
-    int* d_len = reinterpret_cast<int*>(ws->r_table + cr * 72);
-    float* d_fn = reinterpret_cast<float*>(ws->r_table + cr * 76);
-    float* d_rn = reinterpret_cast<float*>(ws->r_table + cr * 80);
-    int* d_ns = reinterpret_cast<int*>(ws->r_table + cr * 84);
-    int* d_first = reinterpret_cast<int*>(ws->r_table + cr * 88);
-    HIP_TRY(hipMemcpyAsync(d_off, rd->offset, (size_t)nr * 8, hipMemcpyHostToDevice, hs));
-    HIP_TRY(hipMemcpyAsync(d_len, rd->length, (size_t)nr * 4, hipMemcpyHostToDevice, hs));
-    HIP_TRY(hipMemcpyAsync(d_fn, rd->fn, (size_t)nr * 4, hipMemcpyHostToDevice, hs));
-    HIP_TRY(hipMemcpyAsync(d_rn, rd->rn, (size_t)nr * 4, hipMemcpyHostToDevice, hs));
+    auto at = [&](uint8_t* base, size_t off) { return base + cr * off; };
+    long long* d_off = reinterpret_cast<long long*>(at(ws->r_table, 0));
+    double* d_stats = reinterpret_cast<double*>(at(ws->r_table, 8));
+    int* d_len = reinterpret_cast<int*>(at(ws->r_table, 72));
+    float* d_fn = reinterpret_cast<float*>(at(ws->r_table, 76));
+    float* d_rn = reinterpret_cast<float*>(at(ws->r_table, 80));
+    int* d_ns = reinterpret_cast<int*>(at(ws->r_table, 84));
+    int* d_first = reinterpret_cast<int*>(at(ws->r_table, 88));        // nr + 1 entries (capacity: cr + 16)
+    std::memcpy(at(ws->rp_table, 0), rd->offset, (size_t)nr * 8);
+    std::memcpy(at(ws->rp_table, 72), rd->length, (size_t)nr * 4);
+    std::memcpy(at(ws->rp_table, 76), rd->fn, (size_t)nr * 4);
+    std::memcpy(at(ws->rp_table, 80), rd->rn, (size_t)nr * 4);
+    HIP_TRY(hipMemcpyAsync(d_off, at(ws->rp_table, 0), (size_t)nr * 8, hipMemcpyHostToDevice, hs));
+    HIP_TRY(hipMemcpyAsync(d_len, at(ws->rp_table, 72), (size_t)nr * 4, hipMemcpyHostToDevice, hs));
+    HIP_TRY(hipMemcpyAsync(d_fn, at(ws->rp_table, 76), (size_t)nr * 4, hipMemcpyHostToDevice, hs));
+    HIP_TRY(hipMemcpyAsync(d_rn, at(ws->rp_table, 80), (size_t)nr * 4, hipMemcpyHostToDevice, hs));
     ccsm_extract::ReadTable rt{d_off, d_len, d_fn, d_rn};
     hipLaunchKernelGGL(ccsm_extract::extract_stats_kernel, dim3(nr), dim3(256), 0, hs, rt, d_arr[0], d_arr[1], d_arr[2], d_arr[3],
                        d_arr[4], d_stats, d_ns);
     HIP_TRY(hipGetLastError());
-    // the number of rows is data dependent: one round trip for the per-read site counts
-    HIP_TRY(hipMemcpyAsync(first_site + 1, d_ns, (size_t)nr * 4, hipMemcpyDeviceToHost, hs));
-    HIP_TRY(hipStreamSynchronize(hs));
-    first_site[0] = 0;
+    int32_t* h_first = reinterpret_cast<int32_t*>(at(ws->rp_table, 88));
+    h_first[0] = 0;
+    if (site_counts) {
+        for (int r = 0; r < nr; ++r) h_first[r + 1] = site_counts[r];
+    } else {   // the number of rows is data dependent: one round trip for the per-read site counts
+        HIP_TRY(hipMemcpyAsync(h_first + 1, d_ns, (size_t)nr * 4, hipMemcpyDeviceToHost, hs));
+        HIP_TRY(hipStreamSynchronize(hs));
+    }
     long long acc = 0;
     for (int r = 0; r < nr; ++r) {
-        acc += first_site[r + 1];
+        if (h_first[r + 1] < 0) return fail(CCSM_ERR_INVALID_ARG, "negative site count");
+        acc += h_first[r + 1];
         if (acc > ws->max_sites) return fail(CCSM_ERR_CAPACITY, "reads hold more sites than the workspace's max_sites");
-        first_site[r + 1] = (int32_t)acc;
+        h_first[r + 1] = (int32_t)acc;
     }
     const int n_sites = (int)acc;
-    *n_sites_out = n_sites;
+    ws->r_pending = true;
+    ws->r_nreads = nr;
+    ws->r_nsites = n_sites;
+    ws->r_checked = site_counts != nullptr;
+    ws->r_stream = hs;
     if (n_sites == 0) return CCSM_OK;
-    HIP_TRY(hipMemcpyAsync(d_first, first_site, (size_t)nr * 4, hipMemcpyHostToDevice, hs));
+    HIP_TRY(hipMemcpyAsync(d_first, h_first, (size_t)(nr + 1) * 4, hipMemcpyHostToDevice, hs));
     const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
     const float *h0a = nullptr, *h0b = nullptr;
     if (mode == CCSM_H0_EXPLICIT) {   // host tensors (6, n_sites, 256) per strand: parity/test path only
-        if (!h0->h0[0] || !h0->h0[1]) return fail(CCSM_ERR_INVALID_ARG, "explicit h0 needs both strand tensors");
+        if (!h0->h0[0] || !h0->h0[1]) { ws->r_pending = false; return fail(CCSM_ERR_INVALID_ARG, "explicit h0 needs both strand tensors"); }
         const size_t cap = (size_t)2 * 2 * kLayers * ws->max_sites * kHidden * sizeof(float);
         if (!ws->d_h0) {
             HIP_TRY(hipMalloc((void**)&ws->d_h0, cap));
@@ -864,7 +899,7 @@ ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, con
     const size_t total4 = (size_t)2 * kLayers * 2 * n_sites * (kHidden / 4);
     hipLaunchKernelGGL(prep_h0_kernel, dim3((int)std::min<size_t>((total4 + 255) / 256, 4096)), dim3(256), 0, hs, ws->h0buf, h0a,
                        h0b, n_sites, 0, ws->rows_p, mode, h0 ? h0->seed : 0, h0 ? h0->offset : 0);
-    hipLaunchKernelGGL(ccsm_extract::extract_pack_kernel, dim3(nr), dim3(256), 0, hs, rt, d_arr[0], d_arr[1], d_arr[2], d_arr[3],
+    hipLaunchKernelGGL(ccsm_extract::extract_pack_kernel, dim3(nr, ccsm_extract::kPackParts), dim3(256), 0, hs, rt, d_arr[0], d_arr[1], d_arr[2], d_arr[3],
                        d_arr[4], d_stats, d_first, m->embed, ws->x0, ws->r_locs, n_sites, 0);
     HIP_TRY(hipGetLastError());
     ws->n_slices = 1;
@@ -874,13 +909,48 @@ ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, con
     ws->slice_logits[0] = ws->d_out;
     ws->slice_probs[0] = ws->d_out + (size_t)n_sites * 2;
     ccsm_status st = dispatch_run(m, ws, hs);
-    if (st != CCSM_OK) return st;
+    if (st != CCSM_OK) { ws->r_pending = false; return st; }
     HIP_TRY(hipMemcpyAsync(ws->p_out, ws->d_out, (size_t)n_sites * 4 * sizeof(float), hipMemcpyDeviceToHost, hs));
-    HIP_TRY(hipMemcpyAsync(locs, ws->r_locs, (size_t)n_sites * sizeof(int), hipMemcpyDeviceToHost, hs));
-    HIP_TRY(hipStreamSynchronize(hs));
+    HIP_TRY(hipMemcpyAsync(ws->rp_locs, ws->r_locs, (size_t)n_sites * sizeof(int), hipMemcpyDeviceToHost, hs));
+    if (ws->r_checked) HIP_TRY(hipMemcpyAsync(at(ws->rp_table, 84), d_ns, (size_t)nr * 4, hipMemcpyDeviceToHost, hs));
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_wait_reads_host(ccsm_workspace* ws, int32_t* first_site, int32_t* locs, float* logits, float* probs,
+                                 int32_t* n_sites_out) {
+    if (!ws || !first_site || !locs || !logits || !probs || !n_sites_out)
+        return fail(CCSM_ERR_INVALID_ARG, "workspace and every output must be non-NULL");
+    if (!ws->r_pending) return fail(CCSM_ERR_INVALID_ARG, "no read chunk in flight on this workspace");
+    HIP_TRY(hipSetDevice(ws->device));
+    ws->r_pending = false;
+    const int nr = ws->r_nreads, n_sites = ws->r_nsites;
+    const size_t cr = (size_t)ws->r_cap_reads;
+    const int32_t* h_first = reinterpret_cast<const int32_t*>(ws->rp_table + cr * 88);
+    HIP_TRY(hipStreamSynchronize(ws->r_stream));
+    std::memcpy(first_site, h_first, (size_t)(nr + 1) * 4);
+    *n_sites_out = n_sites;
+    if (n_sites == 0) return CCSM_OK;
+    if (ws->r_checked) {   // the caller's counts against the device's own scan
+        const int32_t* h_ns = reinterpret_cast<const int32_t*>(ws->rp_table + cr * 84);
+        for (int r = 0; r < nr; ++r)
+            if (h_ns[r] != h_first[r + 1] - h_first[r])
+                return fail(CCSM_ERR_INVALID_ARG, "site_counts disagree with the reads (read " + std::to_string(r) + ")");
+    }
+    std::memcpy(locs, ws->rp_locs, (size_t)n_sites * sizeof(int));
     std::memcpy(logits, ws->p_out, (size_t)n_sites * 2 * sizeof(float));
     std::memcpy(probs, ws->p_out + (size_t)n_sites * 2, (size_t)n_sites * 2 * sizeof(float));
     return CCSM_OK;
+}
+
+ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, const ccsm_reads* rd, const ccsm_h0* h0,
+                                    int32_t* first_site, int32_t* locs, float* logits, float* probs, int32_t* n_sites_out,
+                                    void* stream) {
+    if (!first_site || !locs || !logits || !probs || !n_sites_out)
+        return fail(CCSM_ERR_INVALID_ARG, "model, workspace, reads and every output must be non-NULL");
+    *n_sites_out = 0;
+    ccsm_status st = ccsm_submit_reads_host(m, ws, rd, nullptr, h0, stream);
+    if (st != CCSM_OK) return st;
+    return ccsm_wait_reads_host(ws, first_site, locs, logits, probs, n_sites_out);
 }
 
 ccsm_status ccsm_workspace_set_timing(ccsm_workspace* ws, int enable) {

@@ -24,6 +24,8 @@ namespace ccsm_extract {
 
 using namespace ccsm;
 
+constexpr int kPackParts = 8;      // workgroups per read of extract_pack_kernel
+
 __device__ __forceinline__ int codec_v1(int c) {   // utils/process_utils.py:426-449
     return c < 64 ? c : (c < 128 ? 64 + 2 * (c - 64) : (c < 192 ? 192 + 4 * (c - 128) : 448 + 8 * (c - 192)));
 }
@@ -117,40 +119,48 @@ __device__ __forceinline__ uint32_t pack2h(_Float16 a, _Float16 b) {
 __global__ __launch_bounds__(256) void extract_pack_kernel(ReadTable rt, const uint8_t* __restrict__ seq,
                                                            const uint8_t* __restrict__ fi, const uint8_t* __restrict__ ri,
                                                            const uint8_t* __restrict__ fp, const uint8_t* __restrict__ rp,
-                                                           const double* __restrict__ stats, const int* __restrict__ first_site,
+                                                           const double* __restrict__ stats, const int* __restrict__ first_site /* n_reads + 1 */,
                                                            const float* __restrict__ embed, uint4* __restrict__ x0,
                                                            int* __restrict__ locs, int n_sites_total, int row_base) {
-    __shared__ int s_cnt[256];
-    __shared__ int s_base;
+    // grid = (reads, kPackParts): every part redoes the (cheap) ordered scan of the read's CG sites and writes the rows of
+    // its own share of them, so that a chunk of a few long reads still spreads over the chip
+    __shared__ int s_wtot[4];
     const int r = blockIdx.x;
     const long long off = rt.offset[r];
     const int n = rt.length[r];
     const double* st = stats + (size_t)r * 8;
     const float fn = rt.fn[r], rn = rt.rn[r];
     const int first = first_site[r];
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
-    // ordered compaction of the kept sites, 256 candidate positions per round
-    for (int start = 0; start < n; start += blockDim.x) {
+    const int cap = first_site[r + 1] - first;     // rows reserved for this read (the caller's count when it supplied one)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ordered compaction of the kept sites, 256 candidate positions per round: wave ballots + four wave totals
+    int base = 0;
+    for (int start = 0; start < n; start += 256) {
         const int i = start + threadIdx.x;
         const bool hit = i + 1 < n && seq[off + i] == 'C' && seq[off + i + 1] == 'G' && keep_site(i, n);
-        s_cnt[threadIdx.x] = hit ? 1 : 0;
+        const unsigned long long mask = __ballot(hit);
+        if (lane == 0) s_wtot[wave] = __popcll(mask);
         __syncthreads();
-        for (int o = 1; o < (int)blockDim.x; o <<= 1) {       // inclusive scan
-            const int v = threadIdx.x >= o ? s_cnt[threadIdx.x - o] : 0;
-            __syncthreads();
-            s_cnt[threadIdx.x] += v;
-            __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = s_wtot[w];
+            woff += w < wave ? c : 0;
+            tot += c;
         }
-        const int base = s_base;
-        if (hit) locs[first + base + s_cnt[threadIdx.x] - 1] = i;
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) s_base = base + s_cnt[threadIdx.x];
+        const int idx = base + woff + __popcll(mask & ((1ull << lane) - 1ull));
+        if (hit && idx < cap) locs[first + idx] = i;     // every part writes the same values
+        base += tot;
         __syncthreads();
     }
-    const int nk = s_base;
+    const int nk = min(base, cap);
+    __threadfence_block();
+    __syncthreads();
+    const int items = nk * 2 * kSeqLen * 2;
+    const int per_part = (items + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int w_begin = blockIdx.y * per_part, w_end = min(items, w_begin + per_part);
     // one thread per (site, strand, t, g): a 16-byte hi and a 16-byte lo fragment piece
-    for (int w = threadIdx.x; w < nk * 2 * kSeqLen * 2; w += blockDim.x) {
+    for (int w = w_begin + threadIdx.x; w < w_end; w += blockDim.x) {
         const int g = w & 1;
         const int t = (w >> 1) % kSeqLen;
         const int strand = ((w >> 1) / kSeqLen) & 1;

@@ -241,6 +241,54 @@ class Workspace:
         n = n.value
         return first, locs[:n], logits[:n], probs[:n]
 
+    def submit_reads_arrays(self, offset, length, seq, fi, ri, fp, rp, fn, rn, site_counts=None, seed=0, offset_counter=0,
+                            h0=None, stream=None):
+        """ccsm_submit_reads_host: enqueue one chunk of reads (arrays as forward_reads_arrays); with site_counts (int32 per
+        read, e.g. bamnative.Batch.n_sites) the call does not wait for the GPU.  Collect with wait_reads()."""
+        offset = np.ascontiguousarray(offset, np.int64)
+        length = np.ascontiguousarray(length, np.int32)
+        fn, rn = np.ascontiguousarray(fn, np.float32), np.ascontiguousarray(rn, np.float32)
+        nr = len(offset)
+        if not (len(length) == len(fn) == len(rn) == nr) or nr == 0:
+            raise ValueError("per-read arrays must have the same, non-zero length")
+        arrs = [np.ascontiguousarray(a, np.uint8) for a in (seq, fi, ri, fp, rp)]
+        if any(len(a) < int((offset + length).max()) for a in arrs):
+            raise ValueError("byte arrays are shorter than offset + length")
+        cnt = None
+        if site_counts is not None:
+            cnt = np.ascontiguousarray(site_counts, np.int32)
+            if len(cnt) != nr:
+                raise ValueError("site_counts must have one entry per read")
+        rd = _lib.Reads()
+        rd.n_reads = nr
+        rd.offset, rd.length = offset.ctypes.data, length.ctypes.data
+        rd.seq, rd.fi, rd.ri, rd.fp, rd.rp = (a.ctypes.data for a in arrs)
+        rd.fn, rd.rn = fn.ctypes.data, rn.ctypes.data
+        h = _lib.H0()
+        if h0 is None:
+            h.mode = _lib.H0_DEVICE_RNG
+        elif isinstance(h0, str) and h0 == "zero":
+            h.mode = _lib.H0_ZERO
+        else:
+            raise ValueError("submit_reads_arrays takes h0=None (device RNG) or 'zero'")
+        h.seed, h.offset = int(seed), int(offset_counter)
+        _lib.check(self.model._lib.ccsm_submit_reads_host(self.model.handle, self.handle, C.byref(rd), cnt.ctypes.data if cnt is not None else None,
+                                                          C.byref(h), stream))
+        self._reads_pending = nr
+
+    def wait_reads(self):
+        """ccsm_wait_reads_host -> (first_site, locs, logits, probs) of the chunk submitted last."""
+        nr = self._reads_pending
+        first = np.zeros(nr + 1, np.int32)
+        locs = np.empty(self.max_sites, np.int32)
+        logits = np.empty((self.max_sites, 2), np.float32)
+        probs = np.empty((self.max_sites, 2), np.float32)
+        n = C.c_int32(0)
+        _lib.check(self.model._lib.ccsm_wait_reads_host(self.handle, first.ctypes.data, locs.ctypes.data, logits.ctypes.data,
+                                                        probs.ctypes.data, C.byref(n)))
+        n = n.value
+        return first, locs[:n], logits[:n], probs[:n]
+
     def forward_torch(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None,
                       out=None):
         """torch CUDA tensors in / out, asynchronous on `stream` (default: torch's current stream)."""

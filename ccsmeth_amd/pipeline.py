@@ -41,6 +41,7 @@ class CallModsPipeline:
         self.seed = seed
         self.extract = extract
         self._rws = None
+        self._rwss = [None, None]                       # read-level workspaces of the double-buffered native path
         dev = torch.device("cuda", device_model.device)
         self._streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
         self._slots = [_Slot(device_model, self.batch_size, s.cuda_stream) for s in self._streams]
@@ -51,6 +52,9 @@ class CallModsPipeline:
             s.ws.close()
         if self._rws is not None:
             self._rws.close()
+        for w in self._rwss:
+            if w is not None:
+                w.close()
 
     # ---- device-side extraction -----------------------------------------------------------------------------------
     def _run_device(self, reads):
@@ -130,7 +134,9 @@ class CallModsPipeline:
 
     # ---- native BAM batches (ccsmeth_amd/bamnative.py): no per-read Python objects ------------------------------------------
     def run_native_batch(self, batch):
-        """One bamnative.Batch through ccsm_forward_reads_host, in chunks of whole reads holding <= batch_size sites.
+        """One bamnative.Batch through ccsm_submit_reads_host / ccsm_wait_reads_host, in chunks of whole reads holding
+        <= batch_size sites, double-buffered over two workspaces and two streams: chunk k+1 is copied, extracted and queued
+        while chunk k runs (the reader's site counts make the submit non-blocking).
         Returns (first_site int32 (n_reads+1), locs int32, prob1 float32, tagged uint8 (n_reads), n_failed) in the batch's read
         order, i.e. exactly the arguments of NativeBamWriter.write_batch."""
         nr = batch.n_reads
@@ -142,26 +148,39 @@ class CallModsPipeline:
         prob1 = np.empty(total, np.float32)
         tagged = (cnt > 0).astype(np.uint8)
         idx = np.flatnonzero(cnt > 0)
-        start = 0
+        inflight = []                                   # [(workspace slot, selection)]
+
+        def collect():
+            k, sel = inflight.pop(0)
+            f, lc, _, pr = self._rwss[k].wait_reads()
+            if not np.array_equal(np.diff(f), cnt[sel]):
+                raise RuntimeError("device and host site counts disagree")
+            a = int(first[sel[0]])
+            locs[a:a + len(lc)] = lc                      # sel is a run of consecutive usable reads: their spans are adjacent
+            prob1[a:a + len(lc)] = prob1_norm_round6(pr)
+
+        start, turn = 0, 0
         while start < len(idx):
             csum = np.cumsum(cnt[idx[start:]])
             take = max(1, int(np.searchsorted(csum, self.batch_size, side="right")))
             sel = idx[start:start + take]
             csites = int(cnt[sel].sum())
-            if self._rws is None or self._rws.max_sites < csites:
-                if self._rws is not None:
-                    self._rws.close()
-                self._rws = self.dm.workspace(max(csites, self.batch_size))
-            f, lc, _, pr = self._rws.forward_reads_arrays(batch.offset[sel], batch.length[sel], batch.seq, batch.fi, batch.ri, batch.fp,
-                                                          batch.rp, batch.fn[sel], batch.rn[sel], seed=self.seed,
-                                                          offset_counter=self._site_counter, stream=self._slots[0].stream)
-            if not np.array_equal(np.diff(f), cnt[sel]):
-                raise RuntimeError("device and host site counts disagree")
-            self._site_counter += len(lc)
-            a = int(first[sel[0]])
-            locs[a:a + len(lc)] = lc                      # sel is a run of consecutive usable reads: their spans are adjacent
-            prob1[a:a + len(lc)] = prob1_norm_round6(pr)
+            k = turn & 1
+            if len(inflight) == 2:
+                collect()
+            if self._rwss[k] is None or self._rwss[k].max_sites < csites:
+                if self._rwss[k] is not None:
+                    self._rwss[k].close()
+                self._rwss[k] = self.dm.workspace(max(csites, self.batch_size))
+            self._rwss[k].submit_reads_arrays(batch.offset[sel], batch.length[sel], batch.seq, batch.fi, batch.ri, batch.fp, batch.rp,
+                                              batch.fn[sel], batch.rn[sel], site_counts=cnt[sel], seed=self.seed,
+                                              offset_counter=self._site_counter, stream=self._slots[k].stream)
+            self._site_counter += csites
+            inflight.append((k, sel))
             start += take
+            turn += 1
+        while inflight:
+            collect()
         return first, locs, prob1, tagged, int(nr - len(idx))
 
     # ---- host side ------------------------------------------------------------------------------------------------

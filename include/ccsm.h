@@ -172,6 +172,15 @@ typedef struct ccsm_reads {
  * each site's C in its read, in read order then ascending; logits / probs (capacity max_sites x 2); *n_sites.
  * h0 explicit tensors, if given, are HOST (6, n_sites, 256) per strand.  CCSM_ERR_CAPACITY when the reads hold more
  * than the workspace's max_sites sites (nothing is computed; *n_sites is not set).  Blocks until done. */
+/* Pipelined form (two workspaces on two streams keep the GPU busy while the host prepares the next chunk): submit copies the
+ * arrays into the workspace's pinned block and enqueues everything on `stream`.  site_counts = the caller's per-read kept-site
+ * counts (e.g. ccsm_bam_batch.n_sites): with them nothing in submit waits for the GPU; the device scan must agree, or wait
+ * returns CCSM_ERR_INVALID_ARG.  NULL: submit makes one round trip for the counts (that is what ccsm_forward_reads_host does).
+ * Explicit h0 tensors must stay valid until submit returns. */
+ccsm_status ccsm_submit_reads_host(const ccsm_model* m, ccsm_workspace* ws, const ccsm_reads* reads, const int32_t* site_counts,
+                                   const ccsm_h0* h0, void* stream);
+ccsm_status ccsm_wait_reads_host(ccsm_workspace* ws, int32_t* first_site, int32_t* locs, float* logits, float* probs,
+                                 int32_t* n_sites);
 ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, const ccsm_reads* reads, const ccsm_h0* h0,
                                     int32_t* first_site, int32_t* locs, float* logits, float* probs, int32_t* n_sites,
                                     void* stream);

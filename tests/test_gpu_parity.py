@@ -619,3 +619,57 @@ def test_call_mods_two_ranks_equal_single_process(tmp_path):
     assert len(r1) == 23 and r1 == r2
     assert h1.split("@PG")[0] == h2.split("@PG")[0]
     assert sum(1 for r in r1 if any(t == "ML" for t, _, _ in r[3])) >= 20
+
+
+def test_read_level_submit_wait_pipelined(model7):
+    """ccsm_submit_reads_host / ccsm_wait_reads_host: two chunks in flight on two workspaces and two streams, with the
+    caller's site counts (no GPU round trip in submit), equal the blocking call; wrong counts are refused at wait."""
+    import torch
+    from ccsmeth_amd import _lib
+    from ccsmeth_amd import extract_features as ef
+    w, dm = model7
+    rng = np.random.default_rng(31)
+    reads = []
+    for length in [3000, 900, 5000, 64, 1200, 2500]:
+        seq = rng.choice(list("ACGT"), size=length)
+        for j in range(11, length - 1, 29):
+            seq[j], seq[j + 1] = "C", "G"
+        code = lambda: np.clip(rng.gamma(2.0, 20.0, size=length), 0, 255).astype(np.uint8)  # noqa: E731
+        reads.append(("".join(seq), code(), code(), code(), code(), 9.0, 12.0))
+
+    def arrays(rs):
+        lens = np.array([len(r[0]) for r in rs], np.int32)
+        offs = np.zeros(len(rs), np.int64)
+        offs[1:] = np.cumsum(lens[:-1])
+        cat = [np.frombuffer("".join(r[0] for r in rs).encode(), np.uint8)] + [np.concatenate([r[k] for r in rs]) for k in range(1, 5)]
+        cnt = np.array([ef.count_kept_sites(np.frombuffer(r[0].encode(), np.uint8)) for r in rs], np.int32)
+        return (offs, lens, *cat, np.array([r[5] for r in rs], np.float32), np.array([r[6] for r in rs], np.float32)), cnt
+    (a1, c1), (a2, c2) = arrays(reads[:3]), arrays(reads[3:])
+    ws = [dm.workspace(int(max(c1.sum(), c2.sum()))) for _ in range(2)]
+    streams = [torch.cuda.Stream(torch.device("cuda", 0)) for _ in range(2)]
+    ws[0].submit_reads_arrays(*a1, site_counts=c1, seed=3, offset_counter=0, stream=streams[0].cuda_stream)
+    ws[1].submit_reads_arrays(*a2, site_counts=c2, seed=3, offset_counter=int(c1.sum()), stream=streams[1].cuda_stream)
+    out1, out2 = ws[0].wait_reads(), ws[1].wait_reads()
+    ref = dm.workspace(int(c1.sum() + c2.sum()))
+    f, locs, logits, probs = ref.forward_reads(reads, seed=3, offset=0)
+    n1 = int(c1.sum())
+    assert np.array_equal(np.diff(f), np.concatenate([c1, c2]))
+    assert np.array_equal(np.concatenate([out1[1], out2[1]]), locs)
+    assert np.abs(np.concatenate([out1[3], out2[3]]) - probs).max() < 2e-6
+    assert out1[0][-1] == n1 and out2[0][-1] == int(c2.sum())
+    # wrong counts: refused when collected, workspace usable afterwards
+    bad = c1.copy()
+    bad[1] -= 1
+    ws[0].submit_reads_arrays(*a1, site_counts=bad, seed=3)
+    with pytest.raises(_lib.CcsmError):
+        ws[0].wait_reads()
+    ws[0].submit_reads_arrays(*a1, seed=3)                     # no counts: one round trip inside submit
+    again = ws[0].wait_reads()
+    assert np.array_equal(again[1], out1[1]) and np.abs(again[3] - out1[3]).max() < 2e-6
+    # a second submit before the wait is an error
+    ws[1].submit_reads_arrays(*a2, site_counts=c2, seed=3)
+    with pytest.raises(_lib.CcsmError):
+        ws[1].submit_reads_arrays(*a2, site_counts=c2, seed=3)
+    ws[1].wait_reads()
+    for x in ws + [ref]:
+        x.close()
