@@ -22,32 +22,81 @@ REF_VERSION = "0.5.0"     # VN the reference writes (ccsmeth/_version.py)
 
 
 def build_parser():
+    """Flags, short options and defaults of the reference's `ccsmeth call_mods` (ccsmeth.py:196-326).  Flags whose non-default
+    values select paths outside this build (align mode, transformer models, TSV input, ...) are accepted and
+    rejected with a ValueError in call_mods(), like the reference rejects an unknown --model_type."""
     p = argparse.ArgumentParser("ccsmeth_amd call_mods", description="call 5mCpG from a HiFi BAM with kinetics (MI355X)")
     p.add_argument("--input", "-i", required=True, help="input BAM (fi/ri/fp/rp/fn/rn tags)")
-    p.add_argument("--model_file", "-m", required=True, help=".ckpt (torch state_dict) of attbigru2s")
+    p.add_argument("--holes_batch", type=int, default=50)
     p.add_argument("--output", "-o", required=True, help="output prefix; writes <output>.modbam.bam")
+    p.add_argument("--gzip", action="store_true", default=False, help="(reference: TSV output only) ignored")
+    p.add_argument("--keep_pulse", action="store_true", default=False)
+    p.add_argument("--no_sort", action="store_true", default=False,
+                   help="the output is always in input order (coordinate sort + index are not provided)")
+    p.add_argument("--model_file", "-m", required=True, help=".ckpt (torch state_dict) of attbigru2s")
     p.add_argument("--model_type", default="attbigru2s")
     p.add_argument("--seq_len", type=int, default=21)
-    p.add_argument("--layer_rnn", type=int, default=3)
-    p.add_argument("--hid_rnn", type=int, default=256)
+    p.add_argument("--is_npass", default="yes")
+    p.add_argument("--is_stds", default="no")
+    p.add_argument("--is_sn", default="no")
+    p.add_argument("--is_map", default="no")
     p.add_argument("--class_num", type=int, default=2)
     p.add_argument("--dropout_rate", type=float, default=0)
     p.add_argument("--batch_size", "-b", type=int, default=512)
-    p.add_argument("--holes_batch", type=int, default=50)
-    p.add_argument("--tseed", type=int, default=1234)
-    p.add_argument("--keep_pulse", action="store_true", default=False)
-    p.add_argument("--device", type=int, default=0)
-    p.add_argument("--mode", default="denovo", choices=["denovo"])
-    p.add_argument("--norm", default="zscore", choices=["zscore"])
+    p.add_argument("--layer_rnn", type=int, default=3)
+    p.add_argument("--hid_rnn", type=int, default=256)
+    p.add_argument("--layer_trans", type=int, default=6)
+    p.add_argument("--nhead", type=int, default=4)
+    p.add_argument("--d_model", type=int, default=256)
+    p.add_argument("--dim_ff", type=int, default=512)
+    p.add_argument("--mode", default="denovo")
+    p.add_argument("--holeids_e", default=None)
+    p.add_argument("--holeids_ne", default=None)
     p.add_argument("--motifs", default="CG")
     p.add_argument("--mod_loc", type=int, default=0)
+    p.add_argument("--methy_label", type=int, default=1, choices=[1, 0])
+    p.add_argument("--norm", default="zscore")
+    p.add_argument("--no_decode", action="store_true", default=False)
+    p.add_argument("--ref", default=None)
+    p.add_argument("--mapq", type=int, default=1)
+    p.add_argument("--identity", type=float, default=0.0)
+    p.add_argument("--no_supplementary", action="store_true", default=False)
+    p.add_argument("--skip_unmapped", default="yes")
+    p.add_argument("--threads", "-p", type=int, default=10, help="BGZF inflate / deflate threads of --io native")
+    p.add_argument("--threads_call", type=int, default=3, help="(reference: call workers) ignored: one process per GPU")
+    p.add_argument("--tseed", type=int, default=1234)
+    p.add_argument("--use_compile", default="no")
+    # this build's own switches
+    p.add_argument("--device", type=int, default=0)
     p.add_argument("--io", default="native", choices=["native", "python"],
                    help="BAM reader/writer: libccsm_bam (threaded BGZF, whole read chunks straight to the GPU; implies --extract\n"
                         "device) or the pure-Python record-by-record implementation")
-    p.add_argument("--threads", type=int, default=8, help="BGZF inflate / deflate threads of --io native")
     p.add_argument("--extract", default="device", choices=["device", "host"],
                    help="where the 21-mer features are built: on the GPU from the raw read arrays (default) or NumPy on the host")
     return p
+
+
+def _check_scope(args):
+    """Reject, loudly, the reference options this build does not implement (SURVEY.md 8 scope)."""
+    yes = lambda v: str(v).lower() in ("yes", "true", "t", "1")  # noqa: E731  (ccsmeth str2bool)
+    if args.model_type != "attbigru2s":
+        raise ValueError("--model_type not right!")                    # call_modifications.py:340
+    if not yes(args.is_npass) or yes(args.is_stds) or yes(args.is_sn) or yes(args.is_map):
+        raise ValueError("this build implements --is_npass yes --is_stds no --is_sn no --is_map no")
+    if (args.layer_rnn, args.hid_rnn, args.class_num, args.seq_len) != (3, 256, 2, 21):
+        if args.seq_len % 2 == 0:
+            raise ValueError("--seq_len must be odd")                  # :500-501
+        raise ValueError("this build implements --seq_len 21 --layer_rnn 3 --hid_rnn 256 --class_num 2")
+    if args.mode != "denovo" or args.ref is not None:
+        raise ValueError("this build implements --mode denovo (no --ref)")
+    if args.motifs.upper() != "CG" or args.mod_loc != 0:
+        raise ValueError("this build implements --motifs CG --mod_loc 0")
+    if args.norm != "zscore" or args.no_decode:
+        raise ValueError("this build implements --norm zscore with CodecV1 decoding")
+    if args.holeids_e is not None or args.holeids_ne is not None:
+        raise ValueError("--holeids_e / --holeids_ne are not implemented")
+    if yes(args.use_compile):
+        raise ValueError("--use_compile applies to the reference's torch model only")
 
 
 def _load_state_dict(path):
@@ -73,10 +122,7 @@ def call_mods(args, log=sys.stderr):
         raise ValueError("--model_file is not set right!")            # call_modifications.py:484-485
     if not os.path.exists(args.input):
         raise ValueError("--input_file does not exist!")              # :486-488
-    if args.seq_len % 2 == 0:
-        raise ValueError("--seq_len must be odd")                      # :500-501
-    if args.motifs.upper() != "CG" or args.mod_loc != 0:
-        raise ValueError("this build implements --motifs CG --mod_loc 0")
+    _check_scope(args)
     from collections import OrderedDict
     from .models import ModelAttRNN
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:

@@ -1,0 +1,42 @@
+"""Fixture: flags and defaults of the reference's `ccsmeth call_mods` sub-parser (ccsmeth/ccsmeth.py:196-326), captured by
+running the reference's own main() argument parser in THIS container (reference importable here only).
+Writes tests/golden/cli_golden.json.  usage: python tests/golden/make_cli_golden.py"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _ref_import import import_reference  # noqa: E402
+
+import_reference()
+captured = {}
+orig = argparse.ArgumentParser.parse_args
+
+
+def grab(self, args=None, namespace=None):      # the reference builds its parser inside main(): intercept parse_args
+    captured["parser"] = self
+    raise SystemExit(0)
+
+
+argparse.ArgumentParser.parse_args = grab
+try:
+    from ccsmeth import ccsmeth as ref_cli
+    sys.argv = ["ccsmeth", "call_mods"]
+    try:
+        ref_cli.main()
+    except SystemExit:
+        pass
+finally:
+    argparse.ArgumentParser.parse_args = orig
+top = captured["parser"]
+sub = next(a for a in top._actions if isinstance(a, argparse._SubParsersAction)).choices["call_mods"]
+flags = {}
+for a in sub._actions:
+    if a.dest == "help":
+        continue
+    flags[a.dest] = dict(options=list(a.option_strings), default=a.default, required=bool(a.required),
+                         kind=type(a).__name__, type=getattr(a.type, "__name__", None))
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cli_golden.json")
+json.dump(dict(source="ccsmeth/ccsmeth.py call_mods sub-parser", flags=flags), open(out, "w"), indent=1, sort_keys=True)
+print("wrote", out, len(flags), "flags")

@@ -91,3 +91,24 @@ def test_prob1_norm_round6_is_float32_rounding():
     got = cm.prob1_norm_round6(p)
     exp = np.array([round(b / (a + b), 6) for a, b in p], np.float32)     # NumPy float32 scalar __round__, as the reference
     assert got.dtype == np.float32 and np.array_equal(got, exp)
+
+
+def test_call_mods_cli_matches_reference_parser():
+    """Every flag of the reference's `ccsmeth call_mods` (tests/golden/cli_golden.json, captured from the reference's own
+    argparse) exists here with the same option strings and default; out-of-scope values are rejected with ValueError."""
+    import argparse
+    from ccsmeth_amd.call_mods import _check_scope, build_parser
+    gold = json.load(open(os.path.join(GOLDEN, "cli_golden.json")))["flags"]
+    ours = {a.dest: a for a in build_parser()._actions if a.dest != "help"}
+    for dest, g in gold.items():
+        assert dest in ours, dest
+        assert sorted(ours[dest].option_strings) == sorted(g["options"]), dest
+        assert ours[dest].default == g["default"], dest
+        assert bool(ours[dest].required) == g["required"], dest
+    base = ["-i", "a.bam", "-m", "m.ckpt", "-o", "out"]
+    _check_scope(build_parser().parse_args(base + ["-p", "4", "--threads_call", "2", "--no_sort", "--keep_pulse"]))
+    for extra in (["--seq_len", "20"], ["--mode", "align"], ["--is_sn", "yes"], ["--model_type", "attbilstm2s"], ["--motifs", "CHG"],
+                  ["--norm", "min-max"], ["--no_decode"], ["--hid_rnn", "128"], ["--holeids_e", "ids.txt"], ["--ref", "g.fa"]):
+        with pytest.raises(ValueError):
+            _check_scope(build_parser().parse_args(base + extra))
+    assert isinstance(build_parser(), argparse.ArgumentParser)
