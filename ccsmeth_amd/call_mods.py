@@ -93,10 +93,34 @@ def _check_scope(args):
         raise ValueError("this build implements --motifs CG --mod_loc 0")
     if args.norm != "zscore" or args.no_decode:
         raise ValueError("this build implements --norm zscore with CodecV1 decoding")
-    if args.holeids_e is not None or args.holeids_ne is not None:
-        raise ValueError("--holeids_e / --holeids_ne are not implemented")
     if yes(args.use_compile):
         raise ValueError("--use_compile applies to the reference's torch model only")
+
+
+def _get_holes(holeidfile):
+    """extract_features.py:76-84: one read name per line."""
+    holes = set()
+    with open(holeidfile, "r") as rf:
+        for line in rf:
+            if line.strip():
+                holes.add(line.strip())
+    return holes
+
+
+def _skip_by_name(name, holeids_e, holeids_ne):
+    """extract_features.py:268-271: reads outside --holeids_e or inside --holeids_ne yield no features (written untagged)."""
+    return (holeids_e is not None and name not in holeids_e) or (holeids_ne is not None and name in holeids_ne)
+
+
+def _batch_names(batch):
+    """Read names of a bamnative.Batch (BAM record: block_size i32, 32 fixed bytes with l_read_name at +8, then the name)."""
+    names = []
+    rec = batch.records
+    for r in range(batch.n_reads):
+        o = int(batch.rec_offset[r]) + 4
+        l_name = int(rec[o + 8])
+        names.append(bytes(rec[o + 32:o + 32 + l_name - 1]).decode("ascii"))
+    return names
 
 
 def _load_state_dict(path):
@@ -137,6 +161,9 @@ def call_mods(args, log=sys.stderr):
         model.load_state_dict(OrderedDict((k[7:], v) for k, v in para.items()))
     model.cuda(args.device).eval()
     pipe = CallModsPipeline(model._dev, batch_size=args.batch_size, seed=args.tseed, extract=args.extract)
+    holeids_e = None if args.holeids_e is None else _get_holes(args.holeids_e)          # extract_features.py:561-562
+    holeids_ne = None if args.holeids_ne is None else _get_holes(args.holeids_ne)
+    name_filter = holeids_e is not None or holeids_ne is not None
     out_path = args.output + ".modbam.bam"                             # :494
     cnt_w = cnt_mm = cnt_failed = 0
     rm_pulse = not args.keep_pulse
@@ -181,10 +208,13 @@ def call_mods(args, log=sys.stderr):
                     if b is None:
                         break
                     nxt = rpool.submit(rd.next_batch, args.holes_batch)
-                    batch_sites = int(np.where(b.length > 0, b.n_sites, 0).sum())
+                    skip = None
+                    if name_filter:
+                        skip = np.array([_skip_by_name(nm, holeids_e, holeids_ne) for nm in _batch_names(b)], bool)
+                    batch_sites = int(np.where((b.length > 0) & (~skip if skip is not None else True), b.n_sites, 0).sum())
                     if bi % world == rank:
                         pipe._site_counter = site_base
-                        first, locs, prob1, tagged, failed = pipe.run_native_batch(b)
+                        first, locs, prob1, tagged, failed = pipe.run_native_batch(b, skip)
                         if pending is not None:
                             cnt_mm += pending.result()
                         pending = wpool.submit(write, b, first, locs, prob1, tagged, bi)
@@ -226,7 +256,10 @@ def call_mods(args, log=sys.stderr):
                 nonlocal cnt_w, cnt_mm, cnt_failed
                 if not batch:
                     return
-                calls, failed = pipe.run([_read_of(r) for r in batch])
+                rds = [_read_of(r) for r in batch]
+                if name_filter:       # a filtered read goes through as one without usable kinetics
+                    rds = [r._replace(fi=np.empty(0, np.uint8)) if _skip_by_name(r.name, holeids_e, holeids_ne) else r for r in rds]
+                calls, failed = pipe.run(rds)
                 cnt_failed += failed
                 for rec, c in zip(batch, calls):
                     old = [(t, v) for t, _, v in rec.tags]

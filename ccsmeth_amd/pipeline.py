@@ -133,7 +133,7 @@ class CallModsPipeline:
             pos += k
 
     # ---- native BAM batches (ccsmeth_amd/bamnative.py): no per-read Python objects ------------------------------------------
-    def run_native_batch(self, batch):
+    def run_native_batch(self, batch, skip=None):
         """One bamnative.Batch through ccsm_submit_reads_host / ccsm_wait_reads_host, in chunks of whole reads holding
         <= batch_size sites, double-buffered over two workspaces and two streams: chunk k+1 is copied, extracted and queued
         while chunk k runs (the reader's site counts make the submit non-blocking).
@@ -141,6 +141,8 @@ class CallModsPipeline:
         order, i.e. exactly the arguments of NativeBamWriter.write_batch."""
         nr = batch.n_reads
         cnt = np.where(batch.length > 0, batch.n_sites, 0).astype(np.int64)
+        if skip is not None:                            # reads excluded by name (--holeids_e / --holeids_ne): no features
+            cnt[np.asarray(skip, bool)] = 0
         first = np.zeros(nr + 1, np.int32)
         np.cumsum(cnt, out=first[1:])
         total = int(first[-1])

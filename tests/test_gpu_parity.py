@@ -463,6 +463,15 @@ def test_call_mods_bam_to_modbam(tmp_path):
                     assert o.get_tag("MM") == oh.get_tag("MM")
                     d = np.abs(o.get_tag("ML").astype(int) - oh.get_tag("ML").astype(int)).max()
                     assert d == 0 if exact else d <= 1
+    # --holeids_ne / --holeids_e (extract_features.py:268-271): excluded reads are written untagged, in both I/O paths
+    ids = str(tmp_path / "ids.txt")
+    open(ids, "w").write("hole0\nhole2\n")
+    for extra in ([], ["--io", "python"]):
+        r_ne = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "ne"), "--holeids_ne", ids] + extra))
+        r_e = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "e"), "--holeids_e", ids] + extra))
+        assert r_ne["tagged"] == res["tagged"] - 2 and r_e["tagged"] == 2
+        with bamio.BamReader(r_e["output"]) as rd:
+            assert [o.query_name for o in rd if o.has_tag("MM")] == ["hole0", "hole2"]
     # argument checks of the reference
     bad = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / "o2"), "--seq_len", "20"])
     with pytest.raises(ValueError):

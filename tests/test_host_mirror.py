@@ -108,7 +108,7 @@ def test_call_mods_cli_matches_reference_parser():
     base = ["-i", "a.bam", "-m", "m.ckpt", "-o", "out"]
     _check_scope(build_parser().parse_args(base + ["-p", "4", "--threads_call", "2", "--no_sort", "--keep_pulse"]))
     for extra in (["--seq_len", "20"], ["--mode", "align"], ["--is_sn", "yes"], ["--model_type", "attbilstm2s"], ["--motifs", "CHG"],
-                  ["--norm", "min-max"], ["--no_decode"], ["--hid_rnn", "128"], ["--holeids_e", "ids.txt"], ["--ref", "g.fa"]):
+                  ["--norm", "min-max"], ["--no_decode"], ["--hid_rnn", "128"], ["--ref", "g.fa"]):
         with pytest.raises(ValueError):
             _check_scope(build_parser().parse_args(base + extra))
     assert isinstance(build_parser(), argparse.ArgumentParser)
