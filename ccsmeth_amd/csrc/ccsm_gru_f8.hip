@@ -41,7 +41,11 @@ constexpr float kF8Clamp = 448.0f;                 // e4m3 finite maximum (v_cvt
 __device__ __forceinline__ f32x16 mfma_corr(uint4 w0, uint4 w1, uint4 x0, uint4 x1, f32x16 c, int scale_a) {
     const i32x8 a = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
     const i32x8 b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
+#if defined(CCSM_EXP) && CCSM_EXP == 7
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 2, 0, scale_a, 0, kCorrScaleB);   // timing experiment: fp6 issue rate (wrong numbers)
+#else
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, kCorrScaleB);
+#endif
 }
 
 __device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d) {
