@@ -81,6 +81,7 @@ def gen_forward():
         ("b21_n64", 11, 102, 202, 64, 3, 256),
         ("b21_n513", 12, 103, 203, 513, 3, 256),
         ("small_n37", 13, 104, 204, 37, 2, 32),
+        ("b21_n2048", 14, 105, 205, 2048, 3, 256),      # BASELINE.json configs[1] batch size, full model
     ]
     out = {}
     meta = {}

@@ -76,7 +76,7 @@ def test_forward_vs_reference_goldens():
     from ccsmeth_amd.models import DeviceModel
     fwd = np.load(os.path.join(GOLDEN, "forward_golden.npz"))
     meta = json.load(open(os.path.join(GOLDEN, "forward_golden.json")))
-    for name in ("b21_n1", "b21_n64", "b21_n513"):
+    for name in ("b21_n1", "b21_n64", "b21_n513", "b21_n2048"):
         m = meta[name]
         w = synth.synth_weights(m["weight_seed"])
         s = synth.synth_sites(m["n"], m["site_seed"])

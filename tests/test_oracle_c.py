@@ -18,7 +18,7 @@ def corc():
     return c_oracle
 
 
-@pytest.mark.parametrize("name", ["b21_n1", "b21_n64", "b21_n513"])
+@pytest.mark.parametrize("name", ["b21_n1", "b21_n64", "b21_n513", "b21_n2048"])
 def test_c_oracle_matches_reference(corc, name):
     fwd = np.load(os.path.join(GOLDEN, "forward_golden.npz"))
     m = json.load(open(os.path.join(GOLDEN, "forward_golden.json")))[name]
