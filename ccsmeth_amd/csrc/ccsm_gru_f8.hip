@@ -609,16 +609,28 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     f32x16 qacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
-#pragma unroll 2
-    for (int kb = 0; kb < kKB12; kb += 2) {
-        const int tq = kb < kKBH ? kSeqLen - 1 : 0;
-        const uint4* xp = otile + ((size_t)tq * kKB12 + kb) * 2 * kFragU4 + lane;
-        const uint4 w0h = wap[(kb * 2 + 0) * kFragU4], w0c = wap[(kb * 2 + 1) * kFragU4];
-        const uint4 w1h = wap[(kb * 2 + 2) * kFragU4], w1c = wap[(kb * 2 + 3) * kFragU4];
-        const uint4 x0h = xp[0], x0c = xp[kFragU4], x1h = xp[2 * kFragU4], x1c = xp[3 * kFragU4];
-        qacc = mfma16(w0h, x0h, qacc);
-        qacc = mfma16(w1h, x1h, qacc);
-        qacc = mfma_corr(w0c, w1c, x0c, x1c, qacc, sa_wa);
+    {   // operands of pair p+1 are requested before pair p multiplies (two register sets of 8 fragments)
+        uint4 qa[2][8];
+        auto ldq = [&](uint4 (&d)[8], int kb) {
+            const int tq = kb < kKBH ? kSeqLen - 1 : 0;
+            const uint4* xp = otile + ((size_t)tq * kKB12 + kb) * 2 * kFragU4 + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i] = wap[(kb * 2 + i) * kFragU4];           // hi0, corr0, hi1, corr1
+                d[4 + i] = xp[i * kFragU4];
+            }
+        };
+        ldq(qa[0], 0);
+#pragma unroll
+        for (int p = 0; p < kKB12 / 2; ++p) {
+            if (p + 1 < kKB12 / 2) ldq(qa[(p + 1) & 1], 2 * (p + 1));
+            asm volatile("" ::: "memory");
+            const uint4(&d)[8] = qa[p & 1];
+            qacc = mfma16(d[0], d[4], qacc);
+            qacc = mfma16(d[2], d[6], qacc);
+            qacc = mfma_corr(d[1], d[3], d[5], d[7], qacc, sa_wa);
+            asm volatile("" ::: "memory");
+        }
     }
     float vav[16];
 #pragma unroll
@@ -654,9 +666,10 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
         f32x16 kacc[TG];
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) kacc[tt] = qacc;     // accumulate K_t on top of q
-        float pf[TG][2];
-#pragma unroll
-        for (int tt = 0; tt < TG; ++tt) pf[tt][0] = pf[tt][1] = 0.f;
+        // fc1 partials: wave w takes timestep t0 + w of the group for ALL k-blocks (w < 7): the work of every chunk is spread
+        // over seven waves instead of falling on the two that own its k-blocks (they made the other six wait at the barrier),
+        // and each (row, t) sum is complete in one wave's registers, in a fixed order
+        float pf0 = 0.f, pf1 = 0.f;
 
         stage(t0, 0, 0);
 #pragma unroll 1
@@ -676,16 +689,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             }
             const char* sb0 = s_stage + (c & 1) * CHUNK_FRAGS * 1024;
             const char* sb = sb0 + lane * 16;
-            // each k-block's fc partial is taken by one wave (wave-uniform): kb = 2c + kbl
-            const int own_kbl = ((2 * c) & (kWaves - 1)) == wave ? 0 : (((2 * c + 1) & (kWaves - 1)) == wave ? 1 : -1);
-            float fw[2][8];
-            if (own_kbl >= 0) {
-                const int kb = c * CK + own_kbl;
-#pragma unroll
-                for (int cl = 0; cl < 2; ++cl)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) fw[cl][j] = s_fcw[cl * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8 + j];
-            }
 #pragma unroll
             for (int tt = 0; tt < TG; ++tt) {
                 const uint4 x0h = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 0) * 1024);
@@ -695,21 +698,26 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                 kacc[tt] = mfma16(w[0][0], x0h, kacc[tt]);
                 kacc[tt] = mfma16(w[1][0], x1h, kacc[tt]);
                 kacc[tt] = mfma_corr(w[0][1], w[1][1], x0c, x1c, kacc[tt], sa_ua);
-                if (own_kbl >= 0) {
-                    const half8 xh = as_half8(own_kbl ? x1h : x0h);
-                    // residuals of k = 8hh + 0..7: lane (n, 1) of the corr fragment, dwords hh (k = 8hh..8hh+3) and 2 + hh
-                    const char* cf = sb0 + ((own_kbl * TG + tt) * 2 + 1) * 1024 + (n + 32) * 16;
-                    const int la = *reinterpret_cast<const int*>(cf + 4 * hh);
-                    const int lb = *reinterpret_cast<const int*>(cf + 8 + 4 * hh);
+            }
+            if (wave < TG) {      // straight from the staged fragments: own lane's 8 halfs of hi; residuals from lane (n, 1) of corr
+#pragma unroll
+                for (int kbl = 0; kbl < CK; ++kbl) {
+                    const int kb = c * CK + kbl;
+                    const char* fr = sb0 + ((kbl * TG + wave) * 2) * 1024;
+                    const half8 xh = as_half8(*reinterpret_cast<const uint4*>(fr + lane * 16));
+                    const int la = *reinterpret_cast<const int*>(fr + 1024 + (n + 32) * 16 + 4 * hh);
+                    const int lb = *reinterpret_cast<const int*>(fr + 1024 + (n + 32) * 16 + 8 + 4 * hh);
                     const float xl[8] = {__builtin_amdgcn_cvt_f32_fp8(la, 0), __builtin_amdgcn_cvt_f32_fp8(la, 1),
                                          __builtin_amdgcn_cvt_f32_fp8(la, 2), __builtin_amdgcn_cvt_f32_fp8(la, 3),
                                          __builtin_amdgcn_cvt_f32_fp8(lb, 0), __builtin_amdgcn_cvt_f32_fp8(lb, 1),
                                          __builtin_amdgcn_cvt_f32_fp8(lb, 2), __builtin_amdgcn_cvt_f32_fp8(lb, 3)};
+                    const float* f0 = s_fcw + 0 * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8;
+                    const float* f1 = s_fcw + 1 * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float xv = (float)xh[j] + xl[j] * (1.0f / kCorrActLo);
-                        pf[tt][0] += fw[0][j] * xv;
-                        pf[tt][1] += fw[1][j] * xv;
+                        pf0 += f0[j] * xv;
+                        pf1 += f1[j] * xv;
                     }
                 }
             }
@@ -721,11 +729,13 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             for (int r = 0; r < 16; ++r) e += vav[r] * tanh_f(kacc[tt][r]);
             e += __shfl_xor(e, 32);
             if (hh == 0) s_epart[(wave * kSeqLen + t0 + tt) * 32 + n] = e;
-#pragma unroll
-            for (int cl = 0; cl < 2; ++cl) {
-                float v = pf[tt][cl];
-                v += __shfl_xor(v, 32);
-                if (hh == 0) s_pfc[((wave * kSeqLen + t0 + tt) * 32 + n) * 2 + cl] = v;
+        }
+        if (wave < TG) {
+            pf0 += __shfl_xor(pf0, 32);
+            pf1 += __shfl_xor(pf1, 32);
+            if (hh == 0) {
+                s_pfc[((t0 + wave) * 32 + n) * 2 + 0] = pf0;
+                s_pfc[((t0 + wave) * 32 + n) * 2 + 1] = pf1;
             }
         }
         __syncthreads();   // all waves are done with both staging buffers before the next group restages buffer 0
@@ -753,14 +763,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
 #pragma unroll
         for (int t = 0; t < kSeqLen; ++t) {
             const float a = e[t] * inv;
-            float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-                p0 += s_pfc[((w * kSeqLen + t) * 32 + rl) * 2 + 0];
-                p1 += s_pfc[((w * kSeqLen + t) * 32 + rl) * 2 + 1];
-            }
-            l0 += a * p0;
-            l1 += a * p1;
+            l0 += a * s_pfc[(t * 32 + rl) * 2 + 0];
+            l1 += a * s_pfc[(t * 32 + rl) * 2 + 1];
         }
         part[(size_t)row * 2 + 0] = l0;
         part[(size_t)row * 2 + 1] = l1;
