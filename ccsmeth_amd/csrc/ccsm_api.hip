@@ -393,7 +393,8 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     }
     if (F8 && std::getenv("CCSM_ATTN_SPLIT3") == nullptr)
         hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fcw,
-                           ws->part, tab, m->att_scale[0], m->att_scale[1]);
+                           ws->part, tab, m->att_scale[0], m->att_scale[1],
+                           (std::getenv("CCSM_PHASE_LAYER") && std::atoi(std::getenv("CCSM_PHASE_LAYER")) == 3) ? ws->dbg : nullptr);
     else
         hipLaunchKernelGGL((attn_fc_kernel<NPASS>), dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
                            ws->part, tab);

@@ -583,7 +583,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
 __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
                                                              const uint4* __restrict__ ua, const float* __restrict__ va,
                                                              const float* __restrict__ fcw, float* __restrict__ part,
-                                                             SliceTable slices, int sa_wa, int sa_ua) {
+                                                             SliceTable slices, int sa_wa, int sa_ua,
+                                                             unsigned long long* __restrict__ dbg) {
     constexpr int TG = 7;                      // timesteps per Ua pass (21 = 3 * 7)
     constexpr int CK = 2;                      // k-blocks per staged chunk = one pair
     constexpr int NCHUNK = kKB12 / CK;
@@ -600,6 +601,12 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     const int n = lane & 31, hh = lane >> 5;
 
     for (int i = threadIdx.x; i < kClasses * 4 * kHidden; i += blockDim.x) s_fcw[i] = fcw[i];
+    // dbg (normally NULL): workgroup 0 records the cycle counter per wave: [wave][0 start, 1 q done, 2+2g chunks of group g done,
+    // 3+2g epilogue of group g done, 8 end]
+    auto stamp = [&](int i) {
+        if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[wave * 16 + i] = __builtin_readcyclecounter();
+    };
+    stamp(0);
 
     const uint4* wap = wa + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
     const uint4* uap = ua + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
@@ -645,6 +652,9 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
 
     // stage chunk `c` of timestep group t0 into buffer `buf`: fragment f = (kbl * TG + tt) * 2 + hl
     auto stage = [&](int t0, int c, int buf) {
+#if defined(CCSM_EXP) && CCSM_EXP == 8
+        t0 = 0; c = 0;      // timing experiment: always the same (L2-resident) chunk
+#endif
 #pragma unroll
         for (int i = 0; i < (CHUNK_FRAGS + kWaves - 1) / kWaves; ++i) {
             const int f = wave + kWaves * i;
@@ -657,6 +667,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
         }
     };
 
+    stamp(1);
     uint4 wu[CK][2];       // Ua fragments of the next chunk, requested one chunk ahead
 #pragma unroll
     for (int kbl = 0; kbl < CK; ++kbl) { wu[kbl][0] = uap[(kbl * 2 + 0) * kFragU4]; wu[kbl][1] = uap[(kbl * 2 + 1) * kFragU4]; }
@@ -698,10 +709,10 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                 kacc[tt] = mfma16(w[0][0], x0h, kacc[tt]);
                 kacc[tt] = mfma16(w[1][0], x1h, kacc[tt]);
                 kacc[tt] = mfma_corr(w[0][1], w[1][1], x0c, x1c, kacc[tt], sa_ua);
-            }
-            if (wave < TG) {      // straight from the staged fragments: own lane's 8 halfs of hi; residuals from lane (n, 1) of corr
-#pragma unroll
-                for (int kbl = 0; kbl < CK; ++kbl) {
+                // fc1 partial of k-block (tt & 1) for timestep t0 + wave, issued behind this timestep's MFMAs (tt < 2): vector ALU
+                // and LDS work in the shadow of the matrix pipe instead of a serial block at the end of the chunk
+                if (tt < CK && wave < TG) {
+                    const int kbl = tt;
                     const int kb = c * CK + kbl;
                     const char* fr = sb0 + ((kbl * TG + wave) * 2) * 1024;
                     const half8 xh = as_half8(*reinterpret_cast<const uint4*>(fr + lane * 16));
@@ -711,13 +722,16 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                                          __builtin_amdgcn_cvt_f32_fp8(la, 2), __builtin_amdgcn_cvt_f32_fp8(la, 3),
                                          __builtin_amdgcn_cvt_f32_fp8(lb, 0), __builtin_amdgcn_cvt_f32_fp8(lb, 1),
                                          __builtin_amdgcn_cvt_f32_fp8(lb, 2), __builtin_amdgcn_cvt_f32_fp8(lb, 3)};
-                    const float* f0 = s_fcw + 0 * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8;
-                    const float* f1 = s_fcw + 1 * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8;
+                    const float4* f0 = reinterpret_cast<const float4*>(s_fcw + 0 * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8);
+                    const float4* f1 = reinterpret_cast<const float4*>(s_fcw + 1 * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8);
+                    const float4 a0 = f0[0], a1 = f0[1], b0 = f1[0], b1 = f1[1];
+                    const float fa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const float fb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float xv = (float)xh[j] + xl[j] * (1.0f / kCorrActLo);
-                        pf0 += f0[j] * xv;
-                        pf1 += f1[j] * xv;
+                        pf0 += fa[j] * xv;
+                        pf1 += fb[j] * xv;
                     }
                 }
             }
@@ -739,6 +753,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             }
         }
         __syncthreads();   // all waves are done with both staging buffers before the next group restages buffer 0
+        stamp(3 + 2 * tg);
     }
 
     // ---- softmax over t and the strand-half of the logits (fixed summation order: deterministic)
@@ -769,6 +784,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
         part[(size_t)row * 2 + 0] = l0;
         part[(size_t)row * 2 + 1] = l1;
     }
+    stamp(8);
 }
 
 // Self-test of the split-f8 product: C[unit][row] = sum_k W[unit][k] X[row][k] over 32 k, W fragments packed by the host
