@@ -736,6 +736,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                 }
             }
         }
+        stamp(2 + 2 * tg);
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             float e = 0.f;
