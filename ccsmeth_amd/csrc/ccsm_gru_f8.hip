@@ -616,8 +616,9 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     f32x16 qacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
-    {   // operands of pair p+1 are requested before pair p multiplies (two register sets of 8 fragments)
-        uint4 qa[2][8];
+    {   // operands of pairs p+1 .. p+3 are in flight while pair p multiplies (four register sets of 8 fragments: the activation
+        // fragments come from HBM, one pair of look-ahead left the loop at one round trip per pair)
+        uint4 qa[4][8];
         auto ldq = [&](uint4 (&d)[8], int kb) {
             const int tq = kb < kKBH ? kSeqLen - 1 : 0;
             const uint4* xp = otile + ((size_t)tq * kKB12 + kb) * 2 * kFragU4 + lane;
@@ -628,11 +629,13 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             }
         };
         ldq(qa[0], 0);
+        ldq(qa[1], 2);
+        ldq(qa[2], 4);
 #pragma unroll
         for (int p = 0; p < kKB12 / 2; ++p) {
-            if (p + 1 < kKB12 / 2) ldq(qa[(p + 1) & 1], 2 * (p + 1));
+            if (p + 3 < kKB12 / 2) ldq(qa[(p + 3) & 3], 2 * (p + 3));
             asm volatile("" ::: "memory");
-            const uint4(&d)[8] = qa[p & 1];
+            const uint4(&d)[8] = qa[p & 3];
             qacc = mfma16(d[0], d[4], qacc);
             qacc = mfma16(d[2], d[6], qacc);
             qacc = mfma_corr(d[1], d[3], d[5], d[7], qacc, sa_wa);
