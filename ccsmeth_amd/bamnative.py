@@ -92,7 +92,7 @@ class NativeBamReader:
         text, refs = C.c_void_p(), C.c_void_p()
         tl, rl, nref = C.c_int64(), C.c_int64(), C.c_int32()
         _check(_lib.ccsm_bam_header(self._h, C.byref(text), C.byref(tl), C.byref(refs), C.byref(rl), C.byref(nref)))
-        self.header_text = C.string_at(text, tl.value).decode("utf-8") if tl.value else ""
+        self.header_text = C.string_at(text, tl.value).decode("utf-8", "replace") if tl.value else ""
         self.raw_refs = C.string_at(refs, rl.value) if rl.value else b""
         self.n_ref = nref.value
 

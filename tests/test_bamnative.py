@@ -193,3 +193,48 @@ def test_block_aligned_runs_stitch_back_in_order(tmp_path):
     assert [g.query_name for g in got] == [r.query_name for r in recs]
     for g, r in zip(got, recs):
         assert g.seq == r.seq and [t for t, _, _ in g.tags] == [t for t, _, _ in r.tags if t not in ("MM", "ML")]
+
+
+def test_native_reader_survives_corrupted_records(tmp_path):
+    """Random byte corruption of the (re-compressed) record stream: the native reader / writer either work or raise IOError;
+    run in a child process so that a memory fault would be seen as a non-zero exit instead of killing the test session."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from ccsmeth_amd import bamio, bamnative
+from test_bamnative import _make_bam
+rng = np.random.default_rng(4)
+path, mut, outp = %r, %r, %r
+_make_bam(path, rng, n_reads=10)
+raw = b"".join(bamio.bgzf_blocks(open(path, "rb")))
+ok = err = 0
+for trial in range(80):
+    b = bytearray(raw)
+    for _ in range(int(rng.integers(1, 6))):
+        b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+    with open(mut, "wb") as f:
+        for i in range(0, len(b), 0xff00):
+            f.write(bamio.bgzf_compress_block(bytes(b[i:i + 0xff00]), 1))
+        f.write(bamio._BGZF_EOF)
+    try:
+        with bamnative.NativeBamReader(mut, threads=2) as rd:
+            while True:
+                bt = rd.next_batch(4)
+                if bt is None:
+                    break
+                _ = int(bt.records.sum()) + (int(bt.seq.sum()) if bt.total_bases else 0)
+                w = bamnative.NativeBamWriter(outp, rd.header_text, rd.raw_refs, rd.n_ref, threads=1, level=1)
+                w.write_batch(bt, rm_pulse=True)
+                w.close()
+                bt.close()
+        ok += 1
+    except IOError:
+        err += 1
+print("ok", ok, "ioerror", err)
+assert ok + err == 80 and ok > 0
+''' % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path / "in.bam"), str(tmp_path / "mut.bam"), str(tmp_path / "out.bam"))
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
