@@ -160,7 +160,11 @@ def call_mods(args, log=sys.stderr):
     except RuntimeError:                                               # DDP checkpoints: strip "module." (:350-358)
         model.load_state_dict(OrderedDict((k[7:], v) for k, v in para.items()))
     model.cuda(args.device).eval()
-    pipe = CallModsPipeline(model._dev, batch_size=args.batch_size, seed=args.tseed, extract=args.extract)
+    # --batch_size (reference default 512) is the reference's sites per model call.  On the GPU-extraction paths a launch wants
+    # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
+    # (every site's initial state is a function of the seed and its running index), so the flag is only a lower bound there.
+    chunk_sites = max(args.batch_size, 12288) if args.extract == "device" else args.batch_size
+    pipe = CallModsPipeline(model._dev, batch_size=chunk_sites, seed=args.tseed, extract=args.extract)
     holeids_e = None if args.holeids_e is None else _get_holes(args.holeids_e)          # extract_features.py:561-562
     holeids_ne = None if args.holeids_ne is None else _get_holes(args.holeids_ne)
     name_filter = holeids_e is not None or holeids_ne is not None
