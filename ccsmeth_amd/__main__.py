@@ -1,12 +1,18 @@
-"""python -m ccsmeth_amd call_mods ...   (the sub-command of the reference CLI that sits on the hot path)"""
+"""python -m ccsmeth_amd call_mods ... | call_freqb ...   (the sub-commands of the reference CLI on / next to the hot path)"""
 import sys
 
 
 def main():
-    if len(sys.argv) < 2 or sys.argv[1] != "call_mods":
-        sys.exit("usage: python -m ccsmeth_amd call_mods -i in.bam -m model.ckpt -o out_prefix [options]")
-    from .call_mods import main as cm
-    cm(sys.argv[2:])
+    cmds = ("call_mods", "call_freqb")
+    if len(sys.argv) < 2 or sys.argv[1] not in cmds:
+        sys.exit("usage: python -m ccsmeth_amd call_mods -i in.bam -m model.ckpt -o out_prefix [options]\n"
+                 "       python -m ccsmeth_amd call_freqb --input_bam aligned.modbam.bam --ref genome.fa -o out_prefix [options]")
+    if sys.argv[1] == "call_mods":
+        from .call_mods import main as cm
+        cm(sys.argv[2:])
+    else:
+        from .call_mods_freq_bam import main as cf
+        cf(sys.argv[2:])
 
 
 if __name__ == "__main__":

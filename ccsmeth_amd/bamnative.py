@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libccsm_bam.so")
 
 EXPORTS = ("ccsm_bam_last_error", "ccsm_bam_open", "ccsm_bam_header", "ccsm_bam_next", "ccsm_bam_batch_free", "ccsm_bam_close",
-           "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_flush", "ccsm_bam_writer_close")
+           "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_flush", "ccsm_bam_writer_close",
+           "ccsm_bam_modcalls_of_batch", "ccsm_bam_modcalls_free")
 
 
 class _Batch(C.Structure):
@@ -18,6 +19,17 @@ class _Batch(C.Structure):
                 ("offset", C.c_void_p), ("length", C.c_void_p), ("n_sites", C.c_void_p), ("seq", C.c_void_p), ("fi", C.c_void_p),
                 ("ri", C.c_void_p), ("fp", C.c_void_p), ("rp", C.c_void_p), ("fn", C.c_void_p), ("rn", C.c_void_p),
                 ("total_bases", C.c_int64)]
+
+
+class ModCallOpts(C.Structure):
+    """ccsm_bam_modcall_opts: the per-record options of call_freqb (call_mods_freq_bam.py:486-537)."""
+    _fields_ = [("identity", C.c_double), ("mapq", C.c_int32), ("no_supplementary", C.c_int32), ("base_clip", C.c_int32),
+                ("refsites_all", C.c_int32), ("hap_tag", C.c_char * 2), ("modbase", C.c_char), ("modification", C.c_char)]
+
+
+class _ModCalls(C.Structure):
+    _fields_ = [("n", C.c_int64), ("tid", C.c_void_p), ("pos", C.c_void_p), ("strand", C.c_void_p), ("ml", C.c_void_p),
+                ("hap", C.c_void_p), ("n_records", C.c_int64), ("n_used", C.c_int64)]
 
 
 _lib = None
@@ -43,6 +55,10 @@ def load():
     lib.ccsm_bam_write_batch.argtypes = [vp, C.POINTER(_Batch), vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int32)]
     lib.ccsm_bam_writer_flush.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.ccsm_bam_writer_close.argtypes = [vp]
+    lib.ccsm_bam_modcalls_of_batch.argtypes = [C.POINTER(_Batch), C.POINTER(ModCallOpts), vp, vp, C.c_int32, C.c_int,
+                                               C.POINTER(C.POINTER(_ModCalls))]
+    lib.ccsm_bam_modcalls_free.argtypes = [C.POINTER(_ModCalls)]
+    lib.ccsm_bam_modcalls_free.restype = None
     _lib = lib
     return lib
 
@@ -83,6 +99,32 @@ class Batch:
 
     def __del__(self):
         self.close()
+
+
+def modcalls_of_batch(batch, mapq=1, identity=0.0, no_supplementary=False, base_clip=0, refsites_all=False, hap_tag="HP",
+                      modbase="C", modification="m", site_masks=None, threads=4):
+    """Rows (tid, pos, strand, ml, hap) the records of `batch` contribute to call_freqb's per-position lists, as NumPy
+    arrays (copies), plus (records seen, records used).  site_masks: list over reference ids of uint8 arrays (or None)."""
+    if len(hap_tag) != 2:
+        raise ValueError("--hap_tag must be a two-character tag")
+    o = ModCallOpts(float(identity), int(mapq), int(bool(no_supplementary)), int(base_clip), int(bool(refsites_all)),
+                    hap_tag.encode("ascii"), modbase.encode("ascii"), modification.encode("ascii"))
+    n_ref = len(site_masks) if site_masks is not None else 0
+    ptrs = lens = None
+    if site_masks is not None:
+        keep = [None if m is None else np.ascontiguousarray(m, dtype=np.uint8) for m in site_masks]
+        ptrs = (C.c_void_p * max(n_ref, 1))(*[None if m is None else m.ctypes.data for m in keep])
+        lens = (C.c_int64 * max(n_ref, 1))(*[0 if m is None else len(m) for m in keep])
+    p = C.POINTER(_ModCalls)()
+    _check(load().ccsm_bam_modcalls_of_batch(batch._ptr, C.byref(o), ptrs, lens, n_ref, int(threads), C.byref(p)))
+    try:
+        c = p.contents
+        n = int(c.n)
+        out = tuple(_view(q, dt, n).copy() for q, dt in ((c.tid, np.int32), (c.pos, np.int32), (c.strand, np.uint8),
+                                                         (c.ml, np.uint8), (c.hap, np.uint8)))
+        return out + (int(c.n_records), int(c.n_used))
+    finally:
+        _lib.ccsm_bam_modcalls_free(p)
 
 
 class NativeBamReader:

@@ -105,3 +105,443 @@ def _cal_modfreq_in_aggregate_mode(refposes, refposes_histos, model, seq_len=11,
         raise ValueError("only_close is outside this build")
     y = model.forward_raw(refposes, np.stack(refposes_histos))
     return list(np.round(np.clip(y, 0, 1), 6))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# `call_freqb`: aligned modbam -> per-site modification frequency (count / aggregate mode), the caller side of AggrModel.
+# Host mirror of call_mods_freq_bam.py:51-85 (regions), :209-230 (count mode), :244-262 (discretize), :308-437 (one region),
+# :455-585 (projection on the reference, strand combining, motif filter), :611-668 (writer).  The per-record work (filters,
+# MM/ML, CIGAR walk) is libccsm_bam's ccsm_bam_modcalls_of_batch; no pysam, no BAM index: the file is streamed once and the
+# calls are grouped by region afterwards, which gives the same per-region lists as the reference's fetch() per region.
+# ---------------------------------------------------------------------------------------------------------------------------
+import os
+import sys
+import time
+
+_IUPAC = {'A': 'A', 'T': 'T', 'C': 'C', 'G': 'G', 'R': 'AG', 'M': 'AC', 'S': 'CG', 'Y': 'CT', 'K': 'GT', 'W': 'AT', 'B': 'CGT',
+          'D': 'AGT', 'H': 'ACT', 'V': 'ACG', 'N': 'ACGT'}
+_PAIR = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A', 'N': 'N', 'W': 'W', 'S': 'S', 'M': 'K', 'K': 'M', 'R': 'Y', 'Y': 'R', 'B': 'V',
+         'V': 'B', 'D': 'H', 'H': 'D', 'Z': 'Z'}
+
+
+def get_motif_seqs(motifs):
+    """process_utils.py:140-170: comma-separated IUPAC motifs -> list of plain sequences (order as the reference builds it)."""
+    out = []
+    for m in motifs.strip().split(','):
+        seqs = ['']
+        for b in m.strip().upper():
+            seqs = [s + x for s in seqs for x in _IUPAC[b]]
+        out += seqs
+    return out
+
+
+def complement_seq(seq):
+    """process_utils.py:106-118: reverse complement, unknown letters -> N."""
+    return ''.join(_PAIR.get(x, 'N') for x in seq[::-1])
+
+
+def read_fasta(path):
+    """DNAReference (utils/ref_reader.py:34-52): contig name = header up to the first blank, sequence upper-cased."""
+    names, contigs = [], {}
+    name, parts = None, []
+    with open(path, "r") as rf:
+        for line in rf:
+            if line.startswith('>'):
+                if name is not None:
+                    contigs[name] = ''.join(parts)
+                    if name not in names:
+                        names.append(name)
+                name, parts = line.strip()[1:].split(' ')[0], []
+            else:
+                parts.append(line.strip().upper())
+    if name is not None:
+        contigs[name] = ''.join(parts)
+        if name not in names:
+            names.append(name)
+    return names, contigs
+
+
+def _get_reference_chunks(dnacontigs, contig_str, chunk_len=300000, motifs="CG"):
+    """call_mods_freq_bam.py:51-85: (contig, start, end) in sorted contig order; a CG across a boundary goes to the left chunk."""
+    if contig_str is not None:
+        if os.path.isfile(contig_str):
+            with open(contig_str, "r") as rf:
+                contigs = sorted(set(rf.read().splitlines()))
+        else:
+            contigs = sorted(set(contig_str.strip().split(",")))
+    else:
+        contigs = sorted(dnacontigs.keys())
+    chunks = []
+    for contig in contigs:
+        if contig not in dnacontigs:
+            raise ValueError("contig {} is not in --ref".format(contig))
+        n = len(dnacontigs[contig])
+        for i in range(0, n, chunk_len):
+            chunks.append((contig, i, i + chunk_len if i + chunk_len < n else n))
+    if motifs == "CG":
+        for idx in range(1, len(chunks)):
+            pre_ref, pre_s, pre_e = chunks[idx - 1]
+            cur_ref, cur_s, cur_e = chunks[idx]
+            if pre_ref != cur_ref:
+                continue
+            if dnacontigs[pre_ref][(pre_e - 1):(pre_e + 1)] == "CG":
+                chunks[idx - 1] = (pre_ref, pre_s, pre_e + 1)
+                chunks[idx] = (cur_ref, cur_s + 1, cur_e)
+    return chunks
+
+
+def _motif_site_mask(seq, regions, motifs, mod_loc):
+    """uint8 per base: bit 0 = --refsites_all site of the forward strand, bit 1 = of the reverse strand, found exactly as
+    call_mods_freq_bam.py:473-479 does: inside each region's own slice (a motif cut by a region boundary is not a site)."""
+    s = np.frombuffer(seq.encode("ascii"), dtype=np.uint8)
+    n = len(s)
+    mask = np.zeros(n, np.uint8)
+    if n == 0:
+        return mask
+    mlen = len(motifs[0])
+    starts = np.array([r[0] for r in regions], np.int64)
+    ends = np.array([r[1] for r in regions], np.int64)
+    for motif in set(motifs):
+        for bit, m, site_off in ((1, motif, mod_loc), (2, complement_seq(motif), mlen - 1 - mod_loc)):
+            if n < mlen:
+                continue
+            hit = np.ones(n - mlen + 1, bool)
+            for k, ch in enumerate(m.encode("ascii")):
+                hit &= s[k:n - mlen + 1 + k] == ch
+            st = np.flatnonzero(hit)
+            if len(st) == 0:
+                continue
+            ri = np.searchsorted(starts, st, side="right") - 1          # region of the motif's first base
+            ok = (ri >= 0) & (st + mlen <= ends[np.maximum(ri, 0)])
+            mask[st[ok] + site_off] |= bit
+    return mask
+
+
+def _cal_modfreq_in_count_mode(modprobs, prob_cf=0, no_amb_cov=False):
+    """call_mods_freq_bam.py:209-230 -> (coverage, modified count, frequency)."""
+    cnt_all_filtered, cnt_mod = 0, 0
+    for modprob in modprobs:
+        if abs(modprob - (1 - modprob)) < prob_cf:
+            continue
+        cnt_all_filtered += 1
+        if modprob > 0.5:
+            cnt_mod += 1
+    modfreq = cnt_mod / float(cnt_all_filtered) if cnt_all_filtered > 0 else 0.
+    if no_amb_cov:
+        return cnt_all_filtered, cnt_mod, modfreq
+    if cnt_all_filtered != len(modprobs):
+        cnt_mod = np.round(len(modprobs) * modfreq, 2)
+    return len(modprobs), cnt_mod, modfreq
+
+
+def discretize_score(modprob, coverage):
+    """call_mods_freq_bam.py:244-262."""
+    if modprob > 0.66:
+        mod_reads = int(np.ceil(modprob * float(coverage)))
+    elif modprob <= 0.33:
+        mod_reads = int(np.floor(modprob * float(coverage)))
+    else:
+        mod_reads = round(coverage * modprob, 2)
+    unmod_reads = int(coverage) - mod_reads
+    adjusted_score = 0.0 if mod_reads == 0 else float(mod_reads) / (mod_reads + unmod_reads)
+    return mod_reads, unmod_reads, adjusted_score
+
+
+def _write_one_line(beditem, wf, is_bed):
+    """call_mods_freq_bam.py:611-620."""
+    ref_name, refpos, strand, cov, met, metprob = beditem
+    if is_bed:
+        wf.write("\t".join([ref_name, str(refpos), str(refpos + 1), ".", str(cov), strand, str(refpos), str(refpos + 1),
+                            "0,0,0", str(cov), str(int(round(metprob * 100 + 0.001, 0)))]) + "\n")
+    else:
+        wf.write("\t".join([ref_name, str(refpos), str(refpos + 1), strand, ".", ".", str(met), str(cov - met), str(cov),
+                            str(round(metprob + 0.000001, 4)), "."]) + "\n")
+
+
+class _CountTables:
+    """Per ML byte: is the call kept under --prob_cf, is it a modified call (call_mods_freq_bam.py:211-216)."""
+
+    def __init__(self, prob_cf):
+        probs = [float(p) for p in _ML2PROB]
+        self.kept = np.array([not (abs(p - (1 - p)) < prob_cf) for p in probs], np.int64)
+        self.mod = np.array([(not (abs(p - (1 - p)) < prob_cf)) and p > 0.5 for p in probs], np.int64)
+        # bin of the ML byte's probability in np.histogram(probs, bins=20, range=[0, 1])
+        self.bin = np.array([int(np.argmax(np.histogram([p], bins=20, range=[0, 1])[0])) for p in probs], np.int64)
+
+
+def _count_infos(n, nf, nm, no_amb_cov):
+    """(coverage, modified, frequency) per site from the totals / kept / modified-and-kept counts; None where n == 0."""
+    out = []
+    for a, f, m in zip(n.tolist(), nf.tolist(), nm.tolist()):
+        if a == 0:
+            out.append(None)
+            continue
+        modfreq = m / float(f) if f > 0 else 0.
+        if no_amb_cov:
+            out.append((f, m, modfreq))
+        else:
+            out.append((a, np.round(a * modfreq, 2) if f != a else m, modfreq))
+    return out
+
+
+def _call_modfreq_of_one_region(pos, ml, hap, args, tables, model):
+    """_call_modfreq_of_one_region (call_mods_freq_bam.py:423-451) on the calls of one region and strand dictionary, given
+    as arrays sorted by position.  -> [(refpos, info_all, info_hp1, info_hp2)] ascending in refpos."""
+    if len(pos) == 0:
+        return []
+    first = np.flatnonzero(np.r_[True, pos[1:] != pos[:-1]])
+    refposes = pos[first].tolist()
+    kept, mod = tables.kept[ml], tables.mod[ml]
+    sel = [np.ones(len(pos), np.int64)]
+    if args.no_hap:
+        sel += [np.zeros(len(pos), np.int64)] * 2
+    else:
+        sel += [(hap == 1).astype(np.int64), (hap == 2).astype(np.int64)]
+    red = lambda v: np.add.reduceat(v, first)  # noqa: E731
+    cols = []                                   # per all / hp1 / hp2: list of infos
+    for s in sel:
+        n, nf, nm = red(s), red(s * kept), red(s * mod)
+        if args.call_mode == "count":
+            cols.append(_count_infos(n, nf, nm, args.no_amb_cov))
+            continue
+        infos = _count_infos(np.where(n < args.cov_cf, n, 0), nf, nm, args.no_amb_cov)   # low coverage: count mode
+        cols.append((infos, n, s))
+    if args.call_mode == "count":
+        return list(zip(refposes, cols[0], cols[1], cols[2]))
+    if args.call_mode != "aggregate":
+        raise ValueError("wrong --call_mode")
+    # aggregate mode (:308-420): torch.manual_seed(tseed) once per call of this function, then all -> hp1 -> hp2
+    model.new_region()
+    site_of_row = np.repeat(np.arange(len(first)), np.diff(np.r_[first, len(pos)]))
+    out_cols = []
+    for infos, n, s in cols:
+        high = np.flatnonzero(n >= args.cov_cf)
+        if len(high):
+            rows = np.flatnonzero(s)
+            hist = np.bincount(site_of_row[rows] * 20 + tables.bin[ml[rows]], minlength=len(first) * 20).reshape(-1, 20)[high]
+            histos = np.round(hist / np.sqrt((hist * hist).sum(1, dtype=np.float64))[:, None], 6)
+            probs = _cal_modfreq_in_aggregate_mode([refposes[i] for i in high], list(histos), model, args.seq_len, args.only_close)
+            for i, p in zip(high.tolist(), probs):
+                cov = int(n[i])
+                if args.discrete:
+                    d_cnt_mod, _, d_modprob = discretize_score(p, cov)
+                    infos[i] = (cov, d_cnt_mod, d_modprob)
+                else:
+                    infos[i] = (cov, round(cov * p, 2), p)
+        out_cols.append(infos)
+    return list(zip(refposes, out_cols[0], out_cols[1], out_cols[2]))
+
+
+def _bam_ref_names(raw_refs, n_ref):
+    """Names of the binary reference list of a BAM header (l_name, name\\0, l_ref per entry)."""
+    names, o = [], 0
+    for _ in range(n_ref):
+        ln = int.from_bytes(raw_refs[o:o + 4], "little")
+        names.append(raw_refs[o + 4:o + 4 + ln - 1].decode("ascii", "replace"))
+        o += 8 + ln
+    return names
+
+
+def _bed_of_contig(name, seq, regions, rows, motifs_filter, args, tables, model):
+    """_readmods_to_bed_of_one_region (call_mods_freq_bam.py:538-585) for every region of one contig.
+    rows = (pos, strand, ml, hap) of the contig's calls.  -> (bed_all, bed_hp1, bed_hp2)."""
+    pos, strand, ml, hap = rows
+    beds = ([], [], [])
+    if len(pos) == 0:
+        return beds
+    starts = np.array([r[1] for r in regions], np.int64)
+    ends = np.array([r[2] for r in regions], np.int64)
+    pos = pos.astype(np.int64)
+    ridx = np.searchsorted(starts, pos, side="right") - 1
+    ok = (ridx >= 0) & (pos < ends[np.maximum(ridx, 0)])
+    comb = args.motifs == "CG" and not args.no_comb
+    if comb:                                    # :538-548: a reverse-strand call at the G counts for the C one base to the left
+        ok &= ~((strand == 1) & (pos == 0))
+        pos = np.where(strand == 1, pos - 1, pos)
+        strand = np.zeros_like(strand)
+    pos, strand, ml, hap, ridx = pos[ok], strand[ok], ml[ok], hap[ok], ridx[ok]
+    order = np.lexsort((pos, strand, ridx))     # region, then forward dictionary before reverse, then position
+    pos, strand, ml, hap, ridx = pos[order], strand[order], ml[order], hap[order], ridx[order]
+    key = ridx * 2 + strand
+    cut = np.flatnonzero(np.r_[True, key[1:] != key[:-1], True])
+    mlen = len(motifs_filter[0]) if motifs_filter is not None else 0
+    mset = set(motifs_filter) if motifs_filter is not None else None
+    for a, b in zip(cut[:-1].tolist(), cut[1:].tolist()):
+        rev = bool(strand[a])
+        res = _call_modfreq_of_one_region(pos[a:b], ml[a:b], hap[a:b], args, tables, model)
+        sign = "-" if rev else "+"
+        for refpos, total_info, hp1_info, hp2_info in res:
+            if mset is not None:
+                if rev:
+                    s0, s1 = refpos - (mlen - 1 - args.mod_loc), refpos + args.mod_loc + 1
+                    motif_seq = complement_seq(seq[s0:s1])
+                else:
+                    s0, s1 = refpos - args.mod_loc, refpos + mlen - args.mod_loc
+                    motif_seq = seq[s0:s1]
+                if motif_seq not in mset:
+                    continue
+            for bed, info in zip(beds, (total_info, hp1_info, hp2_info)):
+                if info is not None:
+                    bed.append((name, refpos, sign, info[0], info[1], info[2]))
+    return beds
+
+
+def call_mods_frequency_from_bamfile(args, log=sys.stderr, model=None):
+    """call_mods_freq_bam.py:671-735.  `model` (tests): an object with new_region() / forward_raw() instead of AggrModel."""
+    from . import bamnative
+    t0 = time.time()
+    if args.call_mode == "aggregate" and model is None and not (args.aggre_model and os.path.exists(args.aggre_model)):
+        raise ValueError("--aggre_model is not set right!")
+    if not args.input_bam.endswith(".bam"):
+        raise ValueError("--input_bam not a bam file!")
+    if not os.path.exists(args.input_bam):
+        raise ValueError("--input_bam does not exist!")
+    if not os.path.exists(args.ref):
+        raise ValueError("--ref does not exist!")
+    if args.call_mode == "aggregate":
+        if args.model_type != "attbigru":
+            raise ValueError("--model_type not right!")
+        if (args.seq_len, args.layer_rnn, args.hid_rnn, args.bin_size, args.class_num) != (11, 1, 32, 20, 1) or args.only_close:
+            raise ValueError("this build implements the aggregate model attbigru_b11: --seq_len 11 --layer_rnn 1 --hid_rnn 32 "
+                             "--bin_size 20 --class_num 1, without --only_close")
+    out_dir = os.path.dirname(os.path.abspath(args.output))
+    os.makedirs(out_dir, exist_ok=True)
+
+    _, dnacontigs = read_fasta(args.ref)
+    motifs = get_motif_seqs(args.motifs)
+    motifs_filter = motifs if (args.refsites_only or args.refsites_all) else None
+    chunks = _get_reference_chunks(dnacontigs, args.contigs, args.chunk_len, args.motifs)
+    regions_of = {}
+    for c in chunks:
+        regions_of.setdefault(c[0], []).append(c)
+
+    if args.call_mode == "aggregate" and model is None:
+        import torch
+        model = AggrModel(torch.load(args.aggre_model, map_location="cpu"), device=getattr(args, "device", 0), tseed=args.tseed)
+    tables = _CountTables(args.prob_cf)
+
+    rows_of = {}
+    n_rec = n_used = 0
+    with bamnative.NativeBamReader(args.input_bam, threads=max(1, args.threads)) as rd:
+        names = _bam_ref_names(rd.raw_refs, rd.n_ref)
+        if rd.n_ref == 0:
+            raise ValueError("file has no sequences defined - please make sure that the reads are aligned to the genome reference!")
+        masks = None
+        if args.refsites_all:
+            masks = [(_motif_site_mask(dnacontigs[nm], [(r[1], r[2]) for r in regions_of[nm]], motifs, args.mod_loc)
+                      if nm in regions_of else None) for nm in names]
+        while True:
+            batch = rd.next_batch(4096)
+            if batch is None:
+                break
+            tid, pos, strand, ml, hap, seen, used = bamnative.modcalls_of_batch(
+                batch, mapq=args.mapq, identity=args.identity, no_supplementary=args.no_supplementary, base_clip=args.base_clip,
+                refsites_all=args.refsites_all, hap_tag=args.hap_tag, site_masks=masks, threads=max(1, args.threads))
+            batch.close()
+            n_rec += seen
+            n_used += used
+            if len(tid):
+                for t in np.unique(tid).tolist():
+                    if 0 <= t < len(names) and names[t] in regions_of:
+                        m = tid == t
+                        rows_of.setdefault(t, []).append((pos[m], strand[m], ml[m], hap[m]))
+    tid_of = {nm: t for t, nm in reversed(list(enumerate(names)))}
+    fext = "bed" if args.bed else "freq.txt"
+    paths = [args.output + ".{}.{}.{}".format(args.call_mode, w, fext) for w in ("all", "hp1", "hp2")]
+    files = [open(p, "w") for p in paths]
+    n_sites = 0
+    for name in sorted(regions_of.keys()):
+        t = tid_of.get(name)
+        if t is None or t not in rows_of:
+            continue
+        parts = rows_of.pop(t)
+        rows = tuple(np.concatenate([p[k] for p in parts]) for k in range(4))
+        beds = _bed_of_contig(name, dnacontigs[name], regions_of[name], rows, motifs_filter, args, tables, model)
+        n_sites += len(beds[0])
+        for wf, bed in zip(files, beds):
+            for item in bed:
+                _write_one_line(item, wf, args.bed)
+    for wf in files:
+        wf.close()
+    for p in paths:
+        if os.path.getsize(p) == 0:
+            os.remove(p)
+            continue
+        if args.sort or args.gzip:
+            _sort_bed_file(p)
+        if args.gzip:
+            _bgzip_file(p)
+            log.write("[call_freqb] {}.gz is BGZF (tabix-ready); the .tbi index is not written by this build\n".format(p))
+    log.write("[call_freqb] {} records ({} used), {} sites, {:.1f} s\n".format(n_rec, n_used, n_sites, time.time() - t0))
+    return n_sites
+
+
+def _sort_bed_file(path):
+    """--sort (call_mods_freq_bam.py:655-658, bedtools sort): by contig name, then start; ties keep their order."""
+    with open(path, "r") as rf:
+        lines = rf.readlines()
+    lines.sort(key=lambda ln: (ln.split("\t", 2)[0], int(ln.split("\t", 2)[1])))
+    with open(path, "w") as wf:
+        wf.writelines(lines)
+
+
+def _bgzip_file(path):
+    """--gzip (:659-663): BGZF-compress to <path>.gz and remove the original (keep_original=False)."""
+    from .bamio import bgzf_compress_block
+    eof = bytes([0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    with open(path, "rb") as rf, open(path + ".gz", "wb") as wf:
+        while True:
+            data = rf.read(0xff00)
+            if not data:
+                break
+            wf.write(bgzf_compress_block(data))
+        wf.write(eof)
+    os.remove(path)
+
+
+def build_freqb_parser():
+    """Flags and defaults of `ccsmeth call_freqb` (ccsmeth.py:460-556)."""
+    import argparse
+    p = argparse.ArgumentParser(prog="ccsmeth_amd call_freqb", description="call modification frequencies from an aligned modbam")
+    p.add_argument('--threads', type=int, default=5)
+    p.add_argument('--input_bam', type=str, required=True)
+    p.add_argument('--ref', type=str, required=True)
+    p.add_argument('--contigs', type=str, default=None)
+    p.add_argument('--chunk_len', type=int, default=500000)
+    p.add_argument('--output', '-o', type=str, required=True)
+    p.add_argument('--bed', action='store_true', default=False)
+    p.add_argument('--sort', action='store_true', default=False)
+    p.add_argument('--gzip', action='store_true', default=False)
+    p.add_argument('--modtype', type=str, default="5mC", choices=["5mC"])
+    p.add_argument('--call_mode', type=str, default="count", choices=["count", "aggregate"])
+    p.add_argument('--prob_cf', type=float, default=0.0)
+    p.add_argument('--no_amb_cov', action="store_true", default=False)
+    p.add_argument('--hap_tag', type=str, default="HP")
+    p.add_argument('--mapq', type=int, default=1)
+    p.add_argument('--identity', type=float, default=0.0)
+    p.add_argument('--no_supplementary', action="store_true", default=False)
+    p.add_argument('--motifs', type=str, default='CG')
+    p.add_argument('--mod_loc', type=int, default=0)
+    p.add_argument('--no_comb', action="store_true", default=False)
+    p.add_argument('--refsites_only', action='store_true', default=False)
+    p.add_argument('--refsites_all', action='store_true', default=False)
+    p.add_argument('--no_hap', action="store_true", default=False)
+    p.add_argument('--base_clip', type=int, default=0)
+    p.add_argument('--aggre_model', '-m', type=str, default=None)
+    p.add_argument('--model_type', type=str, default="attbigru", choices=["attbilstm", "attbigru"])
+    p.add_argument('--seq_len', type=int, default=11)
+    p.add_argument('--class_num', type=int, default=1)
+    p.add_argument('--layer_rnn', type=int, default=1)
+    p.add_argument('--hid_rnn', type=int, default=32)
+    p.add_argument('--bin_size', type=int, default=20)
+    p.add_argument('--cov_cf', type=int, default=4)
+    p.add_argument('--only_close', action="store_true", default=False)
+    p.add_argument('--discrete', action="store_true", default=False)
+    p.add_argument('--tseed', type=int, default=1234)
+    p.add_argument('--device', type=int, default=0, help="(this build) GPU of the aggregate model")
+    return p
+
+
+def main(argv=None):
+    args = build_freqb_parser().parse_args(argv)
+    call_mods_frequency_from_bamfile(args)

@@ -112,6 +112,191 @@ struct OwnedBatch {
     std::vector<float> fn, rn;
 };
 
+
+struct OwnedCalls {
+    ccsm_bam_modcalls view;       // first member
+    std::vector<int32_t> tid, pos;
+    std::vector<uint8_t> strand, ml, hap;
+};
+
+struct CallRows {
+    std::vector<int32_t> tid, pos;
+    std::vector<uint8_t> strand, ml, hap;
+    int64_t used = 0;
+};
+
+// int(<tag value>) of the haplotype tag as call_mods_freq_bam.py:502-508 reads it: 1 / 2 kept, everything else 0
+inline uint8_t hap_of(uint8_t typ, const uint8_t* v) {
+    long long x = 0;
+    switch (typ) {
+        case 'c': x = (int8_t)v[0]; break;
+        case 'C': x = v[0]; break;
+        case 's': x = (int16_t)rd16(v); break;
+        case 'S': x = rd16(v); break;
+        case 'i': x = (int32_t)rd32(v); break;
+        case 'I': x = rd32(v); break;
+        case 'f': { uint32_t u = rd32(v); float f; std::memcpy(&f, &u, 4); if (!(f > -1e18f && f < 1e18f)) return 0; x = (long long)f; break; }
+        case 'A': x = (v[0] >= '0' && v[0] <= '9') ? v[0] - '0' : 0; break;
+        case 'Z': {
+            char* e = nullptr;
+            const char* s = (const char*)v;
+            x = std::strtoll(s, &e, 10);
+            if (e == s || *e != 0) return 0;
+            break;
+        }
+        default: return 0;
+    }
+    return (x == 1 || x == 2) ? (uint8_t)x : 0;
+}
+
+// MM:Z / ML:B:C of one record -> calls (query position on SEQ as stored, ML), ascending in query position.
+// false = the record yields no calls (no tags, no C+m group, or tags that do not fit the read).
+bool parse_mm_ml(const char* mm, const uint8_t* ml, int64_t ml_len, const uint8_t* packed, uint32_t l_seq, bool reverse, char modbase,
+                 char modification, std::vector<std::pair<int32_t, uint8_t>>& calls) {
+    calls.clear();
+    if (!mm || !ml) return false;
+    const char* g = mm;
+    int64_t ml_off = 0, my_off = -1;
+    const char* mine = nullptr;       // the deltas of the C+m group (after the comma), or "" when it has none
+    const char* mine_end = nullptr;
+    while (*g) {
+        const char* ge = std::strchr(g, ';');
+        if (!ge) ge = g + std::strlen(g);
+        if (ge > g) {
+            // <base><strand><codes>[?.][,d,d,...]
+            const char* p = g + 1;
+            if (p < ge && (*p == '+' || *p == '-')) ++p; else return false;
+            const char* codes = p;
+            int ncodes = 0;
+            if (p < ge && *p >= '0' && *p <= '9') { while (p < ge && *p >= '0' && *p <= '9') ++p; ncodes = 1; }
+            else { while (p < ge && ((*p >= 'a' && *p <= 'z') || (*p >= 'A' && *p <= 'Z'))) { ++p; ++ncodes; } }
+            const char* codes_end = p;
+            if (p < ge && (*p == '?' || *p == '.')) ++p;
+            int64_t nd = 0;
+            const char* deltas = p;
+            if (p < ge) {
+                if (*p != ',') return false;
+                nd = 1;
+                for (const char* q = p + 1; q < ge; ++q) nd += (*q == ',') ? 1 : 0;
+                deltas = p + 1;
+            }
+            if (!mine && g[0] == modbase && g[1] == '+' && codes_end > codes && codes[0] == modification) {
+                if (ncodes != 1) return false;          // combined codes (C+mh): outside what ccsmeth writes
+                mine = deltas;
+                mine_end = ge;
+                my_off = ml_off;
+                if (nd == 0) return false;              // _get_moddict_in_tags: no deltas -> {}
+            }
+            ml_off += nd * (ncodes > 0 ? ncodes : 1);
+        }
+        g = (*ge) ? ge + 1 : ge;
+    }
+    if (!mine || ml_off != ml_len) return false;
+    // positions of modbase in the forward sequence; a reverse record's forward sequence is the reverse complement of SEQ
+    const uint8_t want = reverse ? comp_fwd((uint8_t)modbase) : (uint8_t)modbase;
+    auto base_at = [&](uint32_t i) -> uint8_t { return (uint8_t)kSeqDecode[(packed[i >> 1] >> ((i & 1) ? 0 : 4)) & 15]; };
+    int64_t k = my_off;
+    int64_t fpos = -1;                 // index in the forward sequence of the last matched base
+    const char* p = mine;
+    while (p < mine_end) {
+        char* e = nullptr;
+        const long long d = std::strtoll(p, &e, 10);
+        if (e == p || d < 0 || (e < mine_end && *e != ',')) return false;
+        p = (e < mine_end) ? e + 1 : e;
+        long long skip = d;
+        int64_t i = fpos + 1;
+        for (; i < (int64_t)l_seq; ++i) {
+            const uint8_t b = base_at(reverse ? (uint32_t)(l_seq - 1 - i) : (uint32_t)i);
+            if (b == want) { if (skip == 0) break; --skip; }
+        }
+        if (i >= (int64_t)l_seq) return false;          // IndexError in the reference -> {}
+        fpos = i;
+        calls.emplace_back((int32_t)(reverse ? (int64_t)l_seq - 1 - i : i), ml[k++]);
+    }
+    if (reverse) std::reverse(calls.begin(), calls.end());
+    return true;
+}
+
+void modcalls_of_record(const uint8_t* src, const ccsm_bam_modcall_opts& o, const uint8_t* const* site_mask, const int64_t* mask_len,
+                        int32_t n_ref, std::vector<std::pair<int32_t, uint8_t>>& calls, CallRows& out) {
+    const uint32_t bs = rd32(src);
+    const uint8_t* body = src + 4;
+    const int32_t tid = (int32_t)rd32(body), pos0 = (int32_t)rd32(body + 4);
+    const uint32_t l_name = body[8], mapq = body[9], n_cig = rd16(body + 12), flag = rd16(body + 14), l_seq = rd32(body + 16);
+    if (flag & (0x4 | 0x100 | 0x400)) return;                        // unmapped / secondary / duplicate (:489-490)
+    if (o.no_supplementary && (flag & 0x800)) return;
+    if ((int32_t)mapq < o.mapq) return;
+    const uint8_t* cig = body + 32 + l_name;
+    const uint8_t* packed = cig + 4 * (size_t)n_cig;
+    const size_t fixed = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    int64_t cnt[16] = {0};
+    for (uint32_t c = 0; c < n_cig; ++c) { const uint32_t v = rd32(cig + 4 * c); cnt[v & 15] += v >> 4; }
+    {   // compute_pct_identity over "MIDNSHP=XB": everything but S and H aligns, M and = match
+        const int64_t nalign = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[6] + cnt[7] + cnt[8] + cnt[9];
+        const int64_t nmatch = cnt[0] + cnt[7];
+        const double identity = nalign > 0 ? (double)nmatch / (double)nalign : 0.0;
+        if (identity < o.identity) return;
+    }
+    const bool reverse = (flag & 16) != 0;
+    const char* mm = nullptr;
+    const uint8_t* ml = nullptr;
+    int64_t ml_len = 0;
+    uint8_t hap = 0;
+    bool have_hap = false;
+    walk_tags(body + fixed, body + bs, [&](uint8_t t0, uint8_t t1, uint8_t typ, uint8_t sub, int64_t count, const uint8_t* val, const uint8_t*, size_t) {
+        if (t0 == 'M' && t1 == 'M' && typ == 'Z') { if (!mm) mm = (const char*)val; }
+        else if (t0 == 'M' && t1 == 'L' && typ == 'B' && sub == 'C') { if (!ml) { ml = val; ml_len = count; } }
+        else if (t0 == (uint8_t)o.hap_tag[0] && t1 == (uint8_t)o.hap_tag[1] && !have_hap) { hap = hap_of(typ, val); have_hap = true; }
+    });
+    out.used += 1;
+    const bool have_calls = parse_mm_ml(mm, ml, ml_len, packed, l_seq, reverse, o.modbase, o.modification, calls);
+    if (!have_calls) calls.clear();
+    const uint8_t* mask = (o.refsites_all && site_mask && tid >= 0 && tid < n_ref) ? site_mask[tid] : nullptr;
+    const int64_t mlen = mask ? mask_len[tid] : 0;
+    const uint8_t mbit = reverse ? 2 : 1;
+    if (calls.empty() && !mask) return;
+    // aligned pairs in CIGAR order: M/=/X (q, r); with refsites_all also I/S (q, None) and D/N (None, r)
+    int64_t n_pairs = cnt[0] + cnt[7] + cnt[8];
+    if (o.refsites_all) n_pairs += cnt[1] + cnt[4] + cnt[2] + cnt[3];
+    const int64_t lo = o.base_clip > 0 ? o.base_clip : 0;
+    const int64_t hi = o.base_clip > 0 ? n_pairs - o.base_clip : n_pairs;
+    int64_t idx = 0;
+    int64_t q = 0, r = pos0;
+    size_t j = 0;
+    auto emit = [&](int64_t rp, uint8_t v) {
+        out.tid.push_back(tid); out.pos.push_back((int32_t)rp); out.strand.push_back(reverse ? 1 : 0); out.ml.push_back(v); out.hap.push_back(hap);
+    };
+    for (uint32_t c = 0; c < n_cig && idx < hi; ++c) {
+        const uint32_t v = rd32(cig + 4 * c);
+        const uint32_t op = v & 15;
+        const int64_t len = v >> 4;
+        switch (op) {
+            case 0: case 7: case 8:
+                for (int64_t t = 0; t < len && idx < hi; ++t, ++idx, ++q, ++r) {
+                    if (idx < lo) continue;
+                    while (j < calls.size() && calls[j].first < q) ++j;
+                    if (j < calls.size() && calls[j].first == q) emit(r, calls[j].second);
+                    else if (mask && r >= 0 && r < mlen && (mask[r] & mbit)) emit(r, 0);
+                }
+                break;
+            case 1: case 4:
+                q += len;
+                if (o.refsites_all) idx += len;
+                break;
+            case 2: case 3:
+                if (o.refsites_all) {
+                    for (int64_t t = 0; t < len && idx < hi; ++t, ++idx, ++r)
+                        if (idx >= lo && mask && r >= 0 && r < mlen && (mask[r] & mbit)) emit(r, 0);
+                    // idx may have stopped early; r is not used after the loop ends in that case
+                } else {
+                    r += len;
+                }
+                break;
+            default: break;   // H, P, B: no pairs
+        }
+    }
+}
+
 }  // namespace
 
 struct ccsm_bam_reader {
@@ -510,5 +695,44 @@ int ccsm_bam_writer_close(ccsm_bam_writer* w) {
     delete w;
     return rc;
 }
+
+int ccsm_bam_modcalls_of_batch(const ccsm_bam_batch* b, const ccsm_bam_modcall_opts* opts, const uint8_t* const* site_mask,
+                               const int64_t* mask_len, int32_t n_ref, int threads, ccsm_bam_modcalls** out) {
+    if (!b || !opts || !out) return fail("batch, opts and out must be non-NULL");
+    *out = nullptr;
+    if (opts->refsites_all && (!site_mask || !mask_len)) return fail("refsites_all needs the reference site masks");
+    const int n = b->n_reads;
+    const int parts = std::max(1, std::min(threads, n));
+    std::vector<CallRows> rows((size_t)parts);
+    parallel_for(parts, parts, [&](int p) {
+        std::vector<std::pair<int32_t, uint8_t>> calls;
+        const int r0 = (int)((int64_t)n * p / parts), r1 = (int)((int64_t)n * (p + 1) / parts);
+        for (int r = r0; r < r1; ++r)
+            modcalls_of_record(b->records + b->rec_offset[r], *opts, site_mask, mask_len, n_ref, calls, rows[(size_t)p]);
+    });
+    OwnedCalls* oc = new (std::nothrow) OwnedCalls();
+    if (!oc) return fail("out of memory");
+    int64_t used = 0;
+    for (auto& cr : rows) {
+        oc->tid.insert(oc->tid.end(), cr.tid.begin(), cr.tid.end());
+        oc->pos.insert(oc->pos.end(), cr.pos.begin(), cr.pos.end());
+        oc->strand.insert(oc->strand.end(), cr.strand.begin(), cr.strand.end());
+        oc->ml.insert(oc->ml.end(), cr.ml.begin(), cr.ml.end());
+        oc->hap.insert(oc->hap.end(), cr.hap.begin(), cr.hap.end());
+        used += cr.used;
+    }
+    oc->view.n = (int64_t)oc->tid.size();
+    oc->view.tid = oc->tid.data();
+    oc->view.pos = oc->pos.data();
+    oc->view.strand = oc->strand.data();
+    oc->view.ml = oc->ml.data();
+    oc->view.hap = oc->hap.data();
+    oc->view.n_records = n;
+    oc->view.n_used = used;
+    *out = &oc->view;
+    return 0;
+}
+
+void ccsm_bam_modcalls_free(ccsm_bam_modcalls* c) { delete reinterpret_cast<OwnedCalls*>(c); }
 
 }  // extern "C"

@@ -74,6 +74,41 @@ int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int3
 int ccsm_bam_writer_flush(ccsm_bam_writer* w, int64_t* file_offset);
 int ccsm_bam_writer_close(ccsm_bam_writer* w);
 
+/* ---- per-read modification calls of an aligned modbam projected on the reference: the feed of `ccsmeth call_freqb` -------
+ * Replaces the per-read part of _readmods_to_bed_of_one_region (call_mods_freq_bam.py:486-537): record filters (:489-500),
+ * haplotype tag (:502-508), MM/ML -> {query position: ML} (_get_moddict :179-205 / _get_moddict_in_tags :125-175) and the walk
+ * over get_aligned_pairs (:509-536).  One output row per (record, reference position) the reference would append to its
+ * refposinfo / refposinfo_rev dictionaries; rows of a record are in CIGAR order, records in batch order.  The caller groups
+ * the rows by region and position. */
+typedef struct ccsm_bam_modcall_opts {
+    double identity;           /* records with (M + =) / (M+I+D+N+P+=+X+B) < identity are skipped (process_utils.py:174-186) */
+    int32_t mapq;              /* records with MAPQ < mapq are skipped */
+    int32_t no_supplementary;  /* skip FLAG 0x800 */
+    int32_t base_clip;         /* drop this many aligned pairs at either end of the record (:512-513) */
+    int32_t refsites_all;      /* walk every CIGAR column (matches_only=False) and report ML 0 at reference motif sites of the
+                                * record's strand that carry no call (site_mask must be given) */
+    char hap_tag[2];           /* "HP" */
+    char modbase;              /* 'C' */
+    char modification;         /* 'm' */
+} ccsm_bam_modcall_opts;
+
+typedef struct ccsm_bam_modcalls {
+    int64_t n;                 /* rows */
+    const int32_t* tid;        /* reference id of the record */
+    const int32_t* pos;        /* 0-based reference position */
+    const uint8_t* strand;     /* 0 = forward record, 1 = reverse (FLAG 0x10) */
+    const uint8_t* ml;         /* ML byte; probability = round(ml/256 + 1e-6, 6), 0 for ml == 0 (_cal_mod_prob :102-107) */
+    const uint8_t* hap;        /* 1, 2, or 0 for anything else / no tag */
+    int64_t n_records;         /* records looked at */
+    int64_t n_used;            /* records that passed the filters */
+} ccsm_bam_modcalls;
+
+/* site_mask[tid] (may be NULL per contig, or site_mask itself NULL): one byte per reference base, bit 0 = motif site on the
+ * forward strand, bit 1 = on the reverse strand; mask_len[tid] = bytes.  threads = workers over the batch's records. */
+int ccsm_bam_modcalls_of_batch(const ccsm_bam_batch* b, const ccsm_bam_modcall_opts* opts, const uint8_t* const* site_mask,
+                               const int64_t* mask_len, int32_t n_ref, int threads, ccsm_bam_modcalls** out);
+void ccsm_bam_modcalls_free(ccsm_bam_modcalls* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -394,6 +394,26 @@ def test_aggregate_mode_vs_reference_golden():
     model.close()
 
 
+@pytest.mark.parametrize("case", ["aggregate_default", "aggregate_bed_cov6", "aggregate_no_comb_discrete", "aggregate_nohap_refsites_only"])
+def test_call_freqb_aggregate_on_gpu_vs_reference_text(case, tmp_path):
+    """`call_freqb --call_mode aggregate` end to end (native pile-up -> per-region windows -> HIP aggregate model -> text)
+    against what the reference's own functions wrote for the same modbam (tests/golden/make_freqb_golden.py)."""
+    import test_call_freqb as tf
+    import torch
+    from ccsmeth_amd import call_mods_freq_bam as fb
+    w = dict(np.load(os.path.join(GOLDEN, "aggr_ckpt_weights.npz")))
+    ckpt = str(tmp_path / "aggr.ckpt")
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in w.items()}, ckpt)
+    a = tf._args(case, str(tmp_path / "o"), aggre_model=ckpt)
+    fb.call_mods_frequency_from_bamfile(a, log=open(os.devnull, "w"))
+    got = tf._outputs(str(tmp_path / "o"), a)
+    diff = total = 0
+    for wch in ("all", "hp1", "hp2"):
+        diff += tf._close(got[wch], tf.CASES[case][wch], a.bed)
+        total += len(got[wch].splitlines())
+    assert total > 1000 and diff <= 0.002 * total
+
+
 def test_call_mods_bam_to_modbam(tmp_path):
     """`python -m ccsmeth_amd call_mods` end to end on a synthetic HiFi BAM: DDP-prefixed .ckpt, @PG line, MM/ML added,
     pulse tags dropped, reads without usable kinetics written untagged, reverse-strand record handled."""
