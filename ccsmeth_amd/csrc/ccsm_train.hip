@@ -1,0 +1,705 @@
+// libccsm_train: the attbigru2s training step (forward with saved activations, backward, Adam) for gfx950, fp32.
+// C-ABI in include/ccsm_train.h.  Dense products go to rocBLAS SGEMM / SGEMV; gates, attention, loss, embedding scatter,
+// dropout and the optimizer are the kernels below.  Activations are time-major: (T, M, features) with M = 2N rows
+// (strand 1 rows first), so that a timestep of a direction is one contiguous (M, H) block and both strands share every product.
+//
+// Reference equations: ModelAttRNN.forward (models.py:89-150), torch.nn.GRU cell (gate order r, z, n), Attention
+// (utils/attention.py:48-70), CrossEntropyLoss(weight) + clip_grad_norm_ + Adam (train_multigpu.py:212-216, 283-312).
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ccsm_train.h"
+
+namespace {
+
+constexpr int T = 21, H = 256, G = 3 * H, H2 = 2 * H, NE = 8, F0 = 11, L = CCSM_LAYERS, NC = 2, NV = 5;
+
+thread_local std::string g_err;
+ccsm_status fail(ccsm_status s, const std::string& m) { g_err = m; return s; }
+#define HIPCHK(x)                                                                                        \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) return fail(CCSM_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define BLASCHK(x)                                                                                              \
+    do {                                                                                                        \
+        rocblas_status s_ = (x);                                                                                \
+        if (s_ != rocblas_status_success) return fail(CCSM_ERR_HIP, std::string(#x) + ": rocblas status " + std::to_string((int)s_)); \
+    } while (0)
+
+// ---- flat parameter order ------------------------------------------------------------------------------------------
+struct Offsets {
+    int64_t embed, w_ih[L][2], w_hh[L][2], b_ih[L][2], b_hh[L][2], wa, ua, va, fcw, fcb, total;
+    int64_t list[31];
+    Offsets() {
+        int64_t o = 0;
+        int k = 0;
+        auto take = [&](int64_t n) { int64_t r = o; list[k++] = o; o += n; return r; };
+        embed = take(NV * NE);
+        for (int l = 0; l < L; ++l)
+            for (int d = 0; d < 2; ++d) {
+                w_ih[l][d] = take((int64_t)G * (l == 0 ? F0 : H2));
+                w_hh[l][d] = take((int64_t)G * H);
+                b_ih[l][d] = take(G);
+                b_hh[l][d] = take(G);
+            }
+        wa = take((int64_t)H * H2);
+        ua = take((int64_t)H * H2);
+        va = take(H);
+        fcw = take((int64_t)NC * 2 * H2);
+        fcb = take(NC);
+        total = o;
+        list[k] = o;
+    }
+};
+const Offsets kOff;
+
+// ---- small device helpers -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t stream, uint64_t idx) {
+    const uint64_t r = mix64(mix64(seed ^ (stream * 0xd1342543de82ef95ull)) + idx);
+    return (float)(r >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// x0[t][m][0..7] = embed[kmer[m][t]], [8] = ipd, [9] = pw, [10] = npass          (models.py:91-106)
+__global__ void build_x0_kernel(const uint8_t* kmer, const float* ipd, const float* pw, const float* npass, const float* embed,
+                                float* x0, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * M) return;
+    const int t = i / M, m = i % M;
+    int b = kmer[m * T + t];
+    b = b > 4 ? 4 : b;
+    float* o = x0 + (size_t)i * F0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) o[e] = embed[b * NE + e];
+    o[8] = ipd[m * T + t];
+    o[9] = pw[m * T + t];
+    o[10] = npass[m * T + t];
+}
+
+// h0 from the counter-based generator (DEVICE_RNG): N(0,1) by Box-Muller
+__global__ void h0_rng_kernel(float* h0, int64_t n, uint64_t seed, uint64_t offset) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float u1 = fmaxf(uniform01(seed, 0x68300, offset + 2 * i), 1e-7f), u2 = uniform01(seed, 0x68300, offset + 2 * i + 1);
+    h0[i] = sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+
+// y = x * mask / keep  (inverted dropout, mask from (seed, stream, element index))
+__global__ void dropout_kernel(const float* x, float* y, int64_t n, float rate, uint64_t seed, uint64_t stream) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    y[i] = uniform01(seed, stream, (uint64_t)i) >= rate ? x[i] * (1.0f / (1.0f - rate)) : 0.0f;
+}
+
+// one GRU step of one direction: gi (M,G) = x_t W_ih^T (no bias yet), gh (M,G) = h_{t-1} W_hh^T (no bias yet)
+//   r = s(gi_r + b_ir + gh_r + b_hr); z likewise; hp = gh_n + b_hn; n = tanh(gi_n + b_in + r * hp); h = (1 - z) n + z h_{t-1}
+__global__ void gru_gate_fwd_kernel(const float* gi, const float* gh, const float* b_ih, const float* b_hh, const float* hprev,
+                                    int ld_hprev, float* out, float* R, float* Z, float* Nn, float* HP, int M, int save) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * H) return;
+    const int m = i / H, j = i % H;
+    const float* a = gi + (size_t)m * G;
+    const float* b = gh + (size_t)m * G;
+    const float r = sigmoidf_(a[j] + b_ih[j] + b[j] + b_hh[j]);
+    const float z = sigmoidf_(a[H + j] + b_ih[H + j] + b[H + j] + b_hh[H + j]);
+    const float hp = b[2 * H + j] + b_hh[2 * H + j];
+    const float n = tanhf(a[2 * H + j] + b_ih[2 * H + j] + r * hp);
+    const float h = (1.0f - z) * n + z * hprev[(size_t)m * ld_hprev + j];
+    out[(size_t)m * H2 + j] = h;
+    if (save) { R[i] = r; Z[i] = z; Nn[i] = n; HP[i] = hp; }
+}
+
+// backward of that step.  dh = dout_t + carry.  Writes dgi = [dr, dz, dn], dgh = [dr, dz, dn * r], carry = dh * z
+// (the caller then adds dgh W_hh to carry).
+__global__ void gru_gate_bwd_kernel(const float* dout, float* carry, const float* R, const float* Z, const float* Nn, const float* HP,
+                                    const float* hprev, int ld_hprev, float* dgi, float* dgh, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * H) return;
+    const int m = i / H, j = i % H;
+    const float dh = dout[(size_t)m * H2 + j] + carry[i];
+    const float r = R[i], z = Z[i], n = Nn[i], hp = HP[i];
+    const float dn = dh * (1.0f - z) * (1.0f - n * n);
+    const float dz = dh * (hprev[(size_t)m * ld_hprev + j] - n) * z * (1.0f - z);
+    const float dr = dn * hp * r * (1.0f - r);
+    float* a = dgi + (size_t)m * G;
+    float* b = dgh + (size_t)m * G;
+    a[j] = dr; a[H + j] = dz; a[2 * H + j] = dn;
+    b[j] = dr; b[H + j] = dz; b[2 * H + j] = dn * r;
+    carry[i] = dh * z;
+}
+
+// h_n = [forward final state = out[T-1][:, :H] | backward final state = out[0][:, H:]]            (models.py:135-137)
+__global__ void gather_hn_kernel(const float* out2, float* hn, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * H2) return;
+    const int m = i / H2, k = i % H2;
+    hn[i] = k < H ? out2[((size_t)(T - 1) * M + m) * H2 + k] : out2[(size_t)m * H2 + k];
+}
+__global__ void scatter_dhn_kernel(const float* dhn, float* dout2, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * H2) return;
+    const int m = i / H2, k = i % H2;
+    float* p = k < H ? dout2 + ((size_t)(T - 1) * M + m) * H2 + k : dout2 + (size_t)m * H2 + k;
+    *p += dhn[i];
+}
+
+// S[t][m][:] = tanh(q[m] + K[t][m]) in place of K; e[t][m] = va . S                (attention.py:69-70); one wave per (t, m)
+__global__ void att_score_kernel(float* KS, const float* q, const float* va, float* e, int M) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= T * M) return;
+    const int m = row % M;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < H / 64; ++c) {
+        const int j = lane + 64 * c;
+        const float s = tanhf(q[(size_t)m * H + j] + KS[(size_t)row * H + j]);
+        KS[(size_t)row * H + j] = s;
+        acc += va[j] * s;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) e[row] = acc;
+}
+// a = softmax over t, per row m                                                  (attention.py:55)
+__global__ void att_softmax_kernel(const float* e, float* a, int M) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float mx = -INFINITY;
+    for (int t = 0; t < T; ++t) mx = fmaxf(mx, e[(size_t)t * M + m]);
+    float den = 0.f;
+    for (int t = 0; t < T; ++t) den += __expf(e[(size_t)t * M + m] - mx);
+    for (int t = 0; t < T; ++t) a[(size_t)t * M + m] = __expf(e[(size_t)t * M + m] - mx) / den;
+}
+// c[m][k] = sum_t a[t][m] out2[t][m][k]                                          (attention.py:57-58)
+__global__ void att_context_kernel(const float* a, const float* out2, float* c, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * H2) return;
+    const int m = i / H2;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += a[(size_t)t * M + m] * out2[(size_t)t * M * H2 + i];
+    c[i] = acc;
+}
+// da[t][m] = dc[m] . out2[t][m]; one wave per (t, m)
+__global__ void att_dalpha_kernel(const float* dc, const float* out2, float* da, int M) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= T * M) return;
+    const int m = row % M;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < H2 / 64; ++c) acc += dc[(size_t)m * H2 + lane + 64 * c] * out2[(size_t)row * H2 + lane + 64 * c];
+    acc = wave_sum(acc);
+    if (lane == 0) da[row] = acc;
+}
+// de = a * (da - sum_t a da)   (softmax backward), in place of da
+__global__ void att_dscore_kernel(const float* a, float* da, int M) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += a[(size_t)t * M + m] * da[(size_t)t * M + m];
+    for (int t = 0; t < T; ++t) da[(size_t)t * M + m] = a[(size_t)t * M + m] * (da[(size_t)t * M + m] - s);
+}
+// dSpre[t][m][j] = de[t][m] va[j] (1 - S^2) in place of S; dva[j] += sum de S; dout2[t][m][k] = a[t][m] dc[m][k]
+__global__ void att_dpre_kernel(float* S, const float* de, const float* va, float* dva, int rows) {
+    const int j = threadIdx.x;                       // blockDim.x == H
+    const int r0 = blockIdx.x * 64, r1 = min(rows, r0 + 64);
+    float acc = 0.f;
+    const float v = va[j];
+    for (int r = r0; r < r1; ++r) {
+        const float s = S[(size_t)r * H + j], d = de[r];
+        acc += d * s;
+        S[(size_t)r * H + j] = d * v * (1.0f - s * s);
+    }
+    atomicAdd(dva + j, acc);
+}
+__global__ void att_dq_kernel(const float* dS, float* dq, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * H) return;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += dS[(size_t)t * M * H + i];
+    dq[i] = acc;
+}
+__global__ void att_dout_init_kernel(const float* a, const float* dc, float* dout2, int M) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)T * M * H2) return;
+    const int64_t row = i / H2;
+    const int k = (int)(i % H2);
+    const int m = (int)(row % M);
+    dout2[i] = a[row] * dc[(size_t)m * H2 + k];
+}
+
+// feat[n] = [c[n] | c[N + n]] (dropout1 applied when rate > 0); logits = feat fc^T + b; p = softmax; weighted CE
+//   loss_sum += w_y * -log p_y ; dlogits[n][c] = w_y (p_c - [c == y]) / wsum            (models.py:145-150, train_multigpu.py:212-214)
+__global__ void fc_loss_kernel(const float* c, const float* fcw, const float* fcb, const int32_t* labels, float pos_weight, float wsum,
+                               float rate, uint64_t seed, float* feat, float* logits, float* dlogits, float* loss_sum, int N) {
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float a0 = 0.f, a1 = 0.f;
+    for (int k = lane; k < 2 * H2; k += 64) {
+        float v = k < H2 ? c[(size_t)n * H2 + k] : c[(size_t)(N + n) * H2 + (k - H2)];
+        if (rate > 0.f) v = uniform01(seed, 0xfc1, (uint64_t)n * 2 * H2 + k) >= rate ? v * (1.0f / (1.0f - rate)) : 0.0f;
+        feat[(size_t)n * 2 * H2 + k] = v;
+        a0 += v * fcw[k];
+        a1 += v * fcw[2 * H2 + k];
+    }
+    a0 = wave_sum(a0) + fcb[0];
+    a1 = wave_sum(a1) + fcb[1];
+    if (lane == 0) {
+        logits[2 * n] = a0;
+        logits[2 * n + 1] = a1;
+        if (labels != nullptr) {
+            const float mx = fmaxf(a0, a1);
+            const float lse = mx + __logf(__expf(a0 - mx) + __expf(a1 - mx));
+            const int y = labels[n] != 0;
+            const float w = y ? pos_weight : 1.0f;
+            atomicAdd(loss_sum, w * (lse - (y ? a1 : a0)));
+            if (dlogits != nullptr) {
+                dlogits[2 * n] = w * (__expf(a0 - lse) - (y ? 0.f : 1.f)) / wsum;
+                dlogits[2 * n + 1] = w * (__expf(a1 - lse) - (y ? 1.f : 0.f)) / wsum;
+            }
+        }
+    }
+}
+// dc[m][k] from dlogits fc_w (through dropout1), db_fc = column sums of dlogits
+__global__ void fc_bwd_kernel(const float* dlogits, const float* fcw, float rate, uint64_t seed, float* dc, float* dfcb, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NC) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dlogits[2 * n + i];
+        dfcb[i] = s;
+    }
+    if (i >= N * 2 * H2) return;
+    const int n = i / (2 * H2), k = i % (2 * H2);
+    float g = dlogits[2 * n] * fcw[k] + dlogits[2 * n + 1] * fcw[2 * H2 + k];
+    if (rate > 0.f) g = uniform01(seed, 0xfc1, (uint64_t)i) >= rate ? g * (1.0f / (1.0f - rate)) : 0.0f;
+    const int m = k < H2 ? n : N + n;
+    dc[(size_t)m * H2 + (k % H2)] = g;
+}
+// dembed[kmer[m][t]][e] += dx0[t][m][e]
+__global__ void embed_bwd_kernel(const float* dx0, const uint8_t* kmer, float* dembed, int M) {
+    __shared__ float part[NV * NE];
+    if (threadIdx.x < NV * NE) part[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T * M) {
+        const int t = i / M, m = i % M;
+        int b = kmer[m * T + t];
+        b = b > 4 ? 4 : b;
+#pragma unroll
+        for (int e = 0; e < NE; ++e) atomicAdd(&part[b * NE + e], dx0[(size_t)i * F0 + e]);
+    }
+    __syncthreads();
+    if (threadIdx.x < NV * NE) atomicAdd(dembed + threadIdx.x, part[threadIdx.x]);
+}
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// torch.optim.Adam (no amsgrad, no weight decay): m, v moments, bias correction by step; g pre-scaled by `clip`
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float clip,
+                            float bc1, float bc2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * clip;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);
+}
+
+inline dim3 blocks(int64_t n, int per = 256) { return dim3((unsigned)((n + per - 1) / per)); }
+
+}  // namespace
+
+struct ccsm_trainer {
+    int device = 0, max_sites = 0;
+    rocblas_handle blas = nullptr;
+    hipStream_t stream = nullptr;
+    float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+    bool own_grads = false;
+    int64_t step = 0;
+    // inputs
+    uint8_t* kmer = nullptr;
+    float *ipd = nullptr, *pw = nullptr, *npass = nullptr, *h0 = nullptr;
+    int32_t* labels = nullptr;
+    // activations
+    float* x0 = nullptr;
+    float* out[L] = {nullptr, nullptr, nullptr};
+    float* xdrop[L] = {nullptr, nullptr, nullptr};     // dropout(out[l]) = input of layer l + 1 (rate > 0 only)
+    float* sav[L][2][4];
+    float *gi = nullptr, *gh = nullptr, *dgi = nullptr, *dgh = nullptr, *carry = nullptr, *ones = nullptr;
+    float *hn = nullptr, *q = nullptr, *KS = nullptr, *e = nullptr, *a = nullptr, *c = nullptr, *feat = nullptr, *logits = nullptr,
+          *dlogits = nullptr, *loss = nullptr;
+    float *dc = nullptr, *dq = nullptr, *dhn = nullptr, *dA = nullptr, *dB = nullptr;   // dA / dB: (T, M, 512) gradient ping-pong
+    std::vector<uint8_t> h_kmer;
+    std::vector<float> h_f;
+};
+
+namespace {
+
+// row-major C(MxN) (+)= op(A) op(B) through column-major rocBLAS
+rocblas_status rm_gemm(rocblas_handle h, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                       int ldb, float beta, float* C, int ldc) {
+    return rocblas_sgemm(h, tB ? rocblas_operation_transpose : rocblas_operation_none, tA ? rocblas_operation_transpose : rocblas_operation_none,
+                         N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
+}
+
+ccsm_status upload_batch(ccsm_trainer* t, int N, const ccsm_batch* batch, const int32_t* labels, const ccsm_h0* h0) {
+    const int M = 2 * N;
+    t->h_kmer.resize((size_t)M * T);
+    t->h_f.resize((size_t)M * T * 3);
+    float* ipd = t->h_f.data();
+    float* pw = ipd + (size_t)M * T;
+    float* np = pw + (size_t)M * T;
+    for (int s = 0; s < 2; ++s) {
+        const ccsm_strand& st = batch->strand[s];
+        if (!st.kmer || !st.ipd || !st.pw || !st.npass) return fail(CCSM_ERR_INVALID_ARG, "batch pointers must be non-NULL");
+        const size_t o = (size_t)s * N * T;
+        for (size_t i = 0; i < (size_t)N * T; ++i) {
+            int b = batch->kmer_is_f32 ? (int)((const float*)st.kmer)[i] : (int)((const uint8_t*)st.kmer)[i];
+            t->h_kmer[o + i] = (uint8_t)(b < 0 ? 4 : (b > 4 ? 4 : b));
+            np[o + i] = batch->npass_per_base ? st.npass[i] : st.npass[i / T];
+        }
+        std::memcpy(ipd + o, st.ipd, sizeof(float) * (size_t)N * T);
+        std::memcpy(pw + o, st.pw, sizeof(float) * (size_t)N * T);
+    }
+    HIPCHK(hipMemcpyAsync(t->kmer, t->h_kmer.data(), (size_t)M * T, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipMemcpyAsync(t->ipd, ipd, sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipMemcpyAsync(t->pw, pw, sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, t->stream));
+    HIPCHK(hipMemcpyAsync(t->npass, np, sizeof(float) * (size_t)M * T, hipMemcpyHostToDevice, t->stream));
+    if (labels) HIPCHK(hipMemcpyAsync(t->labels, labels, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, t->stream));
+    const int64_t nh0 = (int64_t)2 * L * M * H;
+    const int mode = h0 ? h0->mode : CCSM_H0_ZERO;
+    if (mode == CCSM_H0_EXPLICIT) {
+        if (!h0->h0[0] || !h0->h0[1]) return fail(CCSM_ERR_INVALID_ARG, "explicit h0 needs both tensors");
+        for (int k = 0; k < 2 * L; ++k)
+            for (int s = 0; s < 2; ++s)
+                HIPCHK(hipMemcpyAsync(t->h0 + ((size_t)k * M + (size_t)s * N) * H, h0->h0[s] + (size_t)k * N * H, sizeof(float) * (size_t)N * H,
+                                      hipMemcpyHostToDevice, t->stream));
+    } else if (mode == CCSM_H0_ZERO) {
+        HIPCHK(hipMemsetAsync(t->h0, 0, sizeof(float) * nh0, t->stream));
+    } else if (mode == CCSM_H0_DEVICE_RNG) {
+        h0_rng_kernel<<<blocks(nh0), 256, 0, t->stream>>>(t->h0, nh0, h0->seed, h0->offset * (uint64_t)(2 * L * 2 * H));
+    } else {
+        return fail(CCSM_ERR_INVALID_ARG, "unknown h0 mode");
+    }
+    HIPCHK(hipStreamSynchronize(t->stream));      // the host staging vectors are reused by the next call
+    return CCSM_OK;
+}
+
+ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, uint64_t seed, bool have_labels, float pos_weight, float wsum) {
+    const int M = 2 * N;
+    const float* P = t->params;
+    hipStream_t st = t->stream;
+    build_x0_kernel<<<blocks((int64_t)T * M), 256, 0, st>>>(t->kmer, t->ipd, t->pw, t->npass, P + kOff.embed, t->x0, M);
+    const bool drop = train && rate > 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float* X = l == 0 ? t->x0 : (drop ? t->xdrop[l - 1] : t->out[l - 1]);
+        const int in = l == 0 ? F0 : H2;
+        for (int d = 0; d < 2; ++d) {
+            BLASCHK(rm_gemm(t->blas, false, true, T * M, G, in, 1.f, X, in, P + kOff.w_ih[l][d], in, 0.f, t->gi, G));
+            for (int s = 0; s < T; ++s) {
+                const int tt = d == 0 ? s : T - 1 - s;
+                const float* hprev;
+                int ld;
+                if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
+                else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
+                BLASCHK(rm_gemm(t->blas, false, true, M, G, H, 1.f, hprev, ld, P + kOff.w_hh[l][d], H, 0.f, t->gh, G));
+                const size_t so = (size_t)tt * M * H;
+                gru_gate_fwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(t->gi + (size_t)tt * M * G, t->gh, P + kOff.b_ih[l][d], P + kOff.b_hh[l][d],
+                                                                           hprev, ld, t->out[l] + (size_t)tt * M * H2 + d * H, t->sav[l][d][0] + so,
+                                                                           t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, M, train ? 1 : 0);
+            }
+        }
+        if (drop && l + 1 < L)
+            dropout_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(t->out[l], t->xdrop[l], (int64_t)T * M * H2, rate, seed, 0xd0 + l);
+    }
+    const float* O2 = t->out[L - 1];
+    gather_hn_kernel<<<blocks((int64_t)M * H2), 256, 0, st>>>(O2, t->hn, M);
+    BLASCHK(rm_gemm(t->blas, false, true, M, H, H2, 1.f, t->hn, H2, P + kOff.wa, H2, 0.f, t->q, H));
+    BLASCHK(rm_gemm(t->blas, false, true, T * M, H, H2, 1.f, O2, H2, P + kOff.ua, H2, 0.f, t->KS, H));
+    att_score_kernel<<<blocks((int64_t)T * M, 4), 256, 0, st>>>(t->KS, t->q, P + kOff.va, t->e, M);
+    att_softmax_kernel<<<blocks(M), 256, 0, st>>>(t->e, t->a, M);
+    att_context_kernel<<<blocks((int64_t)M * H2), 256, 0, st>>>(t->a, O2, t->c, M);
+    HIPCHK(hipMemsetAsync(t->loss, 0, sizeof(float), st));
+    fc_loss_kernel<<<blocks(N, 4), 256, 0, st>>>(t->c, P + kOff.fcw, P + kOff.fcb, have_labels ? t->labels : nullptr, pos_weight, wsum,
+                                                 drop ? rate : 0.f, seed, t->feat, t->logits, train ? t->dlogits : nullptr, t->loss, N);
+    HIPCHK(hipGetLastError());
+    return CCSM_OK;
+}
+
+ccsm_status backward(ccsm_trainer* t, int N, float rate, uint64_t seed) {
+    const int M = 2 * N;
+    const float* P = t->params;
+    float* Gd = t->grads;
+    hipStream_t st = t->stream;
+    const bool drop = rate > 0.f;
+    HIPCHK(hipMemsetAsync(Gd, 0, sizeof(float) * kOff.total, st));
+    // fc1 and dropout1
+    BLASCHK(rm_gemm(t->blas, true, false, NC, 2 * H2, N, 1.f, t->dlogits, NC, t->feat, 2 * H2, 0.f, Gd + kOff.fcw, 2 * H2));
+    fc_bwd_kernel<<<blocks((int64_t)N * 2 * H2), 256, 0, st>>>(t->dlogits, P + kOff.fcw, drop ? rate : 0.f, seed, t->dc, Gd + kOff.fcb, N);
+    // attention
+    const float* O2 = t->out[L - 1];
+    float* dO = t->dA;
+    att_dalpha_kernel<<<blocks((int64_t)T * M, 4), 256, 0, st>>>(t->dc, O2, t->e, M);        // e <- da
+    att_dscore_kernel<<<blocks(M), 256, 0, st>>>(t->a, t->e, M);                             // e <- de
+    att_dout_init_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(t->a, t->dc, dO, M);
+    att_dpre_kernel<<<blocks((int64_t)T * M, 64), H, 0, st>>>(t->KS, t->e, P + kOff.va, Gd + kOff.va, T * M);   // KS <- dSpre
+    att_dq_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(t->KS, t->dq, M);
+    BLASCHK(rm_gemm(t->blas, true, false, H, H2, T * M, 1.f, t->KS, H, O2, H2, 0.f, Gd + kOff.ua, H2));
+    BLASCHK(rm_gemm(t->blas, false, false, T * M, H2, H, 1.f, t->KS, H, P + kOff.ua, H2, 1.f, dO, H2));
+    BLASCHK(rm_gemm(t->blas, true, false, H, H2, M, 1.f, t->dq, H, t->hn, H2, 0.f, Gd + kOff.wa, H2));
+    BLASCHK(rm_gemm(t->blas, false, false, M, H2, H, 1.f, t->dq, H, P + kOff.wa, H2, 0.f, t->dhn, H2));
+    scatter_dhn_kernel<<<blocks((int64_t)M * H2), 256, 0, st>>>(t->dhn, dO, M);
+    // GRU layers, top down
+    float* dX = t->dB;
+    for (int l = L - 1; l >= 0; --l) {
+        const float* X = l == 0 ? t->x0 : (drop ? t->xdrop[l - 1] : t->out[l - 1]);
+        const int in = l == 0 ? F0 : H2;
+        for (int d = 0; d < 2; ++d) {
+            HIPCHK(hipMemsetAsync(t->carry, 0, sizeof(float) * (size_t)M * H, st));
+            for (int s = T - 1; s >= 0; --s) {
+                const int tt = d == 0 ? s : T - 1 - s;
+                const float* hprev;
+                int ld;
+                if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
+                else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
+                const size_t so = (size_t)tt * M * H;
+                gru_gate_bwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(dO + (size_t)tt * M * H2 + d * H, t->carry, t->sav[l][d][0] + so,
+                                                                           t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, hprev, ld,
+                                                                           t->dgi + (size_t)tt * M * G, t->dgh + (size_t)tt * M * G, M);
+                if (s > 0)
+                    BLASCHK(rm_gemm(t->blas, false, false, M, H, G, 1.f, t->dgh + (size_t)tt * M * G, G, P + kOff.w_hh[l][d], H, 1.f, t->carry, H));
+            }
+            // weight gradients over all steps at once
+            float* dWhh = Gd + kOff.w_hh[l][d];
+            if (d == 0) {
+                BLASCHK(rm_gemm(t->blas, true, false, G, H, (T - 1) * M, 1.f, t->dgh + (size_t)M * G, G, t->out[l], H2, 0.f, dWhh, H));
+                BLASCHK(rm_gemm(t->blas, true, false, G, H, M, 1.f, t->dgh, G, t->h0 + (size_t)(2 * l) * M * H, H, 1.f, dWhh, H));
+            } else {
+                BLASCHK(rm_gemm(t->blas, true, false, G, H, (T - 1) * M, 1.f, t->dgh, G, t->out[l] + (size_t)M * H2 + H, H2, 0.f, dWhh, H));
+                BLASCHK(rm_gemm(t->blas, true, false, G, H, M, 1.f, t->dgh + (size_t)(T - 1) * M * G, G, t->h0 + (size_t)(2 * l + 1) * M * H, H, 1.f, dWhh, H));
+            }
+            BLASCHK(rm_gemm(t->blas, true, false, G, in, T * M, 1.f, t->dgi, G, X, in, 0.f, Gd + kOff.w_ih[l][d], in));
+            const float one = 1.f, zero = 0.f;
+            BLASCHK(rocblas_sgemv(t->blas, rocblas_operation_none, G, T * M, &one, t->dgi, G, t->ones, 1, &zero, Gd + kOff.b_ih[l][d], 1));
+            BLASCHK(rocblas_sgemv(t->blas, rocblas_operation_none, G, T * M, &one, t->dgh, G, t->ones, 1, &zero, Gd + kOff.b_hh[l][d], 1));
+            BLASCHK(rm_gemm(t->blas, false, false, T * M, in, G, 1.f, t->dgi, G, P + kOff.w_ih[l][d], in, d == 0 ? 0.f : 1.f, dX, in));
+        }
+        if (l == 0) {
+            embed_bwd_kernel<<<blocks((int64_t)T * M), 256, 0, st>>>(dX, t->kmer, Gd + kOff.embed, M);
+        } else {
+            if (drop) dropout_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(dX, dX, (int64_t)T * M * H2, rate, seed, 0xd0 + (l - 1));
+            float* tmp = dO; dO = dX; dX = tmp;
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return CCSM_OK;
+}
+
+template <typename Tp>
+ccsm_status dalloc(Tp** p, size_t n) {
+    HIPCHK(hipMalloc((void**)p, n * sizeof(Tp)));
+    return CCSM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ccsm_train_last_error(void) { return g_err.c_str(); }
+int64_t ccsm_train_num_params(void) { return kOff.total; }
+int ccsm_train_param_offsets(int64_t* offsets, int n) {
+    if (!offsets || n < 31) return 1;
+    for (int i = 0; i < 31; ++i) offsets[i] = kOff.list[i];
+    return 0;
+}
+
+ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, float* d_grads, ccsm_trainer** out) {
+    if (!w || !out || max_sites <= 0) return fail(CCSM_ERR_INVALID_ARG, "weights, out must be non-NULL and max_sites > 0");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    ccsm_trainer* t = new ccsm_trainer();
+    t->device = device;
+    t->max_sites = max_sites;
+    const size_t M = 2 * (size_t)max_sites;
+#define TRY(x) do { ccsm_status s__ = (x); if (s__ != CCSM_OK) { ccsm_train_destroy(t); return s__; } } while (0)
+    HIPCHK(hipStreamCreate(&t->stream));
+    if (rocblas_create_handle(&t->blas) != rocblas_status_success) { ccsm_train_destroy(t); return fail(CCSM_ERR_HIP, "rocblas_create_handle failed"); }
+    rocblas_set_stream(t->blas, t->stream);
+    rocblas_set_pointer_mode(t->blas, rocblas_pointer_mode_host);
+    TRY(dalloc(&t->params, kOff.total));
+    TRY(dalloc(&t->adam_m, kOff.total));
+    TRY(dalloc(&t->adam_v, kOff.total));
+    if (d_grads) t->grads = d_grads; else { TRY(dalloc(&t->grads, kOff.total)); t->own_grads = true; }
+    HIPCHK(hipMemset(t->adam_m, 0, sizeof(float) * kOff.total));
+    HIPCHK(hipMemset(t->adam_v, 0, sizeof(float) * kOff.total));
+    TRY(dalloc(&t->kmer, M * T));
+    TRY(dalloc(&t->ipd, M * T)); TRY(dalloc(&t->pw, M * T)); TRY(dalloc(&t->npass, M * T));
+    TRY(dalloc(&t->labels, (size_t)max_sites));
+    TRY(dalloc(&t->h0, 2 * L * M * H));
+    TRY(dalloc(&t->x0, T * M * F0));
+    for (int l = 0; l < L; ++l) {
+        TRY(dalloc(&t->out[l], T * M * H2));
+        if (l + 1 < L) TRY(dalloc(&t->xdrop[l], T * M * H2));
+        for (int d = 0; d < 2; ++d)
+            for (int k = 0; k < 4; ++k) { t->sav[l][d][k] = nullptr; TRY(dalloc(&t->sav[l][d][k], T * M * H)); }
+    }
+    TRY(dalloc(&t->gi, T * M * G)); TRY(dalloc(&t->gh, M * G)); TRY(dalloc(&t->dgi, T * M * G)); TRY(dalloc(&t->dgh, T * M * G));
+    TRY(dalloc(&t->carry, M * H)); TRY(dalloc(&t->ones, T * M));
+    TRY(dalloc(&t->hn, M * H2)); TRY(dalloc(&t->q, M * H)); TRY(dalloc(&t->KS, T * M * H)); TRY(dalloc(&t->e, T * M)); TRY(dalloc(&t->a, T * M));
+    TRY(dalloc(&t->c, M * H2)); TRY(dalloc(&t->feat, (size_t)max_sites * 2 * H2)); TRY(dalloc(&t->logits, (size_t)max_sites * NC));
+    TRY(dalloc(&t->dlogits, (size_t)max_sites * NC)); TRY(dalloc(&t->loss, 1));
+    TRY(dalloc(&t->dc, M * H2)); TRY(dalloc(&t->dq, M * H)); TRY(dalloc(&t->dhn, M * H2)); TRY(dalloc(&t->dA, T * M * H2)); TRY(dalloc(&t->dB, T * M * H2));
+    fill_kernel<<<blocks((int64_t)T * M), 256, 0, t->stream>>>(t->ones, (int64_t)T * M, 1.0f);
+    // parameters: host tensors -> flat order
+    std::vector<float> flat((size_t)kOff.total);
+    auto put = [&](int64_t off, const float* src, int64_t n) { if (src) std::memcpy(flat.data() + off, src, sizeof(float) * (size_t)n); };
+    bool ok = w->embed_weight && w->att_wa && w->att_ua && w->att_va && w->fc1_weight && w->fc1_bias;
+    for (int l = 0; l < L; ++l)
+        for (int d = 0; d < 2; ++d) ok = ok && w->weight_ih[l][d] && w->weight_hh[l][d] && w->bias_ih[l][d] && w->bias_hh[l][d];
+    if (!ok) { ccsm_train_destroy(t); return fail(CCSM_ERR_INVALID_ARG, "every weight tensor must be non-NULL"); }
+    put(kOff.embed, w->embed_weight, NV * NE);
+    for (int l = 0; l < L; ++l)
+        for (int d = 0; d < 2; ++d) {
+            put(kOff.w_ih[l][d], w->weight_ih[l][d], (int64_t)G * (l == 0 ? F0 : H2));
+            put(kOff.w_hh[l][d], w->weight_hh[l][d], (int64_t)G * H);
+            put(kOff.b_ih[l][d], w->bias_ih[l][d], G);
+            put(kOff.b_hh[l][d], w->bias_hh[l][d], G);
+        }
+    put(kOff.wa, w->att_wa, (int64_t)H * H2);
+    put(kOff.ua, w->att_ua, (int64_t)H * H2);
+    put(kOff.va, w->att_va, H);
+    put(kOff.fcw, w->fc1_weight, (int64_t)NC * 2 * H2);
+    put(kOff.fcb, w->fc1_bias, NC);
+    HIPCHK(hipMemcpy(t->params, flat.data(), sizeof(float) * kOff.total, hipMemcpyHostToDevice));
+    HIPCHK(hipStreamSynchronize(t->stream));
+#undef TRY
+    *out = t;
+    return CCSM_OK;
+}
+
+void ccsm_train_destroy(ccsm_trainer* t) {
+    if (!t) return;
+    hipSetDevice(t->device);
+    float* fl[] = {t->params, t->adam_m, t->adam_v, t->own_grads ? t->grads : nullptr, t->ipd, t->pw, t->npass, t->h0, t->x0, t->gi, t->gh, t->dgi,
+                   t->dgh, t->carry, t->ones, t->hn, t->q, t->KS, t->e, t->a, t->c, t->feat, t->logits, t->dlogits, t->loss, t->dc, t->dq, t->dhn, t->dA, t->dB};
+    for (float* p : fl) if (p) hipFree(p);
+    if (t->kmer) hipFree(t->kmer);
+    if (t->labels) hipFree(t->labels);
+    for (int l = 0; l < L; ++l) {
+        if (t->out[l]) hipFree(t->out[l]);
+        if (t->xdrop[l]) hipFree(t->xdrop[l]);
+        for (int d = 0; d < 2; ++d)
+            for (int k = 0; k < 4; ++k) if (t->sav[l][d][k]) hipFree(t->sav[l][d][k]);
+    }
+    if (t->blas) rocblas_destroy_handle(t->blas);
+    if (t->stream) hipStreamDestroy(t->stream);
+    delete t;
+}
+
+static ccsm_status run(ccsm_trainer* t, int n_sites, const ccsm_batch* batch, const int32_t* labels, const ccsm_h0* h0, float pos_weight,
+                       bool train, float rate, uint64_t seed, float* loss, float* logits) {
+    if (!t || !batch) return fail(CCSM_ERR_INVALID_ARG, "trainer and batch must be non-NULL");
+    if (n_sites <= 0) return fail(CCSM_ERR_INVALID_ARG, "n_sites must be > 0");
+    if (n_sites > t->max_sites) return fail(CCSM_ERR_CAPACITY, "n_sites exceeds max_sites");
+    if (train && !labels) return fail(CCSM_ERR_INVALID_ARG, "training needs labels");
+    if (!(rate >= 0.f && rate < 1.f)) return fail(CCSM_ERR_INVALID_ARG, "dropout_rate must be in [0, 1)");
+    HIPCHK(hipSetDevice(t->device));
+    ccsm_status s = upload_batch(t, n_sites, batch, labels, h0);
+    if (s != CCSM_OK) return s;
+    double wsum = 0.0;
+    if (labels) for (int i = 0; i < n_sites; ++i) wsum += labels[i] != 0 ? (double)pos_weight : 1.0;
+    s = forward(t, n_sites, train, rate, seed, labels != nullptr, pos_weight, (float)wsum);
+    if (s != CCSM_OK) return s;
+    if (train) {
+        s = backward(t, n_sites, rate, seed);
+        if (s != CCSM_OK) return s;
+    }
+    float lsum = 0.f;
+    HIPCHK(hipMemcpyAsync(&lsum, t->loss, sizeof(float), hipMemcpyDeviceToHost, t->stream));
+    if (logits) HIPCHK(hipMemcpyAsync(logits, t->logits, sizeof(float) * (size_t)n_sites * NC, hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (loss) *loss = labels ? (float)(lsum / wsum) : 0.f;
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_train_forward_backward(ccsm_trainer* t, int n_sites, const ccsm_batch* batch, const int32_t* labels, const ccsm_h0* h0,
+                                        float pos_weight, float dropout_rate, uint64_t dropout_seed, float* loss, float* logits) {
+    return run(t, n_sites, batch, labels, h0, pos_weight, true, dropout_rate, dropout_seed, loss, logits);
+}
+
+ccsm_status ccsm_train_eval(ccsm_trainer* t, int n_sites, const ccsm_batch* batch, const int32_t* labels, const ccsm_h0* h0, float pos_weight,
+                            float* loss, float* logits) {
+    return run(t, n_sites, batch, labels, h0, pos_weight, false, 0.f, 0, loss, logits);
+}
+
+ccsm_status ccsm_train_step(ccsm_trainer* t, float lr, float beta1, float beta2, float eps, float max_norm, float* grad_norm) {
+    if (!t) return fail(CCSM_ERR_INVALID_ARG, "trainer must be non-NULL");
+    HIPCHK(hipSetDevice(t->device));
+    float norm = 0.f;
+    BLASCHK(rocblas_snrm2(t->blas, (int)kOff.total, t->grads, 1, &norm));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    if (grad_norm) *grad_norm = norm;
+    float clip = 1.f;
+    if (max_norm > 0.f) {                                   // clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+        clip = max_norm / (norm + 1e-6f);
+        if (clip > 1.f) clip = 1.f;
+    }
+    t->step += 1;
+    const float bc1 = 1.0f - std::pow(beta1, (float)t->step), bc2 = 1.0f - std::pow(beta2, (float)t->step);
+    adam_kernel<<<blocks(kOff.total), 256, 0, t->stream>>>(t->params, t->grads, t->adam_m, t->adam_v, kOff.total, lr, beta1, beta2, eps, clip, bc1, bc2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(t->stream));
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_train_grad_ptr(ccsm_trainer* t, float** d_grads) {
+    if (!t || !d_grads) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");
+    *d_grads = t->grads;
+    return CCSM_OK;
+}
+ccsm_status ccsm_train_get_params(ccsm_trainer* t, float* host_flat) {
+    if (!t || !host_flat) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    HIPCHK(hipMemcpy(host_flat, t->params, sizeof(float) * kOff.total, hipMemcpyDeviceToHost));
+    return CCSM_OK;
+}
+ccsm_status ccsm_train_set_params(ccsm_trainer* t, const float* host_flat) {
+    if (!t || !host_flat) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    HIPCHK(hipMemcpy(t->params, host_flat, sizeof(float) * kOff.total, hipMemcpyHostToDevice));
+    return CCSM_OK;
+}
+ccsm_status ccsm_train_get_grads(ccsm_trainer* t, float* host_flat) {
+    if (!t || !host_flat) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");
+    HIPCHK(hipSetDevice(t->device));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    HIPCHK(hipMemcpy(host_flat, t->grads, sizeof(float) * kOff.total, hipMemcpyDeviceToHost));
+    return CCSM_OK;
+}
+
+}  // extern "C"

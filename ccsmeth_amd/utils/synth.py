@@ -103,3 +103,14 @@ def synth_pileup(n_sites, seed, cov_lo=2, cov_hi=60):
     cov = rng.integers(cov_lo, cov_hi + 1, size=n_sites)
     ml = [np.minimum(np.floor(rng.beta(0.3, 0.3, size=c) * 256), 255).astype(np.uint8) for c in cov]
     return dict(pos=pos, ml=ml)
+
+
+def sample_index(name, size, k=1024):
+    """Seeded sample of k flat indices of a tensor called `name` (all of them when size <= k): which entries of the big
+    gradient / parameter tensors the training fixtures store (tests/golden/make_train_golden.py)."""
+    if size <= k:
+        return np.arange(size)
+    h = 0
+    for ch in name:
+        h = (h * 131 + ord(ch)) % 1000000007
+    return np.sort(np.random.default_rng(h).choice(size, k, replace=False))

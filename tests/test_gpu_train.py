@@ -1,0 +1,126 @@
+"""Training step (libccsm_train) on the GPU against the reference model under torch autograd
+(tests/golden/make_train_golden.py): loss, logits, every parameter's gradient, and the parameters after three
+clip_grad_norm_(0.5) + Adam steps.  fp32 on both sides: the tolerances are those of a different summation order."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from ccsmeth_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(GOLDEN, "train_golden.npz"))
+META = json.load(open(os.path.join(GOLDEN, "train_golden.json")))
+
+
+def _inputs(case, k):
+    n = case["n"]
+    sites = synth.synth_sites(n, case["site_seed"] + 1000 * k)
+    h1, h2 = synth.synth_h0(n, case["h0_seed"] + 1000 * k)
+    labels = np.random.default_rng(case["label_seed"] + 1000 * k).integers(0, 2, n).astype(np.int64)
+    return sites, (h1, h2), labels
+
+
+@pytest.mark.parametrize("name", sorted(META))
+def test_gradients_and_adam_steps_match_reference_autograd(name):
+    from ccsmeth_amd.train import Trainer, PARAM_NAMES
+    case = META[name]
+    assert case["param_names"] == PARAM_NAMES                       # flat order = model.parameters() order of the reference
+    tr = Trainer(synth.synth_weights(case["weight_seed"]), device=0, max_sites=case["n"])
+    assert tr.num_params == 3043114
+    losses, norms = [], []
+    for k in range(case["steps"]):
+        sites, h0, labels = _inputs(case, k)
+        loss, logits = tr.forward_backward(sites, labels, h0=h0, pos_weight=case["pos_weight"], want_logits=True)
+        if k == 0:
+            assert np.abs(logits - G[name + "_logits"]).max() < 2e-5
+            grads = tr.grads()
+            for pn in PARAM_NAMES:
+                g = grads[pn].ravel()
+                ref_norm = float(G["%s_gnorm_%s" % (name, pn)])
+                assert abs(np.linalg.norm(g.astype(np.float64)) - ref_norm) <= 2e-4 * ref_norm + 1e-7, pn
+                ref = G["%s_g_%s" % (name, pn)]
+                got = g[synth.sample_index(pn, g.size, case["sample"])]
+                assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, (pn, np.abs(got - ref).max(), np.abs(ref).max())
+        losses.append(loss)
+        norms.append(tr.step(case["lr"], max_norm=0.5))
+    assert np.allclose(losses, case["losses"], rtol=2e-3, atol=2e-4), (losses, case["losses"])
+    assert np.allclose(norms, case["grad_norms"], rtol=5e-3), (norms, case["grad_norms"])
+    sd = tr.state_dict()
+    bad = tot = 0
+    for pn in PARAM_NAMES:
+        v = sd[pn].ravel()
+        got = v[synth.sample_index(pn, v.size, case["sample"])]
+        ref = G["%s_p_%s" % (name, pn)]
+        d = np.abs(got - ref)
+        # Adam's first steps move every entry by about lr * sign(g): an entry whose gradient is at the rounding noise
+        # can take the step the other way (2 * lr per step); everything else agrees to fp32 accuracy
+        assert d.max() <= 2.05 * case["lr"] * case["steps"], (pn, d.max())
+        bad += int((d > 2e-5).sum())
+        tot += d.size
+    assert bad <= 0.01 * tot, (bad, tot)
+    tr.close()
+
+
+def test_eval_matches_inference_library_and_errors():
+    """Forward-only path of the trainer vs libccsm (the product's inference kernels) on the same weights and h0."""
+    from ccsmeth_amd import _lib
+    from ccsmeth_amd.models import DeviceModel
+    from ccsmeth_amd.train import Trainer
+    w = synth.synth_weights(31)
+    n = 130
+    s = synth.synth_sites(n, 32)
+    h1, h2 = synth.synth_h0(n, 33)
+    labels = np.random.default_rng(34).integers(0, 2, n)
+    tr = Trainer(w, device=0, max_sites=160)
+    loss, logits = tr.evaluate(s, labels, h0=(h1, h2), pos_weight=1.7)
+    dm = DeviceModel(w, device=0)
+    ws = dm.workspace(n)
+    ref_logits, probs = ws.forward_host(s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h0=(h1, h2))
+    assert np.abs(logits - ref_logits).max() < 1e-4
+    wts = np.where(labels == 1, 1.7, 1.0)
+    ref_loss = float((wts * -np.log(probs[np.arange(n), labels])).sum() / wts.sum())
+    assert abs(loss - ref_loss) < 1e-4
+    dm.close()
+    with pytest.raises(_lib.CcsmError) as e:
+        tr.forward_backward(synth.synth_sites(161, 1), np.zeros(161, np.int64), h0="zero")
+    assert e.value.status == _lib.ERR_CAPACITY
+    with pytest.raises(_lib.CcsmError):
+        tr.forward_backward(s, labels, h0=(h1, h2), dropout_rate=1.0)
+    with pytest.raises(ValueError):
+        tr.forward_backward(s, labels[:-1], h0=(h1, h2))
+    tr.close()
+
+
+def test_dropout_and_device_rng_h0_train_and_reduce_loss():
+    """With dropout 0.5 and device-drawn h0 the model learns a synthetic labelling (label = sign of the centre IPDs) in a
+    few hundred steps; the same seed reproduces the same masks and h0; dropout 0 differs from dropout 0.5."""
+    from ccsmeth_amd.train import Trainer
+    w = synth.synth_weights(41)
+    n = 512
+    pool = synth.synth_sites(n * 8, 42)
+    val = synth.synth_sites(n, 43)
+    lab = lambda s: (s["ipd1"][:, 10] + s["ipd2"][:, 10] > 0).astype(np.int64)  # noqa: E731
+
+    def run(rate, seed, steps):
+        tr = Trainer(w, device=0, max_sites=n)
+        out = []
+        for k in range(steps):
+            i = (k % 8) * n
+            s = {key: v[i:i + n] for key, v in pool.items()}
+            loss, _ = tr.forward_backward(s, lab(s), h0=None, dropout_rate=rate, seed=seed, step=k)
+            tr.step(1e-3)
+            out.append(loss)
+        ev, logits = tr.evaluate(val, lab(val), h0=None, seed=seed, step=10 ** 6)
+        acc = float((logits.argmax(1) == lab(val)).mean())
+        tr.close()
+        return out, ev, acc
+    a, eva, acca = run(0.5, 7, 320)
+    b, _, _ = run(0.5, 7, 4)
+    c, _, _ = run(0.0, 7, 4)
+    assert np.allclose(a[:4], b, rtol=1e-4)            # same masks and h0 (the float atomics of the reductions are not ordered)
+    assert not np.allclose(a[1:4], c[1:4], rtol=1e-3)
+    assert np.mean(a[-10:]) < 0.45 and eva < 0.45 and acca > 0.85, (a[:3], a[-10:], eva, acca)
