@@ -1,4 +1,4 @@
-"""Fixture: flags and defaults of the reference's `ccsmeth call_mods` sub-parser (ccsmeth/ccsmeth.py:196-326), captured by
+"""Fixture: flags and defaults of the reference's `ccsmeth call_mods`, `call_freqb` and `trainm` sub-parsers (ccsmeth/ccsmeth.py), captured by
 running the reference's own main() argument parser in THIS container (reference importable here only).
 Writes tests/golden/cli_golden.json.  usage: python tests/golden/make_cli_golden.py"""
 import argparse
@@ -30,13 +30,21 @@ try:
 finally:
     argparse.ArgumentParser.parse_args = orig
 top = captured["parser"]
-sub = next(a for a in top._actions if isinstance(a, argparse._SubParsersAction)).choices["call_mods"]
-flags = {}
-for a in sub._actions:
-    if a.dest == "help":
-        continue
-    flags[a.dest] = dict(options=list(a.option_strings), default=a.default, required=bool(a.required),
-                         kind=type(a).__name__, type=getattr(a.type, "__name__", None))
+choices = next(a for a in top._actions if isinstance(a, argparse._SubParsersAction)).choices
+
+
+def flags_of(sub):
+    flags = {}
+    for a in sub._actions:
+        if a.dest == "help":
+            continue
+        flags[a.dest] = dict(options=list(a.option_strings), default=a.default, required=bool(a.required),
+                             kind=type(a).__name__, type=getattr(a.type, "__name__", None))
+    return flags
+
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cli_golden.json")
-json.dump(dict(source="ccsmeth/ccsmeth.py call_mods sub-parser", flags=flags), open(out, "w"), indent=1, sort_keys=True)
-print("wrote", out, len(flags), "flags")
+doc = dict(source="ccsmeth/ccsmeth.py sub-parsers", flags=flags_of(choices["call_mods"]), call_freqb=flags_of(choices["call_freqb"]),
+           trainm=flags_of(choices["trainm"]))
+json.dump(doc, open(out, "w"), indent=1, sort_keys=True)
+print("wrote", out, {k: len(v) for k, v in doc.items() if k != "source"})

@@ -88,6 +88,12 @@ def main():
             out["%s_p_%s" % (name, pn)] = v[synth.sample_index(pn, v.size, SAMPLE)]
         meta[name] = dict(case, losses=losses, grad_norms=norms, steps=STEPS, lr=LR, sample=SAMPLE, param_names=names)
         print(name, losses, norms)
+    # the initial parameters the reference draws after torch.manual_seed(tseed) (train_multigpu.py:470 + ModelAttRNN.__init__)
+    torch.manual_seed(1234)
+    m0 = ref_models.ModelAttRNN(21, 3, 2, 0.5, 256, is_npass=True, is_sn=False, is_map=False, is_stds=False,
+                                model_type="attbigru2s", device=0)
+    meta["init_tseed_1234"] = {k: dict(sum=float(v.detach().double().sum()), head=v.detach().numpy().ravel()[:4].astype(float).tolist())
+                               for k, v in m0.named_parameters()}
     np.savez_compressed(os.path.join(HERE, "train_golden.npz"), **out)
     json.dump(meta, open(os.path.join(HERE, "train_golden.json"), "w"), indent=1, sort_keys=True)
     print(os.path.getsize(os.path.join(HERE, "train_golden.npz")))

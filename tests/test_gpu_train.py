@@ -124,3 +124,69 @@ def test_dropout_and_device_rng_h0_train_and_reduce_loss():
     assert np.allclose(a[:4], b, rtol=1e-4)            # same masks and h0 (the float atomics of the reductions are not ordered)
     assert not np.allclose(a[1:4], c[1:4], rtol=1e-3)
     assert np.mean(a[-10:]) < 0.45 and eva < 0.45 and acca > 0.85, (a[:3], a[-10:], eva, acca)
+
+
+def _write_features(path, sites, labels):
+    code2base = "ACGTN"
+    with open(path, "w") as wf:
+        for i in range(len(labels)):
+            c = lambda a: ",".join(repr(float(x)) for x in a)  # noqa: E731
+            wf.write("\t".join([".", "-1", ".", "m/%d/ccs" % i, "100",
+                                "".join(code2base[b] for b in sites["kmer1"][i]), str(int(sites["npass1"][i])), c(sites["ipd1"][i]), ".",
+                                c(sites["pw1"][i]), ".", ".", ".",
+                                "".join(code2base[b] for b in sites["kmer2"][i]), str(int(sites["npass2"][i])), c(sites["ipd2"][i]), ".",
+                                c(sites["pw2"][i]), ".", ".", ".", str(int(labels[i]))]) + "\n")
+
+
+def _make_tables(tmp_path, n_train=4096, n_valid=1024):
+    lab = lambda s: (s["ipd1"][:, 10] + s["ipd2"][:, 10] > 0).astype(np.int64)  # noqa: E731
+    tr, va = synth.synth_sites(n_train, 61), synth.synth_sites(n_valid, 62)
+    _write_features(str(tmp_path / "train.tsv"), tr, lab(tr))
+    _write_features(str(tmp_path / "valid.tsv"), va, lab(va))
+    return va, lab(va)
+
+
+def test_trainm_end_to_end_checkpoint_serves_inference(tmp_path):
+    """`trainm` from feature tables to checkpoints: epochs run, rank 0 writes <model_type>.b21_epoch<k>.ckpt with the reference's
+    state_dict keys, and the best checkpoint loads into the inference library (libccsm) and classifies the validation set."""
+    import torch
+    from ccsmeth_amd import trainm
+    from ccsmeth_amd.models import DeviceModel
+    va, vlab = _make_tables(tmp_path)
+    (tmp_path / "models").mkdir()
+    (tmp_path / "models" / "attbigru2s.b21_epoch9.ckpt").write_text("stale")          # removed at start like the reference does
+    args = trainm.build_parser().parse_args(["--train_file", str(tmp_path / "train.tsv"), "--valid_file", str(tmp_path / "valid.tsv"),
+                                             "--model_dir", str(tmp_path / "models"), "--max_epoch_num", "6", "--min_epoch_num", "6",
+                                             "--lr_decay", "0.7", "--batch_size", "256", "--step_interval", "8"])
+    res = trainm.train(args, log=open(os.devnull, "w"))
+    assert res["epochs"] == 6 and res["steps"] == 6 * 16 and res["best_acc"] > 0.8, res
+    files = sorted(os.listdir(tmp_path / "models"))
+    assert "attbigru2s.b21_epoch9.ckpt" not in files and "attbigru2s.b21_epoch%d.ckpt" % res["best_epoch"] in files
+    sd = torch.load(str(tmp_path / "models" / ("attbigru2s.b21_epoch%d.ckpt" % res["best_epoch"])), map_location="cpu")
+    from ccsmeth_amd.train import PARAM_NAMES
+    assert list(sd.keys()) == PARAM_NAMES
+    dm = DeviceModel({k: v.numpy() for k, v in sd.items()}, device=0)
+    ws = dm.workspace(len(vlab))
+    _, probs = ws.forward_host(va["kmer1"], va["ipd1"], va["pw1"], va["npass1"], va["kmer2"], va["ipd2"], va["pw2"], va["npass2"])
+    assert float((probs.argmax(1) == vlab).mean()) > 0.8
+    dm.close()
+
+
+def test_trainm_two_ranks_stay_in_sync(tmp_path):
+    """Two ranks (sharing the one GPU of the test box, gradients averaged over gloo): both replicas end with the same
+    parameters, each ran half of every epoch's steps, and the model learns."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    _make_tables(tmp_path, 2048, 512)
+    env = dict(os.environ, CCSM_DIST_BACKEND="gloo", CCSM_TRAINM_REPORT=str(tmp_path / "report"), PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29100 + os.getpid() % 1000), "-m", "ccsmeth_amd", "trainm", "--train_file", str(tmp_path / "train.tsv"),
+           "--valid_file", str(tmp_path / "valid.tsv"), "--model_dir", str(tmp_path / "m2"), "--max_epoch_num", "5", "--min_epoch_num", "5",
+           "--lr_decay", "0.8", "--batch_size", "128"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+    r0, r1 = (json.load(open(str(tmp_path / "report") + ".rank%d.json" % r)) for r in (0, 1))
+    assert r0["world"] == r1["world"] == 2 and r0["steps"] == r1["steps"] == 5 * 8
+    assert abs(r0["param_checksum"] - r1["param_checksum"]) <= 1e-7 * r0["param_checksum"]
+    assert r0["best_acc"] > 0.75, (r0, out.stdout.decode()[-2000:])
