@@ -311,9 +311,22 @@ __global__ void embed_bwd_kernel(const float* dx0, const uint8_t* kmer, float* d
     __syncthreads();
     if (threadIdx.x < NV * NE) atomicAdd(dembed + threadIdx.x, part[threadIdx.x]);
 }
-__global__ void fill_kernel(float* p, int64_t n, float v) {
+// out[c] += sum over rows of a[r][c]  (bias gradients: column sums of the (T*M, 768) gate-gradient blocks); out pre-zeroed
+__global__ void colsum_kernel(const float* a, float* out, int rows, int cols) {
+    const int r0 = blockIdx.x * 128, r1 = min(rows, r0 + 128);
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; ++r) acc += a[(size_t)r * cols + c];
+        atomicAdd(out + c, acc);
+    }
+}
+// out[i] = sum_k part[k][i]   (the per-timestep partial products of a weight gradient)
+__global__ void sum_partials_kernel(const float* part, float* out, int parts, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int k = 0; k < parts; ++k) acc += part[(size_t)k * n + i];
+    out[i] = acc;
 }
 // torch.optim.Adam (no amsgrad, no weight decay): m, v moments, bias correction by step; g pre-scaled by `clip`
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float clip,
@@ -348,10 +361,11 @@ struct ccsm_trainer {
     float* out[L] = {nullptr, nullptr, nullptr};
     float* xdrop[L] = {nullptr, nullptr, nullptr};     // dropout(out[l]) = input of layer l + 1 (rate > 0 only)
     float* sav[L][2][4];
-    float *gi = nullptr, *gh = nullptr, *dgi = nullptr, *dgh = nullptr, *carry = nullptr, *ones = nullptr;
+    float *gi = nullptr, *gh = nullptr, *dgi = nullptr, *dgh = nullptr, *carry = nullptr;
     float *hn = nullptr, *q = nullptr, *KS = nullptr, *e = nullptr, *a = nullptr, *c = nullptr, *feat = nullptr, *logits = nullptr,
           *dlogits = nullptr, *loss = nullptr;
     float *dc = nullptr, *dq = nullptr, *dhn = nullptr, *dA = nullptr, *dB = nullptr;   // dA / dB: (T, M, 512) gradient ping-pong
+    float* part = nullptr;                             // (T, 768, 512) per-timestep partial weight gradients
     std::vector<uint8_t> h_kmer;
     std::vector<float> h_f;
 };
@@ -363,6 +377,20 @@ rocblas_status rm_gemm(rocblas_handle h, bool tA, bool tB, int M, int N, int K, 
                        int ldb, float beta, float* C, int ldc) {
     return rocblas_sgemm(h, tB ? rocblas_operation_transpose : rocblas_operation_none, tA ? rocblas_operation_transpose : rocblas_operation_none,
                          N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
+}
+
+// C (m x n) = sum over `parts` row blocks of A_blk^T B_blk, A_blk = rows_per_part x m (lda), B_blk = rows_per_part x n (ldb): one
+// batched product per block into `scratch` (parts x m x n) and a reduction, so that a weight gradient with a 21504-long inner
+// dimension fills the chip instead of 24 workgroups.  `extra` slots of scratch beyond `parts` are summed too (filled by the caller).
+rocblas_status atb_split(rocblas_handle h, hipStream_t st, int m, int n, int rows_per_part, int parts, const float* A, int lda, const float* B,
+                         int ldb, float* scratch, int extra, float* C) {
+    const float one = 1.f, zero = 0.f;
+    rocblas_status s = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, n, m, rows_per_part, &one, B, ldb,
+                                                     (rocblas_stride)rows_per_part * ldb, A, lda, (rocblas_stride)rows_per_part * lda, &zero, scratch, n,
+                                                     (rocblas_stride)m * n, parts);
+    if (s != rocblas_status_success) return s;
+    sum_partials_kernel<<<blocks((int64_t)m * n), 256, 0, st>>>(scratch, C, parts + extra, (int64_t)m * n);
+    return rocblas_status_success;
 }
 
 ccsm_status upload_batch(ccsm_trainer* t, int N, const ccsm_batch* batch, const int32_t* labels, const ccsm_h0* h0) {
@@ -467,7 +495,7 @@ ccsm_status backward(ccsm_trainer* t, int N, float rate, uint64_t seed) {
     att_dout_init_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(t->a, t->dc, dO, M);
     att_dpre_kernel<<<blocks((int64_t)T * M, 64), H, 0, st>>>(t->KS, t->e, P + kOff.va, Gd + kOff.va, T * M);   // KS <- dSpre
     att_dq_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(t->KS, t->dq, M);
-    BLASCHK(rm_gemm(t->blas, true, false, H, H2, T * M, 1.f, t->KS, H, O2, H2, 0.f, Gd + kOff.ua, H2));
+    BLASCHK(atb_split(t->blas, st, H, H2, M, T, t->KS, H, O2, H2, t->part, 0, Gd + kOff.ua));
     BLASCHK(rm_gemm(t->blas, false, false, T * M, H2, H, 1.f, t->KS, H, P + kOff.ua, H2, 1.f, dO, H2));
     BLASCHK(rm_gemm(t->blas, true, false, H, H2, M, 1.f, t->dq, H, t->hn, H2, 0.f, Gd + kOff.wa, H2));
     BLASCHK(rm_gemm(t->blas, false, false, M, H2, H, 1.f, t->dq, H, P + kOff.wa, H2, 0.f, t->dhn, H2));
@@ -494,17 +522,17 @@ ccsm_status backward(ccsm_trainer* t, int N, float rate, uint64_t seed) {
             }
             // weight gradients over all steps at once
             float* dWhh = Gd + kOff.w_hh[l][d];
+            float* last = t->part + (size_t)(T - 1) * G * H;      // the h0 step's product goes to the last slot
             if (d == 0) {
-                BLASCHK(rm_gemm(t->blas, true, false, G, H, (T - 1) * M, 1.f, t->dgh + (size_t)M * G, G, t->out[l], H2, 0.f, dWhh, H));
-                BLASCHK(rm_gemm(t->blas, true, false, G, H, M, 1.f, t->dgh, G, t->h0 + (size_t)(2 * l) * M * H, H, 1.f, dWhh, H));
+                BLASCHK(rm_gemm(t->blas, true, false, G, H, M, 1.f, t->dgh, G, t->h0 + (size_t)(2 * l) * M * H, H, 0.f, last, H));
+                BLASCHK(atb_split(t->blas, st, G, H, M, T - 1, t->dgh + (size_t)M * G, G, t->out[l], H2, t->part, 1, dWhh));
             } else {
-                BLASCHK(rm_gemm(t->blas, true, false, G, H, (T - 1) * M, 1.f, t->dgh, G, t->out[l] + (size_t)M * H2 + H, H2, 0.f, dWhh, H));
-                BLASCHK(rm_gemm(t->blas, true, false, G, H, M, 1.f, t->dgh + (size_t)(T - 1) * M * G, G, t->h0 + (size_t)(2 * l + 1) * M * H, H, 1.f, dWhh, H));
+                BLASCHK(rm_gemm(t->blas, true, false, G, H, M, 1.f, t->dgh + (size_t)(T - 1) * M * G, G, t->h0 + (size_t)(2 * l + 1) * M * H, H, 0.f, last, H));
+                BLASCHK(atb_split(t->blas, st, G, H, M, T - 1, t->dgh, G, t->out[l] + (size_t)M * H2 + H, H2, t->part, 1, dWhh));
             }
-            BLASCHK(rm_gemm(t->blas, true, false, G, in, T * M, 1.f, t->dgi, G, X, in, 0.f, Gd + kOff.w_ih[l][d], in));
-            const float one = 1.f, zero = 0.f;
-            BLASCHK(rocblas_sgemv(t->blas, rocblas_operation_none, G, T * M, &one, t->dgi, G, t->ones, 1, &zero, Gd + kOff.b_ih[l][d], 1));
-            BLASCHK(rocblas_sgemv(t->blas, rocblas_operation_none, G, T * M, &one, t->dgh, G, t->ones, 1, &zero, Gd + kOff.b_hh[l][d], 1));
+            BLASCHK(atb_split(t->blas, st, G, in, M, T, t->dgi, G, X, in, t->part, 0, Gd + kOff.w_ih[l][d]));
+            colsum_kernel<<<blocks((int64_t)T * M, 128), 256, 0, st>>>(t->dgi, Gd + kOff.b_ih[l][d], T * M, G);
+            colsum_kernel<<<blocks((int64_t)T * M, 128), 256, 0, st>>>(t->dgh, Gd + kOff.b_hh[l][d], T * M, G);
             BLASCHK(rm_gemm(t->blas, false, false, T * M, in, G, 1.f, t->dgi, G, P + kOff.w_ih[l][d], in, d == 0 ? 0.f : 1.f, dX, in));
         }
         if (l == 0) {
@@ -567,12 +595,12 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
             for (int k = 0; k < 4; ++k) { t->sav[l][d][k] = nullptr; TRY(dalloc(&t->sav[l][d][k], T * M * H)); }
     }
     TRY(dalloc(&t->gi, T * M * G)); TRY(dalloc(&t->gh, M * G)); TRY(dalloc(&t->dgi, T * M * G)); TRY(dalloc(&t->dgh, T * M * G));
-    TRY(dalloc(&t->carry, M * H)); TRY(dalloc(&t->ones, T * M));
+    TRY(dalloc(&t->carry, M * H));
     TRY(dalloc(&t->hn, M * H2)); TRY(dalloc(&t->q, M * H)); TRY(dalloc(&t->KS, T * M * H)); TRY(dalloc(&t->e, T * M)); TRY(dalloc(&t->a, T * M));
     TRY(dalloc(&t->c, M * H2)); TRY(dalloc(&t->feat, (size_t)max_sites * 2 * H2)); TRY(dalloc(&t->logits, (size_t)max_sites * NC));
     TRY(dalloc(&t->dlogits, (size_t)max_sites * NC)); TRY(dalloc(&t->loss, 1));
     TRY(dalloc(&t->dc, M * H2)); TRY(dalloc(&t->dq, M * H)); TRY(dalloc(&t->dhn, M * H2)); TRY(dalloc(&t->dA, T * M * H2)); TRY(dalloc(&t->dB, T * M * H2));
-    fill_kernel<<<blocks((int64_t)T * M), 256, 0, t->stream>>>(t->ones, (int64_t)T * M, 1.0f);
+    TRY(dalloc(&t->part, (size_t)T * G * H2));
     // parameters: host tensors -> flat order
     std::vector<float> flat((size_t)kOff.total);
     auto put = [&](int64_t off, const float* src, int64_t n) { if (src) std::memcpy(flat.data() + off, src, sizeof(float) * (size_t)n); };
@@ -602,20 +630,20 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
 
 void ccsm_train_destroy(ccsm_trainer* t) {
     if (!t) return;
-    hipSetDevice(t->device);
+    (void)hipSetDevice(t->device);
     float* fl[] = {t->params, t->adam_m, t->adam_v, t->own_grads ? t->grads : nullptr, t->ipd, t->pw, t->npass, t->h0, t->x0, t->gi, t->gh, t->dgi,
-                   t->dgh, t->carry, t->ones, t->hn, t->q, t->KS, t->e, t->a, t->c, t->feat, t->logits, t->dlogits, t->loss, t->dc, t->dq, t->dhn, t->dA, t->dB};
-    for (float* p : fl) if (p) hipFree(p);
-    if (t->kmer) hipFree(t->kmer);
-    if (t->labels) hipFree(t->labels);
+                   t->dgh, t->carry, t->hn, t->q, t->KS, t->e, t->a, t->c, t->feat, t->logits, t->dlogits, t->loss, t->dc, t->dq, t->dhn, t->dA, t->dB, t->part};
+    for (float* p : fl) if (p) (void)hipFree(p);
+    if (t->kmer) (void)hipFree(t->kmer);
+    if (t->labels) (void)hipFree(t->labels);
     for (int l = 0; l < L; ++l) {
-        if (t->out[l]) hipFree(t->out[l]);
-        if (t->xdrop[l]) hipFree(t->xdrop[l]);
+        if (t->out[l]) (void)hipFree(t->out[l]);
+        if (t->xdrop[l]) (void)hipFree(t->xdrop[l]);
         for (int d = 0; d < 2; ++d)
-            for (int k = 0; k < 4; ++k) if (t->sav[l][d][k]) hipFree(t->sav[l][d][k]);
+            for (int k = 0; k < 4; ++k) if (t->sav[l][d][k]) (void)hipFree(t->sav[l][d][k]);
     }
     if (t->blas) rocblas_destroy_handle(t->blas);
-    if (t->stream) hipStreamDestroy(t->stream);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
 }
 

@@ -86,3 +86,26 @@ def test_bam_header_symbols_exported():
     lib = ctypes.CDLL(bamnative.LIB_PATH)
     for name in declared:
         getattr(lib, name)
+
+
+def test_train_library_exports_match_header_and_reject_bad_arguments():
+    """libccsm_train (include/ccsm_train.h): loads without a GPU, exports every declared symbol, NULL arguments are errors."""
+    path = os.path.join(ROOT, "ccsmeth_amd", "lib", "libccsm_train.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["python", "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT)
+    header = open(os.path.join(ROOT, "include", "ccsm_train.h")).read()
+    declared = set(re.findall(r"\b(ccsm_train_[a-z0-9_]+)\s*\(", header))
+    from ccsmeth_amd import train
+    assert set(train.EXPORTS) == declared
+    lib = train.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ccsm_train_num_params() == 3043114
+    off = train.param_offsets()
+    assert off[0] == 0 and off[1] == 40 and off[-1] == 3043114 and len(off) == 31 and off == sorted(off)
+    sizes = [int(__import__("numpy").prod(train.PARAM_SHAPES[k])) for k in train.PARAM_NAMES]
+    assert [b - a for a, b in zip(off[:-1], off[1:])] == sizes
+    out = ctypes.c_void_p()
+    assert lib.ccsm_train_create(None, 0, 16, None, ctypes.byref(out)) == 1          # CCSM_ERR_INVALID_ARG
+    assert b"non-NULL" in lib.ccsm_train_last_error()
+    assert lib.ccsm_train_step(None, 1e-3, 0.9, 0.999, 1e-8, 0.5, None) == 1
