@@ -313,9 +313,10 @@ __global__ void embed_bwd_kernel(const float* dx0, const uint8_t* kmer, float* d
 }
 // out[c] += sum over rows of a[r][c]  (bias gradients: column sums of the (T*M, 768) gate-gradient blocks); out pre-zeroed
 __global__ void colsum_kernel(const float* a, float* out, int rows, int cols) {
-    const int r0 = blockIdx.x * 128, r1 = min(rows, r0 + 128);
+    const int r0 = blockIdx.x * 32, r1 = min(rows, r0 + 32);
     for (int c = threadIdx.x; c < cols; c += blockDim.x) {
         float acc = 0.f;
+#pragma unroll 8
         for (int r = r0; r < r1; ++r) acc += a[(size_t)r * cols + c];
         atomicAdd(out + c, acc);
     }
@@ -347,8 +348,9 @@ inline dim3 blocks(int64_t n, int per = 256) { return dim3((unsigned)((n + per -
 
 struct ccsm_trainer {
     int device = 0, max_sites = 0;
-    rocblas_handle blas = nullptr;
-    hipStream_t stream = nullptr;
+    rocblas_handle blas = nullptr, blas1 = nullptr;
+    hipStream_t stream = nullptr, stream1 = nullptr;       // stream1 / blas1: the backward direction of a layer
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
     bool own_grads = false;
     int64_t step = 0;
@@ -361,11 +363,12 @@ struct ccsm_trainer {
     float* out[L] = {nullptr, nullptr, nullptr};
     float* xdrop[L] = {nullptr, nullptr, nullptr};     // dropout(out[l]) = input of layer l + 1 (rate > 0 only)
     float* sav[L][2][4];
-    float *gi = nullptr, *gh = nullptr, *dgi = nullptr, *dgh = nullptr, *carry = nullptr;
+    float *gi[2] = {nullptr, nullptr}, *gh[2] = {nullptr, nullptr}, *dgi[2] = {nullptr, nullptr}, *dgh[2] = {nullptr, nullptr},
+          *carry[2] = {nullptr, nullptr};            // per direction
     float *hn = nullptr, *q = nullptr, *KS = nullptr, *e = nullptr, *a = nullptr, *c = nullptr, *feat = nullptr, *logits = nullptr,
           *dlogits = nullptr, *loss = nullptr;
     float *dc = nullptr, *dq = nullptr, *dhn = nullptr, *dA = nullptr, *dB = nullptr;   // dA / dB: (T, M, 512) gradient ping-pong
-    float* part = nullptr;                             // (T, 768, 512) per-timestep partial weight gradients
+    float* part[2] = {nullptr, nullptr};               // per direction: (T, 768, 512) per-timestep partial weight gradients
     std::vector<uint8_t> h_kmer;
     std::vector<float> h_f;
 };
@@ -436,6 +439,40 @@ ccsm_status upload_batch(ccsm_trainer* t, int N, const ccsm_batch* batch, const 
     return CCSM_OK;
 }
 
+// The two directions of a layer are independent: direction 0 runs on the trainer's stream, direction 1 on a second stream with
+// its own rocBLAS handle, joined by events at the layer boundaries (a 1024-row recurrent product alone leaves a quarter of the
+// CUs idle and is latency-bound).
+ccsm_status fork(ccsm_trainer* t) {
+    HIPCHK(hipEventRecord(t->ev_fork, t->stream));
+    HIPCHK(hipStreamWaitEvent(t->stream1, t->ev_fork, 0));
+    return CCSM_OK;
+}
+ccsm_status join(ccsm_trainer* t) {
+    HIPCHK(hipEventRecord(t->ev_join, t->stream1));
+    HIPCHK(hipStreamWaitEvent(t->stream, t->ev_join, 0));
+    return CCSM_OK;
+}
+
+ccsm_status forward_dir(ccsm_trainer* t, int M, int l, int d, const float* X, int in, bool train) {
+    const float* P = t->params;
+    rocblas_handle blas = d == 0 ? t->blas : t->blas1;
+    hipStream_t st = d == 0 ? t->stream : t->stream1;
+    BLASCHK(rm_gemm(blas, false, true, T * M, G, in, 1.f, X, in, P + kOff.w_ih[l][d], in, 0.f, t->gi[d], G));
+    for (int s = 0; s < T; ++s) {
+        const int tt = d == 0 ? s : T - 1 - s;
+        const float* hprev;
+        int ld;
+        if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
+        else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
+        BLASCHK(rm_gemm(blas, false, true, M, G, H, 1.f, hprev, ld, P + kOff.w_hh[l][d], H, 0.f, t->gh[d], G));
+        const size_t so = (size_t)tt * M * H;
+        gru_gate_fwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(t->gi[d] + (size_t)tt * M * G, t->gh[d], P + kOff.b_ih[l][d], P + kOff.b_hh[l][d],
+                                                                   hprev, ld, t->out[l] + (size_t)tt * M * H2 + d * H, t->sav[l][d][0] + so,
+                                                                   t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, M, train ? 1 : 0);
+    }
+    return CCSM_OK;
+}
+
 ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, uint64_t seed, bool have_labels, float pos_weight, float wsum) {
     const int M = 2 * N;
     const float* P = t->params;
@@ -445,21 +482,14 @@ ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, uint64_t see
     for (int l = 0; l < L; ++l) {
         const float* X = l == 0 ? t->x0 : (drop ? t->xdrop[l - 1] : t->out[l - 1]);
         const int in = l == 0 ? F0 : H2;
+        ccsm_status s = fork(t);
+        if (s != CCSM_OK) return s;
         for (int d = 0; d < 2; ++d) {
-            BLASCHK(rm_gemm(t->blas, false, true, T * M, G, in, 1.f, X, in, P + kOff.w_ih[l][d], in, 0.f, t->gi, G));
-            for (int s = 0; s < T; ++s) {
-                const int tt = d == 0 ? s : T - 1 - s;
-                const float* hprev;
-                int ld;
-                if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
-                else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
-                BLASCHK(rm_gemm(t->blas, false, true, M, G, H, 1.f, hprev, ld, P + kOff.w_hh[l][d], H, 0.f, t->gh, G));
-                const size_t so = (size_t)tt * M * H;
-                gru_gate_fwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(t->gi + (size_t)tt * M * G, t->gh, P + kOff.b_ih[l][d], P + kOff.b_hh[l][d],
-                                                                           hprev, ld, t->out[l] + (size_t)tt * M * H2 + d * H, t->sav[l][d][0] + so,
-                                                                           t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, M, train ? 1 : 0);
-            }
+            s = forward_dir(t, M, l, d, X, in, train);
+            if (s != CCSM_OK) return s;
         }
+        s = join(t);
+        if (s != CCSM_OK) return s;
         if (drop && l + 1 < L)
             dropout_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(t->out[l], t->xdrop[l], (int64_t)T * M * H2, rate, seed, 0xd0 + l);
     }
@@ -474,6 +504,41 @@ ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, uint64_t see
     fc_loss_kernel<<<blocks(N, 4), 256, 0, st>>>(t->c, P + kOff.fcw, P + kOff.fcb, have_labels ? t->labels : nullptr, pos_weight, wsum,
                                                  drop ? rate : 0.f, seed, t->feat, t->logits, train ? t->dlogits : nullptr, t->loss, N);
     HIPCHK(hipGetLastError());
+    return CCSM_OK;
+}
+
+ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, const float* X, int in) {
+    const float* P = t->params;
+    float* Gd = t->grads;
+    rocblas_handle blas = d == 0 ? t->blas : t->blas1;
+    hipStream_t st = d == 0 ? t->stream : t->stream1;
+    float *dgi = t->dgi[d], *dgh = t->dgh[d], *carry = t->carry[d], *part = t->part[d];
+    HIPCHK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)M * H, st));
+    for (int s = T - 1; s >= 0; --s) {
+        const int tt = d == 0 ? s : T - 1 - s;
+        const float* hprev;
+        int ld;
+        if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
+        else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
+        const size_t so = (size_t)tt * M * H;
+        gru_gate_bwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(dO + (size_t)tt * M * H2 + d * H, carry, t->sav[l][d][0] + so, t->sav[l][d][1] + so,
+                                                                   t->sav[l][d][2] + so, t->sav[l][d][3] + so, hprev, ld, dgi + (size_t)tt * M * G,
+                                                                   dgh + (size_t)tt * M * G, M);
+        if (s > 0) BLASCHK(rm_gemm(blas, false, false, M, H, G, 1.f, dgh + (size_t)tt * M * G, G, P + kOff.w_hh[l][d], H, 1.f, carry, H));
+    }
+    // weight gradients over all steps at once
+    float* dWhh = Gd + kOff.w_hh[l][d];
+    float* last = part + (size_t)(T - 1) * G * H;      // the h0 step's product goes to the last slot
+    if (d == 0) {
+        BLASCHK(rm_gemm(blas, true, false, G, H, M, 1.f, dgh, G, t->h0 + (size_t)(2 * l) * M * H, H, 0.f, last, H));
+        BLASCHK(atb_split(blas, st, G, H, M, T - 1, dgh + (size_t)M * G, G, t->out[l], H2, part, 1, dWhh));
+    } else {
+        BLASCHK(rm_gemm(blas, true, false, G, H, M, 1.f, dgh + (size_t)(T - 1) * M * G, G, t->h0 + (size_t)(2 * l + 1) * M * H, H, 0.f, last, H));
+        BLASCHK(atb_split(blas, st, G, H, M, T - 1, dgh, G, t->out[l] + (size_t)M * H2 + H, H2, part, 1, dWhh));
+    }
+    BLASCHK(atb_split(blas, st, G, in, M, T, dgi, G, X, in, part, 0, Gd + kOff.w_ih[l][d]));
+    colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgi, Gd + kOff.b_ih[l][d], T * M, G);
+    colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgh, Gd + kOff.b_hh[l][d], T * M, G);
     return CCSM_OK;
 }
 
@@ -495,7 +560,7 @@ ccsm_status backward(ccsm_trainer* t, int N, float rate, uint64_t seed) {
     att_dout_init_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(t->a, t->dc, dO, M);
     att_dpre_kernel<<<blocks((int64_t)T * M, 64), H, 0, st>>>(t->KS, t->e, P + kOff.va, Gd + kOff.va, T * M);   // KS <- dSpre
     att_dq_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(t->KS, t->dq, M);
-    BLASCHK(atb_split(t->blas, st, H, H2, M, T, t->KS, H, O2, H2, t->part, 0, Gd + kOff.ua));
+    BLASCHK(atb_split(t->blas, st, H, H2, M, T, t->KS, H, O2, H2, t->part[0], 0, Gd + kOff.ua));
     BLASCHK(rm_gemm(t->blas, false, false, T * M, H2, H, 1.f, t->KS, H, P + kOff.ua, H2, 1.f, dO, H2));
     BLASCHK(rm_gemm(t->blas, true, false, H, H2, M, 1.f, t->dq, H, t->hn, H2, 0.f, Gd + kOff.wa, H2));
     BLASCHK(rm_gemm(t->blas, false, false, M, H2, H, 1.f, t->dq, H, P + kOff.wa, H2, 0.f, t->dhn, H2));
@@ -505,36 +570,16 @@ ccsm_status backward(ccsm_trainer* t, int N, float rate, uint64_t seed) {
     for (int l = L - 1; l >= 0; --l) {
         const float* X = l == 0 ? t->x0 : (drop ? t->xdrop[l - 1] : t->out[l - 1]);
         const int in = l == 0 ? F0 : H2;
+        ccsm_status s = fork(t);
+        if (s != CCSM_OK) return s;
         for (int d = 0; d < 2; ++d) {
-            HIPCHK(hipMemsetAsync(t->carry, 0, sizeof(float) * (size_t)M * H, st));
-            for (int s = T - 1; s >= 0; --s) {
-                const int tt = d == 0 ? s : T - 1 - s;
-                const float* hprev;
-                int ld;
-                if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
-                else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
-                const size_t so = (size_t)tt * M * H;
-                gru_gate_bwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(dO + (size_t)tt * M * H2 + d * H, t->carry, t->sav[l][d][0] + so,
-                                                                           t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, hprev, ld,
-                                                                           t->dgi + (size_t)tt * M * G, t->dgh + (size_t)tt * M * G, M);
-                if (s > 0)
-                    BLASCHK(rm_gemm(t->blas, false, false, M, H, G, 1.f, t->dgh + (size_t)tt * M * G, G, P + kOff.w_hh[l][d], H, 1.f, t->carry, H));
-            }
-            // weight gradients over all steps at once
-            float* dWhh = Gd + kOff.w_hh[l][d];
-            float* last = t->part + (size_t)(T - 1) * G * H;      // the h0 step's product goes to the last slot
-            if (d == 0) {
-                BLASCHK(rm_gemm(t->blas, true, false, G, H, M, 1.f, t->dgh, G, t->h0 + (size_t)(2 * l) * M * H, H, 0.f, last, H));
-                BLASCHK(atb_split(t->blas, st, G, H, M, T - 1, t->dgh + (size_t)M * G, G, t->out[l], H2, t->part, 1, dWhh));
-            } else {
-                BLASCHK(rm_gemm(t->blas, true, false, G, H, M, 1.f, t->dgh + (size_t)(T - 1) * M * G, G, t->h0 + (size_t)(2 * l + 1) * M * H, H, 0.f, last, H));
-                BLASCHK(atb_split(t->blas, st, G, H, M, T - 1, t->dgh, G, t->out[l] + (size_t)M * H2 + H, H2, t->part, 1, dWhh));
-            }
-            BLASCHK(atb_split(t->blas, st, G, in, M, T, t->dgi, G, X, in, t->part, 0, Gd + kOff.w_ih[l][d]));
-            colsum_kernel<<<blocks((int64_t)T * M, 128), 256, 0, st>>>(t->dgi, Gd + kOff.b_ih[l][d], T * M, G);
-            colsum_kernel<<<blocks((int64_t)T * M, 128), 256, 0, st>>>(t->dgh, Gd + kOff.b_hh[l][d], T * M, G);
-            BLASCHK(rm_gemm(t->blas, false, false, T * M, in, G, 1.f, t->dgi, G, P + kOff.w_ih[l][d], in, d == 0 ? 0.f : 1.f, dX, in));
+            s = backward_dir(t, M, l, d, dO, X, in);
+            if (s != CCSM_OK) return s;
         }
+        s = join(t);
+        if (s != CCSM_OK) return s;
+        for (int d = 0; d < 2; ++d)
+            BLASCHK(rm_gemm(t->blas, false, false, T * M, in, G, 1.f, t->dgi[d], G, P + kOff.w_ih[l][d], in, d == 0 ? 0.f : 1.f, dX, in));
         if (l == 0) {
             embed_bwd_kernel<<<blocks((int64_t)T * M), 256, 0, st>>>(dX, t->kmer, Gd + kOff.embed, M);
         } else {
@@ -574,9 +619,17 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
     const size_t M = 2 * (size_t)max_sites;
 #define TRY(x) do { ccsm_status s__ = (x); if (s__ != CCSM_OK) { ccsm_train_destroy(t); return s__; } } while (0)
     HIPCHK(hipStreamCreate(&t->stream));
-    if (rocblas_create_handle(&t->blas) != rocblas_status_success) { ccsm_train_destroy(t); return fail(CCSM_ERR_HIP, "rocblas_create_handle failed"); }
+    HIPCHK(hipStreamCreate(&t->stream1));
+    HIPCHK(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    if (rocblas_create_handle(&t->blas) != rocblas_status_success || rocblas_create_handle(&t->blas1) != rocblas_status_success) {
+        ccsm_train_destroy(t);
+        return fail(CCSM_ERR_HIP, "rocblas_create_handle failed");
+    }
     rocblas_set_stream(t->blas, t->stream);
+    rocblas_set_stream(t->blas1, t->stream1);
     rocblas_set_pointer_mode(t->blas, rocblas_pointer_mode_host);
+    rocblas_set_pointer_mode(t->blas1, rocblas_pointer_mode_host);
     TRY(dalloc(&t->params, kOff.total));
     TRY(dalloc(&t->adam_m, kOff.total));
     TRY(dalloc(&t->adam_v, kOff.total));
@@ -594,13 +647,14 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
         for (int d = 0; d < 2; ++d)
             for (int k = 0; k < 4; ++k) { t->sav[l][d][k] = nullptr; TRY(dalloc(&t->sav[l][d][k], T * M * H)); }
     }
-    TRY(dalloc(&t->gi, T * M * G)); TRY(dalloc(&t->gh, M * G)); TRY(dalloc(&t->dgi, T * M * G)); TRY(dalloc(&t->dgh, T * M * G));
-    TRY(dalloc(&t->carry, M * H));
+    for (int d = 0; d < 2; ++d) {
+        TRY(dalloc(&t->gi[d], T * M * G)); TRY(dalloc(&t->gh[d], M * G)); TRY(dalloc(&t->dgi[d], T * M * G)); TRY(dalloc(&t->dgh[d], T * M * G));
+        TRY(dalloc(&t->carry[d], M * H)); TRY(dalloc(&t->part[d], (size_t)T * G * H2));
+    }
     TRY(dalloc(&t->hn, M * H2)); TRY(dalloc(&t->q, M * H)); TRY(dalloc(&t->KS, T * M * H)); TRY(dalloc(&t->e, T * M)); TRY(dalloc(&t->a, T * M));
     TRY(dalloc(&t->c, M * H2)); TRY(dalloc(&t->feat, (size_t)max_sites * 2 * H2)); TRY(dalloc(&t->logits, (size_t)max_sites * NC));
     TRY(dalloc(&t->dlogits, (size_t)max_sites * NC)); TRY(dalloc(&t->loss, 1));
     TRY(dalloc(&t->dc, M * H2)); TRY(dalloc(&t->dq, M * H)); TRY(dalloc(&t->dhn, M * H2)); TRY(dalloc(&t->dA, T * M * H2)); TRY(dalloc(&t->dB, T * M * H2));
-    TRY(dalloc(&t->part, (size_t)T * G * H2));
     // parameters: host tensors -> flat order
     std::vector<float> flat((size_t)kOff.total);
     auto put = [&](int64_t off, const float* src, int64_t n) { if (src) std::memcpy(flat.data() + off, src, sizeof(float) * (size_t)n); };
@@ -631,8 +685,8 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
 void ccsm_train_destroy(ccsm_trainer* t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
-    float* fl[] = {t->params, t->adam_m, t->adam_v, t->own_grads ? t->grads : nullptr, t->ipd, t->pw, t->npass, t->h0, t->x0, t->gi, t->gh, t->dgi,
-                   t->dgh, t->carry, t->hn, t->q, t->KS, t->e, t->a, t->c, t->feat, t->logits, t->dlogits, t->loss, t->dc, t->dq, t->dhn, t->dA, t->dB, t->part};
+    float* fl[] = {t->params, t->adam_m, t->adam_v, t->own_grads ? t->grads : nullptr, t->ipd, t->pw, t->npass, t->h0, t->x0, t->gi[0], t->gi[1], t->gh[0], t->gh[1], t->dgi[0],
+                   t->dgi[1], t->dgh[0], t->dgh[1], t->carry[0], t->carry[1], t->part[0], t->part[1], t->hn, t->q, t->KS, t->e, t->a, t->c, t->feat, t->logits, t->dlogits, t->loss, t->dc, t->dq, t->dhn, t->dA, t->dB};
     for (float* p : fl) if (p) (void)hipFree(p);
     if (t->kmer) (void)hipFree(t->kmer);
     if (t->labels) (void)hipFree(t->labels);
@@ -643,6 +697,10 @@ void ccsm_train_destroy(ccsm_trainer* t) {
             for (int k = 0; k < 4; ++k) if (t->sav[l][d][k]) (void)hipFree(t->sav[l][d][k]);
     }
     if (t->blas) rocblas_destroy_handle(t->blas);
+    if (t->blas1) rocblas_destroy_handle(t->blas1);
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+    if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    if (t->stream1) (void)hipStreamDestroy(t->stream1);
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
 }
