@@ -190,3 +190,32 @@ def test_trainm_two_ranks_stay_in_sync(tmp_path):
     assert r0["world"] == r1["world"] == 2 and r0["steps"] == r1["steps"] == 30 * 16
     assert abs(r0["param_checksum"] - r1["param_checksum"]) <= 1e-7 * r0["param_checksum"]
     assert r0["best_acc"] > 0.75, (r0, out.stdout.decode()[-2000:])
+
+
+def test_graph_replay_of_the_step_equals_eager(monkeypatch):
+    """CCSM_TRAIN_GRAPH=1: the first call of a batch shape runs eagerly, the second is captured (both streams, rocBLAS calls
+    included) and later ones replay the graph; per-step seeds / class weights come from device memory, so the run equals the
+    eager one."""
+    from ccsmeth_amd.train import Trainer
+    w = synth.synth_weights(51)
+    n = 192
+    batches = [(synth.synth_sites(n, 52 + k), np.random.default_rng(60 + k).integers(0, 2, n)) for k in range(5)]
+
+    def run():
+        tr = Trainer(w, device=0, max_sites=n)
+        out = []
+        for k, (s, lab) in enumerate(batches):
+            loss, logits = tr.forward_backward(s, lab, h0=None, pos_weight=1.0 + 0.5 * k, dropout_rate=0.3, seed=9, step=k, want_logits=True)
+            out.append((loss, logits, tr.grads()["rnn.weight_hh_l1"].copy(), tr.step(1e-3)))
+        ev = tr.evaluate(batches[0][0], batches[0][1], h0=None, seed=9, step=99)
+        ev2 = tr.evaluate(batches[1][0], batches[1][1], h0=None, seed=9, step=100)       # replayed eval graph
+        tr.close()
+        return out, ev, ev2
+    monkeypatch.setenv("CCSM_TRAIN_GRAPH", "0")
+    eager, e1, e2 = run()
+    monkeypatch.setenv("CCSM_TRAIN_GRAPH", "1")
+    graph, g1, g2 = run()
+    for (la, lo_a, ga, na), (lb, lo_b, gb, nb) in zip(eager[:2], graph[:2]):
+        assert abs(la - lb) < 1e-5 and np.abs(lo_a - lo_b).max() < 1e-4 and np.abs(ga - gb).max() <= 1e-4 * np.abs(ga).max() and abs(na - nb) < 1e-3 * na
+    assert np.allclose([x[0] for x in eager], [x[0] for x in graph], rtol=2e-2)       # later steps: fp32 reduction order only
+    assert abs(e1[0] - g1[0]) < 2e-2 and abs(e2[0] - g2[0]) < 2e-2
