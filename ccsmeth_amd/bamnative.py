@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libccsm_bam.so")
 
 EXPORTS = ("ccsm_bam_last_error", "ccsm_bam_open", "ccsm_bam_header", "ccsm_bam_next", "ccsm_bam_batch_free", "ccsm_bam_close",
            "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_flush", "ccsm_bam_writer_close",
-           "ccsm_bam_modcalls_of_batch", "ccsm_bam_modcalls_free")
+           "ccsm_bam_modcalls_of_batch", "ccsm_bam_modcalls_free", "ccsm_bam_index_build", "ccsm_bam_sort")
 
 
 class _Batch(C.Structure):
@@ -59,6 +59,8 @@ def load():
                                                C.POINTER(C.POINTER(_ModCalls))]
     lib.ccsm_bam_modcalls_free.argtypes = [C.POINTER(_ModCalls)]
     lib.ccsm_bam_modcalls_free.restype = None
+    lib.ccsm_bam_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    lib.ccsm_bam_sort.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int64]
     _lib = lib
     return lib
 
@@ -224,3 +226,25 @@ def stitch_runs(out_path, header_file, header_end, runs):
             for fh in handles.values():
                 fh.close()
         out.write(BGZF_EOF)
+
+
+def index_build(bam_path, bai_path=None, threads=4):
+    """One streaming pass: -> (sorted, n_records); writes <bam>.bai when the records are in coordinate order."""
+    srt, n = C.c_int(), C.c_int64()
+    _check(load().ccsm_bam_index_build(os.fsencode(bam_path), os.fsencode(bai_path or bam_path + ".bai"), int(threads), C.byref(srt), C.byref(n)))
+    return bool(srt.value), int(n.value)
+
+
+def sort_and_index(bam_path, threads=4, level=6, max_bytes=0):
+    """The reference's post-processing (call_modifications.py:592-607: samtools sort -o x.sorted.bam; rename; samtools index):
+    index in place when the file is already in coordinate order, else sort it (in memory) first.  -> True when a sort ran."""
+    ok, _ = index_build(bam_path, threads=threads)
+    if ok:
+        return False
+    tmp = os.path.splitext(bam_path)[0] + ".sorted.bam"
+    _check(load().ccsm_bam_sort(os.fsencode(bam_path), os.fsencode(tmp), int(threads), int(level), int(max_bytes)))
+    os.replace(tmp, bam_path)
+    ok, _ = index_build(bam_path, threads=threads)
+    if not ok:
+        raise IOError("sorted file is not in coordinate order")
+    return True

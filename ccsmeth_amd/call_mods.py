@@ -5,7 +5,8 @@ untagged", end-of-run counters) with one process instead of the reference's read
 default (`--io native`): libccsm_bam (threaded BGZF, include/ccsm_bam.h) -> chunks of `--holes_batch` reads ->
 ccsm_forward_reads_host (feature extraction + model on the GPU) -> libccsm_bam (tag refill, MM/ML, threaded BGZF);
 `--io python`: bamio.BamReader -> pipeline.CallModsPipeline -> bamio.BamWriter, record by record.
-Output order = input order (the reference's `--no_sort`)."""
+Output order = input order; unless `--no_sort`, the file is then coordinate-sorted if it is not already in order and indexed
+(.bai), the reference's samtools post-processing."""
 import argparse
 import os
 import sys
@@ -32,7 +33,7 @@ def build_parser():
     p.add_argument("--gzip", action="store_true", default=False, help="(reference: TSV output only) ignored")
     p.add_argument("--keep_pulse", action="store_true", default=False)
     p.add_argument("--no_sort", action="store_true", default=False,
-                   help="the output is always in input order (coordinate sort + index are not provided)")
+                   help="skip the post-processing (coordinate sort when the records are not in order, then the .bai index)")
     p.add_argument("--model_file", "-m", required=True, help=".ckpt (torch state_dict) of attbigru2s")
     p.add_argument("--model_type", default="attbigru2s")
     p.add_argument("--seq_len", type=int, default=21)
@@ -95,6 +96,38 @@ def _check_scope(args):
         raise ValueError("this build implements --norm zscore with CodecV1 decoding")
     if yes(args.use_compile):
         raise ValueError("--use_compile applies to the reference's torch model only")
+
+
+def _set_coordinate_order(header_text):
+    """@HD ... SO:coordinate, as `samtools sort` leaves the header."""
+    lines = header_text.split("\n")
+    if lines and lines[0].startswith("@HD"):
+        f = [x for x in lines[0].split("\t") if not x.startswith("SO:")]
+        lines[0] = "\t".join(f[:2] + ["SO:coordinate"] + f[2:]) if len(f) >= 2 else lines[0] + "\tSO:coordinate"
+        return "\n".join(lines)
+    return "@HD\tVN:1.6\tSO:coordinate\n" + header_text
+
+
+def _post_sort_index(out_path, args, log):
+    """call_modifications.py:592-607: unless --no_sort, `samtools sort` then `samtools index` of the modbam; failures are
+    warnings there too.  Records already in coordinate order (every unaligned HiFi BAM: the order is kept) are only indexed."""
+    if args.no_sort:
+        return
+    from . import bamnative
+    t = time.time()
+    try:
+        did = bamnative.sort_and_index(out_path, threads=max(1, args.threads), max_bytes=_sort_limit())
+        print("[post_process] bam_sort_index costs %.2f seconds (%s)" % (time.time() - t, "sorted + indexed" if did else "already in order: indexed"),
+              file=log)
+    except Exception as e:  # noqa: BLE001
+        print("[post_process] failed sorting / indexing modbam file: %s" % e, file=log)
+
+
+def _sort_limit():
+    try:
+        return int(os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") * 0.5)
+    except (ValueError, OSError):
+        return 0
 
 
 def _get_holes(holeidfile):
@@ -193,6 +226,8 @@ def call_mods(args, log=sys.stderr):
         runs = []
         with NativeBamReader(args.input, threads=args.threads) as rd:
             header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
+            if not args.no_sort and rd.n_ref == 0:
+                header = _set_coordinate_order(header)             # no reference: every record sorts equal, input order is kept
             with NativeBamWriter(part_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
                     ThreadPoolExecutor(1) as rpool, ThreadPoolExecutor(1) as wpool:
                 header_end = wr.flush()
@@ -247,12 +282,15 @@ def call_mods(args, log=sys.stderr):
             dist.barrier()
             os.remove(part_path)
         if rank == 0:
+            _post_sort_index(out_path, args, log)
             print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
             print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d GPU(s); ccsmeth_amd %s)" %
                   (time.time() - t0, cnt_failed, world, __version__), file=log)
         return dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, output=out_path)
     with BamReader(args.input) as rd:
         header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
+        if not args.no_sort and not rd.references:
+            header = _set_coordinate_order(header)
         with BamWriter(out_path, header, rd.references) as wr:
             batch = []
 
@@ -284,6 +322,7 @@ def call_mods(args, log=sys.stderr):
                     flush()
             flush()
     pipe.close()
+    _post_sort_index(out_path, args, log)
     print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
     print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; ccsmeth_amd %s)" %
           (time.time() - t0, cnt_failed, __version__), file=log)

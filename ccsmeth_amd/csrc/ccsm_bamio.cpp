@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <map>
 #include <new>
 #include <string>
 #include <thread>
@@ -47,6 +49,7 @@ void parallel_for(int n, int threads, F f) {   // f(i) for i in [0, n), static i
 
 struct RawBlock {
     std::vector<uint8_t> cdata;
+    uint64_t coffset = 0;          // file offset of the block's first byte
     uint32_t crc = 0, isize = 0;
     std::vector<uint8_t> data;
     bool ok = true;
@@ -308,10 +311,27 @@ struct ccsm_bam_reader {
     std::string text;
     std::vector<uint8_t> refs;
     int32_t n_ref = 0;
+    // virtual file offsets (BGZF: block file offset << 16 | offset in the block) of positions in `stream`
+    struct BlockPos { uint64_t abs_start, coffset; uint32_t isize; };
+    std::deque<BlockPos> bpos;
+    uint64_t erased = 0;           // bytes dropped from the front of `stream` so far
+    uint64_t next_coffset = 0;
+    uint64_t abs_pos() const { return erased + pos; }
+    // voffset of absolute inflated position p; at a block boundary: the start of the following block when there is one
+    uint64_t voffset(uint64_t p) {
+        while (bpos.size() > 1 && bpos.front().abs_start + bpos.front().isize <= p && bpos[1].abs_start <= p) bpos.pop_front();
+        for (size_t i = 0; i < bpos.size(); ++i) {
+            const BlockPos& b = bpos[i];
+            if (p >= b.abs_start && p < b.abs_start + b.isize) return (b.coffset << 16) | (p - b.abs_start);
+            if (p == b.abs_start + b.isize && (i + 1 == bpos.size() || bpos[i + 1].abs_start > p)) return (b.coffset << 16) | b.isize;
+        }
+        return (next_coffset << 16);
+    }
 
     // read one BGZF block's compressed payload; false at clean EOF; throws through `err`
     bool read_block(RawBlock& b, std::string& err) {
         uint8_t head[12];
+        b.coffset = next_coffset;
         const size_t got = std::fread(head, 1, 12, fh);
         if (got == 0) return false;
         if (got < 12 || head[0] != 0x1f || head[1] != 0x8b || head[2] != 8 || head[3] != 4) {
@@ -338,6 +358,7 @@ struct ccsm_bam_reader {
         }
         b.crc = rd32(tail);
         b.isize = rd32(tail + 4);
+        next_coffset += (uint64_t)bsize + 1;
         return true;
     }
 
@@ -346,6 +367,7 @@ struct ccsm_bam_reader {
         while (stream.size() - pos < need && !file_eof) {
             if (pos > 0 && pos >= stream.size() / 2) {
                 stream.erase(stream.begin(), stream.begin() + (long)pos);
+                erased += pos;
                 pos = 0;
             }
             std::vector<RawBlock> blocks;
@@ -378,6 +400,7 @@ struct ccsm_bam_reader {
             });
             for (auto& b : blocks) {
                 if (!b.ok) return fail("BGZF block failed its CRC / size check");
+                if (b.isize) bpos.push_back({erased + stream.size(), b.coffset, b.isize});
                 stream.insert(stream.end(), b.data.begin(), b.data.end());
             }
         }
@@ -734,5 +757,201 @@ int ccsm_bam_modcalls_of_batch(const ccsm_bam_batch* b, const ccsm_bam_modcall_o
 }
 
 void ccsm_bam_modcalls_free(ccsm_bam_modcalls* c) { delete reinterpret_cast<OwnedCalls*>(c); }
+
+// ---- BAI index and coordinate sort (the reference's pysam.sort + pysam.index post-processing, call_modifications.py:592-607) ----
+namespace {
+
+inline int reg2bin(int64_t beg, int64_t end) {      // SAM spec 5.3, 14-bit minimum interval, 5 levels
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+// samtools sort's coordinate order: reference id with unmapped (-1) last, position, forward strand before reverse
+inline void sort_key(const uint8_t* body, uint64_t& k1, uint32_t& k2) {
+    const uint32_t tid = rd32(body);
+    const int32_t pos = (int32_t)rd32(body + 4);
+    k1 = ((uint64_t)tid << 32) | (uint32_t)(pos + 1);
+    k2 = (rd16(body + 14) & 16) ? 1 : 0;
+}
+
+struct RefIndex {
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> linear;
+    uint64_t off_beg = ~0ull, off_end = 0, n_mapped = 0, n_unmapped = 0;
+};
+
+}  // namespace
+
+int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads, int* sorted, int64_t* n_records) {
+    if (!bam_path || !bai_path) return fail("paths must be non-NULL");
+    ccsm_bam_reader* r = nullptr;
+    if (ccsm_bam_open(bam_path, threads, &r)) return 1;
+    std::vector<RefIndex> refs((size_t)std::max(0, r->n_ref));
+    uint64_t n_no_coor = 0, prev1 = 0;
+    uint32_t prev2 = 0;
+    bool is_sorted = true, first = true;
+    int64_t count = 0;
+    int save_bin = -1, save_tid = -2;
+    uint64_t save_off = 0, last_off = 0;
+    auto flush_bin = [&]() {
+        if (save_bin >= 0 && save_tid >= 0 && save_tid < (int)refs.size()) refs[(size_t)save_tid].bins[(uint32_t)save_bin].emplace_back(save_off, last_off);
+    };
+    int rc = 0;
+    for (;;) {
+        if (r->fill(4)) { rc = 1; break; }
+        if (r->avail() == 0) break;
+        if (r->avail() < 4) { rc = fail("truncated BAM record"); break; }
+        const uint32_t bs = rd32(r->stream.data() + r->pos);
+        if (bs < 32) { rc = fail("corrupt BAM record (block_size < 32)"); break; }
+        if (r->fill(4 + (size_t)bs)) { rc = 1; break; }
+        if (r->avail() < 4 + (size_t)bs) { rc = fail("truncated BAM record"); break; }
+        const uint64_t beg_off = r->voffset(r->abs_pos());
+        const uint8_t* body = r->stream.data() + r->pos + 4;
+        const int32_t tid = (int32_t)rd32(body), pos = (int32_t)rd32(body + 4);
+        const uint32_t l_name = body[8], n_cig = rd16(body + 12), flag = rd16(body + 14);
+        if (32 + (size_t)l_name + 4 * (size_t)n_cig > bs) { rc = fail("corrupt BAM record (field lengths exceed block_size)"); break; }
+        uint64_t k1; uint32_t k2;
+        sort_key(body, k1, k2);
+        if (!first && (k1 < prev1 || (k1 == prev1 && k2 < prev2))) is_sorted = false;
+        first = false; prev1 = k1; prev2 = k2;
+        int64_t reflen = 0;
+        const uint8_t* cig = body + 32 + l_name;
+        for (uint32_t c = 0; c < n_cig; ++c) {
+            const uint32_t v = rd32(cig + 4 * c), op = v & 15;
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;
+        }
+        r->pos += 4 + bs;
+        const uint64_t end_off = r->voffset(r->abs_pos());
+        ++count;
+        if (tid >= r->n_ref) { rc = fail("record refers to a reference id beyond the header"); break; }
+        if (tid < 0) { ++n_no_coor; }
+        if (tid >= 0) {
+            RefIndex& ri = refs[(size_t)tid];
+            const int64_t b = pos < 0 ? 0 : pos, e = (flag & 4) || reflen == 0 ? b + 1 : b + reflen;
+            const int bin = reg2bin(b, e);
+            if (bin != save_bin || tid != save_tid) {
+                last_off = beg_off;
+                flush_bin();
+                save_bin = bin; save_tid = tid; save_off = beg_off;
+            }
+            if (!(flag & 4)) {
+                const size_t w0 = (size_t)(b >> 14), w1 = (size_t)((e - 1) >> 14);
+                if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, ~0ull);
+                for (size_t w = w0; w <= w1; ++w) if (ri.linear[w] == ~0ull) ri.linear[w] = beg_off;
+                ++ri.n_mapped;
+            } else {
+                ++ri.n_unmapped;
+            }
+            if (ri.off_beg == ~0ull) ri.off_beg = beg_off;
+            ri.off_end = end_off;
+        } else if (save_tid >= 0) {
+            last_off = beg_off;
+            flush_bin();
+            save_bin = -1; save_tid = -1;
+        }
+        last_off = end_off;
+    }
+    if (rc == 0) flush_bin();
+    ccsm_bam_close(r);
+    if (rc) return rc;
+    if (sorted) *sorted = is_sorted ? 1 : 0;
+    if (n_records) *n_records = count;
+    if (!is_sorted) return 0;                       // an index over unsorted records is meaningless: none is written
+    FILE* f = std::fopen(bai_path, "wb");
+    if (!f) return fail(std::string("cannot write ") + bai_path);
+    std::vector<uint8_t> out;
+    auto p32 = [&](uint32_t v) { uint8_t b[4]; wr32(b, v); out.insert(out.end(), b, b + 4); };
+    auto p64 = [&](uint64_t v) { p32((uint32_t)v); p32((uint32_t)(v >> 32)); };
+    out.insert(out.end(), {'B', 'A', 'I', 1});
+    p32((uint32_t)refs.size());
+    for (auto& ri : refs) {
+        const bool any = ri.off_beg != ~0ull;
+        p32((uint32_t)(ri.bins.size() + (any ? 1 : 0)));
+        for (auto& kv : ri.bins) {
+            p32(kv.first);
+            p32((uint32_t)kv.second.size());
+            for (auto& ch : kv.second) { p64(ch.first); p64(ch.second); }
+        }
+        if (any) {                                   // htslib's metadata pseudo-bin
+            p32(37450); p32(2);
+            p64(ri.off_beg); p64(ri.off_end); p64(ri.n_mapped); p64(ri.n_unmapped);
+        }
+        for (size_t w = ri.linear.size(); w-- > 0;)  // empty windows take the next window's offset
+            if (ri.linear[w] == ~0ull) ri.linear[w] = (w + 1 < ri.linear.size()) ? ri.linear[w + 1] : 0;
+        p32((uint32_t)ri.linear.size());
+        for (uint64_t v : ri.linear) p64(v);
+    }
+    p64(n_no_coor);
+    const bool okw = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    if (std::fclose(f) != 0 || !okw) return fail("write failed");
+    return 0;
+}
+
+int ccsm_bam_sort(const char* in_path, const char* out_path, int threads, int level, int64_t max_bytes) {
+    if (!in_path || !out_path) return fail("paths must be non-NULL");
+    ccsm_bam_reader* r = nullptr;
+    if (ccsm_bam_open(in_path, threads, &r)) return 1;
+    std::vector<uint8_t> data;
+    std::vector<uint64_t> off, k1;
+    std::vector<uint32_t> k2;
+    int rc = 0;
+    for (;;) {
+        if (r->fill(4)) { rc = 1; break; }
+        if (r->avail() == 0) break;
+        if (r->avail() < 4) { rc = fail("truncated BAM record"); break; }
+        const uint32_t bs = rd32(r->stream.data() + r->pos);
+        if (bs < 32) { rc = fail("corrupt BAM record (block_size < 32)"); break; }
+        if (r->fill(4 + (size_t)bs)) { rc = 1; break; }
+        if (r->avail() < 4 + (size_t)bs) { rc = fail("truncated BAM record"); break; }
+        if (max_bytes > 0 && (int64_t)(data.size() + 4 + bs) > max_bytes) { rc = fail("the records do not fit the in-memory sort limit"); break; }
+        const uint8_t* rec = r->stream.data() + r->pos;
+        uint64_t a; uint32_t b;
+        sort_key(rec + 4, a, b);
+        off.push_back(data.size()); k1.push_back(a); k2.push_back(b);
+        data.insert(data.end(), rec, rec + 4 + bs);
+        r->pos += 4 + bs;
+    }
+    off.push_back(data.size());
+    // header: @HD ... SO:coordinate as samtools sort leaves it
+    std::string text = r->text;
+    {
+        std::string hd = "@HD\tVN:1.6\tSO:coordinate\n";
+        if (text.compare(0, 3, "@HD") == 0) {
+            const size_t eol = text.find('\n');
+            std::string line = text.substr(0, eol == std::string::npos ? text.size() : eol);
+            const size_t so = line.find("\tSO:");
+            if (so != std::string::npos) {
+                size_t e = line.find('\t', so + 1);
+                line.replace(so, (e == std::string::npos ? line.size() : e) - so, "\tSO:coordinate");
+            } else {
+                line += "\tSO:coordinate";
+            }
+            text = line + "\n" + (eol == std::string::npos ? std::string() : text.substr(eol + 1));
+        } else {
+            text = hd + text;
+        }
+    }
+    const std::vector<uint8_t> refs = r->refs;
+    const int32_t n_ref = r->n_ref;
+    ccsm_bam_close(r);
+    if (rc) return rc;
+    const size_t n = k1.size();
+    std::vector<uint32_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    if (n > 0xfffffffeull) return fail("too many records for the in-memory sort");
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return k1[x] < k1[y] || (k1[x] == k1[y] && k2[x] < k2[y]); });
+    ccsm_bam_writer* w = nullptr;
+    if (ccsm_bam_writer_open(out_path, text.data(), (int64_t)text.size(), refs.data(), (int64_t)refs.size(), n_ref, threads, level, &w)) return 1;
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t j = order[i];
+        if (w->put(data.data() + off[j], (size_t)(off[j + 1] - off[j]))) { ccsm_bam_writer_close(w); return 1; }
+    }
+    return ccsm_bam_writer_close(w);
+}
 
 }  // extern "C"

@@ -109,6 +109,14 @@ int ccsm_bam_modcalls_of_batch(const ccsm_bam_batch* b, const ccsm_bam_modcall_o
                                const int64_t* mask_len, int32_t n_ref, int threads, ccsm_bam_modcalls** out);
 void ccsm_bam_modcalls_free(ccsm_bam_modcalls* c);
 
+/* ---- post-processing of the output modbam: the reference's pysam.sort + pysam.index (call_modifications.py:592-607) ----------
+ * ccsm_bam_index_build streams the file once: *sorted = 1 when the records are in samtools' coordinate order (reference id with
+ * unmapped last, position, forward before reverse strand) and then writes the BAI index (SAM spec 5.2: binning index, 16 kb
+ * linear index, htslib's metadata pseudo-bin 37450, n_no_coor); *sorted = 0 leaves no index.  ccsm_bam_sort rewrites the file
+ * in that order (stable, in memory: fails when the uncompressed records exceed max_bytes > 0) with @HD SO:coordinate. */
+int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads, int* sorted, int64_t* n_records);
+int ccsm_bam_sort(const char* in_path, const char* out_path, int threads, int level, int64_t max_bytes);
+
 #ifdef __cplusplus
 }
 #endif

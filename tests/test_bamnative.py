@@ -238,3 +238,147 @@ assert ok + err == 80 and ok > 0
 ''' % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path / "in.bam"), str(tmp_path / "mut.bam"), str(tmp_path / "out.bam"))
     res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+# ---- coordinate sort + BAI index (the reference's pysam.sort / pysam.index post-processing) -------------------------------
+def _bai_parse(path):
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == b"BAI\x01"
+    off = 4
+    (n_ref,) = struct.unpack_from("<i", b, off); off += 4
+    refs = []
+    for _ in range(n_ref):
+        (n_bin,) = struct.unpack_from("<i", b, off); off += 4
+        bins = {}
+        for _ in range(n_bin):
+            bin_, n_chunk = struct.unpack_from("<Ii", b, off); off += 8
+            bins[bin_] = [struct.unpack_from("<QQ", b, off + 16 * k) for k in range(n_chunk)]
+            off += 16 * n_chunk
+        (n_intv,) = struct.unpack_from("<i", b, off); off += 4
+        lin = list(struct.unpack_from("<%dQ" % n_intv, b, off)); off += 8 * n_intv
+        refs.append((bins, lin))
+    (n_no_coor,) = struct.unpack_from("<Q", b, off); off += 8
+    assert off == len(b)
+    return refs, n_no_coor
+
+
+def _record_voffsets(path):
+    """(virtual offset, ref id, pos, end, flag) of every record, from an independent walk over the BGZF blocks."""
+    import struct
+    blocks, data = [], bytearray()
+    with open(path, "rb") as fh:
+        while True:
+            c0 = fh.tell()
+            head = fh.read(18)
+            if len(head) < 18:
+                break
+            bsize = struct.unpack_from("<H", head, 16)[0] + 1
+            fh.seek(c0)
+            raw = fh.read(bsize)
+            import zlib
+            payload = zlib.decompress(raw[18:-8], -15)
+            blocks.append((len(data), c0, len(payload)))
+            data += payload
+    def voff(p):
+        for a, c, n in blocks:
+            if a <= p < a + n:
+                return (c << 16) | (p - a)
+        a, c, n = blocks[-1]
+        return (c << 16) | n
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    off = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, off)[0]; off += 4
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", data, off)[0]; off += 8 + ln
+    recs = []
+    while off < len(data):
+        bs = struct.unpack_from("<i", data, off)[0]
+        tid, pos, l_name, _mq, _bin, n_cig, flag = struct.unpack_from("<iiBBHHH", data, off + 4)
+        cig = np.frombuffer(bytes(data[off + 36 + l_name:off + 36 + l_name + 4 * n_cig]), "<u4")
+        reflen = int(sum(int(c >> 4) for c in cig if int(c & 15) in (0, 2, 3, 7, 8)))
+        recs.append((voff(off), tid, pos, pos + (reflen if reflen and not flag & 4 else 1), flag))
+        off += 4 + bs
+    return recs
+
+
+def _reg2bins(beg, end):
+    end -= 1
+    out = [0]
+    for shift, base in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        out += list(range(base + (beg >> shift), base + (end >> shift) + 1))
+    return out
+
+
+def _aligned_records(rng, n, n_ref=3, ref_len=300000):
+    recs = []
+    for i in range(n):
+        tid = int(rng.integers(0, n_ref))
+        pos = int(rng.integers(0, ref_len - 20000))
+        ln = int(rng.integers(200, 18000))
+        flag = int(rng.choice([0, 16, 0x800, 0x100 | 16]))
+        cigar = [(4, 3), (0, ln // 2), (2, 5), (1, 2), (0, ln - ln // 2)]
+        seq = "".join(rng.choice(list("ACGT"), size=3 + ln + 2))
+        recs.append(bamio.BamRecord("r%d" % i, flag=flag, ref_id=tid, pos=pos, mapq=30, cigar=cigar, seq=seq, tags=[("NM", "i", i)]))
+    recs.append(bamio.BamRecord("placed_unmapped", flag=4, ref_id=1, pos=500, seq="ACGT"))
+    for i in range(5):
+        recs.append(bamio.BamRecord("u%d" % i, flag=4, seq="ACGTACGT"))
+    return recs
+
+
+def test_sort_and_index_aligned_bam(tmp_path):
+    rng = np.random.default_rng(3)
+    recs = _aligned_records(rng, 400)
+    order = rng.permutation(len(recs))
+    path = str(tmp_path / "a.bam")
+    refs = [("c%d" % i, 300000) for i in range(3)]
+    with bamio.BamWriter(path, "@HD\tVN:1.5\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs) + "@CO\tx\n", refs, level=1) as w:
+        for i in order:
+            w.write(recs[i])
+    ok, n = bamnative.index_build(path, threads=3)
+    assert not ok and n == len(recs) and not os.path.exists(path + ".bai")
+    assert bamnative.sort_and_index(path, threads=3) is True
+    with bamio.BamReader(path) as rd:
+        assert rd.header_text.startswith("@HD\tVN:1.5\tSO:coordinate\n@SQ") and rd.header_text.endswith("@CO\tx\n")
+        got = list(rd)
+    key = lambda r: ((r.ref_id if r.ref_id >= 0 else 1 << 31), r.pos + 1, 1 if r.flag & 16 else 0)  # noqa: E731
+    want = sorted([recs[i] for i in order], key=key)                 # Python's sort is stable, like samtools'
+    assert [r.query_name for r in got] == [r.query_name for r in want]
+    assert all(a.cigar == b.cigar and a.seq == b.seq and a.tags[0][2] == b.tags[0][2] for a, b in zip(got[:50], want[:50]))
+    assert bamnative.sort_and_index(path, threads=2) is False       # already sorted: index only
+    # the index finds every overlapping record: SAM spec 5.3 query, checked against an independent walk of the file
+    idx, n_no_coor = _bai_parse(path + ".bai")
+    allrec = _record_voffsets(path)
+    assert n_no_coor == 5 and len(idx) == 3 and len(allrec) == len(recs)
+    for tid in range(3):
+        bins, lin = idx[tid]
+        meta = bins.pop(37450)
+        mine = [r for r in allrec if r[1] == tid]
+        assert meta[0] == (mine[0][0], [r for r in allrec][allrec.index(mine[-1]) + 1][0] if allrec.index(mine[-1]) + 1 < len(allrec) else meta[0][1])
+        assert meta[1] == (sum(1 for r in mine if not r[4] & 4), sum(1 for r in mine if r[4] & 4))
+        for _ in range(40):
+            beg = int(rng.integers(0, 299000)); end = beg + int(rng.integers(1, 40000))
+            overl = [r[0] for r in mine if r[2] < end and r[3] > beg]
+            chunks = [c for b in _reg2bins(beg, end) for c in bins.get(b, [])]
+            min_off = lin[beg >> 14] if (beg >> 14) < len(lin) else (lin[-1] if lin else 0)
+            for v in overl:
+                assert any(c0 <= v < c1 for c0, c1 in chunks), (tid, beg, end, v)
+                assert v >= min_off
+
+
+def test_index_of_unaligned_bam_and_errors(tmp_path):
+    path = str(tmp_path / "u.bam")
+    with bamio.BamWriter(path, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
+        for i in range(7):
+            w.write(bamio.BamRecord("m/%d/ccs" % i, flag=4, seq="ACGT" * 10))
+    assert bamnative.sort_and_index(path) is False                  # unaligned reads are already "sorted": input order is kept
+    assert open(path + ".bai", "rb").read() == b"BAI\x01" + (0).to_bytes(4, "little") + (7).to_bytes(8, "little")
+    with pytest.raises(IOError):
+        bamnative.index_build(str(tmp_path / "missing.bam"))
+    with pytest.raises(IOError, match="in-memory sort limit"):
+        p2 = str(tmp_path / "b.bam")
+        with bamio.BamWriter(p2, "", [("c", 1000)]) as w:
+            w.write(bamio.BamRecord("a", flag=0, ref_id=0, pos=500, cigar=[(0, 4)], seq="ACGT"))
+            w.write(bamio.BamRecord("b", flag=0, ref_id=0, pos=100, cigar=[(0, 4)], seq="ACGT"))
+        bamnative.load().ccsm_bam_sort  # noqa: B018
+        bamnative._check(bamnative.load().ccsm_bam_sort(p2.encode(), (p2 + ".s").encode(), 1, 6, 10))

@@ -702,3 +702,64 @@ def test_read_level_submit_wait_pipelined(model7):
     ws[1].wait_reads()
     for x in ws + [ref]:
         x.close()
+
+
+def test_call_mods_post_processing_sort_and_index(tmp_path):
+    """Without --no_sort the reference runs samtools sort + index on the modbam (call_modifications.py:592-607): an unaligned
+    input keeps its order, gets @HD SO:coordinate and a .bai; an aligned, unsorted input comes out in coordinate order with
+    its MM/ML tags, indexed; --no_sort leaves neither."""
+    import torch
+    from collections import OrderedDict
+    from ccsmeth_amd import bamio
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    rng = np.random.default_rng(77)
+    wts = synth.synth_weights(5)
+    ckpt = str(tmp_path / "m.ckpt")
+    torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in wts.items()), ckpt)
+
+    def reads(aligned):
+        out = []
+        for i in range(12):
+            L = int(rng.integers(300, 900))
+            seq = rng.choice(list("ACGT"), size=L)
+            for j in range(12, L - 12, 23):
+                seq[j], seq[j + 1] = "C", "G"
+            kin = lambda: rng.integers(0, 256, L).astype(np.uint8)  # noqa: E731
+            tags = [("fi", "BC", kin()), ("fp", "BC", kin()), ("ri", "BC", kin()), ("rp", "BC", kin()), ("fn", "C", 9), ("rn", "C", 8)]
+            if aligned:
+                out.append(bamio.BamRecord("h%d" % i, flag=16 * (i % 2), ref_id=i % 2, pos=int(rng.integers(0, 5000)), mapq=60, cigar=[(0, L)],
+                                           seq="".join(seq), tags=tags))
+            else:
+                out.append(bamio.BamRecord("h%d" % i, flag=4, seq="".join(seq), tags=tags))
+        return out
+    for aligned in (False, True):
+        inp = str(tmp_path / ("in%d.bam" % aligned))
+        refs = [("c0", 9000), ("c1", 9000)] if aligned else []
+        recs = reads(aligned)
+        with bamio.BamWriter(inp, "@HD\tVN:1.5\tSO:unknown\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs), refs) as w:
+            for r in recs:
+                w.write(r)
+        for io in ("native", "python"):
+            prefix = str(tmp_path / ("o%d%s" % (aligned, io)))
+            res = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", prefix, "--io", io]), log=open(os.devnull, "w"))
+            assert os.path.exists(res["output"] + ".bai")
+            with bamio.BamReader(res["output"]) as rd:
+                out = list(rd)
+                assert "SO:coordinate" in rd.header_text.split("\n")[0]
+            assert all(o.has_tag("MM") and o.has_tag("ML") for o in out)
+            if aligned:
+                keys = [(o.ref_id, o.pos) for o in out]
+                assert keys == sorted(keys) and keys != [(r.ref_id, r.pos) for r in recs]
+                by_name = {o.query_name: o for o in out}
+            else:
+                assert [o.query_name for o in out] == [r.query_name for r in recs]
+                by_name = {o.query_name: o for o in out}
+            if io == "native":
+                first = by_name
+            else:
+                for k, o in by_name.items():
+                    assert o.get_tag("MM") == first[k].get_tag("MM") and np.abs(o.get_tag("ML").astype(int) - first[k].get_tag("ML").astype(int)).max() <= 1
+        res = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / ("n%d" % aligned)), "--no_sort"]), log=open(os.devnull, "w"))
+        assert not os.path.exists(res["output"] + ".bai")
+        with bamio.BamReader(res["output"]) as rd:
+            assert [o.query_name for o in rd] == [r.query_name for r in recs] and "SO:unknown" in rd.header_text
