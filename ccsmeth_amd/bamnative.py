@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libccsm_bam.so")
 
 EXPORTS = ("ccsm_bam_last_error", "ccsm_bam_open", "ccsm_bam_header", "ccsm_bam_next", "ccsm_bam_batch_free", "ccsm_bam_close",
            "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_flush", "ccsm_bam_writer_close",
-           "ccsm_bam_modcalls_of_batch", "ccsm_bam_modcalls_free", "ccsm_bam_index_build", "ccsm_bam_sort")
+           "ccsm_bam_modcalls_of_batch", "ccsm_bam_modcalls_free", "ccsm_bam_index_build", "ccsm_bam_sort",
+           "ccsm_bam_align_info")
 
 
 class _Batch(C.Structure):
@@ -61,6 +62,7 @@ def load():
     lib.ccsm_bam_modcalls_free.restype = None
     lib.ccsm_bam_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     lib.ccsm_bam_sort.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int64]
+    lib.ccsm_bam_align_info.argtypes = [C.POINTER(_Batch), vp, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -226,6 +228,14 @@ def stitch_runs(out_path, header_file, header_end, runs):
             for fh in handles.values():
                 fh.close()
         out.write(BGZF_EOF)
+
+
+def align_info(batch):
+    """-> (mapq int32, query_alignment_start int32, query_alignment_end int32, identity float64) per record of the batch."""
+    n = batch.n_reads
+    mapq, qs, qe, ident = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float64)
+    _check(load().ccsm_bam_align_info(batch._ptr, mapq.ctypes.data, qs.ctypes.data, qe.ctypes.data, ident.ctypes.data))
+    return mapq, qs, qe, ident
 
 
 def index_build(bam_path, bai_path=None, threads=4):

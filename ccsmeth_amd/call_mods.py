@@ -15,7 +15,7 @@ import time
 import numpy as np
 
 from . import __version__
-from ._bam2modbam import _refill_tags
+from ._bam2modbam import _convert_locs_to_mmtag, _convert_probs_to_mltag, _refill_tags
 from .bamio import BamReader, BamWriter, add_pg_line
 from .pipeline import CallModsPipeline, Read
 
@@ -88,8 +88,10 @@ def _check_scope(args):
         if args.seq_len % 2 == 0:
             raise ValueError("--seq_len must be odd")                  # :500-501
         raise ValueError("this build implements --seq_len 21 --layer_rnn 3 --hid_rnn 256 --class_num 2")
-    if args.mode != "denovo" or args.ref is not None:
-        raise ValueError("this build implements --mode denovo (no --ref)")
+    if args.mode not in ("denovo", "align"):
+        raise ValueError("--mode must be denovo or align")
+    if args.mode == "align" and args.ref is not None and not os.path.exists(args.ref):
+        raise ValueError("--ref does not exist")       # only --is_map yes reads the reference sequence (outside this build)
     if args.motifs.upper() != "CG" or args.mod_loc != 0:
         raise ValueError("this build implements --motifs CG --mod_loc 0")
     if args.norm != "zscore" or args.no_decode:
@@ -128,6 +130,59 @@ def _sort_limit():
         return int(os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") * 0.5)
     except (ValueError, OSError):
         return 0
+
+
+def _align_skip_and_window(flag, mapq, identity, qstart, qend, length, args):
+    """--mode align (extract_features.py:272-304, 383-391): reads that are unmapped / secondary / duplicate, supplementary with
+    --no_supplementary, below --mapq or below --identity give no features; with --skip_unmapped yes a site is kept only inside
+    the aligned part of the read, [seq_start, seq_end) in forward-sequence coordinates (flipped for reverse-strand records)."""
+    flag, mapq = np.asarray(flag), np.asarray(mapq)
+    skip = (flag & (0x4 | 0x100 | 0x400)) != 0
+    if args.no_supplementary:
+        skip |= (flag & 0x800) != 0
+    skip |= mapq < args.mapq
+    skip |= np.asarray(identity) < args.identity
+    if str(args.skip_unmapped).lower() not in ("yes", "true", "t", "1"):
+        return skip, None
+    rev = (flag & 16) != 0
+    lo = np.where(rev, length - qend, qstart).astype(np.int64)
+    hi = np.where(rev, length - qstart, qend).astype(np.int64)
+    return skip, (lo, hi)
+
+
+def _cigar_align_info(cigar, l_seq):
+    """(query_alignment_start, query_alignment_end, identity) of a record's CIGAR [(op, len)], as ccsm_bam_align_info."""
+    qs, qe = 0, l_seq
+    for op, ln in cigar:
+        if op == 5:
+            continue
+        if op != 4:
+            break
+        qs += ln
+    for op, ln in reversed(cigar):
+        if op == 5:
+            continue
+        if op != 4:
+            break
+        qe -= ln
+    cnt = [0] * 16
+    for op, ln in cigar:
+        cnt[op] += ln
+    nalign = sum(cnt[i] for i in (0, 1, 2, 3, 6, 7, 8, 9))
+    return qs, qe, ((cnt[0] + cnt[7]) / float(nalign) if nalign > 0 else 0.0)
+
+
+def _filter_sites_by_window(first, locs, prob1, tagged, window):
+    """Drop the sites outside each read's [lo, hi): same arrays, compacted."""
+    lo, hi = window
+    n = len(first) - 1
+    cnt = np.diff(first)
+    rid = np.repeat(np.arange(n), cnt)
+    keep = (locs >= lo[rid]) & (locs < hi[rid])
+    newcnt = np.bincount(rid[keep], minlength=n).astype(np.int32)
+    nf = np.zeros(n + 1, np.int32)
+    np.cumsum(newcnt, out=nf[1:])
+    return nf, np.ascontiguousarray(locs[keep]), np.ascontiguousarray(prob1[keep]), (np.asarray(tagged, bool) & (newcnt > 0)).astype(np.uint8)
 
 
 def _get_holes(holeidfile):
@@ -201,6 +256,7 @@ def call_mods(args, log=sys.stderr):
     holeids_e = None if args.holeids_e is None else _get_holes(args.holeids_e)          # extract_features.py:561-562
     holeids_ne = None if args.holeids_ne is None else _get_holes(args.holeids_ne)
     name_filter = holeids_e is not None or holeids_ne is not None
+    align = args.mode == "align"
     out_path = args.output + ".modbam.bam"                             # :494
     cnt_w = cnt_mm = cnt_failed = 0
     rm_pulse = not args.keep_pulse
@@ -247,13 +303,20 @@ def call_mods(args, log=sys.stderr):
                     if b is None:
                         break
                     nxt = rpool.submit(rd.next_batch, args.holes_batch)
-                    skip = None
+                    skip, window = None, None
                     if name_filter:
                         skip = np.array([_skip_by_name(nm, holeids_e, holeids_ne) for nm in _batch_names(b)], bool)
+                    if align:
+                        from .bamnative import align_info
+                        mq, qs, qe, ident = align_info(b)
+                        askip, window = _align_skip_and_window(b.flag, mq, ident, qs, qe, b.length, args)
+                        skip = askip if skip is None else (skip | askip)
                     batch_sites = int(np.where((b.length > 0) & (~skip if skip is not None else True), b.n_sites, 0).sum())
                     if bi % world == rank:
                         pipe._site_counter = site_base
                         first, locs, prob1, tagged, failed = pipe.run_native_batch(b, skip)
+                        if window is not None:
+                            first, locs, prob1, tagged = _filter_sites_by_window(first, locs, prob1, tagged, window)
                         if pending is not None:
                             cnt_mm += pending.result()
                         pending = wpool.submit(write, b, first, locs, prob1, tagged, bi)
@@ -301,9 +364,26 @@ def call_mods(args, log=sys.stderr):
                 rds = [_read_of(r) for r in batch]
                 if name_filter:       # a filtered read goes through as one without usable kinetics
                     rds = [r._replace(fi=np.empty(0, np.uint8)) if _skip_by_name(r.name, holeids_e, holeids_ne) else r for r in rds]
+                windows = None
+                if align:
+                    L = np.array([len(r.seq) for r in batch], np.int64)
+                    info = [_cigar_align_info(r.cigar, len(r.seq)) for r in batch]
+                    qs, qe, ident = (np.array([x[k] for x in info]) for k in range(3))
+                    askip, windows = _align_skip_and_window(np.array([r.flag for r in batch]), np.array([r.mapq for r in batch]), ident, qs, qe, L, args)
+                    rds = [r._replace(fi=np.empty(0, np.uint8)) if sk else r for r, sk in zip(rds, askip)]
                 calls, failed = pipe.run(rds)
                 cnt_failed += failed
-                for rec, c in zip(batch, calls):
+                for ri, (rec, c) in enumerate(zip(batch, calls)):
+                    if windows is not None and c.mm_flag:
+                        keep = (np.asarray(c.locs) >= windows[0][ri]) & (np.asarray(c.locs) < windows[1][ri])
+                        if not keep.all():
+                            locs_k = [int(x) for x in np.asarray(c.locs)[keep]]
+                            probs_k = np.asarray(c.probs)[keep]
+                            if locs_k:
+                                c = c._replace(locs=locs_k, probs=probs_k, mm=_convert_locs_to_mmtag(locs_k, rds[ri].seq),
+                                               ml=_convert_probs_to_mltag(list(probs_k)))
+                            else:
+                                c = c._replace(mm_flag=0)
                     old = [(t, v) for t, _, v in rec.tags]
                     mm_vals = c.mm if c.mm_flag else None
                     kept = {t for t, _ in _refill_tags(old, None, None, rm_pulse)}

@@ -954,4 +954,34 @@ int ccsm_bam_sort(const char* in_path, const char* out_path, int threads, int le
     return ccsm_bam_writer_close(w);
 }
 
+int ccsm_bam_align_info(const ccsm_bam_batch* b, int32_t* mapq, int32_t* qstart, int32_t* qend, double* identity) {
+    if (!b || !mapq || !qstart || !qend || !identity) return fail("arguments must be non-NULL");
+    for (int32_t r = 0; r < b->n_reads; ++r) {
+        const uint8_t* body = b->records + b->rec_offset[r] + 4;
+        const uint32_t l_name = body[8], n_cig = rd16(body + 12), l_seq = rd32(body + 16);
+        const uint8_t* cig = body + 32 + l_name;
+        int64_t cnt[16] = {0};
+        for (uint32_t c = 0; c < n_cig; ++c) { const uint32_t v = rd32(cig + 4 * c); cnt[v & 15] += v >> 4; }
+        int64_t qs = 0, qe = l_seq;
+        for (uint32_t c = 0; c < n_cig; ++c) {                       // leading clips (pysam query_alignment_start)
+            const uint32_t v = rd32(cig + 4 * c), op = v & 15;
+            if (op == 5) continue;
+            if (op == 4) { qs += v >> 4; continue; }
+            break;
+        }
+        for (uint32_t c = n_cig; c-- > 0;) {                          // trailing clips (query_alignment_end)
+            const uint32_t v = rd32(cig + 4 * c), op = v & 15;
+            if (op == 5) continue;
+            if (op == 4) { qe -= v >> 4; continue; }
+            break;
+        }
+        const int64_t nalign = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[6] + cnt[7] + cnt[8] + cnt[9];
+        mapq[r] = body[9];
+        qstart[r] = (int32_t)qs;
+        qend[r] = (int32_t)qe;
+        identity[r] = nalign > 0 ? (double)(cnt[0] + cnt[7]) / (double)nalign : 0.0;
+    }
+    return 0;
+}
+
 }  // extern "C"

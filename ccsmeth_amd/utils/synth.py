@@ -114,3 +114,33 @@ def sample_index(name, size, k=1024):
     for ch in name:
         h = (h * 131 + ord(ch)) % 1000000007
     return np.sort(np.random.default_rng(h).choice(size, k, replace=False))
+
+
+def synth_aligned_reads(seed, n=14):
+    """Aligned HiFi records for the --mode align fixtures: [(name, flag, mapq, cigar [(op, len)], SEQ as stored, fi, ri, fp, rp,
+    fn, rn)] with soft / hard clips, = / X operators, all flag classes and a spread of MAPQ."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        body = int(rng.integers(150, 500))
+        lead, trail = int(rng.choice([0, 0, 15, 40])), int(rng.choice([0, 0, 11, 33]))
+        cigar = []
+        if i % 5 == 1:
+            cigar.append((5, 9))
+        if lead:
+            cigar.append((4, lead))
+        a = body // 3
+        cigar += [(0 if i % 3 else 7, a), (1, 2), (0, a), (2, 4), (8 if i % 4 == 0 else 0, body - 2 * a - 2)]
+        if trail:
+            cigar.append((4, trail))
+        if i % 5 == 1:
+            cigar.append((5, 4))
+        L = lead + body + trail
+        seq = rng.choice(list("ACGT"), size=L)
+        for j in range(3, L - 1, 13):
+            seq[j], seq[j + 1] = "C", "G"
+        flag = [0, 16, 0, 16, 0x800, 0x800 | 16, 0x100, 0x400, 0x4, 0, 16, 0, 16, 0][i % 14]
+        mapq = int([60, 60, 0, 5, 60, 60, 60, 60, 0, 1, 20, 60, 60, 3][i % 14])
+        kin = lambda: rng.integers(0, 256, L).astype(np.uint8)  # noqa: E731
+        out.append(("a%d" % i, flag, mapq, cigar, "".join(seq), kin(), kin(), kin(), kin(), int(rng.integers(3, 30)), int(rng.integers(3, 30))))
+    return out

@@ -117,6 +117,11 @@ void ccsm_bam_modcalls_free(ccsm_bam_modcalls* c);
 int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads, int* sorted, int64_t* n_records);
 int ccsm_bam_sort(const char* in_path, const char* out_path, int threads, int level, int64_t max_bytes);
 
+/* Per record of a batch, what --mode align of extract_features.py needs besides FLAG (extract_features.py:88-126, 272-304):
+ * MAPQ, pysam's query_alignment_start / query_alignment_end (soft clips excluded, hard clips are not in SEQ) and the CIGAR
+ * identity (M + =) / (M+I+D+N+P+=+X+B) of process_utils.py:174-186 (0 for an empty CIGAR). */
+int ccsm_bam_align_info(const ccsm_bam_batch* b, int32_t* mapq, int32_t* qstart, int32_t* qend, double* identity);
+
 #ifdef __cplusplus
 }
 #endif

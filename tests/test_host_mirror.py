@@ -107,8 +107,9 @@ def test_call_mods_cli_matches_reference_parser():
         assert bool(ours[dest].required) == g["required"], dest
     base = ["-i", "a.bam", "-m", "m.ckpt", "-o", "out"]
     _check_scope(build_parser().parse_args(base + ["-p", "4", "--threads_call", "2", "--no_sort", "--keep_pulse"]))
-    for extra in (["--seq_len", "20"], ["--mode", "align"], ["--is_sn", "yes"], ["--model_type", "attbilstm2s"], ["--motifs", "CHG"],
-                  ["--norm", "min-max"], ["--no_decode"], ["--hid_rnn", "128"], ["--ref", "g.fa"]):
+    _check_scope(build_parser().parse_args(base + ["--mode", "align", "--mapq", "10", "--identity", "0.9", "--no_supplementary", "--skip_unmapped", "no"]))
+    for extra in (["--seq_len", "20"], ["--mode", "reference"], ["--is_sn", "yes"], ["--model_type", "attbilstm2s"], ["--motifs", "CHG"],
+                  ["--norm", "min-max"], ["--no_decode"], ["--hid_rnn", "128"], ["--mode", "align", "--ref", "/nonexistent/g.fa"], ["--is_map", "yes"]):
         with pytest.raises(ValueError):
             _check_scope(build_parser().parse_args(base + extra))
     assert isinstance(build_parser(), argparse.ArgumentParser)
