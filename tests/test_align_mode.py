@@ -98,3 +98,51 @@ def test_call_mods_align_mode_end_to_end(io, tmp_path):
             deltas = [int(x) for x in o.get_tag("MM")[len("C+m?,"):-1].split(",")]
             got = cs[np.cumsum(np.array(deltas) + 1) - 1].tolist()
             assert got == want and len(o.get_tag("ML")) == len(want), (case, name)
+
+
+# ---- `extract`: the feature table trainm reads, text-identical to the reference's writer --------------------------------
+@pytest.mark.parametrize("case", sorted(GOLD["cases"]))
+def test_extract_table_is_the_reference_text(case, tmp_path):
+    import hashlib
+    from ccsmeth_amd import extract_cli as ex
+    path = str(tmp_path / "a.bam")
+    _write_bam(path)
+    over = GOLD["cases"][case]["args"]
+    argv = ["-i", path, "-o", str(tmp_path / "f.tsv"), "--ref", path] + (["--mode", "align"] if "mode" not in over else [])
+    for k, v in over.items():
+        argv += ["--" + k] + ([] if v is True else [str(v)])
+    res = ex.extract_hifireads_features(ex.build_parser().parse_args(argv), log=open(os.devnull, "w"))
+    by_read = {}
+    with open(res["output"]) as rf:
+        for line in rf:
+            by_read.setdefault(line.split("\t")[3], []).append(line)
+    for name, gl in GOLD["cases"][case]["lines"].items():
+        lines = by_read.get(name, [])
+        assert [int(x.split("\t")[1]) for x in lines] == gl["pos"], (case, name)
+        if lines:
+            assert lines[0].rstrip("\n") == gl["first"], (case, name)
+        assert hashlib.sha256("".join(lines).encode()).hexdigest() == gl["sha256"], (case, name)
+    assert res["sites"] == sum(len(v) for v in GOLD["cases"][case]["locs"].values())
+
+
+def test_extract_cli_flags_gzip_and_feeds_trainm_reader(tmp_path):
+    import gzip
+    from ccsmeth_amd import extract_cli as ex
+    from ccsmeth_amd import trainm
+    cli = json.load(open(os.path.join(GOLDEN, "cli_golden.json")))["extract"]
+    ours = {a.dest: a for a in ex.build_parser()._actions if a.dest != "help"}
+    for dest, g in cli.items():
+        assert dest in ours and sorted(ours[dest].option_strings) == sorted(g["options"]) and ours[dest].default == g["default"], dest
+    path = str(tmp_path / "a.bam")
+    _write_bam(path)
+    res = ex.extract_hifireads_features(ex.build_parser().parse_args(["-i", path, "--gzip", "--methy_label", "0"]), log=open(os.devnull, "w"))
+    assert res["output"] == str(tmp_path / "a.features.tsv.gz")
+    with gzip.open(res["output"], "rt") as rf, open(str(tmp_path / "plain.tsv"), "w") as wf:
+        wf.write(rf.read())
+    d = trainm.read_feature_file(str(tmp_path / "plain.tsv"))
+    assert len(d["labels"]) == res["sites"] and set(d["labels"].tolist()) == {0} and d["kmer1"][:, 10].tolist() == [1] * res["sites"]
+    for bad in (["--seq_len", "20"], ["--mode", "align"], ["--norm", "mad"], ["--is_map", "yes"], ["--motifs", "GATC"]):
+        with pytest.raises(ValueError):
+            ex.extract_hifireads_features(ex.build_parser().parse_args(["-i", path] + bad))
+    with pytest.raises(IOError):
+        ex.extract_hifireads_features(ex.build_parser().parse_args(["-i", str(tmp_path / "none.bam")]))

@@ -219,3 +219,49 @@ def test_graph_replay_of_the_step_equals_eager(monkeypatch):
         assert abs(la - lb) < 1e-5 and np.abs(lo_a - lo_b).max() < 1e-4 and np.abs(ga - gb).max() <= 1e-4 * np.abs(ga).max() and abs(na - nb) < 1e-3 * na
     assert np.allclose([x[0] for x in eager], [x[0] for x in graph], rtol=2e-2)       # later steps: fp32 reduction order only
     assert abs(e1[0] - g1[0]) < 2e-2 and abs(e2[0] - g2[0]) < 2e-2
+
+
+def test_whole_chain_bam_extract_trainm_call_mods(tmp_path):
+    """The reference's workflow end to end without the reference: HiFi BAM -> `extract` (two label classes) -> `trainm` ->
+    checkpoint -> `call_mods` -> modbam whose ML values follow the class the model was trained to separate."""
+    from ccsmeth_amd import bamio, extract_cli, trainm
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    rng = np.random.default_rng(5)
+
+    def write_bam(path, shift, n_reads=24):
+        with bamio.BamWriter(path, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
+            for i in range(n_reads):
+                L = int(rng.integers(900, 1500))
+                seq = rng.choice(list("ACGT"), size=L)
+                for j in range(11, L - 12, 19):
+                    seq[j], seq[j + 1] = "C", "G"
+                kin = lambda s: np.clip(rng.gamma(2.0, 12.0, size=L) + s, 0, 255).astype(np.uint8)  # noqa: E731
+                fi, ri = kin(0), kin(0)
+                cg = np.flatnonzero((seq[:-1] == "C") & (seq[1:] == "G"))
+                fi[cg] = np.clip(fi[cg].astype(int) + shift, 0, 255)                 # the "methylated" class: slower IPD at the C
+                w.write(bamio.BamRecord("m/%d/ccs" % (i + 1000 * shift), flag=4, seq="".join(seq),
+                                        tags=[("fi", "BC", fi), ("ri", "BC", ri), ("fp", "BC", kin(0)), ("rp", "BC", kin(0)), ("fn", "C", 10), ("rn", "C", 11)]))
+    tables = []
+    for label, shift in ((0, 0), (1, 60)):
+        bam = str(tmp_path / ("c%d.bam" % label))
+        write_bam(bam, shift)
+        res = extract_cli.extract_hifireads_features(extract_cli.build_parser().parse_args(["-i", bam, "--methy_label", str(label)]), log=open(os.devnull, "w"))
+        tables.append(open(res["output"]).read().splitlines(True))
+    lines = tables[0] + tables[1]
+    order = rng.permutation(len(lines))
+    cut = int(0.85 * len(lines))
+    open(str(tmp_path / "train.tsv"), "w").writelines(lines[i] for i in order[:cut])
+    open(str(tmp_path / "valid.tsv"), "w").writelines(lines[i] for i in order[cut:])
+    res = trainm.train(trainm.build_parser().parse_args(["--train_file", str(tmp_path / "train.tsv"), "--valid_file", str(tmp_path / "valid.tsv"),
+                                                         "--model_dir", str(tmp_path / "m"), "--max_epoch_num", "25", "--min_epoch_num", "25",
+                                                         "--lr_decay", "1.0", "--batch_size", "256"]), log=open(os.devnull, "w"))
+    assert res["best_acc"] > 0.85, res
+    ckpt = str(tmp_path / "m" / ("attbigru2s.b21_epoch%d.ckpt" % res["best_epoch"]))
+    means = []
+    for label in (0, 1):
+        out = call_mods(build_parser().parse_args(["-i", str(tmp_path / ("c%d.bam" % label)), "-m", ckpt, "-o", str(tmp_path / ("o%d" % label))]),
+                        log=open(os.devnull, "w"))
+        with bamio.BamReader(out["output"]) as rd:
+            ml = np.concatenate([r.get_tag("ML") for r in rd if r.has_tag("ML")])
+        means.append(float(ml.mean()))
+    assert means[1] > means[0] + 100, means                     # ML bytes: the trained model separates the two classes
