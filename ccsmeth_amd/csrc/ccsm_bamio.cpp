@@ -832,7 +832,10 @@ int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads
         if (tid < 0) { ++n_no_coor; }
         if (tid >= 0) {
             RefIndex& ri = refs[(size_t)tid];
-            const int64_t b = pos < 0 ? 0 : pos, e = (flag & 4) || reflen == 0 ? b + 1 : b + reflen;
+            const int64_t b = pos < 0 ? 0 : pos;
+            int64_t e = (flag & 4) || reflen == 0 ? b + 1 : b + reflen;
+            if (b >= (1LL << 29)) { rc = fail("record position beyond the range of a BAI index (2^29)"); break; }
+            if (e > (1LL << 29)) e = 1LL << 29;
             const int bin = reg2bin(b, e);
             if (bin != save_bin || tid != save_tid) {
                 last_off = beg_off;

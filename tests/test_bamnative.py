@@ -382,3 +382,51 @@ def test_index_of_unaligned_bam_and_errors(tmp_path):
             w.write(bamio.BamRecord("b", flag=0, ref_id=0, pos=100, cigar=[(0, 4)], seq="ACGT"))
         bamnative.load().ccsm_bam_sort  # noqa: B018
         bamnative._check(bamnative.load().ccsm_bam_sort(p2.encode(), (p2 + ".s").encode(), 1, 6, 10))
+
+
+def test_modcalls_index_sort_survive_corrupted_records(tmp_path):
+    """The same byte-corruption fuzz over the newer parsers: ccsm_bam_modcalls_of_batch (MM/ML, CIGAR walk, with and without
+    reference site masks), ccsm_bam_align_info, ccsm_bam_index_build and ccsm_bam_sort either work or raise IOError."""
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    script = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from ccsmeth_amd import bamio, bamnative
+rng = np.random.default_rng(9)
+src, mut, outp = %r, %r, %r
+raw = b"".join(bamio.bgzf_blocks(open(src, "rb")))
+masks = [np.ones(6000, np.uint8) * 3, np.ones(5200, np.uint8) * 3, None]
+ok = err = rows = 0
+for trial in range(120):
+    b = bytearray(raw)
+    lo = 200 if trial %% 3 else 0                      # most trials leave the header intact so that records are reached
+    for _ in range(int(rng.integers(1, 8))):
+        b[int(rng.integers(lo, len(b)))] = int(rng.integers(0, 256))
+    with open(mut, "wb") as f:
+        for i in range(0, len(b), 0xff00):
+            f.write(bamio.bgzf_compress_block(bytes(b[i:i + 0xff00]), 1))
+        f.write(bamio._BGZF_EOF)
+    try:
+        with bamnative.NativeBamReader(mut, threads=2) as rd:
+            while True:
+                bt = rd.next_batch(16)
+                if bt is None:
+                    break
+                for kw in (dict(), dict(refsites_all=True, site_masks=masks[:rd.n_ref] + [None] * max(0, rd.n_ref - 3), base_clip=3)):
+                    out = bamnative.modcalls_of_batch(bt, threads=2, **kw)
+                    rows += len(out[0])
+                    assert all(len(a) == len(out[0]) for a in out[:5])
+                bamnative.align_info(bt)
+                bt.close()
+        bamnative.index_build(mut, mut + ".bai", threads=2)
+        bamnative._check(bamnative.load().ccsm_bam_sort(mut.encode(), outp.encode(), 2, 1, 1 << 28))
+        ok += 1
+    except IOError:
+        err += 1
+print("ok", ok, "ioerror", err, "rows", rows)
+assert ok + err == 120 and ok > 0 and rows > 10000
+''' % (ROOT, os.path.join(GOLDEN, "freqb", "aligned.modbam.bam"), str(tmp_path / "mut.bam"), str(tmp_path / "out.bam"))
+    res = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
