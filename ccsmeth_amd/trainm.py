@@ -68,6 +68,21 @@ def build_parser():
     return p
 
 
+def build_train_parser():
+    """ccsmeth.py `train` (single process; the reference wraps the model in nn.DataParallel, train.py:128-130): the same flags
+    without the launcher options, plus --dl_offsets (how the reference's data loader seeks lines; the table is loaded whole here).
+    Runs the same trainer on one GPU."""
+    p = build_parser()
+    p.prog = "ccsmeth_amd train"
+    for dest in ("nodes", "ngpus_per_node", "dist_url", "node_rank", "epoch_sync"):
+        act = next(a for a in p._actions if a.dest == dest)
+        p._remove_action(act)
+        for o in act.option_strings:
+            p._option_string_actions.pop(o, None)
+    p.add_argument('--dl_offsets', action="store_true", default=False)
+    return p
+
+
 def _yes(v):
     return str(v).lower() in ("yes", "true", "t", "1")
 
@@ -324,3 +339,7 @@ def _save(trainer, path):
 
 def main(argv=None):
     train(build_parser().parse_args(argv))
+
+
+def main_train(argv=None):
+    train(build_train_parser().parse_args(argv))

@@ -1,4 +1,4 @@
-"""Fixture: flags and defaults of the reference's `ccsmeth call_mods`, `call_freqb`, `trainm` and `extract` sub-parsers (ccsmeth/ccsmeth.py), captured by
+"""Fixture: flags and defaults of the reference's `ccsmeth call_mods`, `call_freqb`, `trainm`, `train` and `extract` sub-parsers (ccsmeth/ccsmeth.py), captured by
 running the reference's own main() argument parser in THIS container (reference importable here only).
 Writes tests/golden/cli_golden.json.  usage: python tests/golden/make_cli_golden.py"""
 import argparse
@@ -45,6 +45,7 @@ def flags_of(sub):
 
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cli_golden.json")
 doc = dict(source="ccsmeth/ccsmeth.py sub-parsers", flags=flags_of(choices["call_mods"]), call_freqb=flags_of(choices["call_freqb"]),
-           trainm=flags_of(choices["trainm"]), extract=flags_of(choices["extract"]))
+           trainm=flags_of(choices["trainm"]), extract=flags_of(choices["extract"]),
+           train=flags_of(choices["train"]))
 json.dump(doc, open(out, "w"), indent=1, sort_keys=True)
 print("wrote", out, {k: len(v) for k, v in doc.items() if k != "source"})

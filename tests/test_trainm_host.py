@@ -29,6 +29,8 @@ def test_trainm_and_call_freqb_cli_match_reference_parsers():
     from ccsmeth_amd.call_mods_freq_bam import build_freqb_parser
     _same_flags(trainm.build_parser(), CLI["trainm"])
     _same_flags(build_freqb_parser(), CLI["call_freqb"])
+    _same_flags(trainm.build_train_parser(), CLI["train"])
+    assert not any(a.dest in ("nodes", "node_rank", "dist_url") for a in trainm.build_train_parser()._actions)
     base = ["--train_file", "t", "--valid_file", "v", "--model_dir", "d"]
     trainm.check_scope(trainm.build_parser().parse_args(base))
     for extra in (["--model_type", "attbilstm2s"], ["--optim_type", "SGD"], ["--is_sn", "yes"], ["--hid_rnn", "128"],
