@@ -470,8 +470,7 @@ def call_mods_frequency_from_bamfile(args, log=sys.stderr, model=None):
         if args.sort or args.gzip:
             _sort_bed_file(p)
         if args.gzip:
-            _bgzip_file(p)
-            log.write("[call_freqb] {}.gz is BGZF (tabix-ready); the .tbi index is not written by this build\n".format(p))
+            _bgzip_and_tabix(p)
     log.write("[call_freqb] {} records ({} used), {} sites, {:.1f} s\n".format(n_rec, n_used, n_sites, time.time() - t0))
     return n_sites
 
@@ -485,16 +484,99 @@ def _sort_bed_file(path):
         wf.writelines(lines)
 
 
-def _bgzip_file(path):
-    """--gzip (:659-663): BGZF-compress to <path>.gz and remove the original (keep_original=False)."""
+def _reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def _reg2bins(beg, end):
+    """Bins that may hold records overlapping [beg, end) (SAM spec 5.3)."""
+    end -= 1
+    out = [0]
+    for shift, base in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        out += list(range(base + (beg >> shift), base + (end >> shift) + 1))
+    return out
+
+
+def _bgzip_and_tabix(path):
+    """--gzip (call_mods_freq_bam.py:659-663: pysam.tabix_index(bedfile, force=True, preset="bed", keep_original=False)):
+    BGZF-compress the (sorted) file to <path>.gz, write the tabix index <path>.gz.tbi (TBI v1: UCSC/BED preset = sequence, begin,
+    end in columns 1-3, 0-based half-open; binning + 16 kb linear index over BGZF virtual offsets) and remove the original."""
+    import struct
     from .bamio import bgzf_compress_block
     eof = bytes([0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0])
-    with open(path, "rb") as rf, open(path + ".gz", "wb") as wf:
-        while True:
-            data = rf.read(0xff00)
-            if not data:
-                break
-            wf.write(bgzf_compress_block(data))
+    with open(path, "rb") as rf:
+        data = rf.read()
+    blk = 0xff00
+    starts, coffs = [], []
+    with open(path + ".gz", "wb") as wf:
+        for i in range(0, len(data), blk):
+            starts.append(i)
+            coffs.append(wf.tell())
+            wf.write(bgzf_compress_block(data[i:i + blk]))
+        end_coff = wf.tell()
+        wf.write(eof)
+
+    def voff(p):
+        if p >= len(data):
+            return end_coff << 16
+        k = p // blk
+        return (coffs[k] << 16) | (p - starts[k])
+    names, idx = [], {}
+    pos = 0
+    prev = None
+    for line in data.split(b"\n"):
+        ln = len(line) + 1
+        if line and not line.startswith(b"#"):
+            f = line.split(b"\t", 3)
+            name, beg, end = f[0].decode(), int(f[1]), int(f[2])
+            if name not in idx:
+                if prev is not None and name in names:
+                    raise ValueError("the file is not sorted by sequence name")
+                names.append(name)
+                idx[name] = dict(bins={}, lin=[], n=0, beg=voff(pos), end=0)
+            elif name != prev:
+                raise ValueError("the file is not sorted by sequence name")
+            d = idx[name]
+            v0, v1 = voff(pos), voff(pos + ln)
+            end = max(end, beg + 1)
+            chunks = d["bins"].setdefault(_reg2bin(beg, end), [])
+            if chunks and chunks[-1][1] == v0:
+                chunks[-1][1] = v1                                # adjacent records of a bin form one chunk
+            else:
+                chunks.append([v0, v1])
+            w1 = (end - 1) >> 14
+            if len(d["lin"]) <= w1:
+                d["lin"] += [None] * (w1 + 1 - len(d["lin"]))
+            for w in range(beg >> 14, w1 + 1):
+                if d["lin"][w] is None:
+                    d["lin"][w] = v0
+            d["n"] += 1
+            d["end"] = v1
+            prev = name
+        pos += ln
+    out = bytearray(b"TBI\x01")
+    nm = b"".join(n.encode() + b"\x00" for n in names)
+    out += struct.pack("<8i", len(names), 0x10000, 1, 2, 3, ord("#"), 0, len(nm)) + nm
+    for n in names:
+        d = idx[n]
+        out += struct.pack("<i", len(d["bins"]) + 1)
+        for b_, chunks in sorted(d["bins"].items()):
+            out += struct.pack("<Ii", b_, len(chunks))
+            for c0, c1 in chunks:
+                out += struct.pack("<QQ", c0, c1)
+        out += struct.pack("<IiQQQQ", 37450, 2, d["beg"], d["end"], d["n"], 0)      # htslib's metadata pseudo-bin
+        lin = d["lin"]
+        for w in range(len(lin) - 1, -1, -1):
+            if lin[w] is None:
+                lin[w] = lin[w + 1] if w + 1 < len(lin) else 0
+        out += struct.pack("<i", len(lin)) + struct.pack("<%dQ" % len(lin), *lin)
+    with open(path + ".gz.tbi", "wb") as wf:
+        for i in range(0, len(out), blk):
+            wf.write(bgzf_compress_block(bytes(out[i:i + blk])))
         wf.write(eof)
     os.remove(path)
 
