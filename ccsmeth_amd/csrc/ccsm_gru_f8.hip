@@ -72,6 +72,28 @@ __device__ __forceinline__ uint32_t cvt4_fp8_l(uint32_t seed, float a, float b, 
     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, 1.0f / kCorrActLo, true);
     return __builtin_bit_cast(uint32_t, r);
 }
+// 16 bytes per lane from global memory straight into LDS (lane l lands at lds_base + 16 l), issued as inline assembly ON PURPOSE:
+// for the builtin the compiler cannot tell which LDS bytes the transfer writes and puts an s_waitcnt vmcnt(0) in front of every
+// later ds_read, i.e. the chunk being prefetched had to land before the chunk already in LDS could be multiplied.  The caller
+// orders the transfer itself: s_waitcnt vmcnt(0) (wait_dma) before the barrier that publishes the buffer.
+// (m0 carries the LDS address; nothing else in these kernels uses m0, and the compiler does not accept it as a clobber.)
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
+}
+// the same through a buffer descriptor: wave-uniform byte offset `soff` in an SGPR, per-lane offset `voff` in ONE VGPR (no 64-bit
+// per-lane address pair)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t dma_rsrc(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    return u32x4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)b), (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) & 0xffffu,
+                   0x7fffffffu, 0x00020000u};
+}
+__device__ __forceinline__ void dma16_buf(u32x4_t rsrc, int voff, int soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ float tanh_fold(float x) {    // 1 - 2 / (e^{2x} + 1) with the doubling folded into the exp2 constant
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f);
 }
@@ -181,45 +203,39 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
     }
 
     // ---- x staging (as gru_layer_v2_kernel): fragment f = (kbl*NB + bt)*2 + hl of chunk c of timestep t
-    static_assert(SPW <= 3, "staging registers");
-    uint4 sreg0, sreg1, sreg2;
+    // x staging: LDS-DMA (dma16: global -> LDS without a register hop), issued where the register loads used to be; stage_wait<N>
+    // stands where the ds_write used to be: N = vector-memory loads this wave issued after the transfer (they may stay in flight).
+    static_assert(SPW <= 3, "staging transfers per wave");
     const int lane16 = lane * 16;
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xin);
+    const u32x4_t xrs = dma_rsrc(xin);
+    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_x;
     auto stage_off = [&](int t, int c, int i) -> int {
         const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
         const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
         return (((((tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) << 10);
     };
-    auto stage_dst = [&](int buf, int i) -> uint4* {
+    auto stage_dst = [&](int buf, int i) -> unsigned {
         const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
-        return reinterpret_cast<uint4*>(s_x + ((buf * CHF + f) << 10) + lane * 16);
+        return sx_base + (unsigned)((buf * CHF + f) << 10);
     };
-    auto stage_load = [&](int t, int c) {
+    auto stage_load = [&](int t, int c, int buf) {
 #if defined(CCSM_EXP) && CCSM_EXP == 1
         t = 0; c = 0;                               // timing experiment: always the same (L2-resident) chunk
 #endif
 #if defined(CCSM_EXP) && (CCSM_EXP == 2 || CCSM_EXP == 4)
         return;                                     // timing experiment: no staging traffic at all
 #endif
-        auto ldx = [&](int soff) { return buf_load(xrs, lane16, soff); };   // (nt on these loads: no change in step cycles)
-        sreg0 = ldx(stage_off(t, c, 0));
-        if constexpr (SPW > 1) sreg1 = ldx(stage_off(t, c, 1));
-        if constexpr (SPW > 2) sreg2 = ldx(stage_off(t, c, 2));
+#pragma unroll
+        for (int i = 0; i < SPW; ++i)
+            dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(stage_off(t, c, i)), __builtin_amdgcn_readfirstlane(stage_dst(buf, i)));
     };
-    auto stage_store = [&](int buf) {
-#if defined(CCSM_EXP) && (CCSM_EXP == 2 || CCSM_EXP == 4)
-        return;
-#endif
-        *stage_dst(buf, 0) = sreg0;
-        if constexpr (SPW > 1) *stage_dst(buf, 1) = sreg1;
-        if constexpr (SPW > 2) *stage_dst(buf, 2) = sreg2;
-    };
+#define CCSM_STAGE_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4);
     const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
 
-    stage_load(dir ? kSeqLen - 1 : 0, 0);
-    stage_store(0);
+    stage_load(dir ? kSeqLen - 1 : 0, 0, 0);
+    CCSM_STAGE_WAIT(0);
 
 #if defined(CCSM_EXP) && (CCSM_EXP == 3 || CCSM_EXP == 4)
     auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, (frag & 3) << 10); };   // timing experiment: L1-resident weights
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         rdx(xh1, buf, 2 * (P) + 1, 0);                                                                         \
         CCSM_MAIN(wah[P][0], xh, 2, 0);                                                                        \
         L1;                                                                                                    \
-        if ((P) == 0) stage_load(t, more ? c + 1 : 0);        /* after the weight prefetch: younger in vmcnt */ \
+        if ((P) == 0) stage_load(t, more ? c + 1 : 0, (c + 1) & 1);   /* after the weight prefetch: younger in vmcnt */ \
         rdx(xc[0], buf, 2 * (P), 1);                                                                           \
         rdx(xc[1], buf, 2 * (P) + 1, 1);                                                                       \
         CCSM_MAIN(wah[P][1], xh1, 2, 0);                                                                       \
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                 rdx(xh, buf, 0, 0);
                 CCSM_PAIR_A(0, ldAh(wah[0][0], k0), ldAh(wah[0][1], k0 + 1), { ldAc(wac[0][0], k0); ldAc(wac[0][1], k0 + 1); })
                 CCSM_PAIR_A(1, ldAh(wah[1][0], k0 + 2), ldAh(wah[1][1], k0 + 3), { ldAc(wac[1][0], k0 + 2); ldAc(wac[1][1], k0 + 3); })
-                stage_store((c + 1) & 1);
+                CCSM_STAGE_WAIT(14);                           // 2 + 4 + 2 + 2 + 4 weight fragments were requested after the transfer
             }
             {   // last chunk: its ring slots are refilled with phase B's first pair instead of fragments past the end
                 constexpr int c = NCH - 1;
@@ -371,14 +387,17 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                 rdx(xh, buf, 0, 0);
                 CCSM_PAIR_A(0, (void)0, (void)0, { ldBh(wbh[0], 0); ldBh(wbh[1], 1); })
                 CCSM_PAIR_A(1, ldBc(wbc[0], 0), ldBc(wbc[1], 1), (void)0)
-                stage_store((c + 1) & 1);                      // C chunk 0 into buffer NCH & 1 == 0
+                CCSM_STAGE_WAIT(12);                           // C chunk 0 into buffer NCH & 1 == 0; 6 + 3 + 3 phase-B fragments after it
             }
 #undef CCSM_PAIR_A
         } else {
             // layer 0: one k-block (11 features padded to 16), three fp16 passes, [hi|lo] fragments on both sides
             uint4 x0[NB][2];
+            // the transfer of this step's x (issued one step ago) is older than the 16 weight fragments and 12 output stores the
+            // previous tail issued: once at most those are outstanding it has landed
+            CCSM_STAGE_WAIT(28);
             __syncthreads();
-            stage_load(tn, 0);
+            stage_load(tn, 0, (s + 1) & 1);
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + lane * 16);
@@ -394,7 +413,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                     acc[g][bt] = mfma16(wac[0][0][g], x0[bt][0], acc[g][bt]);
                 }
             CCSM_FENCE;
-            stage_store((s + 1) & 1);
         }
 
         stamp(1);
@@ -473,11 +491,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         const int buf = (C) & 1;                                                                               \
         const bool more = (C) + 1 < NCH;                                                                       \
         LNEXT;                                                                                                 \
-        stage_load(more ? t : tn, more ? (C) + 1 : 0);   /* next C chunk / next step's first A chunk */        \
+        stage_load(more ? t : tn, more ? (C) + 1 : 0, ((C) + 1) & 1);   /* next C chunk / next step's first A chunk */ \
         rdx(xh, buf, 0, 0);                                                                                    \
         CCSM_PAIR_C(CUR, 0)                                                                                    \
         CCSM_PAIR_C(CUR, 1)                                                                                    \
-        stage_store(((C) + 1) & 1);                                                                            \
+        CCSM_STAGE_WAIT(0);                                                                                    \
     }
 #pragma unroll 1
             for (int c2 = 0; c2 < NCH - 2; c2 += 2) {
@@ -664,8 +682,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             if (f < CHUNK_FRAGS) {
                 const int hl = f & 1, tt = (f >> 1) % TG, kbl = (f >> 1) / TG;
                 const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024),
-                                                 16, 0, 0);
+                dma16(src, __builtin_amdgcn_readfirstlane(
+                               (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024)));
             }
         }
     };
@@ -691,7 +709,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             uint4 w[CK][2];
 #pragma unroll
             for (int kbl = 0; kbl < CK; ++kbl) { w[kbl][0] = wu[kbl][0]; w[kbl][1] = wu[kbl][1]; }
-            __syncthreads();   // chunk c has landed; buffer (c+1)&1 is free
+            wait_dma();        // this wave's part of chunk c (and the Ua fragments above) has arrived ...
+            __syncthreads();   // ... and so has everybody else's: chunk c is in LDS; buffer (c+1)&1 is free
             if (c + 1 < NCHUNK) stage(t0, c + 1, (c + 1) & 1);
             {
                 const int cn = c + 1 < NCHUNK ? c + 1 : 0;       // Ua is re-streamed for every timestep group
