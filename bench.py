@@ -34,7 +34,7 @@ PEAK_HBM = 8.0e12
 # shape (profiles/r01_c_pmc_coalesced.md: 2 x FETCH_SIZE + WRITE_SIZE, KiB, gfx950 read correction per MI355X_MICROARCH.md).
 # PMC counters cannot be read from inside this process; the figure is per-launch like `achieved` and scales with sites.
 TRAFFIC_BYTES_PER_SITE_GRU12 = {3: (2 * 1241546 + 516096) * 1024 / 6144.0,      # profiles/r01_c_pmc_coalesced.md
-                                4: (2 * 1257700 + 518660) * 1024 / 6144.0}      # profiles/r01_i_pmc_coalesced.md; other modes: null
+                                4: (2 * 1252400 + 518150) * 1024 / 6144.0}      # profiles/r01_l_pmc_coalesced.md; other modes: null
 
 
 def parse():
@@ -191,7 +191,7 @@ def main():
                          "frac": achieved / PEAK_F16_MFMA,
                          "traffic": TRAFFIC_BYTES_PER_SITE_GRU12.get(a.precision, 0) * sites_per_launch or None,
                          "traffic_source": "profiles/r01_%s_pmc_coalesced.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on a 6144-site launch, "
-                                           "scaled per site)" % ("i" if a.precision == 4 else "c"),
+                                           "scaled per site)" % ("l" if a.precision == 4 else "c"),
                          "launch_ms": dom_ms, "mfma_passes_per_flop": passes,
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,
                          "note": "achieved = algorithmic flops of one launch (%d sites x 99.09 MFLOP) / its HIP-event "
