@@ -164,7 +164,8 @@ def main():
     nruns = sum(n for _, n in tms)
     kt = np.sum([np.array(t) * n for t, n in tms], axis=0) / max(nruns, 1)     # ms: gru0, gru1, gru2, attn, finalize
     dom_ms = float(kt[1:3].mean())
-    sites_per_launch = a.steps * BATCH / max(nruns, 1)      # = BATCH * coalesce when steps is a multiple of it
+    launches = -(-a.steps // grp)                           # group runs in the timed region (the timers keep the last 128 of them)
+    sites_per_launch = a.steps * BATCH / launches           # = BATCH * coalesce when steps is a multiple of it
     assert bool(torch.isfinite(outs[0][0][1]).all())
 
     if rank == 0:
