@@ -72,28 +72,6 @@ __device__ __forceinline__ uint32_t cvt4_fp8_l(uint32_t seed, float a, float b, 
     r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(r, c, d, 1.0f / kCorrActLo, true);
     return __builtin_bit_cast(uint32_t, r);
 }
-// 16 bytes per lane from global memory straight into LDS (lane l lands at lds_base + 16 l), issued as inline assembly ON PURPOSE:
-// for the builtin the compiler cannot tell which LDS bytes the transfer writes and puts an s_waitcnt vmcnt(0) in front of every
-// later ds_read, i.e. the chunk being prefetched had to land before the chunk already in LDS could be multiplied.  The caller
-// orders the transfer itself: s_waitcnt vmcnt(0) (wait_dma) before the barrier that publishes the buffer.
-// (m0 carries the LDS address; nothing else in these kernels uses m0, and the compiler does not accept it as a clobber.)
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
-}
-// the same through a buffer descriptor: wave-uniform byte offset `soff` in an SGPR, per-lane offset `voff` in ONE VGPR (no 64-bit
-// per-lane address pair)
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4_t dma_rsrc(const void* base) {
-    const unsigned long long b = (unsigned long long)base;
-    return u32x4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)b), (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) & 0xffffu,
-                   0x7fffffffu, 0x00020000u};
-}
-__device__ __forceinline__ void dma16_buf(u32x4_t rsrc, int voff, int soff, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
-                 : "memory");
-}
-__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 __device__ __forceinline__ float tanh_fold(float x) {    // 1 - 2 / (e^{2x} + 1) with the doubling folded into the exp2 constant
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f);
 }

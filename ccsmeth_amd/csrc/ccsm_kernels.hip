@@ -47,6 +47,28 @@ __device__ __forceinline__ uint4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ void buf_store(uint4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
+// 16 bytes per lane from global memory straight into LDS (lane l lands at lds_base + 16 l), issued as inline assembly ON PURPOSE:
+// for the builtin the compiler cannot tell which LDS bytes the transfer writes and puts an s_waitcnt vmcnt(0) in front of every
+// later ds_read, i.e. the chunk being prefetched had to land before the chunk already in LDS could be multiplied.  The caller
+// orders the transfer itself: s_waitcnt vmcnt(0) (wait_dma) before the barrier that publishes the buffer.
+// (m0 carries the LDS address; nothing else in these kernels uses m0, and the compiler does not accept it as a clobber.)
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
+}
+// the same through a buffer descriptor: wave-uniform byte offset `soff` in an SGPR, per-lane offset `voff` in ONE VGPR (no 64-bit
+// per-lane address pair)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t dma_rsrc(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    return u32x4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)b), (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) & 0xffffu,
+                   0x7fffffffu, 0x00020000u};
+}
+__device__ __forceinline__ void dma16_buf(u32x4_t rsrc, int voff, int soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
+                 : "memory");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ half8 as_half8(uint4 v) { return __builtin_bit_cast(half8, v); }
 __device__ __forceinline__ half4 as_half4(uint2 v) { return __builtin_bit_cast(half4, v); }
 
@@ -820,8 +842,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
             if (f < CHUNK_FRAGS) {
                 const int hl = f & 1, tt = (f >> 1) % TG, kbl = (f >> 1) / TG;
                 const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
-                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024),
-                                                 16, 0, 0);
+                dma16(src, __builtin_amdgcn_readfirstlane(
+                               (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024)));
             }
         }
     };
@@ -848,6 +870,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
             uint4 w[CK][2];
 #pragma unroll
             for (int kbl = 0; kbl < CK; ++kbl) { w[kbl][0] = wu[kbl][0]; w[kbl][1] = wu[kbl][1]; }
+            wait_dma();        // this wave's part of chunk c has arrived (see dma16)
             __syncthreads();   // chunk c has landed; buffer (c+1)&1 is free
             if (c + 1 < NCHUNK) stage(t0, c + 1, (c + 1) & 1);
             {
