@@ -41,7 +41,7 @@ constexpr int kNBGru2 = 3;   // ... of the version-2 GRU kernel (default)
 constexpr int kRowPad = 32 * kNBGru * kNBGru2;  // rows are padded so that either kernel tiles them exactly
 constexpr int gru2_lds(int kx) { return (kKBH * kNBGru2 * 2 + 2 * (kx >= 4 ? 4 : kx) * kNBGru2 * 2) * 1024; }
 // attention kernel dynamic LDS: 2 staging buffers x 28 KiB + e partials + fc partials + fc1.weight
-constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kWaves * kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4;
+constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kWaves * kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4;   // staging, e / fc partials, fc1.weight, va
 
 inline int rows_padded(int n_sites) { return ((2 * n_sites + kRowPad - 1) / kRowPad) * kRowPad; }
 

@@ -590,6 +590,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     float* s_epart = reinterpret_cast<float*>(smem + 2 * CHUNK_FRAGS * 1024);  // [wave][t][32]
     float* s_pfc = s_epart + kWaves * kSeqLen * 32;                            // [wave][t][32][2]
     float* s_fcw = s_pfc + kWaves * kSeqLen * 32 * 2;                          // [2][1024]
+    float* s_va = s_fcw + kClasses * 4 * kHidden;                              // [256]: in LDS, the 16 registers go to the operand pipeline
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -597,6 +598,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     const int n = lane & 31, hh = lane >> 5;
 
     for (int i = threadIdx.x; i < kClasses * 4 * kHidden; i += blockDim.x) s_fcw[i] = fcw[i];
+    if (threadIdx.x < kHidden) s_va[threadIdx.x] = va[threadIdx.x];
     // dbg (normally NULL): workgroup 0 records the cycle counter per wave: [wave][0 start, 1 q done, 2+2g chunks of group g done,
     // 3+2g epilogue of group g done, 8 end]
     auto stamp = [&](int i) {
@@ -638,9 +640,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             asm volatile("" ::: "memory");
         }
     }
-    float vav[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) vav[r] = va[(wave * 2 + hh) * 16 + r];
     int strand = 0;   // which half of fc1.weight this lane's row multiplies: strand 2 rows are the upper half of a slice
     {
         const int row = tile * 32 + n;
@@ -700,12 +699,23 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             }
             const char* sb0 = s_stage + (c & 1) * CHUNK_FRAGS * 1024;
             const char* sb = sb0 + lane * 16;
+            // operands of timestep tt + 1 are read from LDS before the three MFMAs of timestep tt are issued (two register sets,
+            // pinned with compiler fences: left alone the compiler reads each operand right in front of its MFMA and every MFMA
+            // waits out an LDS round trip — 4.2 k cycles per chunk for 1.85 k of matrix work)
+            uint4 xo[2][4];
+            auto rdop = [&](uint4 (&d)[4], int tt) {
+                d[0] = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 0) * 1024);
+                d[1] = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 1) * 1024);
+                d[2] = *reinterpret_cast<const uint4*>(sb + ((1 * TG + tt) * 2 + 0) * 1024);
+                d[3] = *reinterpret_cast<const uint4*>(sb + ((1 * TG + tt) * 2 + 1) * 1024);
+            };
+            rdop(xo[0], 0);
 #pragma unroll
             for (int tt = 0; tt < TG; ++tt) {
-                const uint4 x0h = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 0) * 1024);
-                const uint4 x0c = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 1) * 1024);
-                const uint4 x1h = *reinterpret_cast<const uint4*>(sb + ((1 * TG + tt) * 2 + 0) * 1024);
-                const uint4 x1c = *reinterpret_cast<const uint4*>(sb + ((1 * TG + tt) * 2 + 1) * 1024);
+                asm volatile("" ::: "memory");
+                if (tt + 1 < TG) rdop(xo[(tt + 1) & 1], tt + 1);
+                asm volatile("" ::: "memory");
+                const uint4 x0h = xo[tt & 1][0], x0c = xo[tt & 1][1], x1h = xo[tt & 1][2], x1c = xo[tt & 1][3];
                 kacc[tt] = mfma16(w[0][0], x0h, kacc[tt]);
                 kacc[tt] = mfma16(w[1][0], x1h, kacc[tt]);
                 kacc[tt] = mfma_corr(w[0][1], w[1][1], x0c, x1c, kacc[tt], sa_ua);
@@ -741,7 +751,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
         for (int tt = 0; tt < TG; ++tt) {
             float e = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e += vav[r] * tanh_f(kacc[tt][r]);
+            for (int r = 0; r < 16; ++r) e += s_va[(wave * 2 + hh) * 16 + r] * tanh_f(kacc[tt][r]);
             e += __shfl_xor(e, 32);
             if (hh == 0) s_epart[(wave * kSeqLen + t0 + tt) * 32 + n] = e;
         }
