@@ -56,8 +56,9 @@ void run(const char* name) {
     k<MODE><<<256, 512>>>(out, cyc, iters);
     k<MODE><<<256, 512>>>(out, cyc, iters);
     (void)hipDeviceSynchronize();
-    unsigned long long h[8];
+    unsigned long long h[8], last = 0;
     (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
-    printf("%-12s cycles per iteration (21 MFMAs per wave, 2 waves per SIMD): %.0f  (ideal issue 2 x 7 x (34 + 34 + 64) = 1848)\n", name, (double)h[0] / iters);
+    for (int w = 0; w < 8; ++w) last = h[w] > last ? h[w] : last;      // the oldest wave of a SIMD is served first: report the slowest
+    printf("%-12s cycles per iteration (21 MFMAs per wave, 2 waves per SIMD): %.0f  (issue 2 x 7 x (32 + 32 + 64) = 1792)\n", name, (double)last / iters);
 }
 int main() { run<0>("chain"); run<1>("interleaved"); return 0; }
