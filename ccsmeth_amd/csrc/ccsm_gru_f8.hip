@@ -353,6 +353,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                 const bool more = true;
                 const int k0 = 4 * c + 4;                      // first k-block of the pair two pairs ahead of pair 0
                 rdx(xh, buf, 0, 0);
+#if defined(CCSM_EXP) && CCSM_EXP == 9
+                CCSM_CORR(wac[1][0], wac[1][1], xc, 2, 0, sa_x);   /* timing experiment: an extra correction group (operands already in
+                                                                      registers) right behind the barrier: free if the pipe idles there */
+#endif
                 CCSM_PAIR_A(0, ldAh(wah[0][0], k0), ldAh(wah[0][1], k0 + 1), { ldAc(wac[0][0], k0); ldAc(wac[0][1], k0 + 1); })
                 CCSM_PAIR_A(1, ldAh(wah[1][0], k0 + 2), ldAh(wah[1][1], k0 + 3), { ldAc(wac[1][0], k0 + 2); ldAc(wac[1][1], k0 + 3); })
                 CCSM_STAGE_WAIT(14);                           // 2 + 4 + 2 + 2 + 4 weight fragments were requested after the transfer
