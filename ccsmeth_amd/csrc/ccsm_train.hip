@@ -136,14 +136,17 @@ __global__ void gru_gate_fwd_kernel(const float* gi, const float* gh, const floa
     if (save) { R[i] = r; Z[i] = z; Nn[i] = n; HP[i] = hp; }
 }
 
-// backward of that step.  dh = dout_t + carry.  Writes dgi = [dr, dz, dn], dgh = [dr, dz, dn * r], carry = dh * z
-// (the caller then adds dgh W_hh to carry).
-__global__ void gru_gate_bwd_kernel(const float* dout, float* carry, const float* R, const float* Z, const float* Nn, const float* HP,
-                                    const float* hprev, int ld_hprev, float* dgi, float* dgh, int M) {
+// backward of that step.  Writes dgi = [dr, dz, dn], dgh = [dr, dz, dn * r], carry = dh * z; the caller then computes the three
+// per-gate products dgh[gate] W_hh[gate] into cpart (one batched GEMM: three times the workgroups of a single K = 768 product,
+// which left three quarters of the CUs idle at 1024 rows), and the next step's launch adds them up.
+__global__ void gru_gate_bwd_kernel(const float* dout, float* carry, const float* cpart, const float* R, const float* Z, const float* Nn,
+                                    const float* HP, const float* hprev, int ld_hprev, float* dgi, float* dgh, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M * H) return;
     const int m = i / H, j = i % H;
-    const float dh = dout[(size_t)m * H2 + j] + carry[i];
+    // dh_t = d out_t + (dh_{t+1} z_{t+1}) + the three per-gate products dgh_{t+1}[gate] W_hh[gate] of the previous launch
+    const size_t ps = (size_t)M * H;
+    const float dh = dout[(size_t)m * H2 + j] + carry[i] + cpart[i] + cpart[ps + i] + cpart[2 * ps + i];
     const float r = R[i], z = Z[i], n = Nn[i], hp = HP[i];
     const float dn = dh * (1.0f - z) * (1.0f - n * n);
     const float dz = dh * (hprev[(size_t)m * ld_hprev + j] - n) * z * (1.0f - z);
@@ -375,7 +378,7 @@ struct ccsm_trainer {
     float* xdrop[L] = {nullptr, nullptr, nullptr};     // dropout(out[l]) = input of layer l + 1 (rate > 0 only)
     float* sav[L][2][4];
     float *gi[2] = {nullptr, nullptr}, *gh[2] = {nullptr, nullptr}, *dgi[2] = {nullptr, nullptr}, *dgh[2] = {nullptr, nullptr},
-          *carry[2] = {nullptr, nullptr};            // per direction
+          *carry[2] = {nullptr, nullptr}, *cpart[2] = {nullptr, nullptr};            // per direction
     float *hn = nullptr, *q = nullptr, *KS = nullptr, *e = nullptr, *a = nullptr, *c = nullptr, *feat = nullptr, *logits = nullptr,
           *dlogits = nullptr, *loss = nullptr;
     float *dc = nullptr, *dq = nullptr, *dhn = nullptr, *dA = nullptr, *dB = nullptr;   // dA / dB: (T, M, 512) gradient ping-pong
@@ -532,7 +535,9 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
     float *dgi = t->dgi[d], *dgh = t->dgh[d], *carry = t->carry[d], *part = t->part[d];
     // timesteps per batched weight-gradient product: measured best 2 / 3 up to 1024 sites per step (6.98 vs 8.30 ms at 512), 4 / 3 above
     const int sp20 = t->sp20 ? t->sp20 : (M <= 2048 ? 2 : 4), sp21 = t->sp21 ? t->sp21 : 3;
+    float* cpart = t->cpart[d];
     HIPCHK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)M * H, st));
+    HIPCHK(hipMemsetAsync(cpart, 0, sizeof(float) * (size_t)3 * M * H, st));
     for (int s = T - 1; s >= 0; --s) {
         const int tt = d == 0 ? s : T - 1 - s;
         const float* hprev;
@@ -540,10 +545,15 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
         if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
         else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
         const size_t so = (size_t)tt * M * H;
-        gru_gate_bwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(dO + (size_t)tt * M * H2 + d * H, carry, t->sav[l][d][0] + so, t->sav[l][d][1] + so,
-                                                                   t->sav[l][d][2] + so, t->sav[l][d][3] + so, hprev, ld, dgi + (size_t)tt * M * G,
-                                                                   dgh + (size_t)tt * M * G, M);
-        if (s > 0) BLASCHK(rm_gemm(blas, false, false, M, H, G, 1.f, dgh + (size_t)tt * M * G, G, P + kOff.w_hh[l][d], H, 1.f, carry, H));
+        gru_gate_bwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(dO + (size_t)tt * M * H2 + d * H, carry, cpart, t->sav[l][d][0] + so,
+                                                                   t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, hprev, ld,
+                                                                   dgi + (size_t)tt * M * G, dgh + (size_t)tt * M * G, M);
+        if (s > 0) {
+            const float one = 1.f, zero = 0.f;      // cpart[g] (M x 256) = dgh_t[:, g*256 : (g+1)*256] W_hh[g*256 : (g+1)*256, :]
+            BLASCHK(rocblas_sgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, H, M, H, &one, P + kOff.w_hh[l][d], H,
+                                                  (rocblas_stride)H * H, dgh + (size_t)tt * M * G, G, (rocblas_stride)H, &zero, cpart, H,
+                                                  (rocblas_stride)M * H, 3));
+        }
     }
     // weight gradients over all steps at once
     float* dWhh = Gd + kOff.w_hh[l][d];
@@ -669,7 +679,7 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
     }
     for (int d = 0; d < 2; ++d) {
         TRY(dalloc(&t->gi[d], T * M * G)); TRY(dalloc(&t->gh[d], M * G)); TRY(dalloc(&t->dgi[d], T * M * G)); TRY(dalloc(&t->dgh[d], T * M * G));
-        TRY(dalloc(&t->carry[d], M * H)); TRY(dalloc(&t->part[d], (size_t)T * G * H2));
+        TRY(dalloc(&t->carry[d], M * H)); TRY(dalloc(&t->cpart[d], 3 * M * H)); TRY(dalloc(&t->part[d], (size_t)T * G * H2));
     }
     TRY(dalloc(&t->hn, M * H2)); TRY(dalloc(&t->q, M * H)); TRY(dalloc(&t->KS, T * M * H)); TRY(dalloc(&t->e, T * M)); TRY(dalloc(&t->a, T * M));
     TRY(dalloc(&t->c, M * H2)); TRY(dalloc(&t->feat, (size_t)max_sites * 2 * H2)); TRY(dalloc(&t->logits, (size_t)max_sites * NC));
@@ -710,7 +720,7 @@ void ccsm_train_destroy(ccsm_trainer* t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     float* fl[] = {t->params, t->adam_m, t->adam_v, t->own_grads ? t->grads : nullptr, t->ipd, t->pw, t->npass, t->h0, t->x0, t->gi[0], t->gi[1], t->gh[0], t->gh[1], t->dgi[0],
-                   t->dgi[1], t->dgh[0], t->dgh[1], t->carry[0], t->carry[1], t->part[0], t->part[1], t->hn, t->q, t->KS, t->e, t->a, t->c, t->feat, t->logits, t->dlogits, t->loss, t->dc, t->dq, t->dhn, t->dA, t->dB};
+                   t->dgi[1], t->dgh[0], t->dgh[1], t->carry[0], t->carry[1], t->cpart[0], t->cpart[1], t->part[0], t->part[1], t->hn, t->q, t->KS, t->e, t->a, t->c, t->feat, t->logits, t->dlogits, t->loss, t->dc, t->dq, t->dhn, t->dA, t->dB};
     for (float* p : fl) if (p) (void)hipFree(p);
     for (auto& c : t->graphs) if (c.exec) (void)hipGraphExecDestroy(c.exec);
     if (t->ctl) (void)hipFree(t->ctl);
