@@ -280,7 +280,10 @@ def call_mods(args, log=sys.stderr):
                 dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side bookkeeping only
         part_path = out_path if world == 1 else "%s.part%d" % (out_path, rank)
         runs = []
-        with NativeBamReader(args.input, threads=args.threads) as rd:
+        # every rank inflates the whole input (it needs the site counts of the batches it skips): give the scan the rank's share of
+        # the host cores when that is more than --threads
+        scan_threads = max(args.threads, (os.cpu_count() or 1) // max(world, 1)) if world > 1 else args.threads
+        with NativeBamReader(args.input, threads=scan_threads) as rd:
             header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
             if not args.no_sort and rd.n_ref == 0:
                 header = _set_coordinate_order(header)             # no reference: every record sorts equal, input order is kept
