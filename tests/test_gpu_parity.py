@@ -763,3 +763,33 @@ def test_call_mods_post_processing_sort_and_index(tmp_path):
         assert not os.path.exists(res["output"] + ".bai")
         with bamio.BamReader(res["output"]) as rd:
             assert [o.query_name for o in rd] == [r.query_name for r in recs] and "SO:unknown" in rd.header_text
+
+
+def test_call_mods_empty_and_siteless_inputs(tmp_path):
+    """Edge inputs of the CLI: a BAM with no records, and one whose reads carry no CpG that keeps a full 21-mer window."""
+    import torch
+    from collections import OrderedDict
+    from ccsmeth_amd import bamio
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    ckpt = str(tmp_path / "m.ckpt")
+    torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
+    empty = str(tmp_path / "empty.bam")
+    with bamio.BamWriter(empty, "@HD\tVN:1.5\tSO:unknown\n", []):
+        pass
+    siteless = str(tmp_path / "siteless.bam")
+    with bamio.BamWriter(siteless, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
+        for i, seq in enumerate(["ATATATATATATATATATATATATATATAT", "CG", "ACGTACGTAC", "TTTTTTTTTTCGTTTTTTTTT"]):
+            L = len(seq)
+            k = np.arange(L, dtype=np.uint8)
+            w.write(bamio.BamRecord("r%d" % i, flag=4, seq=seq, tags=[("fi", "BC", k), ("fp", "BC", k), ("ri", "BC", k), ("rp", "BC", k), ("fn", "C", 5), ("rn", "C", 5)]))
+    for io in ("native", "python"):
+        res = call_mods(build_parser().parse_args(["-i", empty, "-m", ckpt, "-o", str(tmp_path / ("e" + io)), "--io", io]), log=open(os.devnull, "w"))
+        assert res["reads"] == 0 and res["tagged"] == 0
+        with bamio.BamReader(res["output"]) as rd:
+            assert list(rd) == [] and "@PG\tID:ccsmeth" in rd.header_text
+        assert open(res["output"] + ".bai", "rb").read() == b"BAI\x01" + bytes(4) + bytes(8)
+        res = call_mods(build_parser().parse_args(["-i", siteless, "-m", ckpt, "-o", str(tmp_path / ("s" + io)), "--io", io]), log=open(os.devnull, "w"))
+        assert res["reads"] == 4 and res["tagged"] == 0
+        with bamio.BamReader(res["output"]) as rd:
+            out = list(rd)
+        assert [o.query_name for o in out] == ["r0", "r1", "r2", "r3"] and not any(o.has_tag("MM") for o in out)
