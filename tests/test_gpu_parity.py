@@ -793,3 +793,37 @@ def test_call_mods_empty_and_siteless_inputs(tmp_path):
         with bamio.BamReader(res["output"]) as rd:
             out = list(rd)
         assert [o.query_name for o in out] == ["r0", "r1", "r2", "r3"] and not any(o.has_tag("MM") for o in out)
+
+
+def test_config2_one_million_sites_properties():
+    """BASELINE.json configs[1] at its full size (1 000 000 sites, batches of 2048, the last one 576) through size-independent
+    properties: every output finite and a probability pair; with the device generator keyed by the global site index the result of
+    a site does not depend on how the run is cut into batches (2048-site batches vs 8192-site batches: bit-identical); a repeated run
+    is bit-identical; a checksum of the per-batch checksums equals the checksum of the whole."""
+    from ccsmeth_amd.models import DeviceModel
+    n = 1_000_000
+    s = synth.synth_sites(n, 20260928)
+    dm = DeviceModel(synth.synth_weights(20260928), device=0)
+    ws = dm.workspace(8192)
+
+    def run(batch):
+        out = np.empty((n, 2), np.float32)
+        for a in range(0, n, batch):
+            b = min(n, a + batch)
+            sub = {k: v[a:b] for k, v in s.items()}
+            _, p = ws.forward_host(sub["kmer1"], sub["ipd1"], sub["pw1"], sub["npass1"], sub["kmer2"], sub["ipd2"], sub["pw2"], sub["npass2"],
+                                   h0=None, seed=1234, offset=a)
+            out[a:b] = p
+        return out
+    p2048 = run(2048)
+    assert (n - 1) // 2048 + 1 == 489 and n - 488 * 2048 == 576
+    assert np.isfinite(p2048).all() and (p2048 >= 0).all() and (p2048 <= 1).all() and np.abs(p2048.sum(1) - 1).max() < 1e-6
+    p8192 = run(8192)
+    assert np.array_equal(p2048, p8192)
+    assert np.array_equal(p2048, run(2048))
+    whole = np.float64(p2048[:, 1].astype(np.float64).sum())
+    parts = sum(np.float64(p2048[a:a + 2048, 1].astype(np.float64).sum()) for a in range(0, n, 2048))
+    assert abs(whole - parts) < 1e-6 * whole
+    assert 0.05 < p2048[:, 1].mean() < 0.95 and p2048[:, 1].std() > 1e-3          # not a constant: random weights, real variation
+    ws.close()
+    dm.close()
