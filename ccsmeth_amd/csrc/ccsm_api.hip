@@ -36,10 +36,10 @@ ccsm_status fail(ccsm_status st, const std::string& msg) {
     } while (0)
 
 constexpr size_t kReadTableBytes = 8 + 64 + 4 * 5 + 4;   // per read: offset | stats | length, fn, rn, nsites, first_site | spare
-constexpr int kNBGru = 2;    // batch tiles (of 32 rows) per workgroup of the version-1 GRU kernel (A/B testing only)
-constexpr int kNBGru2 = 3;   // ... of the version-2 GRU kernel (default)
-constexpr int kRowPad = 32 * kNBGru * kNBGru2;  // rows are padded so that either kernel tiles them exactly
-constexpr int gru2_lds(int kx) { return (kKBH * kNBGru2 * 2 + 2 * (kx >= 4 ? 4 : kx) * kNBGru2 * 2) * 1024; }
+constexpr int kNBGru2 = 3;   // batch tiles (of 32 rows) per workgroup of the GRU kernels
+constexpr int kRowPad = 32 * kNBGru2;           // rows are padded to whole workgroups
+// GRU kernels' dynamic LDS: h fragments + x chunk ring + 4 KiB bias table
+constexpr int gru2_lds(int kx) { return (kKBH * kNBGru2 * 2 + 2 * (kx >= 4 ? 4 : kx) * kNBGru2 * 2) * 1024 + kWaves * 4 * 32 * 4; }
 // attention kernel dynamic LDS: 2 staging buffers x 28 KiB + e partials + fc partials + fc1.weight
 constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kWaves * kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4;   // staging, e / fc partials, fc1.weight, va
 
@@ -61,9 +61,7 @@ inline int crow(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }  // M
 struct ccsm_model {
     int device = 0;
     int precision = 3;
-    int gru_version = 2;
-    uint4* wst[kLayers] = {nullptr, nullptr, nullptr};  // v1: [dir][wave][KX+16][gate][hl][64]
-    uint4* wst2[kLayers] = {nullptr, nullptr, nullptr}; // v2: [dir][wave][A: KX x (r,z) | B: 16 x (r,z,n) | C: KX x (n)][hl][64]
+    uint4* wst2[kLayers] = {nullptr, nullptr, nullptr}; // split3: [dir][wave][A: KX x (r,z) | B: 16 x (r,z,n) | C: KX x (n)][hl][64]
     uint4* wst3[kLayers] = {nullptr, nullptr, nullptr}; // split-f8: as wst2 with the second fragment of a k-block = fp8 corr
     int4 wscale[kLayers] = {};                           // E8M0 scales of the corr weight operands (x-part/h-part per dir)
     uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
@@ -129,37 +127,7 @@ struct ccsm_workspace {
 
 namespace {
 
-// One (layer) weight stream: A fragments of [W_ih | W_hh], x-part k-blocks first.
-void pack_wstream(int layer, const float* const wih[2], const float* const whh[2], std::vector<_Float16>& out) {
-    const int kx = layer_kx(layer);
-    const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
-    const int kt = kx + kKBH;
-    out.assign((size_t)2 * kWaves * kt * kGates * 2 * 512, (_Float16)0.f);
-    for (int dir = 0; dir < 2; ++dir)
-        for (int wave = 0; wave < kWaves; ++wave)
-            for (int kb = 0; kb < kt; ++kb)
-                for (int g = 0; g < kGates; ++g)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int i = lane & 31, q = lane >> 5;
-                        const int row = g * kHidden + kUnitTile * wave + i;
-                        const size_t base = ((((size_t)(dir * kWaves + wave) * kt + kb) * kGates + g) * 2) * 512 + lane * 8;
-                        for (int j = 0; j < 8; ++j) {
-                            float v;
-                            if (kb < kx) {
-                                const int k = 16 * kb + 8 * q + j;
-                                v = k < k_in ? wih[dir][(size_t)row * k_in + k] : 0.f;
-                            } else {
-                                const int k = 16 * (kb - kx) + 8 * q + j;
-                                v = whh[dir][(size_t)row * kHidden + k];
-                            }
-                            const HalfPair p = split_host(v);
-                            out[base + j] = p.hi;
-                            out[base + 512 + j] = p.lo;
-                        }
-                    }
-}
-
-// Version-2 weight stream: per (dir, wave) the fragments in the order the three phases consume them.
+// Split-fp16 weight stream: per (dir, wave) the [hi | lo] fragments in the order the three phases consume them.
 void pack_wstream_v2(int layer, const float* const wih[2], const float* const whh[2], std::vector<_Float16>& out) {
     const int kx = layer_kx(layer);
     const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
@@ -337,8 +305,18 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
     return CCSM_OK;
 }
 
+// One GRU layer in split-f8 arithmetic; the DBG instantiation (phase time stamps, tools/gpu_phases.py) only when asked for.
+template <int KX>
+void launch_gru_f8(dim3 grid, hipStream_t st, const uint4* xin, uint4* out, const uint4* wst, const float* bias, const float* h0,
+                   int rows_p, int4 sc, unsigned long long* dbg) {
+    if (dbg)
+        hipLaunchKernelGGL((gru_layer_f8_kernel<KX, true>), grid, dim3(512), gru2_lds(KX), st, xin, out, wst, bias, h0, rows_p, sc, dbg);
+    else
+        hipLaunchKernelGGL((gru_layer_f8_kernel<KX, false>), grid, dim3(512), gru2_lds(KX), st, xin, out, wst, bias, h0, rows_p, sc, nullptr);
+}
+
 // Heavy kernels, once over every row used by the current slices, then the per-slice logits/softmax.
-template <int NPASS, bool F8 = false>
+template <bool F8>
 ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
     const int rows_run = ((ws->rows_used + kRowPad - 1) / kRowPad) * kRowPad;
     const int tiles = rows_run / 32;
@@ -346,42 +324,25 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     if (tm) ws->ev = ws->evs[ws->ev_runs % ccsm_workspace::kEvSets];
     if (tm) HIP_TRY(hipEventRecord(ws->ev[1], st));
     const size_t slab = (size_t)2 * ws->rows_p * kHidden;  // floats per layer (two directions)
+    const dim3 ggrid(2 * (tiles / kNBGru2));
+    static const int dbg_layer = std::getenv("CCSM_PHASE_LAYER") ? std::atoi(std::getenv("CCSM_PHASE_LAYER")) : 1;
     if constexpr (F8) {
-        const dim3 ggrid(2 * (tiles / kNBGru2));
-        static const int dbg_layer = std::getenv("CCSM_PHASE_LAYER") ? std::atoi(std::getenv("CCSM_PHASE_LAYER")) : 1;
-        hipLaunchKernelGGL((gru_layer_f8_kernel<kKB0, false>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
-                           m->wst3[0], m->bias[0], ws->h0buf, ws->rows_p, m->wscale[0], dbg_layer == 0 ? ws->dbg : nullptr);
+        launch_gru_f8<kKB0>(ggrid, st, ws->x0, ws->act[0], m->wst3[0], m->bias[0], ws->h0buf, ws->rows_p, m->wscale[0],
+                            dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
-        hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, false>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
-                           m->wst3[1], m->bias[1], ws->h0buf + slab, ws->rows_p, m->wscale[1], dbg_layer == 1 ? ws->dbg : nullptr);
+        launch_gru_f8<kKB12>(ggrid, st, ws->act[0], ws->act[1], m->wst3[1], m->bias[1], ws->h0buf + slab, ws->rows_p, m->wscale[1],
+                             dbg_layer == 1 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-        static const bool att_f16 = std::getenv("CCSM_ATTN_SPLIT3") != nullptr;   // A/B switch: fp16-split attention pool
-        if (att_f16)
-            hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, true>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
-                               m->wst3[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, m->wscale[2], dbg_layer == 2 ? ws->dbg : nullptr);
-        else
-            hipLaunchKernelGGL((gru_layer_f8_kernel<kKB12, false>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
-                               m->wst3[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, m->wscale[2], dbg_layer == 2 ? ws->dbg : nullptr);
-    } else if (m->gru_version == 1) {
-        const size_t lds = (size_t)kKBH * kNBGru * 2 * 1024;
-        const dim3 ggrid(2 * (tiles / kNBGru));
-        hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB0, NPASS>), ggrid, dim3(512), lds, st, ws->x0, ws->act[0], m->wst[0],
-                           m->bias[0], ws->h0buf, ws->rows_p);
-        if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
-        hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[0], ws->act[1],
-                           m->wst[1], m->bias[1], ws->h0buf + slab, ws->rows_p);
-        if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-        hipLaunchKernelGGL((gru_layer_kernel<kNBGru, kKB12, NPASS>), ggrid, dim3(512), lds, st, ws->act[1], ws->act[0],
-                           m->wst[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p);
+        launch_gru_f8<kKB12>(ggrid, st, ws->act[1], ws->act[0], m->wst3[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, m->wscale[2],
+                             dbg_layer == 2 ? ws->dbg : nullptr);
     } else {
-        const dim3 ggrid(2 * (tiles / kNBGru2));
-        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0, NPASS>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
+        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
                            m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p, nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
-        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12, NPASS>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
+        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
                            m->wst2[1], m->bias[1], ws->h0buf + slab, ws->rows_p, ws->dbg);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12, NPASS>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
+        hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
                            m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, nullptr);
     }
     if (tm) HIP_TRY(hipEventRecord(ws->ev[4], st));
@@ -391,12 +352,11 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         tab.row_base[i] = i < ws->n_slices ? ws->slice_row[i] : 0;
         tab.n_sites[i] = i < ws->n_slices ? ws->slice_n[i] : 0;
     }
-    if (F8 && std::getenv("CCSM_ATTN_SPLIT3") == nullptr)
+    if constexpr (F8)
         hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fcw,
-                           ws->part, tab, m->att_scale[0], m->att_scale[1],
-                           (std::getenv("CCSM_PHASE_LAYER") && std::atoi(std::getenv("CCSM_PHASE_LAYER")) == 3) ? ws->dbg : nullptr);
+                           ws->part, tab, m->att_scale[0], m->att_scale[1], dbg_layer == 3 ? ws->dbg : nullptr);
     else
-        hipLaunchKernelGGL((attn_fc_kernel<NPASS>), dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
+        hipLaunchKernelGGL(attn_fc_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
                            ws->part, tab);
     if (tm) HIP_TRY(hipEventRecord(ws->ev[5], st));
     for (int i = 0; i < ws->n_slices; ++i)
@@ -415,12 +375,10 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
 
 ccsm_status dispatch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
     switch (m->precision) {
-        case 4: return launch_run<3, true>(m, ws, st);
-        case 3: return launch_run<3>(m, ws, st);
-        case 2: return launch_run<2>(m, ws, st);
-        case 1: return launch_run<1>(m, ws, st);
+        case CCSM_PRECISION_SPLIT_F8: return launch_run<true>(m, ws, st);
+        case CCSM_PRECISION_SPLIT3: return launch_run<false>(m, ws, st);
     }
-    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 1, 2, 3 or 4");
+    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 3 (split-fp16) or 4 (split-f8)");
 }
 
 // add one slice (device pointers) to the workspace
@@ -486,7 +444,8 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     if (!cfg->is_npass || cfg->is_sn || cfg->is_map || cfg->is_stds)
         return fail(CCSM_ERR_UNSUPPORTED, "this build implements is_npass=yes, is_sn=no, is_map=no, is_stds=no");
     const int prec = cfg->precision == 0 ? 4 : cfg->precision;
-    if (prec < 1 || prec > 4) return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default), 1, 2, 3 or 4");
+    if (prec != CCSM_PRECISION_SPLIT3 && prec != CCSM_PRECISION_SPLIT_F8)
+        return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default), 3 (split-fp16) or 4 (split-f8)");
     if (!w->embed_weight || !w->att_wa || !w->att_ua || !w->att_va || !w->fc1_weight || !w->fc1_bias)
         return fail(CCSM_ERR_INVALID_ARG, "weights: NULL tensor");
     for (int l = 0; l < kLayers; ++l)
@@ -501,11 +460,7 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     ccsm_status st = CCSM_OK;
     std::vector<_Float16> hbuf;
     std::vector<float> fbuf;
-    if (const char* e = std::getenv("CCSM_GRU_VERSION")) m->gru_version = std::atoi(e) == 1 ? 1 : 2;
     for (int l = 0; l < kLayers && st == CCSM_OK; ++l) {
-        pack_wstream(l, w->weight_ih[l], w->weight_hh[l], hbuf);
-        st = upload(&m->wst[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
-        if (st != CCSM_OK) break;
         pack_wstream_v2(l, w->weight_ih[l], w->weight_hh[l], hbuf);
         st = upload(&m->wst2[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
         if (st != CCSM_OK) break;
@@ -532,38 +487,20 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     if (st == CCSM_OK) st = upload(&m->fcb, w->fc1_bias, sizeof(float) * kClasses);
     if (st == CCSM_OK) st = upload(&m->embed, w->embed_weight, sizeof(float) * kVocab * kEmbed);
     if (st == CCSM_OK) {
-        // 64 KiB of dynamic LDS for the hidden-state fragments
-        const int lds = kKBH * kNBGru * 2 * 1024;
         hipError_t e = hipSuccess;
-#define CCSM_SET_LDS(NP)                                                                                                  \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_kernel<kNBGru, kKB0, NP>),     \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);                         \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_kernel<kNBGru, kKB12, NP>),    \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (prec >= 3) { CCSM_SET_LDS(3) } else if (prec == 2) { CCSM_SET_LDS(2) } else { CCSM_SET_LDS(1) }
-#undef CCSM_SET_LDS
-#define CCSM_SET_LDS2(NP)                                                                                                \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB0, NP>),           \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB0));              \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB12, NP>),          \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
-        if (prec >= 3) { CCSM_SET_LDS2(3) } else if (prec == 2) { CCSM_SET_LDS2(2) } else { CCSM_SET_LDS2(1) }
-#undef CCSM_SET_LDS2
-        if (prec == 4) {
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB0, false>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB0));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, false>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, gru2_lds(kKB12));
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fc_f8_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kAttLds);
+        auto set_lds = [&](const void* fn, int bytes) {
+            if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        };
+        set_lds(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB0>), gru2_lds(kKB0));
+        set_lds(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB12>), gru2_lds(kKB12));
+        set_lds(reinterpret_cast<const void*>(&attn_fc_kernel), kAttLds);
+        if (prec == CCSM_PRECISION_SPLIT_F8) {
+            set_lds(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB0, false>), gru2_lds(kKB0));
+            set_lds(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, false>), gru2_lds(kKB12));
+            set_lds(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB0, true>), gru2_lds(kKB0));
+            set_lds(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, true>), gru2_lds(kKB12));
+            set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttLds);
         }
-#define CCSM_SET_ALDS(NP)                                                                                   \
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fc_kernel<NP>),         \
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, kAttLds);
-        if (prec >= 3) { CCSM_SET_ALDS(3) } else if (prec == 2) { CCSM_SET_ALDS(2) } else { CCSM_SET_ALDS(1) }
-#undef CCSM_SET_ALDS
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }
     if (st != CCSM_OK) {
@@ -578,7 +515,6 @@ void ccsm_destroy(ccsm_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     for (int l = 0; l < kLayers; ++l) {
-        (void)hipFree(m->wst[l]);
         (void)hipFree(m->wst2[l]);
         (void)hipFree(m->wst3[l]);
         (void)hipFree(m->bias[l]);

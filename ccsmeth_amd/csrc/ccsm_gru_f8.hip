@@ -25,8 +25,7 @@
 // The recurrent state is carried as hi + fp8(lo) too (h_{t-1} is re-read from these fragments): 2^-16 relative per step.
 //
 // Layer 0 (KX == 1, K = 11 padded to 16, inputs up to hundreds in magnitude) keeps three f16 passes for its x-part.
-// The attention pool (attn_fc_f8_kernel below) consumes the same [hi | corr] fragments; OUT_F16LO makes a layer write
-// [hi | lo] fp16 instead, for the fp16-split attention kernel (CCSM_ATTN_SPLIT3=1 A/B runs).
+// The attention pool (attn_fc_f8_kernel below) consumes the same [hi | corr] fragments.
 #include <hip/hip_runtime.h>
 
 namespace ccsm {
@@ -41,11 +40,7 @@ constexpr float kF8Clamp = 448.0f;                 // e4m3 finite maximum (v_cvt
 __device__ __forceinline__ f32x16 mfma_corr(uint4 w0, uint4 w1, uint4 x0, uint4 x1, f32x16 c, int scale_a) {
     const i32x8 a = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w};
     const i32x8 b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, (int)x1.z, (int)x1.w};
-#if defined(CCSM_EXP) && CCSM_EXP == 7
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 2, 0, scale_a, 0, kCorrScaleB);   // timing experiment: fp6 issue rate (wrong numbers)
-#else
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, scale_a, 0, kCorrScaleB);
-#endif
 }
 
 __device__ __forceinline__ uint32_t cvt4_fp8(float a, float b, float c, float d) {
@@ -77,9 +72,8 @@ __device__ __forceinline__ float tanh_fold(float x) {    // 1 - 2 / (e^{2x} + 1)
 }
 
 // Eight MFMA-C-layout values of one k-block held by lane (n, hh): v[0..3] = units e + 4hh, v[4..7] = units 8 + e + 4hh of
-// batch row n.  Produces this lane's 16 bytes of the k-block's hi fragment, corr fragment and (WITH_LO) fp16 lo fragment.
-template <bool WITH_LO>
-__device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint4& co_out, uint4& lo_out) {
+// batch row n.  Produces this lane's 16 bytes of the k-block's hi fragment and corr fragment.
+__device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint4& co_out) {
     typedef _Float16 half2p __attribute__((ext_vector_type(2)));
     uint32_t hp[4];
     float lf[8];
@@ -101,13 +95,6 @@ __device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint
     swap32(h0, l0);   // lower lanes: (own hi, partner's hi) ; upper lanes: (partner's lo, own lo)
     swap32(h1, l1);
     co_out = make_uint4(h0, h1, l0, l1);
-    if constexpr (WITH_LO) {
-        uint32_t c0 = pack2((_Float16)lf[0], (_Float16)lf[1]), c1 = pack2((_Float16)lf[2], (_Float16)lf[3]);
-        uint32_t d0 = pack2((_Float16)lf[4], (_Float16)lf[5]), d1 = pack2((_Float16)lf[6], (_Float16)lf[7]);
-        swap32(c0, d0);
-        swap32(c1, d1);
-        lo_out = make_uint4(c0, c1, d0, d1);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -116,12 +103,12 @@ __device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint
 //   G1: main MFMAs of k-block 2p      G2: main MFMAs of k-block 2p+1      G3: corr MFMAs of the pair
 // Weight registers are reloaded immediately after the group that used them, two pairs ahead in phase A (ring of two
 // pairs), one pair ahead in phase B (one pair resident) and one chunk (two pairs) ahead in phase C.
-//   xin  : [tile][t][KX][hi|corr][64] uint4 (KX == 1: [hi|lo] fp16)       out : [tile][t][32][hi|corr or hi|lo][64]
+//   xin  : [tile][t][KX][hi|corr][64] uint4 (KX == 1: [hi|lo] fp16)       out : [tile][t][32][hi|corr][64]
 //   wst  : [dir][wave][ A: KX x (r,z) x 2 | B: 16 x (r,z,n) x 2 | C: KX x (n) x 2 ][64] uint4, second fragment = corr
 //          (KX == 1: A and C second fragment = fp16 lo)
 //   sc   : E8M0 weight-operand scales: x = x-part dir 0, y = h-part dir 0, z = x-part dir 1, w = h-part dir 1
 // ---------------------------------------------------------------------------------------------------------
-template <int KX, bool OUT_F16LO>
+template <int KX, bool DBG>
 __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                const float* __restrict__ h0, int rows_p, int4 sc,
@@ -136,12 +123,18 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_h = smem;                               // h fragments  [kb 16][bt 3][hi|corr] x 1 KiB = 96 KiB
     char* s_x = smem + kKBH * NB * 2 * 1024;        // x chunk ring [buf 2][kbl CK][bt 3][2] x 1 KiB
+    float* s_bias = reinterpret_cast<float*>(s_x + 2 * CHF * 1024);   // [wave][set 4][hh 2][16] fp32 = 4 KiB (this direction's biases)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dir = blockIdx.x & 1;
     const int tile0 = (blockIdx.x >> 1) * NB;
     const int n = lane & 31, hh = lane >> 5;
     const int sa_x = dir ? sc.z : sc.x, sa_h = dir ? sc.w : sc.y;
+
+    // ---- biases -> LDS, once: the accumulator sets are initialised from there every step (ds_read_b128, lgkmcnt) instead of
+    // global loads, whose s_waitcnt vmcnt(0) drained the weight prefetch queue three times per timestep
+    if (threadIdx.x < kWaves * 4 * 32 / 4)
+        reinterpret_cast<float4*>(s_bias)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
 
     auto hfrag = [&](int kb, int bt, int f) -> char* { return s_h + (((kb * NB + bt) * 2 + f) << 10); };
     auto xfrag = [&](int buf, int kbl, int bt, int f) -> char* { return s_x + ((((buf * CK + kbl) * NB + bt) * 2 + f) << 10); };
@@ -197,12 +190,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         return sx_base + (unsigned)((buf * CHF + f) << 10);
     };
     auto stage_load = [&](int t, int c, int buf) {
-#if defined(CCSM_EXP) && CCSM_EXP == 1
-        t = 0; c = 0;                               // timing experiment: always the same (L2-resident) chunk
-#endif
-#if defined(CCSM_EXP) && (CCSM_EXP == 2 || CCSM_EXP == 4)
-        return;                                     // timing experiment: no staging traffic at all
-#endif
 #pragma unroll
         for (int i = 0; i < SPW; ++i)
             dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(stage_off(t, c, i)), __builtin_amdgcn_readfirstlane(stage_dst(buf, i)));
@@ -210,22 +197,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
 #define CCSM_STAGE_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4);
-    const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
+    const int bias_off = (int)(reinterpret_cast<char*>(s_bias) - smem) + wave * 4 * 32 * 4;   // wave-uniform byte offset of this wave's table
 
     stage_load(dir ? kSeqLen - 1 : 0, 0, 0);
     CCSM_STAGE_WAIT(0);
 
-#if defined(CCSM_EXP) && (CCSM_EXP == 3 || CCSM_EXP == 4)
-    auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, (frag & 3) << 10); };   // timing experiment: L1-resident weights
-#elif defined(CCSM_EXP) && CCSM_EXP == 6
-    auto w_at = [&](int frag) -> uint4 {      // timing experiment: same instruction count and addresses, half the bytes
-        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(wrs, lane16, frag << 10, 0);
-        return make_uint4(v[0], v[1], v[0], v[1]);
-    };
-#else
     auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, frag << 10); };
-#endif
     // Weight registers.  Every phase's FIRST fragments are requested while the previous phase still has MFMAs to issue (in the
     // slots whose "two ahead" reload would run past the end of that phase), so no phase starts behind an exposed L2 round trip:
     //   phase A pair 0  <- last chunk of phase C (previous step)      phase A pair 1 <- start of the tail (previous step)
@@ -273,21 +250,33 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         ldB_first();
     }
 
+#if defined(CCSM_AB) && CCSM_AB == 1
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // A/B: static priority for the second-dispatched half of the workgroup
+#endif
     for (int s = 0; s < kSeqLen; ++s) {
         const int t = dir ? (kSeqLen - 1 - s) : s;
-        auto stamp = [&](int k) {
-            if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
+        auto stamp = [&](int k) {     // DBG instantiation only (tools/gpu_phases.py): cycle counter at the phase boundaries
+            if constexpr (DBG) {
+                if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
+            }
         };
         stamp(0);
         const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;
         f32x16 acc[3][NB];                            // R, Z, N
-        const float* bps = bp;
-        asm volatile("" : "+v"(bps));
-        auto bias_set = [&](int set) {
+        // Per-lane LDS addresses are derived from lane16 through an opaque copy wherever a phase needs them: a loop-invariant
+        // address would otherwise be kept live across the whole step, spilled, and every reload of a spill is a scratch_load +
+        // s_waitcnt vmcnt(0), i.e. a full drain of the weight prefetch queue (two VALU instructions instead).
+        auto lane16_here = [&]() -> int {
+            int v = lane16;
+            asm volatile("" : "+v"(v));
+            return v;
+        };
+        auto bias_set = [&](int set) {                // from LDS (written once before the first barrier)
             f32x16 b;
+            const char* bp = smem + (bias_off + ((lane16_here() >> 9) << 6));      // + hh * 64 bytes
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(bps + set * 32 + q * 4);
+                const float4 v = *reinterpret_cast<const float4*>(bp + set * 128 + q * 16);
                 b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
             }
             return b;
@@ -353,10 +342,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                 const bool more = true;
                 const int k0 = 4 * c + 4;                      // first k-block of the pair two pairs ahead of pair 0
                 rdx(xh, buf, 0, 0);
-#if defined(CCSM_EXP) && CCSM_EXP == 9
-                CCSM_CORR(wac[1][0], wac[1][1], xc, 2, 0, sa_x);   /* timing experiment: an extra correction group (operands already in
-                                                                      registers) right behind the barrier: free if the pipe idles there */
-#endif
                 CCSM_PAIR_A(0, ldAh(wah[0][0], k0), ldAh(wah[0][1], k0 + 1), { ldAc(wac[0][0], k0); ldAc(wac[0][1], k0 + 1); })
                 CCSM_PAIR_A(1, ldAh(wah[1][0], k0 + 2), ldAh(wah[1][1], k0 + 3), { ldAc(wac[1][0], k0 + 2); ldAc(wac[1][1], k0 + 3); })
                 CCSM_STAGE_WAIT(14);                           // 2 + 4 + 2 + 2 + 4 weight fragments were requested after the transfer
@@ -380,10 +365,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
             CCSM_STAGE_WAIT(28);
             __syncthreads();
             stage_load(tn, 0, (s + 1) & 1);
+            const int l16 = lane16_here();
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
-                x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + lane * 16);
-                x0[bt][1] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 1) + lane * 16);
+                x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + l16);
+                x0[bt][1] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 1) + l16);
             }
             CCSM_FENCE;
 #pragma unroll
@@ -472,12 +458,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         __syncthreads();                                                                                       \
         const int buf = (C) & 1;                                                                               \
         const bool more = (C) + 1 < NCH;                                                                       \
-        LNEXT;                                                                                                 \
         stage_load(more ? t : tn, more ? (C) + 1 : 0, ((C) + 1) & 1);   /* next C chunk / next step's first A chunk */ \
+        LNEXT;                               /* 8 weight fragments, younger than the transfer: they stay in flight */ \
         rdx(xh, buf, 0, 0);                                                                                    \
         CCSM_PAIR_C(CUR, 0)                                                                                    \
         CCSM_PAIR_C(CUR, 1)                                                                                    \
-        CCSM_STAGE_WAIT(0);                                                                                    \
+        CCSM_STAGE_WAIT(8);                                                                                    \
     }
 #pragma unroll 1
             for (int c2 = 0; c2 < NCH - 2; c2 += 2) {
@@ -492,10 +478,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
 #undef CCSM_PAIR_C
         } else {
             uint4 x0[NB][2];
+            const int l16 = lane16_here();
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
-                x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + lane * 16);
-                x0[bt][1] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 1) + lane * 16);
+                x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + l16);
+                x0[bt][1] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 1) + l16);
             }
             CCSM_FENCE;
 #pragma unroll
@@ -528,16 +515,25 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
         }
         // ---------------- tail: h_{t-1} of this wave's own units (MFMA C layout) = hi fragment + fp8 residual of the corr
         // fragment; n = tanh(N); h' = n + z (h_{t-1} - n); fragments for the next step / next layer
+        // addresses of this wave's own two k-blocks (kb = 2 wave + kbl), rebuilt here from an opaque copy of lane16 (see above)
+        const int own_off = wave * (2 * NB * 2 * 1024);                       // hfrag(2 wave, 0, 0)
+        const char* t_wr;                                                     // + lane * 16       (fragment writes)
+        const char* t_rd;                                                     // + n * 16 + hh * 8 (own-unit reads, MFMA C layout)
+        int t16;                                                              // lane * 16 (output stores)
+        {
+            t16 = lane16_here();
+            t_wr = smem + (own_off + t16);
+            t_rd = smem + (own_off + (t16 & 0x1f0) + ((t16 >> 9) << 3));
+        }
+        auto own_frag = [&](int kbl, int bt, int f) -> int { return ((kbl * NB + bt) * 2 + f) << 10; };
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt) {
             float hn[16];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int kb = 2 * wave + (q >> 1);
-                const int src_lane = n + 32 * (q & 1);
-                const half4 hi = as_half4(*reinterpret_cast<const uint2*>(hfrag(kb, bt, 0) + src_lane * 16 + hh * 8));
+                const half4 hi = as_half4(*reinterpret_cast<const uint2*>(t_rd + own_frag(q >> 1, bt, 0) + 512 * (q & 1)));
                 // residuals: lane (n, g = 1) of the corr fragment, bytes 4*(q&1) + 8*hh .. +3  (kCorrPerm order)
-                const int lo4 = *reinterpret_cast<const int*>(hfrag(kb, bt, 1) + (n + 32) * 16 + 4 * (q & 1) + 8 * hh);
+                const int lo4 = *reinterpret_cast<const int*>(t_rd + own_frag(q >> 1, bt, 1) + 512 + 4 * (q & 1));
                 const float hp[4] = {(float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo4, 0) * (1.0f / kCorrActLo),
                                      (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo4, 1) * (1.0f / kCorrActLo),
                                      (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo4, 2) * (1.0f / kCorrActLo),
@@ -548,26 +544,20 @@ __global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __res
                     hn[4 * q + e] = (hp[e] - nn) * acc[1][bt][4 * q + e] + nn;
                 }
             }
-#if defined(CCSM_EXP) && CCSM_EXP == 5
-            if (bt == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp(1); }   /* tail timing: blend of tile 0 done */
-#endif
 #pragma unroll
             for (int kbl = 0; kbl < 2; ++kbl) {
                 const float v[8] = {hn[8 * kbl + 0], hn[8 * kbl + 1], hn[8 * kbl + 2], hn[8 * kbl + 3],
                                     hn[8 * kbl + 4], hn[8 * kbl + 5], hn[8 * kbl + 6], hn[8 * kbl + 7]};
-                uint4 fh, fc, fl;
-                pack_kb<OUT_F16LO>(v, fh, fc, fl);
+                uint4 fh, fc;
+                pack_kb(v, fh, fc);
                 const int kb = 2 * wave + kbl;
-                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) = fh;
-                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) = fc;
-                uint4* o = out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4;
+                *reinterpret_cast<uint4*>(const_cast<char*>(t_wr) + own_frag(kbl, bt, 0)) = fh;
+                *reinterpret_cast<uint4*>(const_cast<char*>(t_wr) + own_frag(kbl, bt, 1)) = fc;
+                char* o = reinterpret_cast<char*>(out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4);
                 // streaming stores: the next reader is another kernel 0.5 GB later, keep the L2 for the weight stream (-0.7 % step cycles)
-                nt_store(fh, o + lane);
-                if constexpr (OUT_F16LO) nt_store(fl, o + kFragU4 + lane); else nt_store(fc, o + kFragU4 + lane);
+                nt_store(fh, reinterpret_cast<uint4*>(o + t16));
+                nt_store(fc, reinterpret_cast<uint4*>(o + 1024 + t16));
             }
-#if defined(CCSM_EXP) && CCSM_EXP == 5
-            if (bt == 0) stamp(2);                                                            /* pack + stores of tile 0 issued */
-#endif
         }
         stamp(4);
     }
@@ -654,9 +644,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
 
     // stage chunk `c` of timestep group t0 into buffer `buf`: fragment f = (kbl * TG + tt) * 2 + hl
     auto stage = [&](int t0, int c, int buf) {
-#if defined(CCSM_EXP) && CCSM_EXP == 8
-        t0 = 0; c = 0;      // timing experiment: always the same (L2-resident) chunk
-#endif
 #pragma unroll
         for (int i = 0; i < (CHUNK_FRAGS + kWaves - 1) / kWaves; ++i) {
             const int f = wave + kWaves * i;
@@ -808,7 +795,7 @@ __global__ void corr_selftest_kernel(const uint4* __restrict__ wfrag /* [kb 2][h
                                      float* __restrict__ c /* [unit 32][row 32] */, int scale_a, int with_corr) {
     const int lane = threadIdx.x & 63;
     const int n = lane & 31, hh = lane >> 5;
-    uint4 xh[2], xc[2], dummy;
+    uint4 xh[2], xc[2];
 #pragma unroll
     for (int kbl = 0; kbl < 2; ++kbl) {
         float v[8];
@@ -817,7 +804,7 @@ __global__ void corr_selftest_kernel(const uint4* __restrict__ wfrag /* [kb 2][h
             v[e] = x[n * 32 + 16 * kbl + e + 4 * hh];
             v[4 + e] = x[n * 32 + 16 * kbl + 8 + e + 4 * hh];
         }
-        pack_kb<false>(v, xh[kbl], xc[kbl], dummy);
+        pack_kb(v, xh[kbl], xc[kbl]);
     }
     f32x16 acc;
 #pragma unroll

@@ -89,19 +89,16 @@ __device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
-// NPASS: 3 = hi*hi + hi*lo + lo*hi (default, fp32-class); 2 = hi*hi + hi*lo (fp16 weights, split activations);
-//        1 = hi*hi (plain fp16 operands).  Pass p uses weight fragment (p == 2 ? lo : hi) and activation
-//        fragment (p == 1 ? lo : hi).  Callers issue pass-major so that consecutive MFMAs hit different accumulators.
+// Split-fp16 product of one k-block (CCSM_PRECISION_SPLIT3): hi*hi + hi*lo + lo*hi, fp32 accumulate.  Callers that hold several
+// accumulators issue pass-major (mma_pass) so that consecutive MFMAs hit different accumulators.
 template <int P>
 __device__ __forceinline__ f32x16 mma_pass(const uint4 (&w)[2], const uint4 (&x)[2], f32x16 c) {
     return mfma16(w[P == 2 ? 1 : 0], x[P == 1 ? 1 : 0], c);
 }
-template <int NPASS>
-__device__ __forceinline__ f32x16 mma_split(const uint4 (&w)[2], const uint4 (&x)[2], f32x16 c) {
+__device__ __forceinline__ f32x16 mma_split3(const uint4 (&w)[2], const uint4 (&x)[2], f32x16 c) {
     c = mma_pass<0>(w, x, c);
-    if constexpr (NPASS >= 2) c = mma_pass<1>(w, x, c);
-    if constexpr (NPASS >= 3) c = mma_pass<2>(w, x, c);
-    return c;
+    c = mma_pass<1>(w, x, c);
+    return mma_pass<2>(w, x, c);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -212,220 +209,13 @@ __global__ void pack_x0_kernel(uint4* __restrict__ x0, StrandDev s1, StrandDev s
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// One bidirectional GRU layer.  grid = 2 * (rows_p / (32*NB)); block = 512 (8 waves, 2 per SIMD, <=256 VGPR).
-// blockIdx.x & 1 = direction, so even XCDs (blockIdx % 8) hold the forward weights in L2 and odd XCDs the backward.
-//
-//   xin  : input fragments  [tile][t][KX][hl][64] uint4        (KX = 1 layer 0, 32 layers 1-2)
-//   out  : output fragments [tile][t][32][hl][64] uint4        (forward units -> kb 0..15, backward -> 16..31)
-//   wst  : weight stream    [dir][wave][KX+16][gate][hl][64]   (x-part k-blocks first, then h-part)
+// GRU layer in split-fp16 arithmetic (CCSM_PRECISION_SPLIT3): 96 batch rows per workgroup (NB = 3 tiles), three accumulator
+// sets, x staged through LDS.  grid = 2 * (rows_p / 96); block = 512 (8 waves, 2 per SIMD, <= 256 VGPR); blockIdx.x & 1 =
+// direction, so even XCDs (blockIdx % 8) hold the forward weights in L2 and odd XCDs the backward.
 //   bias : [dir][wave][4 sets: r=b_ir+b_hr, z=b_iz+b_hz, nx=b_in, nh=b_hn][hh][16] in MFMA C-row order
 //   h0   : [dir][rows_p][256] fp32 (this layer's two slabs)
-// ---------------------------------------------------------------------------------------------------------
-template <int NB, int KX, int NPASS>
-__global__ __launch_bounds__(512, 2) void gru_layer_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
-                                                            const uint4* __restrict__ wst, const float* __restrict__ bias,
-                                                            const float* __restrict__ h0, int rows_p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // h fragments [kb 16][bt NB][hl 2][64 lanes][16 B]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dir = blockIdx.x & 1;
-    const int tile0 = (blockIdx.x >> 1) * NB;
-    const int n = lane & 31, hh = lane >> 5;
-    constexpr int KT = KX + kKBH;
-
-    auto hfrag = [&](int kb, int bt, int hl) -> char* { return smem + (((kb * NB + bt) * 2 + hl) << 10); };
-
-    // ---- h0 -> LDS fragments: this wave converts its own two k-blocks (its own 32 units) for every batch tile
-    {
-        const float* h0d = h0 + (size_t)dir * rows_p * kHidden;
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt) {
-            const float* src = h0d + ((size_t)(tile0 + bt) * 32 + n) * kHidden;
-#pragma unroll
-            for (int kbl = 0; kbl < 2; ++kbl) {
-                const int kb = 2 * wave + kbl;
-                const float4 a = *reinterpret_cast<const float4*>(src + kb * 16 + hh * 8);
-                const float4 b = *reinterpret_cast<const float4*>(src + kb * 16 + hh * 8 + 4);
-                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                _Float16 hi[8], lo[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) split16(v[j], hi[j], lo[j]);
-                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) =
-                    make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
-                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) =
-                    make_uint4(pack2(lo[0], lo[1]), pack2(lo[2], lo[3]), pack2(lo[4], lo[5]), pack2(lo[6], lo[7]));
-            }
-        }
-    }
-    __syncthreads();
-
-    const uint4* wp = wst + (size_t)(dir * kWaves + wave) * KT * (kGates * 2 * kFragU4) + lane;
-    const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
-
-    for (int s = 0; s < kSeqLen; ++s) {
-        const int t = dir ? (kSeqLen - 1 - s) : s;
-        f32x16 acc[4][NB];
-        // The bias table is loop-invariant; launder the pointer so the 64 values are re-read (L1/L2 hits) every step
-        // instead of being hoisted into 64 permanently live VGPRs (which spills the accumulators).
-        const float* bps = bp;
-        asm volatile("" : "+v"(bps));
-#pragma unroll
-        for (int set = 0; set < 4; ++set) {
-            f32x16 b;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(bps + set * 32 + q * 4);
-                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
-            }
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) acc[set][bt] = b;
-        }
-
-        // Weight / activation fragment movers.  The k-loops below are kept ROLLED with two named register sets
-        // (A/B) so that exactly one k-block of operands is in flight behind the one being multiplied.
-        auto load_w = [&](uint4 (&wf)[kGates][2], int kbt) {
-#pragma unroll
-            for (int g = 0; g < kGates; ++g)
-#pragma unroll
-                for (int hl = 0; hl < 2; ++hl) wf[g][hl] = wp[((kbt * kGates + g) * 2 + hl) * kFragU4];
-        };
-        const uint4* xp = xin + ((size_t)tile0 * kSeqLen + t) * KX * 2 * kFragU4 + lane;
-        auto load_x = [&](uint4 (&xf)[NB][2], int kb) {
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                for (int hl = 0; hl < 2; ++hl) xf[bt][hl] = xp[((size_t)bt * kSeqLen * KX + kb) * 2 * kFragU4 + hl * kFragU4];
-        };
-        auto load_h = [&](uint4 (&hf)[NB][2], int kb) {
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                for (int hl = 0; hl < 2; ++hl) hf[bt][hl] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, hl) + lane * 16);
-        };
-        // pass-major issue order: consecutive MFMAs always target different accumulators
-        auto mul_x = [&](const uint4 (&wf)[kGates][2], const uint4 (&xf)[NB][2]) {
-#define CCSM_XPASS(P)                                                                                   \
-    _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < kGates; ++g) \
-        acc[g][bt] = mma_pass<P>(wf[g], xf[bt], acc[g][bt]);
-            CCSM_XPASS(0)
-            if constexpr (NPASS >= 2) { CCSM_XPASS(1) }
-            if constexpr (NPASS >= 3) { CCSM_XPASS(2) }
-#undef CCSM_XPASS
-        };
-        auto mul_h = [&](const uint4 (&wf)[kGates][2], const uint4 (&hf)[NB][2]) {
-#define CCSM_HPASS(P)                                                \
-    _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) {                \
-        acc[0][bt] = mma_pass<P>(wf[0], hf[bt], acc[0][bt]);           \
-        acc[1][bt] = mma_pass<P>(wf[1], hf[bt], acc[1][bt]);           \
-        acc[3][bt] = mma_pass<P>(wf[2], hf[bt], acc[3][bt]);           \
-    }
-            CCSM_HPASS(0)
-            if constexpr (NPASS >= 2) { CCSM_HPASS(1) }
-            if constexpr (NPASS >= 3) { CCSM_HPASS(2) }
-#undef CCSM_HPASS
-        };
-
-        uint4 wA[kGates][2], wB[kGates][2], bA[NB][2], bB[NB][2];
-        // ---------------- x-part: acc[g] += W_ih[g] * x_t^T -------------------------------------------------
-        load_w(wA, 0);
-        load_x(bA, 0);
-        if constexpr (KX == 1) {
-            mul_x(wA, bA);
-        } else {
-#pragma unroll 1
-            for (int kb = 0; kb < KX; kb += 2) {
-                load_w(wB, kb + 1);
-                load_x(bB, kb + 1);
-                mul_x(wA, bA);
-                if (kb + 2 < KX) {
-                    load_w(wA, kb + 2);
-                    load_x(bA, kb + 2);
-                }
-                mul_x(wB, bB);
-            }
-        }
-        load_w(wA, KX);   // first recurrent weight k-block: in flight across the barrier
-        __syncthreads();  // B1: every wave's h_{t-1} fragments are in LDS
-
-        // ---------------- h-part: acc[r,z] += W_hh[r,z] * h^T ; acc[nh] += W_hn * h^T ------------------------
-        load_h(bA, 0);
-#pragma unroll 1
-        for (int kb = 0; kb < kKBH; kb += 2) {
-            load_w(wB, KX + kb + 1);
-            load_h(bB, kb + 1);
-            mul_h(wA, bA);
-            if (kb + 2 < kKBH) {
-                load_w(wA, KX + kb + 2);
-                load_h(bA, kb + 2);
-            }
-            mul_h(wB, bB);
-        }
-
-        // ---------------- h_{t-1} of this wave's own units, in MFMA C layout: reg r <-> unit (r&3)+8(r>>2)+4hh --
-        float hprev[NB][16];
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int kb = 2 * wave + (q >> 1);
-                const int src_lane = n + 32 * (q & 1);
-                const half4 hi = as_half4(*reinterpret_cast<const uint2*>(hfrag(kb, bt, 0) + src_lane * 16 + hh * 8));
-                const half4 lo = as_half4(*reinterpret_cast<const uint2*>(hfrag(kb, bt, 1) + src_lane * 16 + hh * 8));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hprev[bt][4 * q + e] = (float)hi[e] + (float)lo[e];
-            }
-        __syncthreads();  // B2: every wave has finished reading h_{t-1}
-
-        // ---------------- gates, new state, fragment write-back (LDS for the next step, HBM for the next layer) --
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt) {
-            uint32_t phi[8], plo[8];  // packed pairs: index 2*q + (e>>1)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float hn2[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const float rr = sigmoid_f(acc[0][bt][r + e]);
-                    const float zz = sigmoid_f(acc[1][bt][r + e]);
-                    const float nn = tanh_f(acc[2][bt][r + e] + rr * acc[3][bt][r + e]);
-                    hn2[e] = (hprev[bt][r + e] - nn) * zz + nn;  // ATen gru_cell: (h - n) * z + n
-                }
-                _Float16 h0a, l0a, h1a, l1a;
-                split16(hn2[0], h0a, l0a);
-                split16(hn2[1], h1a, l1a);
-                phi[r >> 1] = pack2(h0a, h1a);
-                plo[r >> 1] = pack2(l0a, l1a);
-            }
-#pragma unroll
-            for (int kbl = 0; kbl < 2; ++kbl) {
-                // regs 8kbl..8kbl+3 ("a": q even) and 8kbl+4..8kbl+7 ("b": q odd); packed index base 4*kbl
-                uint4 v[2];
-#pragma unroll
-                for (int hl = 0; hl < 2; ++hl) {
-                    const uint32_t* p = hl ? plo : phi;
-                    const uint32_t a0 = p[4 * kbl + 0], a1 = p[4 * kbl + 1], b0 = p[4 * kbl + 2], b1 = p[4 * kbl + 3];
-                    const uint32_t own0 = hh ? b0 : a0, own1 = hh ? b1 : a1;
-                    const uint32_t snd0 = hh ? a0 : b0, snd1 = hh ? a1 : b1;
-                    const uint32_t rcv0 = __shfl_xor(snd0, 32), rcv1 = __shfl_xor(snd1, 32);
-                    v[hl] = hh ? make_uint4(rcv0, rcv1, own0, own1) : make_uint4(own0, own1, rcv0, rcv1);
-                }
-                const int kb = 2 * wave + kbl;
-                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) = v[0];
-                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) = v[1];
-                uint4* o = out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4 + lane;
-                o[0] = v[0];
-                o[kFragU4] = v[1];
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// GRU layer, version 2: 96 batch rows per workgroup (NB = 3 tiles), three accumulator sets, x staged through LDS.
-//
-// Why: version 1 streams the whole (layer, direction) weight set (2.36 MB of fragments) from L2 every timestep for
-// only 64 rows, which is load-path bound (~30 B/clk/CU measured) at ~49 % MFMA utilisation.  96 rows amortise the same
-// weight stream over 1.5x the MFMA work.  The accumulators for 96 rows x 4 quantities (r, z, n_x, n_h) do not fit in
+// The whole (layer, direction) weight set (2.36 MB of fragments) streams from L2 every timestep; 96 rows amortise it over
+// 1.5x the MFMA work of 64.  The accumulators for 96 rows x 4 quantities (r, z, n_x, n_h) do not fit in
 // 256 VGPRs next to double-buffered weight fragments, so each step runs in three phases over three sets:
 //   A  x-part of r and z            (K = 16*KX)   sets R, Z
 //   B  h-part of r, z and n         (K = 256)     sets R, Z, N(= W_hn h + b_hn)
@@ -438,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_kernel(const uint4* __restri
 // the hidden-state fragments (no extra barriers).
 //   wst : [dir][wave][ A: KX x (r,z) x hl | B: 16 x (r,z,n) x hl | C: KX x (n) x hl ][64] uint4
 // ---------------------------------------------------------------------------------------------------------
-template <int KX, int NPASS>
+template <int KX>
 __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                const float* __restrict__ h0, int rows_p,
@@ -454,11 +244,15 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_h = smem;                               // h fragments  [kb 16][bt 3][hl 2] x 1 KiB = 96 KiB
     char* s_x = smem + kKBH * NB * 2 * 1024;        // x chunk ring [buf 2][kbl CK][bt 3][hl 2] x 1 KiB
+    float* s_bias = reinterpret_cast<float*>(s_x + 2 * CHF * 1024);   // [wave][set 4][hh 2][16] fp32 = 4 KiB (this direction's biases)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dir = blockIdx.x & 1;
     const int tile0 = (blockIdx.x >> 1) * NB;
     const int n = lane & 31, hh = lane >> 5;
+    // biases -> LDS once; the accumulator sets are initialised from there every step (no global loads on the step path)
+    if (threadIdx.x < kWaves * 4 * 32 / 4)
+        reinterpret_cast<float4*>(s_bias)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
 
     auto hfrag = [&](int kb, int bt, int hl) -> char* { return s_h + (((kb * NB + bt) * 2 + hl) << 10); };
     auto xfrag = [&](int buf, int kbl, int bt, int hl) -> char* { return s_x + ((((buf * CK + kbl) * NB + bt) * 2 + hl) << 10); };
@@ -514,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
     };
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4);   // wave-uniform
-    const float* bp = bias + (size_t)(dir * kWaves + wave) * 4 * 32 + hh * 16;
+    const float* bp = s_bias + wave * 4 * 32 + hh * 16;
 
     stage_load(dir ? kSeqLen - 1 : 0, 0);
     stage_store(0);
@@ -527,13 +321,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
         stamp(0);
         const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;   // next step's timestep (last step: harmless reload)
         f32x16 acc[3][NB];                            // R, Z, N
-        const float* bps = bp;
-        asm volatile("" : "+v"(bps));                 // keep the bias table out of permanently live registers
-        auto bias_set = [&](int set) {
+        auto bias_set = [&](int set) {                // from LDS
             f32x16 b;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(bps + set * 32 + q * 4);
+                const float4 v = *reinterpret_cast<const float4*>(bp + set * 32 + q * 4);
                 b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
             }
             return b;
@@ -562,29 +354,29 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int hl = 0; hl < (NPASS >= 3 ? 2 : 1); ++hl) dst[g][hl] = w_at(kb * FA + g * 2 + hl);
+                for (int hl = 0; hl < 2; ++hl) dst[g][hl] = w_at(kb * FA + g * 2 + hl);
         };
         auto ldB = [&](uint4 (&dst)[3][2], int kb) {
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int hl = 0; hl < (NPASS >= 3 ? 2 : 1); ++hl) dst[g][hl] = w_at(OFF_B + kb * FB + g * 2 + hl);
+                for (int hl = 0; hl < 2; ++hl) dst[g][hl] = w_at(OFF_B + kb * FB + g * 2 + hl);
         };
         auto ldC = [&](uint4 (&dst)[4][2], int c) {     // the n-gate fragments of a whole chunk
 #pragma unroll
             for (int j = 0; j < CK; ++j)
 #pragma unroll
-                for (int hl = 0; hl < (NPASS >= 3 ? 2 : 1); ++hl) dst[j][hl] = w_at(OFF_C + (c * CK + j) * FC + hl);
+                for (int hl = 0; hl < 2; ++hl) dst[j][hl] = w_at(OFF_C + (c * CK + j) * FC + hl);
         };
         auto rdx = [&](uint4 (&x)[NB][2], int buf, int kbl) {
 #pragma unroll
-            for (int hl = 0; hl < (NPASS >= 2 ? 2 : 1); ++hl)
+            for (int hl = 0; hl < 2; ++hl)
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) x[bt][hl] = *reinterpret_cast<const uint4*>(xfrag(buf, kbl, bt, hl) + lane * 16);
         };
         auto rdh = [&](uint4 (&x)[NB][2], int kb) {
 #pragma unroll
-            for (int hl = 0; hl < (NPASS >= 2 ? 2 : 1); ++hl)
+            for (int hl = 0; hl < 2; ++hl)
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) x[bt][hl] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, hl) + lane * 16);
         };
@@ -597,14 +389,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
         CCSM_FENCE;                                                                                                 \
         _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)             \
             acc[S0 + g][bt] = mfma16(W[g][0], X[bt][0], acc[S0 + g][bt]);                                           \
-        if constexpr (NPASS >= 2) {                                                                                 \
-            _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)         \
-                acc[S0 + g][bt] = mfma16(W[g][0], X[bt][1], acc[S0 + g][bt]);                                       \
-        }                                                                                                           \
-        if constexpr (NPASS >= 3) {                                                                                 \
-            _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)         \
-                acc[S0 + g][bt] = mfma16(W[g][1], X[bt][0], acc[S0 + g][bt]);                                       \
-        }                                                                                                           \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)             \
+            acc[S0 + g][bt] = mfma16(W[g][0], X[bt][1], acc[S0 + g][bt]);                                           \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)             \
+            acc[S0 + g][bt] = mfma16(W[g][1], X[bt][0], acc[S0 + g][bt]);                                           \
         CCSM_FENCE;                                                                                                 \
     } while (0)
 
@@ -676,12 +464,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
     do {                                                                                                            \
         CCSM_FENCE;                                                                                                 \
         _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(WKB[0], X[bt][0], acc[2][bt]);        \
-        if constexpr (NPASS >= 2) {                                                                                 \
-            _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(WKB[0], X[bt][1], acc[2][bt]);    \
-        }                                                                                                           \
-        if constexpr (NPASS >= 3) {                                                                                 \
-            _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(WKB[1], X[bt][0], acc[2][bt]);    \
-        }                                                                                                           \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(WKB[0], X[bt][1], acc[2][bt]);        \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(WKB[1], X[bt][0], acc[2][bt]);        \
         CCSM_FENCE;                                                                                                 \
     } while (0)
         if constexpr (CK == 4) {
@@ -785,7 +569,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
 // (2 k-blocks x 7 timesteps x hi/lo = 28 KiB per chunk, double-buffered).
 //   wa / ua : [wave][kb 32][hl][64] uint4 ; va : [wave][hh][16] floats (C-row order) ; fcw : fc1.weight (2,1024) fp32
 // ---------------------------------------------------------------------------------------------------------
-template <int NPASS>
 __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
                                                           const uint4* __restrict__ ua, const float* __restrict__ va,
                                                           const float* __restrict__ fcw, float* __restrict__ part,
@@ -821,7 +604,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
         const int tq = kb < kKBH ? kSeqLen - 1 : 0;
         const uint4* xp = otile + ((size_t)tq * kKB12 + kb) * 2 * kFragU4 + lane;
         const uint4 x[2] = {xp[0], xp[kFragU4]};
-        qacc = mma_split<NPASS>(w, x, qacc);
+        qacc = mma_split3(w, x, qacc);
     }
     float vav[16];
 #pragma unroll
@@ -897,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
                 for (int tt = 0; tt < TG; ++tt) {
                     const uint4 x[2] = {*reinterpret_cast<const uint4*>(sb + ((kbl * TG + tt) * 2 + 0) * 1024),
                                         *reinterpret_cast<const uint4*>(sb + ((kbl * TG + tt) * 2 + 1) * 1024)};
-                    kacc[tt] = mma_split<NPASS>(w[kbl], x, kacc[tt]);
+                    kacc[tt] = mma_split3(w[kbl], x, kacc[tt]);
                     if (fc_owner) {
                         const half8 xh = as_half8(x[0]), xl = as_half8(x[1]);
 #pragma unroll

@@ -40,12 +40,11 @@ typedef enum {
 /* Arithmetic of the contraction (matmul) work; everything else is fp32.
  * SPLIT3: every fp32 operand v carried as fp16 pair (hi, lo); products hi*hi + hi*lo + lo*hi accumulate in fp32
  *         on v_mfma_f32_32x32x16_f16 (fp32-class accuracy: max |dprob| ~2e-7).
- * SPLIT2: fp16-rounded weights, split activations (2 MFMA passes).   FP16: plain fp16 operands (1 pass).
  * SPLIT_F8: hi*hi on the fp16 MFMA, the two correction products hi*lo + lo*hi with fp8 (e4m3) operands on the gfx950
  *         block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) into the same fp32 accumulators: 2/3 of SPLIT3's MFMA
  *         cycles, max |dprob| ~4e-6 on the parity suite, 20x inside the 1e-4 bar (GRU layers and attention pool; only
  *         layer 0's K = 11 input projection keeps three fp16 passes).  The default. */
-typedef enum { CCSM_PRECISION_SPLIT_F8 = 4, CCSM_PRECISION_SPLIT3 = 3, CCSM_PRECISION_SPLIT2 = 2, CCSM_PRECISION_FP16 = 1 } ccsm_precision;
+typedef enum { CCSM_PRECISION_SPLIT_F8 = 4, CCSM_PRECISION_SPLIT3 = 3 } ccsm_precision;
 
 /* Mirrors ModelAttRNN.__init__ (models.py:18-22) as called from call_modifications.py:315-323. */
 typedef struct {
