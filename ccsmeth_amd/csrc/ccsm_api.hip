@@ -7,10 +7,12 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <functional>
 
 #include "../../include/ccsm.h"
 #include "ccsm_kernels.hip"
 #include "ccsm_gru_f8.hip"
+#include "ccsm_gru_mx.hip"
 #include "ccsm_aggr.hip"
 #include "ccsm_extract.hip"
 
@@ -62,8 +64,8 @@ struct ccsm_model {
     int device = 0;
     int precision = 3;
     uint4* wst2[kLayers] = {nullptr, nullptr, nullptr}; // split3: [dir][wave][A: KX x (r,z) | B: 16 x (r,z,n) | C: KX x (n)][hl][64]
-    uint4* wst3[kLayers] = {nullptr, nullptr, nullptr}; // split-f8: as wst2 with the second fragment of a k-block = fp8 corr
-    int4 wscale[kLayers] = {};                           // E8M0 scales of the corr weight operands (x-part/h-part per dir)
+    float mx_quant_err = 0.f;                            // largest relative quantisation error of a weight correction blob
+    uint4* wstmx[kLayers] = {nullptr, nullptr, nullptr};// split-mx weight streams (ccsm_gru_mx.hip: hi fragments + MX correction blobs)
     uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
     uint4* ua3 = nullptr;
     int att_scale[2] = {127, 127};                       // E8M0 scales of the Wa / Ua corr operands
@@ -205,37 +207,135 @@ void emit_corr_frag(uint8_t* dst, int kb, int log2sw, Get get) {
     }
 }
 
-// Split-f8 weight stream: the version-2 order with the second fragment of every k-block replaced by its corr fragment
-// (layer 0 keeps fp16 lo for its x-part).  scales = E8M0 bytes {x-part dir 0, h-part dir 0, x-part dir 1, h-part dir 1}.
-void pack_wstream_v3(int layer, const float* const wih[2], const float* const whh[2], std::vector<_Float16>& out, int4& scales) {
-    const int kx = layer_kx(layer);
-    const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
-    const int nfrag = kx * 4 + kKBH * 6 + kx * 2;
-    pack_wstream_v2(layer, wih, whh, out);               // hi fragments (and layer 0's fp16 lo) are already in place
-    int lg[2][2];
-    for (int dir = 0; dir < 2; ++dir) {
-        lg[dir][0] = corr_scale_log2(wih[dir], (size_t)kGates * kHidden * k_in);
-        lg[dir][1] = corr_scale_log2(whh[dir], (size_t)kGates * kHidden * kHidden);
+// ---- split-mx correction blobs (ccsm_gru_mx.hip).  MX element codes, round to nearest even, saturating:
+//   fp6 e2m3: 1-2-3 bits, bias 1: 0 .. 0.875 in steps of 1/8 (subnormal), then 1 .. 7.5         fp4 e2m1: 0, 0.5, 1, 1.5, 2, 3, 4, 6
+uint8_t mx_code(float v, int fmt) {
+    const int mb = fmt == 2 ? 3 : 1;                                   // mantissa bits
+    const float vmax = fmt == 2 ? 7.5f : 6.0f;
+    const uint8_t sign = std::signbit(v) ? (uint8_t)(1u << (2 + mb)) : 0;
+    float a = std::fabs(v);
+    if (!(a == a)) a = 0.f;
+    if (a > vmax) a = vmax;
+    int e;
+    (void)std::frexp(a, &e);
+    int ex = a > 0.f ? e - 1 : 0;                                      // a in [2^ex, 2^(ex+1))
+    if (ex < 0) ex = 0;                                                // subnormal range shares the step of [1, 2)
+    const float step = std::ldexp(1.0f, ex - mb);
+    float r = std::nearbyint(a / step) * step;
+    if (r > vmax) r = vmax;
+    uint8_t code;
+    if (r < 1.0f) code = (uint8_t)std::lrint(r * (float)(1 << mb));    // exponent field 0
+    else {
+        int e2;
+        const float m2 = std::frexp(r, &e2);                           // r = m2 2^e2, m2 in [0.5, 1)
+        code = (uint8_t)(((e2 - 1 + 1) << mb) | (int)std::lrint((m2 * 2.0f - 1.0f) * (float)(1 << mb)));
     }
-    scales = make_int4(127 - 11 - lg[0][0], 127 - 11 - lg[0][1], 127 - 11 - lg[1][0], 127 - 11 - lg[1][1]);
-    uint8_t* bytes = reinterpret_cast<uint8_t*>(out.data());
+    return sign | code;
+}
+float mx_value(uint8_t code, int fmt) {
+    const int mb = fmt == 2 ? 3 : 1;
+    const int m = code & ((1 << mb) - 1), e = (code >> mb) & 3;
+    const float v = e == 0 ? (float)m / (float)(1 << mb) : std::ldexp(1.0f + (float)m / (float)(1 << mb), e - 1);
+    return (code >> (2 + mb)) & 1 ? -v : v;
+}
+inline int mx_perm(int j) { return 8 * ((j & 15) >> 2) + (j & 3) + 4 * (j >> 4); }   // blob position -> k within the pair (kMxPerm)
+
+// One lane's weight blob of 32 values `val[j]` (already in blob order): E8M0 scale from the block's largest magnitude (max |val| s
+// <= top of the format), fp4 codes packed little-endian (element j in nibble j & 1 of byte j >> 1) into 16 bytes; *scale = the
+// scale byte of the TRUE value (exp_bias = -11 for the W_lo lanes, which carry W_lo 2^11).  Returns the block's largest
+// quantisation error relative to its largest magnitude (a-priori accuracy figure, see ccsm_create).
+float emit_blob(uint8_t* dst16, uint8_t* scale, const float (&val)[32], int exp_bias) {
+    float mx = 0.f;
+    for (int j = 0; j < 32; ++j) mx = std::fmax(mx, std::fabs(val[j]));
+    int lg = 0;
+    if (mx > 0.f && std::isfinite(mx)) lg = (int)std::floor(std::log2(6.0f / mx));
+    lg = std::max(-100, std::min(100, lg));
+    std::memset(dst16, 0, 16);
+    float worst = 0.f;
+    for (int j = 0; j < 32; ++j) {
+        const float sv = std::ldexp(val[j], lg);
+        const uint8_t code = mx_code(sv, 4);
+        worst = std::fmax(worst, std::fabs(mx_value(code, 4) - sv));
+        dst16[j >> 1] |= (uint8_t)(code << (4 * (j & 1)));
+    }
+    *scale = (uint8_t)std::max(0, std::min(254, 127 + exp_bias - lg));
+    return mx > 0.f ? worst / std::ldexp(mx, lg) : 0.f;
+}
+
+// blob fragment (1 KiB) of one (32-row block, pair of k-blocks) and its scale bytes: lane (i, g = 0) <- W_lo 2^11, (i, 1) <- W_hi;
+// scales = the pair's 256-byte scale block (lane * 4 + gate); get(i, k) = fp32 weight of row i of the block, k in [0, 32) of the pair
+template <typename Get>
+float emit_blob_frag(uint8_t* blob, uint8_t* scales, int gate, Get get) {
+    float worst = 0.f;
+    for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 31, g = lane >> 5;
+        float val[32];
+        for (int j = 0; j < 32; ++j) {
+            const float v = get(i, mx_perm(j));
+            const float hi = (float)(_Float16)v;
+            val[j] = g ? hi : std::ldexp(v - hi, 11);
+        }
+        worst = std::fmax(worst, emit_blob(blob + lane * 16, scales + lane * 4 + gate, val, g ? 0 : -11));
+    }
+    return worst;
+}
+inline void emit_hi_frag(_Float16* dst, int kb, const std::function<float(int, int)>& get) {   // lane (i, g) <- hi of k = 16 kb + 8 g + j
+    for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) dst[lane * 8 + j] = (_Float16)get(lane & 31, 16 * kb + 8 * (lane >> 5) + j);
+}
+
+// Split-mx weight stream of one layer (byte layouts: ccsm_gru_mx.hip).  Returns the largest relative blob quantisation error.
+float pack_wstream_mx(int layer, const float* const wih[2], const float* const whh[2], std::vector<uint8_t>& out) {
+    const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
+    const size_t wbytes = layer == 0 ? kMx0WBytes : kMx12WBytes;
+    out.assign((size_t)2 * kWaves * wbytes, 0);
+    float worst = 0.f;
     for (int dir = 0; dir < 2; ++dir)
         for (int wave = 0; wave < kWaves; ++wave) {
-            size_t f = (size_t)(dir * kWaves + wave) * nfrag;
-            auto emit = [&](bool xpart, int kb, int g) {
-                if (!(xpart && layer == 0)) {
-                    auto get = [&](int i, int k) -> float {
-                        const int row = g * kHidden + kUnitTile * wave + i;
-                        return xpart ? (k < k_in ? wih[dir][(size_t)row * k_in + k] : 0.f) : whh[dir][(size_t)row * kHidden + k];
-                    };
-                    emit_corr_frag(bytes + (f + 1) * 1024, kb, lg[dir][xpart ? 0 : 1], get);
-                }
-                f += 2;
+            uint8_t* base = out.data() + (size_t)(dir * kWaves + wave) * wbytes;
+            auto wx = [&](int g) { return [=](int i, int k) -> float { return k < k_in ? wih[dir][(size_t)(g * kHidden + kUnitTile * wave + i) * k_in + k] : 0.f; }; };
+            auto wh = [&](int g) { return [=](int i, int k) -> float { return whh[dir][(size_t)(g * kHidden + kUnitTile * wave + i) * kHidden + k]; }; };
+            auto hi_at = [&](size_t off, const std::function<float(int, int)>& get, int kb) { emit_hi_frag(reinterpret_cast<_Float16*>(base + off), kb, get); };
+            auto lo_at = [&](size_t off, const std::function<float(int, int)>& get, int kb) {      // fp16 residual fragment (layer 0's x-part)
+                _Float16* dst = reinterpret_cast<_Float16*>(base + off);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = get(lane & 31, 16 * kb + 8 * (lane >> 5) + j);
+                        dst[lane * 8 + j] = (_Float16)(v - (float)(_Float16)v);
+                    }
             };
-            for (int kb = 0; kb < kx; ++kb) { emit(true, kb, 0); emit(true, kb, 1); }
-            for (int kb = 0; kb < kKBH; ++kb) { emit(false, kb, 0); emit(false, kb, 1); emit(false, kb, 2); }
-            for (int kb = 0; kb < kx; ++kb) emit(true, kb, 2);
+            auto blob_at = [&](size_t off, size_t sc_off, int gate_byte, const std::function<float(int, int)>& get, int pair) {
+                worst = std::fmax(worst, emit_blob_frag(base + off, base + sc_off, gate_byte, [&](int i, int k) { return get(i, 32 * pair + k); }));
+            };
+            auto phase_b = [&](size_t off_b) {
+                for (int q = 0; q < kKBH / 2; ++q) {
+                    const size_t pb = off_b + (size_t)q * kMxPairB;
+                    for (int kbl = 0; kbl < 2; ++kbl)
+                        for (int g = 0; g < 3; ++g) hi_at(pb + (size_t)(3 * kbl + g) * 1024, wh(g), 2 * q + kbl);
+                    for (int g = 0; g < 3; ++g) blob_at(pb + (size_t)(6 + g) * 1024, pb + 9 * 1024, g, wh(g), q);
+                }
+            };
+            if (layer == 0) {
+                for (int g = 0; g < 2; ++g) { hi_at((size_t)(2 * g) * 1024, wx(g), 0); lo_at((size_t)(2 * g + 1) * 1024, wx(g), 0); }
+                phase_b(4 * 1024);
+                const size_t oc = 4 * 1024 + (size_t)(kKBH / 2) * kMxPairB;
+                hi_at(oc, wx(2), 0); lo_at(oc + 1024, wx(2), 0);
+            } else {
+                for (int p = 0; p < kKB12 / 2; ++p) {
+                    const size_t pa = (size_t)p * kMxPairA;
+                    for (int kbl = 0; kbl < 2; ++kbl)
+                        for (int g = 0; g < 2; ++g) hi_at(pa + (size_t)(2 * kbl + g) * 1024, wx(g), 2 * p + kbl);
+                    for (int g = 0; g < 2; ++g) blob_at(pa + (size_t)(4 + g) * 1024, pa + 6 * 1024, g, wx(g), p);
+                }
+                phase_b(kMx12OffB);
+                for (int p = 0; p < kKB12 / 2; ++p) {
+                    const size_t pc = kMx12OffC + (size_t)p * kMxPairC;
+                    hi_at(pc, wx(2), 2 * p); hi_at(pc + 1024, wx(2), 2 * p + 1);
+                    blob_at(pc + 2 * 1024, pc + 3 * 1024, 0, wx(2), p);
+                }
+            }
         }
+    return worst;
 }
 
 void pack_bias(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
@@ -306,13 +406,19 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
 }
 
 // One GRU layer in split-f8 arithmetic; the DBG instantiation (phase time stamps, tools/gpu_phases.py) only when asked for.
-template <int KX>
-void launch_gru_f8(dim3 grid, hipStream_t st, const uint4* xin, uint4* out, const uint4* wst, const float* bias, const float* h0,
-                   int rows_p, int4 sc, unsigned long long* dbg) {
-    if (dbg)
-        hipLaunchKernelGGL((gru_layer_f8_kernel<KX, true>), grid, dim3(512), gru2_lds(KX), st, xin, out, wst, bias, h0, rows_p, sc, dbg);
-    else
-        hipLaunchKernelGGL((gru_layer_f8_kernel<KX, false>), grid, dim3(512), gru2_lds(KX), st, xin, out, wst, bias, h0, rows_p, sc, nullptr);
+// GRU layers in split-mx arithmetic; the DBG instantiations (phase time stamps, tools/gpu_phases.py) only when asked for
+void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4* out, const uint4* wst, const float* bias, const float* h0,
+                   int rows_p, unsigned long long* dbg) {
+    if (layer == 0) {
+        if (dbg) hipLaunchKernelGGL((gru_layer0_mx_kernel<true>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else hipLaunchKernelGGL((gru_layer0_mx_kernel<false>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    } else if (layer == 1) {
+        if (dbg) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    } else {        // the last layer feeds the attention kernel: fp8 corr fragments
+        if (dbg) hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    }
 }
 
 // Heavy kernels, once over every row used by the current slices, then the per-slice logits/softmax.
@@ -327,14 +433,11 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     const dim3 ggrid(2 * (tiles / kNBGru2));
     static const int dbg_layer = std::getenv("CCSM_PHASE_LAYER") ? std::atoi(std::getenv("CCSM_PHASE_LAYER")) : 1;
     if constexpr (F8) {
-        launch_gru_f8<kKB0>(ggrid, st, ws->x0, ws->act[0], m->wst3[0], m->bias[0], ws->h0buf, ws->rows_p, m->wscale[0],
-                            dbg_layer == 0 ? ws->dbg : nullptr);
+        launch_gru_mx(0, ggrid, st, ws->x0, ws->act[0], m->wstmx[0], m->bias[0], ws->h0buf, ws->rows_p, dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
-        launch_gru_f8<kKB12>(ggrid, st, ws->act[0], ws->act[1], m->wst3[1], m->bias[1], ws->h0buf + slab, ws->rows_p, m->wscale[1],
-                             dbg_layer == 1 ? ws->dbg : nullptr);
+        launch_gru_mx(1, ggrid, st, ws->act[0], ws->act[1], m->wstmx[1], m->bias[1], ws->h0buf + slab, ws->rows_p, dbg_layer == 1 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-        launch_gru_f8<kKB12>(ggrid, st, ws->act[1], ws->act[0], m->wst3[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, m->wscale[2],
-                             dbg_layer == 2 ? ws->dbg : nullptr);
+        launch_gru_mx(2, ggrid, st, ws->act[1], ws->act[0], m->wstmx[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, dbg_layer == 2 ? ws->dbg : nullptr);
     } else {
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
                            m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p, nullptr);
@@ -465,8 +568,9 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         st = upload(&m->wst2[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
         if (st != CCSM_OK) break;
         if (prec == 4) {
-            pack_wstream_v3(l, w->weight_ih[l], w->weight_hh[l], hbuf, m->wscale[l]);
-            st = upload(&m->wst3[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
+            std::vector<uint8_t> bbuf;
+            m->mx_quant_err = std::fmax(m->mx_quant_err, pack_wstream_mx(l, w->weight_ih[l], w->weight_hh[l], bbuf));
+            st = upload(&m->wstmx[l], bbuf.data(), bbuf.size());
             if (st != CCSM_OK) break;
         }
         pack_bias(w->bias_ih[l], w->bias_hh[l], fbuf);
@@ -495,10 +599,12 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         set_lds(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB12>), gru2_lds(kKB12));
         set_lds(reinterpret_cast<const void*>(&attn_fc_kernel), kAttLds);
         if (prec == CCSM_PRECISION_SPLIT_F8) {
-            set_lds(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB0, false>), gru2_lds(kKB0));
-            set_lds(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, false>), gru2_lds(kKB12));
-            set_lds(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB0, true>), gru2_lds(kKB0));
-            set_lds(reinterpret_cast<const void*>(&gru_layer_f8_kernel<kKB12, true>), gru2_lds(kKB12));
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttLds);
         }
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
@@ -516,7 +622,7 @@ void ccsm_destroy(ccsm_model* m) {
     (void)hipSetDevice(m->device);
     for (int l = 0; l < kLayers; ++l) {
         (void)hipFree(m->wst2[l]);
-        (void)hipFree(m->wst3[l]);
+        (void)hipFree(m->wstmx[l]);
         (void)hipFree(m->bias[l]);
     }
     (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);
@@ -996,6 +1102,68 @@ ccsm_status ccsm_selftest_split_f8(int device, float* err_corr, float* err_main_
         *outs[pass] = (float)err;
     }
     (void)hipFree(dw); (void)hipFree(dx); (void)hipFree(dc);
+    return CCSM_OK;
+}
+
+ccsm_status ccsm_selftest_split_mx(int device, float* err_corr, float* err_main_only, int* blob_mismatch) {
+    if (!err_corr || !err_main_only || !blob_mismatch) return fail(CCSM_ERR_INVALID_ARG, "outputs must be non-NULL");
+    HIP_TRY(hipSetDevice(device));
+    // W: 32 units x 32 k, X: 32 rows x 32 k, deterministic, non-symmetric, weights ~ U(-0.07, 0.07), activations in (-1, 1)
+    std::vector<float> w(32 * 32), x(32 * 32);
+    uint32_t sd = 12345u;
+    auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return (float)(sd >> 8) * (1.0f / 16777216.0f); };
+    for (auto& v : w) v = (rnd() - 0.5f) * 0.14f;
+    for (auto& v : x) v = (rnd() - 0.5f) * 1.9f;
+    std::vector<_Float16> frag(4 * 512, (_Float16)0.f);       // hi kb0, hi kb1, blob, scale dwords (byte 0)
+    auto get = [&](int i, int k) { return w[i * 32 + k]; };
+    emit_hi_frag(frag.data(), 0, get);
+    emit_hi_frag(frag.data() + 512, 1, get);
+    (void)emit_blob_frag(reinterpret_cast<uint8_t*>(frag.data()) + 2048, reinterpret_cast<uint8_t*>(frag.data()) + 3072, 0, get);
+    uint4* dw = nullptr;
+    float *dx = nullptr, *dc = nullptr;
+    uint32_t* db = nullptr;
+    HIP_TRY(hipMalloc((void**)&dw, 4096));
+    HIP_TRY(hipMalloc((void**)&dx, 4096));
+    HIP_TRY(hipMalloc((void**)&dc, 4096));
+    HIP_TRY(hipMalloc((void**)&db, 64 * 24));
+    HIP_TRY(hipMemcpy(dw, frag.data(), 4096, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dx, x.data(), 4096, hipMemcpyHostToDevice));
+    float* outs[2] = {err_corr, err_main_only};
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(mx_selftest_kernel, dim3(1), dim3(64), 0, 0, dw, dx, dc, db, pass == 0 ? 1 : 0, 0.25f, kMxScaleHi, kMxScaleLo);
+        HIP_TRY(hipGetLastError());
+        std::vector<float> c(1024);
+        HIP_TRY(hipMemcpy(c.data(), dc, 4096, hipMemcpyDeviceToHost));
+        double err = 0.0;
+        for (int u = 0; u < 32; ++u)
+            for (int r = 0; r < 32; ++r) {
+                double ref = 0.0;
+                for (int k = 0; k < 32; ++k) ref += (double)w[u * 32 + k] * (double)x[r * 32 + k];
+                err = std::fmax(err, std::fabs(ref - (double)c[u * 32 + r]));
+            }
+        *outs[pass] = (float)err;
+    }
+    // the host's fp6 encoder against the instruction's: the same activations packed here (x_hi * 4 | x_lo * 2^14, kMxPerm order)
+    std::vector<uint8_t> dev_blob(64 * 24), host_blob(64 * 24, 0);
+    HIP_TRY(hipMemcpy(dev_blob.data(), db, 64 * 24, hipMemcpyDeviceToHost));
+    for (int lane = 0; lane < 64; ++lane) {
+        const int n = lane & 31, g = lane >> 5;
+        uint8_t bits[24] = {0};
+        for (int j = 0; j < 32; ++j) {
+            const float v = x[n * 32 + mx_perm(j)];
+            const float hi = (float)(_Float16)v;
+            const float lo12 = (float)(_Float16)((v - hi) * 4096.0f);
+            const uint8_t code = mx_code((g ? lo12 : hi) * 4.0f, 2);
+            const int bit = j * 6;
+            bits[bit >> 3] |= (uint8_t)(code << (bit & 7));
+            if ((bit & 7) + 6 > 8) bits[(bit >> 3) + 1] |= (uint8_t)(code >> (8 - (bit & 7)));
+        }
+        std::memcpy(host_blob.data() + lane * 24, bits, 24);
+    }
+    int mism = 0;
+    for (size_t i = 0; i < dev_blob.size(); ++i) mism += dev_blob[i] != host_blob[i];
+    *blob_mismatch = mism;
+    (void)hipFree(dw); (void)hipFree(dx); (void)hipFree(dc); (void)hipFree(db);
     return CCSM_OK;
 }
 

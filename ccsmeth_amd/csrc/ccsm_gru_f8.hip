@@ -98,472 +98,6 @@ __device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// One bidirectional GRU layer, 96 batch rows per workgroup, phases A (x-part of r, z), B (h-part of r, z, n), C (x-part
-// of n) as in gru_layer_v2_kernel; the unit of work inside a phase is a PAIR of k-blocks:
-//   G1: main MFMAs of k-block 2p      G2: main MFMAs of k-block 2p+1      G3: corr MFMAs of the pair
-// Weight registers are reloaded immediately after the group that used them, two pairs ahead in phase A (ring of two
-// pairs), one pair ahead in phase B (one pair resident) and one chunk (two pairs) ahead in phase C.
-//   xin  : [tile][t][KX][hi|corr][64] uint4 (KX == 1: [hi|lo] fp16)       out : [tile][t][32][hi|corr][64]
-//   wst  : [dir][wave][ A: KX x (r,z) x 2 | B: 16 x (r,z,n) x 2 | C: KX x (n) x 2 ][64] uint4, second fragment = corr
-//          (KX == 1: A and C second fragment = fp16 lo)
-//   sc   : E8M0 weight-operand scales: x = x-part dir 0, y = h-part dir 0, z = x-part dir 1, w = h-part dir 1
-// ---------------------------------------------------------------------------------------------------------
-template <int KX, bool DBG>
-__global__ __launch_bounds__(512, 2) void gru_layer_f8_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
-                                                               const uint4* __restrict__ wst, const float* __restrict__ bias,
-                                                               const float* __restrict__ h0, int rows_p, int4 sc,
-                                                               unsigned long long* __restrict__ dbg) {
-    constexpr int NB = 3;
-    constexpr int CK = KX >= 4 ? 4 : KX;
-    constexpr int NCH = KX / CK;
-    constexpr int CHF = CK * NB * 2;
-    constexpr int SPW = (CHF + kWaves - 1) / kWaves;
-    constexpr int FA = 4, FB = 6, FC = 2;
-    constexpr int OFF_B = KX * FA, OFF_C = OFF_B + kKBH * FB, WFRAGS = OFF_C + KX * FC;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* s_h = smem;                               // h fragments  [kb 16][bt 3][hi|corr] x 1 KiB = 96 KiB
-    char* s_x = smem + kKBH * NB * 2 * 1024;        // x chunk ring [buf 2][kbl CK][bt 3][2] x 1 KiB
-    float* s_bias = reinterpret_cast<float*>(s_x + 2 * CHF * 1024);   // [wave][set 4][hh 2][16] fp32 = 4 KiB (this direction's biases)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dir = blockIdx.x & 1;
-    const int tile0 = (blockIdx.x >> 1) * NB;
-    const int n = lane & 31, hh = lane >> 5;
-    const int sa_x = dir ? sc.z : sc.x, sa_h = dir ? sc.w : sc.y;
-
-    // ---- biases -> LDS, once: the accumulator sets are initialised from there every step (ds_read_b128, lgkmcnt) instead of
-    // global loads, whose s_waitcnt vmcnt(0) drained the weight prefetch queue three times per timestep
-    if (threadIdx.x < kWaves * 4 * 32 / 4)
-        reinterpret_cast<float4*>(s_bias)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
-
-    auto hfrag = [&](int kb, int bt, int f) -> char* { return s_h + (((kb * NB + bt) * 2 + f) << 10); };
-    auto xfrag = [&](int buf, int kbl, int bt, int f) -> char* { return s_x + ((((buf * CK + kbl) * NB + bt) * 2 + f) << 10); };
-
-    // ---- h0 -> LDS fragments (this wave's own two k-blocks, every batch tile)
-    {
-        const float* h0d = h0 + (size_t)dir * rows_p * kHidden;
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt) {
-            const float* src = h0d + ((size_t)(tile0 + bt) * 32 + n) * kHidden;
-#pragma unroll
-            for (int kbl = 0; kbl < 2; ++kbl) {
-                const int kb = 2 * wave + kbl;
-                const float4 q0 = *reinterpret_cast<const float4*>(src + kb * 16 + 0);
-                const float4 q1 = *reinterpret_cast<const float4*>(src + kb * 16 + 4);
-                const float4 q2 = *reinterpret_cast<const float4*>(src + kb * 16 + 8);
-                const float4 q3 = *reinterpret_cast<const float4*>(src + kb * 16 + 12);
-                const float u[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-                _Float16 hi[16];
-                float cv[16];                        // this lane's corr values in natural k order
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    hi[j] = (_Float16)u[j];
-                    const float hf = (float)hi[j];
-                    const float c = hh ? (u[j] - hf) * kCorrActLo : hf * kCorrActHi;
-                    cv[j] = fminf(fmaxf(c, -kF8Clamp), kF8Clamp);
-                }
-                *reinterpret_cast<uint4*>(hfrag(kb, bt, 0) + lane * 16) =
-                    hh ? make_uint4(pack2(hi[8], hi[9]), pack2(hi[10], hi[11]), pack2(hi[12], hi[13]), pack2(hi[14], hi[15]))
-                       : make_uint4(pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), pack2(hi[4], hi[5]), pack2(hi[6], hi[7]));
-                // kCorrPerm order: k = 0..3, 8..11, 4..7, 12..15
-                *reinterpret_cast<uint4*>(hfrag(kb, bt, 1) + lane * 16) =
-                    make_uint4(cvt4_fp8(cv[0], cv[1], cv[2], cv[3]), cvt4_fp8(cv[8], cv[9], cv[10], cv[11]),
-                               cvt4_fp8(cv[4], cv[5], cv[6], cv[7]), cvt4_fp8(cv[12], cv[13], cv[14], cv[15]));
-            }
-        }
-    }
-
-    // ---- x staging (as gru_layer_v2_kernel): fragment f = (kbl*NB + bt)*2 + hl of chunk c of timestep t
-    // x staging: LDS-DMA (dma16: global -> LDS without a register hop), issued where the register loads used to be; stage_wait<N>
-    // stands where the ds_write used to be: N = vector-memory loads this wave issued after the transfer (they may stay in flight).
-    static_assert(SPW <= 3, "staging transfers per wave");
-    const int lane16 = lane * 16;
-    const u32x4_t xrs = dma_rsrc(xin);
-    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)s_x;
-    auto stage_off = [&](int t, int c, int i) -> int {
-        const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
-        const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
-        return (((((tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) << 10);
-    };
-    auto stage_dst = [&](int buf, int i) -> unsigned {
-        const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
-        return sx_base + (unsigned)((buf * CHF + f) << 10);
-    };
-    auto stage_load = [&](int t, int c, int buf) {
-#pragma unroll
-        for (int i = 0; i < SPW; ++i)
-            dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(stage_off(t, c, i)), __builtin_amdgcn_readfirstlane(stage_dst(buf, i)));
-    };
-#define CCSM_STAGE_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wst + (size_t)(dir * kWaves + wave) * WFRAGS * kFragU4);
-    const int bias_off = (int)(reinterpret_cast<char*>(s_bias) - smem) + wave * 4 * 32 * 4;   // wave-uniform byte offset of this wave's table
-
-    stage_load(dir ? kSeqLen - 1 : 0, 0, 0);
-    CCSM_STAGE_WAIT(0);
-
-    auto w_at = [&](int frag) -> uint4 { return buf_load(wrs, lane16, frag << 10); };
-    // Weight registers.  Every phase's FIRST fragments are requested while the previous phase still has MFMAs to issue (in the
-    // slots whose "two ahead" reload would run past the end of that phase), so no phase starts behind an exposed L2 round trip:
-    //   phase A pair 0  <- last chunk of phase C (previous step)      phase A pair 1 <- start of the tail (previous step)
-    //   phase B pair 0  <- last chunk of phase A                      phase C chunk 0 <- last pair of phase B
-    uint4 wah[2][2][2], wac[2][2][2];             // phase A ring of two pairs: [pair slot][kb in pair][gate] main / corr
-    uint4 wbh[2][3], wbc[2][3];                   // phase B resident pair: [kb in pair][gate]
-    uint4 wch[2][4], wcc[2][4];                   // phase C, n gate: [chunk parity][kb in chunk]
-    auto ldAh = [&](uint4 (&d)[2], int kb) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) d[g] = w_at(kb * FA + g * 2);
-    };
-    auto ldAc = [&](uint4 (&d)[2], int kb) {      // KX == 1: the fp16 lo fragments
-#pragma unroll
-        for (int g = 0; g < 2; ++g) d[g] = w_at(kb * FA + g * 2 + 1);
-    };
-    auto ldBh = [&](uint4 (&d)[3], int kb) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) d[g] = w_at(OFF_B + kb * FB + g * 2);
-    };
-    auto ldBc = [&](uint4 (&d)[3], int kb) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g) d[g] = w_at(OFF_B + kb * FB + g * 2 + 1);
-    };
-    auto ldC = [&](int par, int c) {              // the n-gate fragments of a whole chunk
-#pragma unroll
-        for (int j = 0; j < CK; ++j) {
-            wch[par][j] = w_at(OFF_C + (c * CK + j) * FC);
-            wcc[par][j] = w_at(OFF_C + (c * CK + j) * FC + 1);
-        }
-    };
-    auto ldA_pair = [&](int p) {
-        ldAh(wah[p][0], 2 * p); ldAh(wah[p][1], 2 * p + 1);
-        ldAc(wac[p][0], 2 * p); ldAc(wac[p][1], 2 * p + 1);
-    };
-    auto ldB_first = [&]() {
-        ldBh(wbh[0], 0); ldBh(wbh[1], 1);
-        ldBc(wbc[0], 0); ldBc(wbc[1], 1);
-    };
-    if constexpr (CK == 4) {
-        ldA_pair(0);
-        ldA_pair(1);
-    } else {
-        ldAh(wah[0][0], 0);
-        ldAc(wac[0][0], 0);
-        ldB_first();
-    }
-
-#if defined(CCSM_AB) && CCSM_AB == 1
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // A/B: static priority for the second-dispatched half of the workgroup
-#endif
-    for (int s = 0; s < kSeqLen; ++s) {
-        const int t = dir ? (kSeqLen - 1 - s) : s;
-        auto stamp = [&](int k) {     // DBG instantiation only (tools/gpu_phases.py): cycle counter at the phase boundaries
-            if constexpr (DBG) {
-                if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
-            }
-        };
-        stamp(0);
-        const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;
-        f32x16 acc[3][NB];                            // R, Z, N
-        // Per-lane LDS addresses are derived from lane16 through an opaque copy wherever a phase needs them: a loop-invariant
-        // address would otherwise be kept live across the whole step, spilled, and every reload of a spill is a scratch_load +
-        // s_waitcnt vmcnt(0), i.e. a full drain of the weight prefetch queue (two VALU instructions instead).
-        auto lane16_here = [&]() -> int {
-            int v = lane16;
-            asm volatile("" : "+v"(v));
-            return v;
-        };
-        auto bias_set = [&](int set) {                // from LDS (written once before the first barrier)
-            f32x16 b;
-            const char* bp = smem + (bias_off + ((lane16_here() >> 9) << 6));      // + hh * 64 bytes
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(bp + set * 128 + q * 16);
-                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
-            }
-            return b;
-        };
-        {
-            const f32x16 b0 = bias_set(0), b1 = bias_set(1);
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) { acc[0][bt] = b0; acc[1][bt] = b1; }
-        }
-
-        uint4 xh[NB], xh1[NB], xc[2][NB];             // main fragments of two k-blocks, corr fragments of a pair
-        auto rdx = [&](uint4 (&x)[NB], int buf, int kbl, int f) {
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(xfrag(buf, kbl, bt, f) + lane * 16);
-        };
-        auto rdh = [&](uint4 (&x)[NB], int kb, int f) {
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(hfrag(kb, bt, f) + lane * 16);
-        };
-#define CCSM_FENCE asm volatile("" ::: "memory")
-        // G gates of one k-block, main product: W[g] (hi) x X[bt] (hi) into accumulator set S0 + g
-#define CCSM_MAIN(W, X, G, S0)                                                                                \
-    do {                                                                                                      \
-        CCSM_FENCE;                                                                                           \
-        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)       \
-            acc[S0 + g][bt] = mfma16(W[g], X[bt], acc[S0 + g][bt]);                                           \
-        CCSM_FENCE;                                                                                           \
-    } while (0)
-        // correction product of a pair of k-blocks: corr fragments W0[g], W1[g] x X[0][bt], X[1][bt]
-#define CCSM_CORR(W0, W1, X, G, S0, SA)                                                                       \
-    do {                                                                                                      \
-        CCSM_FENCE;                                                                                           \
-        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)       \
-            acc[S0 + g][bt] = mfma_corr(W0[g], W1[g], X[0][bt], X[1][bt], acc[S0 + g][bt], SA);               \
-        CCSM_FENCE;                                                                                           \
-    } while (0)
-
-        // ---------------- phase A: R, Z += W_i{r,z} x_t -------------------------------------------------------------
-        if constexpr (CK == 4) {
-            // one pair of one chunk; L1 / L2 / L3 = the weight requests issued after the pair's three MFMA groups; every LDS
-            // read is issued one MFMA group ahead of its use (xh / xh1 / xc are three register sets)
-#define CCSM_PAIR_A(P, L1, L2, L3)                                                                             \
-    {                                                                                                          \
-        rdx(xh1, buf, 2 * (P) + 1, 0);                                                                         \
-        CCSM_MAIN(wah[P][0], xh, 2, 0);                                                                        \
-        L1;                                                                                                    \
-        if ((P) == 0) stage_load(t, more ? c + 1 : 0, (c + 1) & 1);   /* after the weight prefetch: younger in vmcnt */ \
-        rdx(xc[0], buf, 2 * (P), 1);                                                                           \
-        rdx(xc[1], buf, 2 * (P) + 1, 1);                                                                       \
-        CCSM_MAIN(wah[P][1], xh1, 2, 0);                                                                       \
-        L2;                                                                                                    \
-        if ((P) == 0) rdx(xh, buf, 2, 0);                     /* the chunk's second pair */                    \
-        CCSM_CORR(wac[P][0], wac[P][1], xc, 2, 0, sa_x);                                                       \
-        L3;                                                                                                    \
-    }
-#pragma unroll 1
-            for (int c = 0; c < NCH - 1; ++c) {
-                // chunk c (buffer c&1) is in LDS and the other buffer is free.  Chunk 0 was staged by the previous step's
-                // last phase-C chunk and is ordered by the barrier that follows phase C (before the tail), so a wave leaving
-                // the tail early starts its chunk-0 MFMAs while its SIMD partner is still in the vector-ALU-only tail.
-                if (c > 0 || s == 0) __syncthreads();
-                const int buf = c & 1;
-                const bool more = true;
-                const int k0 = 4 * c + 4;                      // first k-block of the pair two pairs ahead of pair 0
-                rdx(xh, buf, 0, 0);
-                CCSM_PAIR_A(0, ldAh(wah[0][0], k0), ldAh(wah[0][1], k0 + 1), { ldAc(wac[0][0], k0); ldAc(wac[0][1], k0 + 1); })
-                CCSM_PAIR_A(1, ldAh(wah[1][0], k0 + 2), ldAh(wah[1][1], k0 + 3), { ldAc(wac[1][0], k0 + 2); ldAc(wac[1][1], k0 + 3); })
-                CCSM_STAGE_WAIT(14);                           // 2 + 4 + 2 + 2 + 4 weight fragments were requested after the transfer
-            }
-            {   // last chunk: its ring slots are refilled with phase B's first pair instead of fragments past the end
-                constexpr int c = NCH - 1;
-                __syncthreads();
-                const int buf = c & 1;
-                const bool more = false;
-                rdx(xh, buf, 0, 0);
-                CCSM_PAIR_A(0, (void)0, (void)0, { ldBh(wbh[0], 0); ldBh(wbh[1], 1); })
-                CCSM_PAIR_A(1, ldBc(wbc[0], 0), ldBc(wbc[1], 1), (void)0)
-                CCSM_STAGE_WAIT(12);                           // C chunk 0 into buffer NCH & 1 == 0; 6 + 3 + 3 phase-B fragments after it
-            }
-#undef CCSM_PAIR_A
-        } else {
-            // layer 0: one k-block (11 features padded to 16), three fp16 passes, [hi|lo] fragments on both sides
-            uint4 x0[NB][2];
-            // the transfer of this step's x (issued one step ago) is older than the 16 weight fragments and 12 output stores the
-            // previous tail issued: once at most those are outstanding it has landed
-            CCSM_STAGE_WAIT(28);
-            __syncthreads();
-            stage_load(tn, 0, (s + 1) & 1);
-            const int l16 = lane16_here();
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + l16);
-                x0[bt][1] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 1) + l16);
-            }
-            CCSM_FENCE;
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    acc[g][bt] = mfma16(wah[0][0][g], x0[bt][0], acc[g][bt]);
-                    acc[g][bt] = mfma16(wah[0][0][g], x0[bt][1], acc[g][bt]);
-                    acc[g][bt] = mfma16(wac[0][0][g], x0[bt][0], acc[g][bt]);
-                }
-            CCSM_FENCE;
-        }
-
-        stamp(1);
-        // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------------
-        {
-            const f32x16 b3 = bias_set(3);
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
-        }
-#define CCSM_PAIR_B(KB, L1, L2, L3)                                                                            \
-    {                                                                                                          \
-        rdh(xh, KB, 0);                                                                                        \
-        rdh(xc[0], KB, 1);                                                                                     \
-        rdh(xc[1], (KB) + 1, 1);                                                                               \
-        CCSM_MAIN(wbh[0], xh, 3, 0);                                                                           \
-        L1;                                                                                                    \
-        rdh(xh, (KB) + 1, 0);                                                                                  \
-        CCSM_MAIN(wbh[1], xh, 3, 0);                                                                           \
-        L2;                                                                                                    \
-        CCSM_CORR(wbc[0], wbc[1], xc, 3, 0, sa_h);                                                             \
-        L3;                                                                                                    \
-    }
-#pragma unroll 1
-        for (int kb = 0; kb < kKBH - 2; kb += 2)
-            CCSM_PAIR_B(kb, ldBh(wbh[0], kb + 2), ldBh(wbh[1], kb + 3), { ldBc(wbc[0], kb + 2); ldBc(wbc[1], kb + 3); })
-        // last pair: its registers are refilled with phase C's first chunk of n-gate fragments
-        if constexpr (CK == 4) {
-            CCSM_PAIR_B(kKBH - 2, { wch[0][0] = w_at(OFF_C + 0 * FC); wch[0][1] = w_at(OFF_C + 1 * FC); },
-                        { wch[0][2] = w_at(OFF_C + 2 * FC); wch[0][3] = w_at(OFF_C + 3 * FC); },
-                        { wcc[0][0] = w_at(OFF_C + 0 * FC + 1); wcc[0][1] = w_at(OFF_C + 1 * FC + 1);
-                          wcc[0][2] = w_at(OFF_C + 2 * FC + 1); wcc[0][3] = w_at(OFF_C + 3 * FC + 1); })
-        } else {
-            CCSM_PAIR_B(kKBH - 2, wch[0][0] = w_at(OFF_C), wcc[0][0] = w_at(OFF_C + 1), (void)0)
-        }
-#undef CCSM_PAIR_B
-        // r = sigmoid(R) ; N = b_in + r * N
-        {
-            const f32x16 b2 = bias_set(2);
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
-        }
-
-        // z = sigmoid(Z) of one batch tile, in place, issued inside phase C where the vector ALU is otherwise idle (Z is complete
-        // after phase B); the tail then only needs tanh, the blend and the packing.
-        auto zwork = [&](int bt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
-        };
-
-        stamp(2);
-        // ---------------- phase C: N += W_in x_t ----------------------------------------------------------------------
-        if constexpr (CK == 4) {
-#define CCSM_PAIR_C(CUR, P)                                                                                    \
-    {                                                                                                          \
-        rdx(xh1, buf, 2 * (P) + 1, 0);                                                                         \
-        CCSM_FENCE;                                                                                            \
-        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[CUR][2 * (P)], xh[bt], acc[2][bt]); \
-        CCSM_FENCE;                                                                                            \
-        rdx(xc[0], buf, 2 * (P), 1);                                                                           \
-        rdx(xc[1], buf, 2 * (P) + 1, 1);                                                                       \
-        CCSM_FENCE;                                                                                            \
-        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[CUR][2 * (P) + 1], xh1[bt], acc[2][bt]); \
-        CCSM_FENCE;                                                                                            \
-        if ((P) == 0) rdx(xh, buf, 2, 0);                                                                      \
-        CCSM_FENCE;                                                                                            \
-        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt)                                                      \
-            acc[2][bt] = mfma_corr(wcc[CUR][2 * (P)], wcc[CUR][2 * (P) + 1], xc[0][bt], xc[1][bt], acc[2][bt], sa_x); \
-        CCSM_FENCE;                                                                                            \
-    }
-            // one chunk; LNEXT = the weight request for what comes after it (a whole chunk ahead)
-#define CCSM_CHUNK_C(C, CUR, LNEXT)                                                                            \
-    {                                                                                                          \
-        __syncthreads();                                                                                       \
-        const int buf = (C) & 1;                                                                               \
-        const bool more = (C) + 1 < NCH;                                                                       \
-        stage_load(more ? t : tn, more ? (C) + 1 : 0, ((C) + 1) & 1);   /* next C chunk / next step's first A chunk */ \
-        LNEXT;                               /* 8 weight fragments, younger than the transfer: they stay in flight */ \
-        rdx(xh, buf, 0, 0);                                                                                    \
-        CCSM_PAIR_C(CUR, 0)                                                                                    \
-        CCSM_PAIR_C(CUR, 1)                                                                                    \
-        CCSM_STAGE_WAIT(8);                                                                                    \
-    }
-#pragma unroll 1
-            for (int c2 = 0; c2 < NCH - 2; c2 += 2) {
-                CCSM_CHUNK_C(c2, 0, ldC(1, c2 + 1))
-                if (c2 == 0) zwork(0); else if (c2 == 2) zwork(1); else zwork(2);
-                CCSM_CHUNK_C(c2 + 1, 1, ldC(0, c2 + 2))
-            }
-            static_assert(NCH == 8 || CK != 4, "zwork schedule assumes three loop iterations");
-            CCSM_CHUNK_C(NCH - 2, 0, ldC(1, NCH - 1))
-            CCSM_CHUNK_C(NCH - 1, 1, ldA_pair(0))            // the next step's first phase-A pair
-#undef CCSM_CHUNK_C
-#undef CCSM_PAIR_C
-        } else {
-            uint4 x0[NB][2];
-            const int l16 = lane16_here();
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                x0[bt][0] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 0) + l16);
-                x0[bt][1] = *reinterpret_cast<const uint4*>(xfrag(s & 1, 0, bt, 1) + l16);
-            }
-            CCSM_FENCE;
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                acc[2][bt] = mfma16(wch[0][0], x0[bt][0], acc[2][bt]);
-                acc[2][bt] = mfma16(wch[0][0], x0[bt][1], acc[2][bt]);
-                acc[2][bt] = mfma16(wcc[0][0], x0[bt][0], acc[2][bt]);      // layer 0: second fragment = fp16 lo
-            }
-            CCSM_FENCE;
-        }
-#undef CCSM_CORR
-#undef CCSM_MAIN
-
-        if constexpr (CK == 4) __syncthreads();       // next step's x chunk 0 is staged; every wave is done with this step's x
-        stamp(3);
-        // the rest of the next step's first weight fragments: in flight during the tail
-        if constexpr (CK == 4) {
-            ldA_pair(1);
-        } else {
-            ldAh(wah[0][0], 0);
-            ldAc(wac[0][0], 0);
-            ldB_first();
-        }
-        CCSM_FENCE;
-#undef CCSM_FENCE
-        if constexpr (CK != 4) {
-#pragma unroll
-            for (int bt = 0; bt < NB; ++bt) zwork(bt);
-            __syncthreads();   // KX == 1: no phase-C barriers, so order the h_{t-1} reads explicitly
-        }
-        // ---------------- tail: h_{t-1} of this wave's own units (MFMA C layout) = hi fragment + fp8 residual of the corr
-        // fragment; n = tanh(N); h' = n + z (h_{t-1} - n); fragments for the next step / next layer
-        // addresses of this wave's own two k-blocks (kb = 2 wave + kbl), rebuilt here from an opaque copy of lane16 (see above)
-        const int own_off = wave * (2 * NB * 2 * 1024);                       // hfrag(2 wave, 0, 0)
-        const char* t_wr;                                                     // + lane * 16       (fragment writes)
-        const char* t_rd;                                                     // + n * 16 + hh * 8 (own-unit reads, MFMA C layout)
-        int t16;                                                              // lane * 16 (output stores)
-        {
-            t16 = lane16_here();
-            t_wr = smem + (own_off + t16);
-            t_rd = smem + (own_off + (t16 & 0x1f0) + ((t16 >> 9) << 3));
-        }
-        auto own_frag = [&](int kbl, int bt, int f) -> int { return ((kbl * NB + bt) * 2 + f) << 10; };
-#pragma unroll
-        for (int bt = 0; bt < NB; ++bt) {
-            float hn[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const half4 hi = as_half4(*reinterpret_cast<const uint2*>(t_rd + own_frag(q >> 1, bt, 0) + 512 * (q & 1)));
-                // residuals: lane (n, g = 1) of the corr fragment, bytes 4*(q&1) + 8*hh .. +3  (kCorrPerm order)
-                const int lo4 = *reinterpret_cast<const int*>(t_rd + own_frag(q >> 1, bt, 1) + 512 + 4 * (q & 1));
-                const float hp[4] = {(float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo4, 0) * (1.0f / kCorrActLo),
-                                     (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo4, 1) * (1.0f / kCorrActLo),
-                                     (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo4, 2) * (1.0f / kCorrActLo),
-                                     (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo4, 3) * (1.0f / kCorrActLo)};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float nn = tanh_fold(acc[2][bt][4 * q + e]);
-                    hn[4 * q + e] = (hp[e] - nn) * acc[1][bt][4 * q + e] + nn;
-                }
-            }
-#pragma unroll
-            for (int kbl = 0; kbl < 2; ++kbl) {
-                const float v[8] = {hn[8 * kbl + 0], hn[8 * kbl + 1], hn[8 * kbl + 2], hn[8 * kbl + 3],
-                                    hn[8 * kbl + 4], hn[8 * kbl + 5], hn[8 * kbl + 6], hn[8 * kbl + 7]};
-                uint4 fh, fc;
-                pack_kb(v, fh, fc);
-                const int kb = 2 * wave + kbl;
-                *reinterpret_cast<uint4*>(const_cast<char*>(t_wr) + own_frag(kbl, bt, 0)) = fh;
-                *reinterpret_cast<uint4*>(const_cast<char*>(t_wr) + own_frag(kbl, bt, 1)) = fc;
-                char* o = reinterpret_cast<char*>(out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + kb)) * 2 * kFragU4);
-                // streaming stores: the next reader is another kernel 0.5 GB later, keep the L2 for the weight stream (-0.7 % step cycles)
-                nt_store(fh, reinterpret_cast<uint4*>(o + t16));
-                nt_store(fc, reinterpret_cast<uint4*>(o + 1024 + t16));
-            }
-        }
-        stamp(4);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Attention pool + FC partials in split-f8 arithmetic: attn_fc_kernel (ccsm_kernels.hip) with the activation and the
 // Wa / Ua fragments in [hi | corr] form.  One staged chunk (2 k-blocks) is exactly one pair: per timestep two main MFMAs and
 // one K = 64 corr MFMA instead of six fp16 MFMAs.  The fc1 partial dot products need the activations themselves: hi from the

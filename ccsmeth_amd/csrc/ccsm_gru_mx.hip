@@ -1,0 +1,787 @@
+// libccsm GRU layers in "split-mx" arithmetic: f16 main product + ONE block-scaled MX correction product per pair of k-blocks.
+// Included by ccsm_api.hip after ccsm_kernels.hip and ccsm_gru_f8.hip (fp8 helpers, the attention kernel).
+//
+// Arithmetic.  Every fp32 operand v is carried as hi = fp16(v) plus the residual lo = v - hi.  The product
+//     W x  =  W_hi x_hi  +  W_lo x_hi  +  W_hi x_lo  (+ W_lo x_lo, dropped: 2^-22 relative)
+// is issued per pair of k-blocks (32 k) as
+//     main : 2 x v_mfma_f32_32x32x16_f16 on (W_hi, x_hi)
+//     corr : 1 x v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = [32 k of W_lo x_hi | 32 k of W_hi x_lo], activations (B) in
+//            fp6 e2m3, weights (A) in fp4 e2m1, fp32 accumulation into the SAME accumulator.
+// Why not fp8 operands (round 1): the GRU kernels run at the 1400 W package power cap (profiles/r02_c_power_attribution.md), so
+// their time is their energy; the fp8 x fp8 correction MFMAs cost 16 % of it, fp6 x fp6 half of that, fp4 weights x fp6
+// activations almost none, at 4-7e-6 max |dprob| (tests/diag/emulate_corr_formats.py; fp8: 4e-6, bar 1e-4).
+//
+// Correction operands ("blobs").  One MX operand of one lane = 32 values = one block with one E8M0 scale:
+//   lane (n, g = 0): W_lo[n][k] * 2^11 (A)  /  x_hi[n][k] (B)          lane (n, g = 1): W_hi[n][k] (A)  /  x_lo[n][k] (B)
+//   for the 32 k of the pair in the order kMxPerm[j] = 8 ((j & 15) >> 2) + (j & 3) + 4 (j >> 4)  — what eight
+//   v_permlane32_swap and one v_cvt_scalef32_pk32_fp6_f16 make of the MFMA C layout in the step epilogue; the host packs the
+//   weights in the same order.  An ACTIVATION blob (fp6: 24 bytes per lane) travels in the two 1 KiB "corr" fragments the fp8
+//   scheme had (nothing else about fragments, transfers or LDS changes): bytes 0-15 of a lane in the fragment of the pair's first
+//   k-block, bytes 16-23 in the first half of the second one's.  A WEIGHT blob (fp4: 16 bytes per lane) is one 1 KiB fragment = the
+//   instruction's A operand as loaded (a 24-byte fp6 weight blob would be a 6-register operand assembled from two loads: the
+//   compiler copies it together behind an s_waitcnt vmcnt(0) per load); the lane's E8M0 scale bytes of a pair's gates share one
+//   dword (256 B per pair, byte g = gate g, picked by the instruction's op_sel), chosen by the host PER (row, 32-k block) from the
+//   block's largest magnitude (heavy-tailed matrices keep their small entries' corrections).  Activations use fixed scales: GRU
+//   outputs lie in (-1, 1) (x_hi * 4, x_lo * 2^14); the initial states (any magnitude up to 15) are packed 8x coarser and multiplied
+//   with their own scale in the first step.
+// The recurrent state is carried as fp16 hi + fp8 lo: a wave keeps the fp8 residuals of its own 32 units (MFMA C layout) in LDS
+// next to the fragments (the blend h' = n + z (h - n) needs h_{t-1} itself, and an fp6 blob cannot be picked apart cheaply).
+#include <hip/hip_runtime.h>
+
+namespace ccsm {
+
+constexpr int kMxWFmt = 4;                         // A (weight) operand format of the correction MFMA: fp4 e2m1
+constexpr int kMxBFmt = 2;                         // B (activation) operand: fp6 e2m3
+constexpr int kMxScaleHi = 127 - 2;                // x_hi blob holds x_hi * 4
+constexpr int kMxScaleLo = 127 - 14;               // x_lo blob holds x_lo * 2^14
+constexpr int kMxScaleHi0 = 127 + 1;               // initial states: x_hi / 2 (|h0| < 15)
+constexpr int kMxScaleLo0 = 127 - 11;              //                 x_lo * 2^11
+
+typedef _Float16 half32 __attribute__((ext_vector_type(32)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+
+// correction MFMA of one pair: weight blob w (fp4, 16 bytes per lane), its scale = byte G of ws, activation blob (x0, x1)
+template <int G>
+__device__ __forceinline__ f32x16 mfma_corr_mx(uint4 w, uint32_t ws, uint4 x0, uint2 x1, f32x16 c, int scale_b) {
+    const i32x8 a = {(int)w.x, (int)w.y, (int)w.z, (int)w.w, 0, 0, 0, 0};
+    const i32x8 b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, kMxWFmt, kMxBFmt, G, (int)ws, 0, scale_b);
+}
+
+// 32 fp16 values (16 packed registers) / scale -> one fp6 blob
+__device__ __forceinline__ void blob_of(const uint32_t (&p)[16], float scale, uint4& c0, uint2& c1) {
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    const u32x16 v = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]};
+    const i32x6 r = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(half32, v), scale);
+    c0 = make_uint4((uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+    c1 = make_uint2((uint32_t)r[4], (uint32_t)r[5]);
+}
+
+// The wave's 32 units of one batch row in MFMA C layout, as lane (n, hh) holds them: v[4q + e] = unit 8q + 4hh + e.
+//   hi0, hi1 : this lane's 16 bytes of the hi fragments of the wave's two k-blocks
+//   c0, c1   : this lane's activation blob (lower lanes: x_hi of all 32 units, upper lanes: x_lo)
+//   lo8      : fp8 (x 2^17) residuals of this lane's own 16 values, C-layout order (the wave's private copy)
+// SCALE = what the blob's values are divided by (0.25 for GRU outputs; 2 for initial states).
+template <bool CLAMP>
+__device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, uint4& hi0, uint4& hi1, uint4& c0, uint2& c1, uint4& lo8) {
+    typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+    uint32_t hp[8], lp[8];
+    float lf[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const half2p h = {(_Float16)v[2 * j], (_Float16)v[2 * j + 1]};
+        hp[j] = __builtin_bit_cast(uint32_t, h);
+        lf[2 * j] = v[2 * j] - (float)h[0];
+        lf[2 * j + 1] = v[2 * j + 1] - (float)h[1];
+        lp[j] = pack2((_Float16)(lf[2 * j] * 4096.0f), (_Float16)(lf[2 * j + 1] * 4096.0f));    // |lo| <= 2^-12 |v|: no fp16 underflow
+    }
+    if constexpr (CLAMP) {      // initial states of any magnitude: v_cvt_pk_fp8_f32 does not saturate
+        uint32_t r[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float c[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = fminf(fmaxf(lf[4 * q + e] * kCorrActLo, -kF8Clamp), kF8Clamp);
+            r[q] = cvt4_fp8(c[0], c[1], c[2], c[3]);
+        }
+        lo8 = make_uint4(r[0], r[1], r[2], r[3]);
+    } else {                    // GRU outputs: |lo| 2^17 <= 32
+        lo8 = make_uint4(cvt4_fp8_l(hp[0], lf[0], lf[1], lf[2], lf[3]), cvt4_fp8_l(hp[2], lf[4], lf[5], lf[6], lf[7]),
+                         cvt4_fp8_l(hp[4], lf[8], lf[9], lf[10], lf[11]), cvt4_fp8_l(hp[6], lf[12], lf[13], lf[14], lf[15]));
+    }
+    {   // hi fragments: lane (n, g) <- k = 16 kb + 8 g + j
+        uint32_t a0 = hp[0], a1 = hp[1], b0 = hp[2], b1 = hp[3];
+        swap32(a0, b0);
+        swap32(a1, b1);
+        hi0 = make_uint4(a0, a1, b0, b1);
+        a0 = hp[4]; a1 = hp[5]; b0 = hp[6]; b1 = hp[7];
+        swap32(a0, b0);
+        swap32(a1, b1);
+        hi1 = make_uint4(a0, a1, b0, b1);
+    }
+    // blob: lower lanes end up with (own hi | partner's hi), upper lanes with (partner's lo | own lo): kMxPerm order
+#pragma unroll
+    for (int j = 0; j < 8; ++j) swap32(hp[j], lp[j]);
+    const uint32_t p[16] = {hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], lp[0], lp[1], lp[2], lp[3], lp[4], lp[5], lp[6], lp[7]};
+    blob_of(p, scale, c0, c1);
+}
+
+// LDS byte offsets shared by the two kernels: h fragments [kb 16][bt 3][hi | corr] x 1 KiB at 0 (96 KiB).  The fp8 residuals of a
+// wave's own units (16 B per lane and batch tile) live half in the unused second half of the lane's slot in the corr fragment
+// of the wave's second k-block (bytes 8-15) and half in a 12 KiB region at LO_OFF: [wave][bt][lane] x 8 B.
+constexpr int kMxNB = 3;
+constexpr int kMxHBytes = kKBH * kMxNB * 2 * 1024;
+__device__ __forceinline__ int mx_hfrag(int kb, int bt, int f) { return ((kb * kMxNB + bt) * 2 + f) << 10; }
+
+// ---- h0 -> LDS: hi fragments, blobs (coarse scale) and residuals of this wave's own two k-blocks, every batch tile
+__device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float* __restrict__ h0d, int tile0, int wave, int lane) {
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int bt = 0; bt < kMxNB; ++bt) {
+        const float* src = h0d + ((size_t)(tile0 + bt) * 32 + n) * kHidden + 32 * wave;
+        float v[16];                                                // C layout: v[4q + e] = unit 8q + 4hh + e
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(src + 8 * q + 4 * hh);
+            v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        uint4 hi0, hi1, c0, lo8;
+        uint2 c1;
+        pack_pair_mx<true>(v, 2.0f, hi0, hi1, c0, c1, lo8);
+        *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 0) + lane * 16) = hi0;
+        *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 0) + lane * 16) = hi1;
+        *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 1) + lane * 16) = c0;
+        *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 1) + lane * 16) = make_uint4(c1.x, c1.y, lo8.x, lo8.y);
+        *reinterpret_cast<uint2*>(smem + lo_off + ((wave * kMxNB + bt) * 64 + lane) * 8) = make_uint2(lo8.z, lo8.w);
+    }
+}
+
+// ---- step tail: n = tanh(N); h' = n + z (h_{t-1} - n) for this wave's own units; fragments and blobs for the next step (LDS)
+// and the next layer (HBM).  accz = sigmoid(Z) already, accn = N.  OUT_FP8: the layer feeding the attention kernel writes fp8 corr
+// fragments (attn_fc_f8_kernel's format) instead of blobs.  t16 = lane * 16 (an opaque copy: see lane16_here in the kernels).
+template <bool OUT_FP8>
+__device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&accz)[kMxNB], const f32x16 (&accn)[kMxNB], uint4* __restrict__ out,
+                                        int tile0, int t, int dir, int wave, int t16) {
+    const int own_off = wave * (2 * kMxNB * 2 * 1024);                          // mx_hfrag(2 wave, 0, 0)
+    char* t_wr = smem + (own_off + t16);                                        // + lane * 16       (fragment writes)
+    const char* t_rd = smem + (own_off + (t16 & 0x1f0) + ((t16 >> 9) << 3));    // + n * 16 + hh * 8 (own-unit reads, C layout)
+    char* t_lo = smem + (lo_off + wave * (kMxNB * 64 * 8) + (t16 >> 1));        // + lane * 8
+    auto own_frag = [&](int kbl, int bt, int f) -> int { return ((kbl * kMxNB + bt) * 2 + f) << 10; };
+#pragma unroll
+    for (int bt = 0; bt < kMxNB; ++bt) {
+        float hn[16];
+        const uint2 la = *reinterpret_cast<const uint2*>(t_wr + own_frag(1, bt, 1) + 8);    // residuals of values 0..7
+        const uint2 lb = *reinterpret_cast<const uint2*>(t_lo + bt * (64 * 8));             // 8..15
+        const uint32_t l8[4] = {la.x, la.y, lb.x, lb.y};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const half4 hi = as_half4(*reinterpret_cast<const uint2*>(t_rd + own_frag(q >> 1, bt, 0) + 512 * (q & 1)));
+            const int lo4 = (int)l8[q];
+            const float hp[4] = {(float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo4, 0) * (1.0f / kCorrActLo),
+                                 (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo4, 1) * (1.0f / kCorrActLo),
+                                 (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo4, 2) * (1.0f / kCorrActLo),
+                                 (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo4, 3) * (1.0f / kCorrActLo)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float nn = tanh_fold(accn[bt][4 * q + e]);
+                hn[4 * q + e] = (hp[e] - nn) * accz[bt][4 * q + e] + nn;
+            }
+        }
+        uint4 hi0, hi1, c0, lo8;
+        uint2 c1;
+        pack_pair_mx<false>(hn, 0.25f, hi0, hi1, c0, c1, lo8);
+        const uint4 c1w = make_uint4(c1.x, c1.y, lo8.x, lo8.y);
+        *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 0)) = hi0;
+        *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 0)) = hi1;
+        *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = c0;
+        *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = c1w;
+        *reinterpret_cast<uint2*>(t_lo + bt * (64 * 8)) = make_uint2(lo8.z, lo8.w);
+        // streaming stores: the next reader is another kernel 0.5 GB later, keep the L2 for the weight stream
+        char* o = reinterpret_cast<char*>(out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + 2 * wave)) * 2 * kFragU4) + t16;
+        nt_store(hi0, reinterpret_cast<uint4*>(o));
+        nt_store(hi1, reinterpret_cast<uint4*>(o + 2048));
+        if constexpr (OUT_FP8) {
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                const float v8[8] = {hn[8 * kbl + 0], hn[8 * kbl + 1], hn[8 * kbl + 2], hn[8 * kbl + 3],
+                                     hn[8 * kbl + 4], hn[8 * kbl + 5], hn[8 * kbl + 6], hn[8 * kbl + 7]};
+                uint4 fh, fc;
+                pack_kb(v8, fh, fc);
+                nt_store(fc, reinterpret_cast<uint4*>(o + 1024 + 2048 * kbl));
+            }
+        } else {
+            nt_store(c0, reinterpret_cast<uint4*>(o + 1024));
+            nt_store(c1w, reinterpret_cast<uint4*>(o + 3072));
+        }
+    }
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+#define CCSM_FENCE asm volatile("" ::: "memory")
+
+// Weight streams, per (direction, wave), in bytes.  hi / lo fragments and blobs are 1 KiB (lane * 16), the scale dwords of a pair
+// 256 B (lane * 4; byte g = gate g):
+//   phase-A pair (r, z)    : hi (kbl, g) at (2 kbl + g) KiB | blob (g) at (4 + g) KiB | scales at 6 KiB           = 6400 B
+//   phase-B pair (r, z, n) : hi (kbl, g) at (3 kbl + g) KiB | blob (g) at (6 + g) KiB | scales at 9 KiB           = 9472 B
+//   phase-C pair (n)       : hi (kbl) at kbl KiB            | blob at 2 KiB           | scales at 3 KiB (byte 0)  = 3328 B
+constexpr int kMxPairA = 6 * 1024 + 256, kMxPairB = 9 * 1024 + 256, kMxPairC = 3 * 1024 + 256;
+constexpr int kMx0WBytes = 4 * 1024 + (kKBH / 2) * kMxPairB + 2 * 1024;       // layer 0: [r hi, r lo, z hi, z lo] [B] [n hi, n lo]
+constexpr int kMx12OffB = (kKB12 / 2) * kMxPairA, kMx12OffC = kMx12OffB + (kKBH / 2) * kMxPairB;
+constexpr int kMx12WBytes = kMx12OffC + (kKB12 / 2) * kMxPairC;
+
+// G gates of the pair's correction product: weight blobs W[g] with scale bytes g of WS, activation blobs xc0 / xc1
+#define CCSM_CORR_G(G, W, WS, SB)                                                                             \
+    do {                                                                                                      \
+        CCSM_FENCE;                                                                                           \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) {                                                   \
+            acc[0][bt] = mfma_corr_mx<0>(W[0], WS, xc0[bt], xc1[bt], acc[0][bt], SB);                         \
+            acc[1][bt] = mfma_corr_mx<1>(W[1], WS, xc0[bt], xc1[bt], acc[1][bt], SB);                         \
+            if constexpr (G == 3) acc[2][bt] = mfma_corr_mx<2>(W[2], WS, xc0[bt], xc1[bt], acc[2][bt], SB);   \
+        }                                                                                                     \
+        CCSM_FENCE;                                                                                           \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// Layer 0: K = 11 input features padded to one k-block, [hi | lo] fp16 fragments on both sides, three f16 passes for the x-part
+// (raw z-scores reach hundreds); the recurrent part in split-mx.  96 batch rows of one direction per workgroup, wave w owns hidden
+// units [32w, 32w + 32) of all gates; phases: A x-part of r, z - B h-part of r, z, n - C x-part of n - tail.
+//   xin : [tile][t][hi|lo][64] uint4          out : [tile][t][32 kb][hi | corr][64] uint4 (activation blobs in the corr fragments)
+// LDS : h fragments 96 KiB | x ring 2 x 6 KiB | residuals 12 KiB | biases 4 KiB
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMx0XOff = kMxHBytes, kMx0LoOff = kMx0XOff + 2 * kMxNB * 2 * 1024, kMx0BiasOff = kMx0LoOff + kWaves * kMxNB * 64 * 8;
+constexpr int kMx0Lds = kMx0BiasOff + kWaves * 4 * 32 * 4;
+
+template <bool DBG>
+__global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
+                                                                const uint4* __restrict__ wst, const float* __restrict__ bias,
+                                                                const float* __restrict__ h0, int rows_p,
+                                                                unsigned long long* __restrict__ dbg) {
+    constexpr int NB = kMxNB;
+    constexpr int OFF_B = 4 * 1024, OFF_C = OFF_B + (kKBH / 2) * kMxPairB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dir = blockIdx.x & 1;
+    const int tile0 = (blockIdx.x >> 1) * NB;
+    const int hh = lane >> 5;
+    const int lane16 = lane * 16;
+    const int sb = hh ? kMxScaleLo : kMxScaleHi;
+    static_assert(kMxScaleLo0 - kMxScaleLo == kMxScaleHi0 - kMxScaleHi, "one offset turns the steady scales into the initial-state scales");
+
+    if (threadIdx.x < kWaves * 4 * 32 / 4)
+        reinterpret_cast<float4*>(smem + kMx0BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
+    mx_h0_to_lds(smem, kMx0LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
+
+    // x staging: 6 fragments per step (bt x hi|lo), waves 0-5 move one each
+    const u32x4_t xrs = dma_rsrc(xin);
+    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + kMx0XOff);
+    auto stage_load = [&](int t, int buf) {
+        const int f = wave < 6 ? wave : 5;                          // waves 6, 7 re-stage fragment 5 (same bytes, same place)
+        const int hl = f & 1, bt = f >> 1;
+        const int soff = ((((tile0 + bt) * kSeqLen + t) * 2 + hl) << 10);
+        dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + ((buf * 6 + f) << 10))));
+    };
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * kMx0WBytes);
+    const int bias_off = kMx0BiasOff + wave * 4 * 32 * 4;
+    auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
+    auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
+
+    uint4 wxa[2][2];                                                // phase A: [gate r,z][hi, lo]
+    uint4 wxc[2];                                                   // phase C: n gate [hi, lo]
+    uint4 wbh[2][3], wbb[3];                                        // phase B resident pair: [kb in pair][gate] hi ; [gate] blob
+    uint32_t wbs;                                                   //                        scale bytes
+    auto ld_first = [&]() {                                         // everything a step needs before its second phase-B pair: 14 requests
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { wxa[g][0] = w_at((2 * g) << 10); wxa[g][1] = w_at((2 * g + 1) << 10); }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            wbh[0][g] = w_at(OFF_B + (g << 10)); wbh[1][g] = w_at(OFF_B + ((3 + g) << 10));
+            wbb[g] = w_at(OFF_B + ((6 + g) << 10));
+        }
+        wbs = ws_at(OFF_B + (9 << 10));
+    };
+    stage_load(dir ? kSeqLen - 1 : 0, 0);
+    ld_first();
+    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");               // the first transfer (older than the 14 weight requests)
+
+    for (int s = 0; s < kSeqLen; ++s) {
+        const int t = dir ? (kSeqLen - 1 - s) : s;
+        auto stamp = [&](int k) {
+            if constexpr (DBG) {
+                if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
+            }
+        };
+        stamp(0);
+        const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;
+        f32x16 acc[3][NB];                                          // R, Z, N
+        auto lane16_here = [&]() -> int {                           // opaque copy: per-lane addresses are rebuilt where a phase needs them
+            int v = lane16;
+            asm volatile("" : "+v"(v));
+            return v;
+        };
+        auto bias_set = [&](int set) {
+            f32x16 b;
+            const char* bp = smem + (bias_off + ((lane16_here() >> 9) << 6));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(bp + set * 128 + q * 16);
+                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+            return b;
+        };
+        {
+            const f32x16 b0 = bias_set(0), b1 = bias_set(1);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) { acc[0][bt] = b0; acc[1][bt] = b1; }
+        }
+        // ---------------- phase A: R, Z += W_i{r,z} x_t (three fp16 passes) -------------------------------------------------
+        // the transfer of this step's x (issued one step ago) is older than the 14 weight requests and 12 output stores of the tail
+        asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+        __syncthreads();                                            // x_t in LDS; everybody's h_{t-1} fragments written
+        stage_load(tn, (s + 1) & 1);
+        auto rd_x0 = [&](uint4 (&x0)[NB][2]) {
+            const int l16 = lane16_here();
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                x0[bt][0] = *reinterpret_cast<const uint4*>(smem + kMx0XOff + ((((s & 1) * 3 + bt) * 2 + 0) << 10) + l16);
+                x0[bt][1] = *reinterpret_cast<const uint4*>(smem + kMx0XOff + ((((s & 1) * 3 + bt) * 2 + 1) << 10) + l16);
+            }
+        };
+        {
+            uint4 x0[NB][2];
+            rd_x0(x0);
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    acc[g][bt] = mfma16(wxa[g][0], x0[bt][0], acc[g][bt]);
+                    acc[g][bt] = mfma16(wxa[g][0], x0[bt][1], acc[g][bt]);
+                    acc[g][bt] = mfma16(wxa[g][1], x0[bt][0], acc[g][bt]);
+                }
+            CCSM_FENCE;
+        }
+        wxc[0] = w_at(OFF_C); wxc[1] = w_at(OFF_C + 1024);
+        stamp(1);
+        // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------------
+        {
+            const f32x16 b3 = bias_set(3);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
+        }
+        const int sbh = sb + (s == 0 ? kMxScaleHi0 - kMxScaleHi : 0);
+        uint4 xh[NB], xc0[NB];
+        uint2 xc1[NB];
+        static_for<0, kKBH / 2>([&](auto QC) {
+            constexpr int Q = decltype(QC)::value;
+            constexpr bool LAST = Q == kKBH / 2 - 1;
+            constexpr int NXT = OFF_B + (Q + 1) * kMxPairB;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 0) + lane * 16);
+                xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 1) + lane * 16);
+                xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag(2 * Q + 1, bt, 1) + lane * 16);
+            }
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g][bt] = mfma16(wbh[0][g], xh[bt], acc[g][bt]);
+            CCSM_FENCE;
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wbh[0][g] = w_at(NXT + (g << 10));
+            }
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q + 1, bt, 0) + lane * 16);
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) acc[g][bt] = mfma16(wbh[1][g], xh[bt], acc[g][bt]);
+            CCSM_FENCE;
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wbh[1][g] = w_at(NXT + ((3 + g) << 10));
+            }
+            CCSM_CORR_G(3, wbb, wbs, sbh);
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wbb[g] = w_at(NXT + ((6 + g) << 10));
+                wbs = ws_at(NXT + (9 << 10));
+            }
+            CCSM_FENCE;
+        });
+        // r = sigmoid(R) ; N = b_in + r * N
+        {
+            const f32x16 b2 = bias_set(2);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
+        }
+        stamp(2);
+        // ---------------- phase C: N += W_in x_t (x_t is still in its ring buffer) -------------------------------------------
+        {
+            uint4 x0[NB][2];
+            rd_x0(x0);
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                acc[2][bt] = mfma16(wxc[0], x0[bt][0], acc[2][bt]);
+                acc[2][bt] = mfma16(wxc[0], x0[bt][1], acc[2][bt]);
+                acc[2][bt] = mfma16(wxc[1], x0[bt][0], acc[2][bt]);
+            }
+            CCSM_FENCE;
+        }
+        stamp(3);
+        ld_first();                                                 // the next step's first weight fragments: in flight during the tail
+        CCSM_FENCE;
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
+        __syncthreads();                                            // every wave has read h_{t-1} (phase B) before anybody overwrites its fragments
+        mx_tail<false>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        stamp(4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no transfer may still be writing LDS when the workgroup retires
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Layers 1-2 (KX = 32 k-blocks of input = 16 pairs), on a schedule built around two facts measured on the chunked round-1 kernel
+// (DESIGN.md 7): (i) x_t comes from HBM and a transfer takes ~3.5-4 k cycles to land, (ii) a wave's vector-memory operations
+// retire IN ORDER, so a weight fragment requested after a transfer cannot be used before that transfer has landed.  Hence
+//   * the x ring holds FOUR pairs of k-blocks (4 x 12 KiB); the pair consumed by iteration g is refilled at the END of
+//     iteration g with the pair of iteration g + 4, as the YOUNGEST vector-memory operation of the iteration;
+//   * weights are requested three pairs ahead in phase A (three register slots), one pair ahead in phase B, four pairs ahead
+//     in phase C (four slots of the n gate);
+//   * ONE barrier per pair, in the middle of the pair (after the main MFMAs, before the correction MFMAs whose operands are
+//     already in registers): it publishes pair g + 1 (each wave first waits for its own part of that transfer with a COUNTED
+//     s_waitcnt) and retires pair g (all its operand reads are done), so the first operand of pair g + 1 is read from LDS
+//     while pair g's correction MFMAs run.
+// Iterations ("consumptions") per step: 16 pairs of phase A, then 16 of phase C; phase B touches no x.  The pair code is
+// straight-line (static_for over compile-time pair indices): a rolled pair loop with peeled ends made the compiler shuffle weight
+// slots between register sets at the loop exits, each shuffle behind an s_waitcnt vmcnt(0).  s_waitcnt immediates count the
+// vector-memory operations a wave issues between a transfer and the barrier that needs it: per phase-A pair 7 weight requests
+// (2 + 2 hi fragments, 2 blobs + 1 scale dword) + d transfer instructions, per phase-C pair 4 + d, d = 2 for waves 0-3
+// (fragments w and w + 8 of the pair) and 1 for waves 4-7; every load below is therefore UNCONDITIONAL.
+//   xin : [tile][t][32 kb][hi | corr][64] uint4      out : the same (OUT_FP8: fp8 corr fragments for the attention kernel)
+// LDS : h fragments 96 KiB | x ring 4 x 12 KiB | residuals 12 KiB | biases 4 KiB = 160 KiB
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMxRS = 4;
+constexpr int kMxSlotBytes = 2 * kMxNB * 2 * 1024;
+constexpr int kMx12XOff = kMxHBytes, kMx12LoOff = kMx12XOff + kMxRS * kMxSlotBytes, kMx12BiasOff = kMx12LoOff + kWaves * kMxNB * 64 * 8;
+constexpr int kMx12Lds = kMx12BiasOff + kWaves * 4 * 32 * 4;
+
+template <bool OUT_FP8, bool DBG>
+__global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
+                                                                 const uint4* __restrict__ wst, const float* __restrict__ bias,
+                                                                 const float* __restrict__ h0, int rows_p,
+                                                                 unsigned long long* __restrict__ dbg) {
+    constexpr int NB = kMxNB, KX = kKB12, NPAIR = KX / 2, RS = kMxRS, SLOT_BYTES = kMxSlotBytes;
+    constexpr int PA = kMxPairA, PB = kMxPairB, PC = kMxPairC, OFF_B = kMx12OffB, OFF_C = kMx12OffC;
+    constexpr int X_OFF = kMx12XOff;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dir = blockIdx.x & 1;
+    const int tile0 = (blockIdx.x >> 1) * NB;
+    const int hh = lane >> 5;
+    const int lane16 = lane * 16;
+    const int sb = hh ? kMxScaleLo : kMxScaleHi;
+
+    if (threadIdx.x < kWaves * 4 * 32 / 4)
+        reinterpret_cast<float4*>(smem + kMx12BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
+    mx_h0_to_lds(smem, kMx12LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
+
+    // ---- x transfers: fragment f = (kbl * NB + bt) * 2 + hl of a ring slot; wave w moves fragment w, waves 0-3 also w + 8
+    const u32x4_t xrs = dma_rsrc(xin);
+    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + X_OFF);
+    auto dma_pair = [&](int slot, int sd, int jd) {                 // wave-uniform: ring slot, step (clamped), pair of x_t(sd)
+        const int sc_ = sd < kSeqLen ? sd : kSeqLen - 1;
+        const int td = dir ? kSeqLen - 1 - sc_ : sc_;
+        auto one = [&](int f) {
+            const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
+            const int soff = (((((tile0 + bt) * kSeqLen + td) * KX + (2 * jd + kbl)) * 2 + hl) << 10);
+            dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff),
+                      __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT_BYTES + (f << 10))));
+        };
+        one(wave);
+        if (wave < 4) one(wave + 8);
+    };
+    // the transfer of consumption jj + RS of step s (jj: 0-15 phase A pairs, 16-31 phase C pairs) goes into the slot consumption jj
+    // just vacated
+    auto dma_ahead = [&](int slot, int s, int jj) {
+        const int g = jj + RS;
+        dma_pair(slot, s + (g >> 5), g & (NPAIR - 1));
+    };
+    // wait until this wave's part of a transfer has landed: at most NLO (waves 4-7) / NHI (waves 0-3) younger operations
+#define CCSM_WAIT_XFER(NLO, NHI)                                                        \
+    do {                                                                                \
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(" #NHI ")" ::: "memory");            \
+        else asm volatile("s_waitcnt vmcnt(" #NLO ")" ::: "memory");                     \
+    } while (0)
+
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * kMx12WBytes);
+    const int bias_off = kMx12BiasOff + wave * 4 * 32 * 4;
+    auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
+    auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
+
+    // weight registers: phase A three pair slots: [slot][kb in pair][gate r,z] hi, [slot][gate] blobs, [slot] scale bytes; phase B one
+    // resident pair; phase C four pair slots of the n gate: [slot][kb in pair] hi, [slot] blob, [slot] scale byte
+    uint4 wah[3][2][2], wab[3][2];
+    uint32_t was[3];
+    uint4 wbh[2][3], wbb[3];
+    uint32_t wbs;
+    uint4 wch[4][2], wcb[4];
+    uint32_t wcs[4];
+    auto ldAh = [&](uint4 (&d)[2], int p, int kbl) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) d[g] = w_at(p * PA + ((2 * kbl + g) << 10));
+    };
+    auto ldAb = [&](int ws, int p) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) wab[ws][g] = w_at(p * PA + ((4 + g) << 10));
+        was[ws] = ws_at(p * PA + (6 << 10));
+    };
+    auto ldA_slot = [&](int ws, int p) { ldAh(wah[ws][0], p, 0); ldAh(wah[ws][1], p, 1); ldAb(ws, p); };   // 7 requests
+
+    // ---- prologue: the ring's first pairs, the first three weight slots
+#pragma unroll
+    for (int g = 0; g < RS; ++g) dma_pair(g, 0, g);
+    ldA_slot(0, 0);
+    ldA_slot(1, 1);
+    ldA_slot(2, 2);
+    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");               // all ring transfers (older than the 21 weight requests)
+    __syncthreads();                                                // ring, h0 fragments and biases are in LDS
+
+    int slot = 0;                                                   // ring slot of the next consumption (wave-uniform)
+    for (int s = 0; s < kSeqLen; ++s) {
+        const int t = dir ? (kSeqLen - 1 - s) : s;
+        auto stamp = [&](int k) {
+            if constexpr (DBG) {
+                if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
+            }
+        };
+        stamp(0);
+        f32x16 acc[3][NB];                                          // R, Z, N
+        auto lane16_here = [&]() -> int {                           // opaque copy: per-lane addresses are rebuilt where a phase needs them
+            int v = lane16;
+            asm volatile("" : "+v"(v));
+            return v;
+        };
+        auto bias_set = [&](int set) {
+            f32x16 b;
+            const char* bp = smem + (bias_off + ((lane16_here() >> 9) << 6));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(bp + set * 128 + q * 16);
+                b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+            }
+            return b;
+        };
+        {
+            const f32x16 b0 = bias_set(0), b1 = bias_set(1);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) { acc[0][bt] = b0; acc[1][bt] = b1; }
+        }
+
+        uint4 xh[NB], xh1[NB], xc0[NB];
+        uint2 xc1[NB];
+        auto rdx = [&](uint4 (&x)[NB], int xs, int kbl, int f) {    // xs = byte offset of the slot + lane * 16
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((kbl * NB + bt) * 2 + f) << 10));
+        };
+        auto rdx_blob = [&](int xs) {
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                xc0[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((0 * NB + bt) * 2 + 1) << 10));
+                xc1[bt] = *reinterpret_cast<const uint2*>(smem + xs + (((1 * NB + bt) * 2 + 1) << 10));
+            }
+        };
+        auto slot_off = [&](int sl) -> int { return X_OFF + sl * SLOT_BYTES + lane16; };
+#define CCSM_MAIN(W, X, G, S0)                                                                                \
+    do {                                                                                                      \
+        CCSM_FENCE;                                                                                           \
+        _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)       \
+            acc[S0 + g][bt] = mfma16(W[g], X[bt], acc[S0 + g][bt]);                                           \
+        CCSM_FENCE;                                                                                           \
+    } while (0)
+
+        // ---------------- phase A: R, Z += W_i{r,z} x_t, pairs 0..15 ---------------------------------------------------------
+        // pair P lives in weight slot P % 3; behind its three MFMA groups its slot is refilled with pair P + 3 (2 + 2 + 3
+        // requests); pairs 13 and 14 take phase B's first pair instead (7 + 3 requests), pair 15 has nothing left to request and
+        // its ring refill is deferred to the end of phase B: issued here it would sit in front of phase B's one-pair-ahead
+        // weight requests.
+        rdx(xh, slot_off(slot), 0, 0);
+        int slot_a15 = 0;
+        static_for<0, NPAIR>([&](auto PC_) {
+            constexpr int P = decltype(PC_)::value;
+            constexpr int WS = P % 3;
+            const int xs = slot_off(slot);
+            const int slot_n = slot == RS - 1 ? 0 : slot + 1;
+            rdx(xh1, xs, 1, 0);
+            CCSM_MAIN(wah[WS][0], xh, 2, 0);
+            if constexpr (P + 3 < NPAIR) ldAh(wah[WS][0], P + 3, 0);
+            else if constexpr (P == 13) { wbh[0][0] = w_at(OFF_B + (0 << 10)); wbh[0][1] = w_at(OFF_B + (1 << 10)); }
+            else if constexpr (P == 14) { wbb[1] = w_at(OFF_B + (7 << 10)); wbb[2] = w_at(OFF_B + (8 << 10)); }
+            rdx_blob(xs);
+            CCSM_MAIN(wah[WS][1], xh1, 2, 0);
+            if constexpr (P + 3 < NPAIR) ldAh(wah[WS][1], P + 3, 1);
+            else if constexpr (P == 13) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); }
+            else if constexpr (P == 14) { wbs = ws_at(OFF_B + (9 << 10)); }
+            // this wave's part of the next pair's transfer has landed: younger than it are RS - 2 pairs of 7 + d operations and 4 of
+            // this pair (pair 14: 3 of its own; pair 15: pair 13 with 7 + d, pair 14 with 3 + d, none of its own)
+            if constexpr (P == NPAIR - 1) CCSM_WAIT_XFER(12, 14);
+            else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(19, 21);
+            else CCSM_WAIT_XFER(20, 22);
+            __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
+            if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
+            CCSM_CORR_G(2, wab[WS], was[WS], sb);
+            if constexpr (P + 3 < NPAIR) ldAb(WS, P + 3);
+            else if constexpr (P == 13) { wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10)); wbb[0] = w_at(OFF_B + (6 << 10)); }
+            CCSM_FENCE;
+            if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;
+            slot = slot_n;
+        });
+
+        stamp(1);
+        // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------------
+        {
+            const f32x16 b3 = bias_set(3);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
+        }
+        const int sbh = sb + (s == 0 ? kMxScaleHi0 - kMxScaleHi : 0);
+        // pair Q = k-blocks 2Q, 2Q + 1: one pair resident, refilled with the next pair behind each MFMA group (3 + 3 + 4
+        // requests); the last pair's positions take phase C's first pair slots
+        static_for<0, kKBH / 2>([&](auto QC) {
+            constexpr int Q = decltype(QC)::value;
+            constexpr bool LAST = Q == kKBH / 2 - 1;
+            constexpr int NXT = OFF_B + (Q + 1) * PB;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 0) + lane * 16);
+                xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 1) + lane * 16);
+                xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag(2 * Q + 1, bt, 1) + lane * 16);
+            }
+            CCSM_MAIN(wbh[0], xh, 3, 0);
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wbh[0][g] = w_at(NXT + (g << 10));
+            } else {
+                wch[0][0] = w_at(OFF_C + 0 * PC + (0 << 10)); wch[0][1] = w_at(OFF_C + 0 * PC + (1 << 10)); wcb[0] = w_at(OFF_C + 0 * PC + (2 << 10));
+            }
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q + 1, bt, 0) + lane * 16);
+            CCSM_MAIN(wbh[1], xh, 3, 0);
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wbh[1][g] = w_at(NXT + ((3 + g) << 10));
+            } else {
+                wcs[0] = ws_at(OFF_C + 0 * PC + (3 << 10)); wch[1][0] = w_at(OFF_C + 1 * PC + (0 << 10)); wch[1][1] = w_at(OFF_C + 1 * PC + (1 << 10));
+            }
+            CCSM_CORR_G(3, wbb, wbs, sbh);
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) wbb[g] = w_at(NXT + ((6 + g) << 10));
+                wbs = ws_at(NXT + (9 << 10));
+            } else {
+                wcb[1] = w_at(OFF_C + 1 * PC + (2 << 10)); wcs[1] = ws_at(OFF_C + 1 * PC + (3 << 10));
+                wch[2][0] = w_at(OFF_C + 2 * PC + (0 << 10)); wch[2][1] = w_at(OFF_C + 2 * PC + (1 << 10));
+            }
+            CCSM_FENCE;
+        });
+        dma_ahead(slot_a15, s, NPAIR - 1);                          // the deferred ring refill: phase-C pair RS - 1
+        // r = sigmoid(R) ; N = b_in + r * N
+        {
+            const f32x16 b2 = bias_set(2);
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
+        }
+        // the rest of phase C's first four pair slots: requested once R is dead (the accumulators drop from 144 to 96 registers)
+        CCSM_FENCE;
+        wcb[2] = w_at(OFF_C + 2 * PC + (2 << 10)); wcs[2] = ws_at(OFF_C + 2 * PC + (3 << 10));
+        wch[3][0] = w_at(OFF_C + 3 * PC + (0 << 10)); wch[3][1] = w_at(OFF_C + 3 * PC + (1 << 10));
+        wcb[3] = w_at(OFF_C + 3 * PC + (2 << 10)); wcs[3] = ws_at(OFF_C + 3 * PC + (3 << 10));
+        CCSM_FENCE;
+        auto zwork = [&](int bt) {                                  // z = sigmoid(Z) in place, inside phase C (vector ALU otherwise idle)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
+        };
+
+        stamp(2);
+        // ---------------- phase C: N += W_in x_t, pairs 0..15 (consumptions 16..31) ------------------------------------------
+        // pair P lives in slot P % 4 of the n-gate weights, refilled with pair P + 4 (1 + 1 + 2 requests); the last four pairs take
+        // the next step's phase-A slots 0 and 1 instead (4, 3, 4, 3 requests; slot 2 follows behind the tail)
+        rdx(xh, slot_off(slot), 0, 0);
+        static_for<0, NPAIR>([&](auto PC_) {
+            constexpr int P = decltype(PC_)::value;
+            constexpr int WS = P % 4;
+            constexpr int AS = P >= 12 ? (P - 12) / 2 : 0, AF = P >= 12 ? (P - 12) % 2 : 0;   // pairs 12..15: phase-A slot AS, AF = 0 hi / 1 blobs
+            const int xs = slot_off(slot);
+            const int slot_n = slot == RS - 1 ? 0 : slot + 1;
+            rdx(xh1, xs, 1, 0);
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][0], xh[bt], acc[2][bt]);
+            CCSM_FENCE;
+            if constexpr (P + 4 < NPAIR) wch[WS][0] = w_at(OFF_C + (P + 4) * PC + (0 << 10));
+            else if constexpr (AF == 0) wah[AS][0][0] = w_at(AS * PA + (0 << 10)); else wab[AS][0] = w_at(AS * PA + (4 << 10));
+            rdx_blob(xs);
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][1], xh1[bt], acc[2][bt]);
+            CCSM_FENCE;
+            if constexpr (P + 4 < NPAIR) wch[WS][1] = w_at(OFF_C + (P + 4) * PC + (1 << 10));
+            else if constexpr (AF == 0) wah[AS][0][1] = w_at(AS * PA + (1 << 10)); else wab[AS][1] = w_at(AS * PA + (5 << 10));
+            // RS - 2 pairs of 4 + d operations and 2 of this pair (pairs 14, 15 look back on a blob pair with 3 + d)
+            if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(11, 13); else CCSM_WAIT_XFER(12, 14);
+            __syncthreads();
+            if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma_corr_mx<0>(wcb[WS], wcs[WS], xc0[bt], xc1[bt], acc[2][bt], sb);
+            CCSM_FENCE;
+            if constexpr (P + 4 < NPAIR) { wcb[WS] = w_at(OFF_C + (P + 4) * PC + (2 << 10)); wcs[WS] = ws_at(OFF_C + (P + 4) * PC + (3 << 10)); }
+            else if constexpr (AF == 0) { wah[AS][1][0] = w_at(AS * PA + (2 << 10)); wah[AS][1][1] = w_at(AS * PA + (3 << 10)); }
+            else { was[AS] = ws_at(AS * PA + (6 << 10)); }
+            CCSM_FENCE;
+            dma_ahead(slot, s, NPAIR + P);
+            slot = slot_n;
+            if constexpr (P == 1) zwork(0);
+            if constexpr (P == 5) zwork(1);
+            if constexpr (P == 9) zwork(2);
+        });
+#undef CCSM_MAIN
+        stamp(3);
+        mx_tail<OUT_FP8>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        CCSM_FENCE;
+        ldA_slot(2, 2);                                             // the third weight slot of the next step (needed two pairs in): not live across the tail
+        CCSM_FENCE;
+        stamp(4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no transfer may still be writing LDS when the workgroup retires
+#undef CCSM_WAIT_XFER
+}
+#undef CCSM_CORR_G
+#undef CCSM_FENCE
+
+// Self-test of the split-mx product: C[unit][row] = sum_k W[unit][k] X[row][k] over one pair (32 k).  W fragments packed by the
+// host (hi kb0, hi kb1, blob, scale dwords with the scale in byte 0), X given in fp32 as an MFMA-C-layout image and packed on the device with pack_pair_mx;
+// blob_out receives the activation blobs (24 bytes per lane) so the host can check its own fp6 encoder against the instruction's.
+__global__ void mx_selftest_kernel(const uint4* __restrict__ wfrag, const float* __restrict__ x /* [row 32][k 32] */,
+                                   float* __restrict__ c /* [unit 32][row 32] */, uint32_t* __restrict__ blob_out, int with_corr, float scale, int sb_hi, int sb_lo) {
+    const int lane = threadIdx.x & 63;
+    const int n = lane & 31, hh = lane >> 5;
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = x[n * 32 + 8 * q + 4 * hh + e];
+    uint4 hi0, hi1, c0, lo8;
+    uint2 c1;
+    pack_pair_mx<true>(v, scale, hi0, hi1, c0, c1, lo8);
+    blob_out[lane * 6 + 0] = c0.x; blob_out[lane * 6 + 1] = c0.y; blob_out[lane * 6 + 2] = c0.z; blob_out[lane * 6 + 3] = c0.w;
+    blob_out[lane * 6 + 4] = c1.x; blob_out[lane * 6 + 5] = c1.y;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = mfma16(wfrag[0 * 64 + lane], hi0, acc);
+    acc = mfma16(wfrag[1 * 64 + lane], hi1, acc);
+    if (with_corr) acc = mfma_corr_mx<0>(wfrag[2 * 64 + lane], reinterpret_cast<const uint32_t*>(wfrag + 3 * 64)[lane], c0, c1, acc, hh ? sb_lo : sb_hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + n] = acc[r];
+}
+
+}  // namespace ccsm
