@@ -4,15 +4,24 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step = one forward of the hot path over one batch of 2048 synthetic CpG sites (both strands, 21-mers), features
-already resident in HBM, initial states drawn on the device (Philox) as SURVEY.md 8(d) prescribes for the timed
-run.  Steps are issued round-robin on `--streams` HIP streams (one workspace each) so that several batches are in
-flight, exactly K steps are timed between barrier + synchronize on both sides, MAX over ranks is taken and rank 0
-prints ONE JSON line.  Reads are sharded across GPUs with no collective on the data path (weak scaling).
+A step = one forward of the hot path over one batch of 2048 synthetic CpG sites (both strands, 21-mers), features already
+resident in HBM, initial states drawn on the device (Philox) as SURVEY.md 8(d) prescribes for the timed run.  `--coalesce`
+steps are bound to one workspace and the heavy kernels run once over them (6 x 2048 sites = 512 workgroups of 96 strand rows
+= two full rounds of the 256 CUs); a ragged last group (steps not a multiple of the group size) runs on a second stream next to
+the last full group, so that its partial round fills up.  Exactly K steps are timed between barrier + synchronize on both
+sides, MAX over ranks is taken and rank 0 prints ONE JSON line.  Reads are sharded across GPUs with no collective on the data
+path (weak scaling).  With --gpus N > 1 and no torch.distributed environment, this script re-executes itself under
+torch.distributed.run with N ranks; it refuses to run if fewer than N GPUs are visible.
+
+Besides BASELINE's metric the line carries (rank 0, N = 1; `--extras none` skips them): the same forward in the fp32-class
+split3 arithmetic, the PCIe-inclusive rate through ccsm_submit_host / ccsm_wait_host, `call_mods` end to end on a scaled-down
+configs[2] BAM, and the aggregate kernel on configs[4]'s 50 M sites.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,11 +39,15 @@ FLOP_PER_SITE = 2.0 * (MAC_GRU0 + 2 * MAC_GRU12 + MAC_ATT + 2048)   # = 244.23e6
 BYTES_PER_SITE = 680.0
 PEAK_F16_MFMA = 2.5e15       # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
-# HBM/fabric bytes of ONE launch of the dominant kernel over 3 x 2048 sites, from rocprofv3 PMC passes on the same launch
-# shape (profiles/r01_c_pmc_coalesced.md: 2 x FETCH_SIZE + WRITE_SIZE, KiB, gfx950 read correction per MI355X_MICROARCH.md).
-# PMC counters cannot be read from inside this process; the figure is per-launch like `achieved` and scales with sites.
-TRAFFIC_BYTES_PER_SITE_GRU12 = {3: (2 * 1241546 + 516096) * 1024 / 6144.0,      # profiles/r01_c_pmc_coalesced.md
-                                4: (2 * 1252400 + 518150) * 1024 / 6144.0}      # profiles/r01_l_pmc_coalesced.md; other modes: null
+# HBM/fabric bytes of ONE launch of the dominant kernel per site, from rocprofv3 PMC passes on the launch shape timed here
+# (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
+# read from inside this process)
+TRAFFIC = {4: ((2 * 1252400 + 518150) * 1024 / 6144.0, "profiles/r01_l_pmc_coalesced.md"),
+           3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
+ARITH = {4: ("f16 + MX(fp4 x fp6) split operands, f32 accumulate",
+             "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: fp4 e2m1 weight blobs with "
+             "per-(row, 32-k) E8M0 scales x fp6 e2m3 activation blobs; attention pool: fp8 e4m3 x fp8), one fp32 accumulator", 99.0 / 64.0),
+         3: ("f16x3 split operands, f32 accumulate", "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate", 3.0)}
 
 
 def parse():
@@ -42,18 +55,33 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=24)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the coalesced groups alternate over (2 overlaps launch tails: +3 % value, but the overlapped\n"
-                         "launches then report inflated per-kernel durations; 1 keeps roofline.achieved = a solo launch)")
     ap.add_argument("--coalesce", type=int, default=6,
                     help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
-                         "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds); 3 leaves the\n"
-                         "attention kernel a half-empty second round (+20 %% on its per-site time)")
-    ap.add_argument("--precision", type=int, default=4, choices=(1, 2, 3, 4),
-                    help="4 = split-f8 (default: fp16 main product + fp8 correction products, max |dprob| ~4e-6); 3 = split-fp16\n"
-                         "x3 (fp32-class, ~2e-7); 2/1 = fewer passes, outside the parity margin, reported as such")
+                         "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds)")
+    ap.add_argument("--precision", type=int, default=4, choices=(3, 4),
+                    help="4 = split-mx (default: fp16 main product + MX correction product, max |dprob| 7-8e-6); 3 = split-fp16 x3\n"
+                         "(fp32-class, ~2e-7)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--extras", default="all", choices=("all", "none"), help="the secondary measurements (rank 0 at N = 1)")
     return ap.parse_args()
+
+
+def respawn_under_torchrun(a):
+    """--gpus N > 1 outside torch.distributed: check the devices, then run this script as N ranks."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible; refusing to report a %d-GPU number from fewer devices\n"
+                         % (a.gpus, have, a.gpus))
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def cpu_baseline(weights, target_s, device_model):
@@ -76,7 +104,7 @@ def cpu_baseline(weights, target_s, device_model):
                                    h0=(h1, h2))
     ws.close()
     prob_err = float(np.abs(gpu_probs - ref_probs).max())
-    n = int(min(max(rate * target_s, probe_n), 65536))
+    n = int(min(max(rate * target_s, probe_n), 262144))
     n = (n // (8 * threads)) * 8 * threads or probe_n
     s = synth.synth_sites(n, 779)
     h1, h2 = synth.synth_h0(n, 780)
@@ -84,23 +112,162 @@ def cpu_baseline(weights, target_s, device_model):
     c_oracle.forward(weights, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2)
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "sites/s", "cores": threads, "kind": "port",
-            "sample": "%d synthetic sites (same generator as the GPU run), explicit h0, oracle/attbigru2s_oracle.c fp32 "
-                      "AVX2+OpenMP, %.1f s" % (n, dt),
+            "GFLOPs": n / dt * FLOP_PER_SITE / 1e9,
+            "sample": "%d synthetic sites (same generator as the GPU run), explicit h0, %s, %.1f s" % (n, c_oracle.DESCRIPTION, dt),
             "gpu_prob_max_abs_err": prob_err, "gpu_prob_err_sites": probe_n}
+
+
+class Runner:
+    """K steps of one DeviceModel: full groups on stream 0, a ragged last group on stream 1 next to the last full group."""
+
+    def __init__(self, dm, pool, dev, grp, rank):
+        import torch
+        self.torch, self.dm, self.pool, self.dev, self.grp, self.rank = torch, dm, pool, dev, grp, rank
+        self.ws = [dm.workspace(BATCH * grp) for _ in range(2)]
+        self.streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        self.outs = [[(torch.empty((BATCH, 2), device=dev), torch.empty((BATCH, 2), device=dev)) for _ in range(grp)] for _ in range(2)]
+        self.step0 = 0
+
+    def run(self, steps):
+        """Enqueue `steps` steps (no synchronisation)."""
+        full, rag = divmod(steps, self.grp)
+        plan = [(0, self.grp)] * full
+        if rag:
+            plan.insert(max(len(plan) - 1, 0), (1, rag))      # the ragged group is enqueued just before the last full one, on stream 1
+        i = self.step0
+        for k, nb in plan:
+            for j in range(nb):
+                self.ws[k].group_add_torch(*self.pool[i % len(self.pool)], stream=self.streams[k].cuda_stream, out=self.outs[k][j], seed=1234,
+                                           offset=(self.rank * 10**9 + i * BATCH))
+                i += 1
+            self.ws[k].group_run(stream=self.streams[k].cuda_stream)
+        self.step0 = i
+        return full, rag
+
+    def arm(self):
+        for w in self.ws:
+            w.set_timing(True)
+
+    def close(self):
+        for w in self.ws:
+            w.close()
+
+
+def timed(runner, steps, warmup, fence):
+    grp = runner.grp
+    # warm-up: at least W steps, at least one full group, and one group of the ragged shape if the timed region has one
+    w_steps = max(-(-warmup // grp), 1) * grp + steps % grp
+    runner.run(w_steps)
+    fence()
+    runner.arm()                 # average only the timed region's launches
+    t0 = time.perf_counter()
+    full, rag = runner.run(steps)
+    fence()
+    return time.perf_counter() - t0, full, rag, w_steps
+
+
+def extras(weights, dm, dev, pool, grp):
+    """Secondary measurements, each bounded to a few seconds; failures are reported, not raised."""
+    import torch
+    out = {}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    def fence():
+        torch.cuda.synchronize(dev)
+
+    def split3():
+        from ccsmeth_amd.models import DeviceModel
+        dm3 = DeviceModel(weights, device=dev.index, precision=3)
+        r = Runner(dm3, pool, dev, grp, 0)
+        steps = 4 * grp
+        dt, full, _, _ = timed(r, steps, grp, fence)
+        kt, nr = r.ws[0].timing_mean()
+        r.close(); dm3.close()
+        ach = 2.0 * MAC_GRU12 * BATCH * grp / (float(np.mean(kt[1:3])) * 1e-3)
+        return {"value": steps * BATCH / dt, "unit": "sites/s", "dtype": ARITH[3][0], "steps": steps,
+                "roofline_frac": ach / PEAK_F16_MFMA, "launch_ms": float(np.mean(kt[1:3])), "mfma_passes_per_flop": 3}
+
+    def pcie():
+        # features in host memory every step, logits/probs back to host memory: ccsm_submit_host / ccsm_wait_host on two workspaces
+        import ctypes as C
+        from ccsmeth_amd import _lib
+        from ccsmeth_amd.utils import synth
+        n = BATCH * grp
+        s = synth.synth_sites(n, 4242)
+        lib = dm._lib
+        wss = [dm.workspace(n) for _ in range(2)]
+        sts = [torch.cuda.Stream(dev) for _ in range(2)]
+        b = _lib.Batch()
+        keep = []
+        for k, sfx in enumerate(("1", "2")):
+            arrs = [np.ascontiguousarray(s["kmer" + sfx], np.uint8), np.ascontiguousarray(s["ipd" + sfx], np.float32),
+                    np.ascontiguousarray(s["pw" + sfx], np.float32), np.ascontiguousarray(s["npass" + sfx], np.float32)]
+            keep += arrs
+            b.strand[k].kmer, b.strand[k].ipd, b.strand[k].pw, b.strand[k].npass = (a.ctypes.data for a in arrs)
+        b.kmer_is_f32, b.npass_per_base = 0, 0
+        logits, probs = np.empty((n, 2), np.float32), np.empty((n, 2), np.float32)
+
+        def submit(k, i):
+            h = _lib.H0()
+            h.mode, h.seed, h.offset = _lib.H0_DEVICE_RNG, 1234, i * n
+            _lib.check(lib.ccsm_submit_host(dm.handle, wss[k].handle, n, C.byref(b), C.byref(h), sts[k].cuda_stream))
+
+        def wait(k):
+            _lib.check(lib.ccsm_wait_host(wss[k].handle, logits.ctypes.data, probs.ctypes.data))
+        reps = 10
+        for phase in (2, reps):
+            fence()
+            t0 = time.perf_counter()
+            submit(0, 0)
+            for i in range(1, phase):
+                submit(i & 1, i)
+                wait((i - 1) & 1)
+            wait((phase - 1) & 1)
+            dt = time.perf_counter() - t0
+        for w in wss:
+            w.close()
+        return {"value": reps * n / dt, "unit": "sites/s", "sites_per_call": n, "calls": reps,
+                "what": "ccsm_submit_host / ccsm_wait_host double-buffered: H2D of the 680 B/site features from host memory, model, D2H of logits + probs"}
+
+    def call_mods_e2e():
+        from ccsmeth_amd.utils import benchdata
+        return benchdata.call_mods_end_to_end(n_reads=int(os.environ.get("CCSM_BENCH_READS", "1500")), read_len=15000)
+
+    def aggregate():
+        from ccsmeth_amd.utils import benchdata
+        return benchdata.aggregate_50m(dev)
+
+    leg("split3", split3)
+    leg("pcie_inclusive", pcie)
+    leg("call_mods_end_to_end", call_mods_e2e)
+    leg("aggregate_50M", aggregate)
+    return out
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(a)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node == --gpus\n" % (a.gpus, world))
+        sys.exit(2)
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d has no GPU (device_count %d)\n" % (local_rank, torch.cuda.device_count()))
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert a.gpus == world or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     n_gpus = world
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -118,24 +285,8 @@ def main():
         sl = slice(b * BATCH, (b + 1) * BATCH)
         pool.append(tuple(torch.from_numpy(np.ascontiguousarray(sites[k][sl])).to(dev) for k in
                           ("kmer1", "ipd1", "pw1", "npass1", "kmer2", "ipd2", "pw2", "npass2")))
-    # Micro-batch coalescing (ccsm_group_*): every step binds its own 2048-site batch (own outputs, own initial states)
-    # to a workspace; after `--coalesce` steps the heavy kernels run ONCE over those batches, so that one launch fills the
-    # chip (3 x 2048 sites = 256 workgroups of 96 strand rows = one per CU; the default 6 = two full rounds).  Workspaces
-    # alternate over `--streams` streams.
-    nst = max(1, a.streams)
     grp = max(1, a.coalesce)
-    wss = [dm.workspace(BATCH * grp) for _ in range(nst)]
-    streams = [torch.cuda.Stream(dev) for _ in range(nst)]
-    outs = [[(torch.empty((BATCH, 2), device=dev), torch.empty((BATCH, 2), device=dev)) for _ in range(grp)] for _ in range(nst)]
-    for w in wss:
-        w.set_timing(True)       # HIP events around each kernel, on the stream the kernel runs on
-
-    def step(i, last=False):
-        k = (i // grp) % nst
-        wss[k].group_add_torch(*pool[i % npool], stream=streams[k].cuda_stream, out=outs[k][i % grp], seed=1234,
-                               offset=(rank * 10**9 + i * BATCH))
-        if (i + 1) % grp == 0 or last:
-            wss[k].group_run(stream=streams[k].cuda_stream)
+    runner = Runner(dm, pool, dev, grp, rank)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -143,61 +294,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(a.warmup):
-        step(i, last=(i == a.warmup - 1))
-    fence()
-    for w in wss:
-        w.set_timing(True)       # re-arm: average only the timed region's launches
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i, last=(i == a.steps - 1))
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, full, rag, w_steps = timed(runner, a.steps, a.warmup, fence)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-kernel launch durations: mean over every run of the timed region (HIP events recorded on the stream each
-    # kernel was launched on; the warm-up runs were dropped by re-arming the timers after the warm-up fence)
-    tms = [w.timing_mean() for w in wss]
-    nruns = sum(n for _, n in tms)
-    kt = np.sum([np.array(t) * n for t, n in tms], axis=0) / max(nruns, 1)     # ms: gru0, gru1, gru2, attn, finalize
+    # ---- per-kernel launch durations: mean over the FULL groups of the timed region (HIP events recorded on the stream each
+    # kernel was launched on; the warm-up runs were dropped by re-arming the timers after the warm-up fence).  With a ragged group
+    # the last full group shares the chip with it: its durations are in the mean (slightly inflated: the figure is conservative).
+    kt, nruns = runner.ws[0].timing_mean() if full else runner.ws[1].timing_mean()
+    kt = np.array(kt)
     dom_ms = float(kt[1:3].mean())
-    launches = -(-a.steps // grp)                           # group runs in the timed region (the timers keep the last 128 of them)
-    sites_per_launch = a.steps * BATCH / launches           # = BATCH * coalesce when steps is a multiple of it
-    assert bool(torch.isfinite(outs[0][0][1]).all())
+    sites_per_launch = BATCH * (grp if full else rag)
+    assert bool(torch.isfinite(runner.outs[0][0][1]).all())
 
     if rank == 0:
         value = n_gpus * a.steps * BATCH / elapsed
-        passes = {4: 2, 3: 3, 2: 2, 1: 1}[a.precision]     # MFMA issue cycles per algorithmic flop, in fp16-rate units
+        dtype, arith, passes = ARITH[a.precision]
         achieved = 2.0 * MAC_GRU12 * sites_per_launch / (dom_ms * 1e-3)
+        traffic, traffic_src = TRAFFIC[a.precision]
         line = {
             "metric": "CpG sites/sec (call_mods, attbigru2s b21)", "value": value, "unit": "sites/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {4: "f16+f8 split operands, f32 accumulate", 3: "f16x3 split operands, f32 accumulate",
-                      2: "f16 weights x split-f16 activations, f32 accumulate", 1: "f16 operands, f32 accumulate"}[a.precision],
-            "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"workload": "attbigru2s_b21 forward on synthetic 21-mer CpG batches (BASELINE.json configs[1])",
-                       "batch": BATCH, "sites_per_step": BATCH, "streams": nst, "coalesce": grp, "h0": "device Philox N(0,1)",
-                       "arithmetic": {4: "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) with fp8 e4m3 operands on "
-                                         "v_mfma_scale_f32_32x32x64_f8f6f4, one fp32 accumulator (GRU layers and attention pool)",
-                                      3: "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate",
-                                      2: "fp16 weights x split-fp16 activations (2 MFMA passes), fp32 accumulate",
-                                      1: "fp16 operands (1 MFMA pass), fp32 accumulate"}[a.precision],
+                       "batch": BATCH, "sites_per_step": BATCH, "coalesce": grp, "full_groups": full, "ragged_group_batches": rag,
+                       "warmup_steps_run": w_steps, "h0": "device Philox N(0,1)", "arithmetic": arith,
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": ("gru_layer_f8_kernel<KX=32>" if a.precision == 4 else "gru_layer_v2_kernel<KX=32>") + " (BiGRU layers 1-2)",
+            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if a.precision == 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
-                         "traffic": TRAFFIC_BYTES_PER_SITE_GRU12.get(a.precision, 0) * sites_per_launch or None,
-                         "traffic_source": "profiles/r01_%s_pmc_coalesced.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on a 6144-site launch, "
-                                           "scaled per site)" % ("l" if a.precision == 4 else "c"),
+                         "traffic": traffic * sites_per_launch, "traffic_source": traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled per site)",
                          "launch_ms": dom_ms, "mfma_passes_per_flop": passes,
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,
-                         "note": "achieved = algorithmic flops of one launch (%d sites x 99.09 MFLOP) / its HIP-event "
-                                 "duration; one launch = %d workgroups of 96 strand rows on 256 CUs; launches of %d streams "
-                                 "may overlap" % (sites_per_launch, 2 * ((2 * int(sites_per_launch) + 95) // 96), nst),
+                         "power_note": "the kernel runs at the 1400 W package power cap (sclk ~1.65-1.75 GHz of 2.4): profiles/r02_c_power_attribution.md",
+                         "note": "achieved = algorithmic flops of one launch (%d sites x 99.09 MFLOP) / its HIP-event duration; one launch = "
+                                 "%d workgroups of 96 strand rows on 256 CUs" % (sites_per_launch, 2 * ((2 * int(sites_per_launch) + 95) // 96)),
                          "hbm_algorithmic_GBps": value / n_gpus * BYTES_PER_SITE / 1e9,
                          "hbm_frac": value / n_gpus * BYTES_PER_SITE / PEAK_HBM},
             "kernel_ms": {"gru0": float(kt[0]), "gru1": float(kt[1]), "gru2": float(kt[2]), "attn_fc": float(kt[3]),
@@ -209,9 +343,10 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(weights, a.cpu_seconds, dm)
             except ImportError as e:
                 line["cpu_baseline"] = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
+        if n_gpus == 1 and a.extras == "all":
+            line["extras"] = extras(weights, dm, dev, pool, grp)
         print(json.dumps(line), flush=True)
-    for w in wss:
-        w.close()
+    runner.close()
     dm.close()
     if world > 1:
         dist.barrier()

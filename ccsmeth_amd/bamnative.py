@@ -12,14 +12,14 @@ LIB_PATH = os.path.join(_HERE, "lib", "libccsm_bam.so")
 EXPORTS = ("ccsm_bam_last_error", "ccsm_bam_open", "ccsm_bam_header", "ccsm_bam_next", "ccsm_bam_batch_free", "ccsm_bam_close",
            "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_flush", "ccsm_bam_writer_close",
            "ccsm_bam_modcalls_of_batch", "ccsm_bam_modcalls_free", "ccsm_bam_index_build", "ccsm_bam_sort",
-           "ccsm_bam_align_info")
+           "ccsm_bam_align_info", "ccsm_bam_seek", "ccsm_bam_tell", "ccsm_bam_inflated_bytes")
 
 
 class _Batch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("records", C.c_void_p), ("rec_offset", C.c_void_p), ("flag", C.c_void_p),
                 ("offset", C.c_void_p), ("length", C.c_void_p), ("n_sites", C.c_void_p), ("seq", C.c_void_p), ("fi", C.c_void_p),
                 ("ri", C.c_void_p), ("fp", C.c_void_p), ("rp", C.c_void_p), ("fn", C.c_void_p), ("rn", C.c_void_p),
-                ("total_bases", C.c_int64)]
+                ("total_bases", C.c_int64), ("voffset_start", C.c_uint64), ("voffset_end", C.c_uint64)]
 
 
 class ModCallOpts(C.Structure):
@@ -63,6 +63,10 @@ def load():
     lib.ccsm_bam_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     lib.ccsm_bam_sort.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int64]
     lib.ccsm_bam_align_info.argtypes = [C.POINTER(_Batch), vp, vp, vp, vp]
+    lib.ccsm_bam_seek.argtypes = [vp, C.c_uint64, C.c_uint64]
+    lib.ccsm_bam_tell.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.ccsm_bam_inflated_bytes.argtypes = [vp]
+    lib.ccsm_bam_inflated_bytes.restype = C.c_int64
     _lib = lib
     return lib
 
@@ -95,6 +99,7 @@ class Batch:
         self.seq, self.fi, self.ri, self.fp, self.rp = (_view(p, np.uint8, self.total_bases) for p in (b.seq, b.fi, b.ri, b.fp, b.rp))
         self.fn = _view(b.fn, np.float32, n)
         self.rn = _view(b.rn, np.float32, n)
+        self.voffset_start, self.voffset_end = int(b.voffset_start), int(b.voffset_end)
 
     def close(self):
         if self._ptr is not None:
@@ -147,6 +152,19 @@ class NativeBamReader:
         p = C.POINTER(_Batch)()
         _check(_lib.ccsm_bam_next(self._h, int(max_reads), C.byref(p)))
         return Batch(p) if p else None
+
+    def seek(self, voffset_start, voffset_end=0):
+        """Continue at a BGZF virtual offset; with voffset_end the range ends like a file (nothing behind its block is inflated)."""
+        _check(_lib.ccsm_bam_seek(self._h, int(voffset_start), int(voffset_end)))
+
+    def tell(self):
+        v = C.c_uint64(0)
+        _check(_lib.ccsm_bam_tell(self._h, C.byref(v)))
+        return v.value
+
+    @property
+    def inflated_bytes(self):
+        return int(_lib.ccsm_bam_inflated_bytes(self._h))
 
     def close(self):
         if self._h:

@@ -64,6 +64,9 @@ def build_parser():
     p.add_argument("--no_supplementary", action="store_true", default=False)
     p.add_argument("--skip_unmapped", default="yes")
     p.add_argument("--threads", "-p", type=int, default=10, help="BGZF inflate / deflate threads of --io native")
+    p.add_argument("--dispatch", default="dynamic", choices=("dynamic", "static"),
+                   help="multi-GPU runs (torch.distributed.run): dynamic = every rank claims the next unclaimed hole-batch (the reference's "
+                        "shared queue); static = hole-batch i goes to rank i mod world")
     p.add_argument("--threads_call", type=int, default=3, help="(reference: call workers) ignored: one process per GPU")
     p.add_argument("--tseed", type=int, default=1234)
     p.add_argument("--use_compile", default="no")
@@ -228,37 +231,40 @@ def _read_of(rec):
                 np.asarray(tag("rp", [])), tag("fn", 0), tag("rn", 0), rec.is_reverse)
 
 
-def call_mods(args, log=sys.stderr):
+def call_mods(args, log=sys.stderr, pipe=None):
+    """`pipe`: an object with CallModsPipeline's run_native_batch / _site_counter / close (the CPU tests of the multi-rank
+    hand-out pass a stand-in; None = the GPU pipeline on the checkpoint of --model_file)."""
     t0 = time.time()
-    if not os.path.exists(args.model_file):
+    if pipe is None and not os.path.exists(args.model_file):
         raise ValueError("--model_file is not set right!")            # call_modifications.py:484-485
     if not os.path.exists(args.input):
         raise ValueError("--input_file does not exist!")              # :486-488
     _check_scope(args)
     from collections import OrderedDict
-    from .models import ModelAttRNN
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        import torch
-        args.device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)    # one process per GPU
-    model = ModelAttRNN(args.seq_len, args.layer_rnn, args.class_num, args.dropout_rate, args.hid_rnn, is_npass=True,
-                        model_type=args.model_type, device=args.device, seed=args.tseed, max_batch=args.batch_size)
-    para = _load_state_dict(args.model_file)
-    try:
-        model.load_state_dict(para)
-    except RuntimeError:                                               # DDP checkpoints: strip "module." (:350-358)
-        model.load_state_dict(OrderedDict((k[7:], v) for k, v in para.items()))
-    model.cuda(args.device).eval()
-    # --batch_size (reference default 512) is the reference's sites per model call.  On the GPU-extraction paths a launch wants
-    # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
-    # (every site's initial state is a function of the seed and its running index), so the flag is only a lower bound there.
-    chunk_sites = max(args.batch_size, 12288) if args.extract == "device" else args.batch_size
-    pipe = CallModsPipeline(model._dev, batch_size=chunk_sites, seed=args.tseed, extract=args.extract)
+    if pipe is None:
+        from .models import ModelAttRNN
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            import torch
+            args.device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)    # one process per GPU
+        model = ModelAttRNN(args.seq_len, args.layer_rnn, args.class_num, args.dropout_rate, args.hid_rnn, is_npass=True,
+                            model_type=args.model_type, device=args.device, seed=args.tseed, max_batch=args.batch_size)
+        para = _load_state_dict(args.model_file)
+        try:
+            model.load_state_dict(para)
+        except RuntimeError:                                               # DDP checkpoints: strip "module." (:350-358)
+            model.load_state_dict(OrderedDict((k[7:], v) for k, v in para.items()))
+        model.cuda(args.device).eval()
+        # --batch_size (reference default 512) is the reference's sites per model call.  On the GPU-extraction paths a launch wants
+        # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
+        # (every site's initial state is a function of the seed and its running index), so the flag is only a lower bound there.
+        chunk_sites = max(args.batch_size, 12288) if args.extract == "device" else args.batch_size
+        pipe = CallModsPipeline(model._dev, batch_size=chunk_sites, seed=args.tseed, extract=args.extract)
     holeids_e = None if args.holeids_e is None else _get_holes(args.holeids_e)          # extract_features.py:561-562
     holeids_ne = None if args.holeids_ne is None else _get_holes(args.holeids_ne)
     name_filter = holeids_e is not None or holeids_ne is not None
     align = args.mode == "align"
     out_path = args.output + ".modbam.bam"                             # :494
-    cnt_w = cnt_mm = cnt_failed = 0
+    cnt_w = cnt_mm = cnt_failed = cnt_sites = 0
     rm_pulse = not args.keep_pulse
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1 and not (args.io == "native" and args.extract == "device"):
@@ -266,34 +272,72 @@ def call_mods(args, log=sys.stderr):
     if args.io == "native" and args.extract == "device":
         # file -> libccsm_bam -> ccsm_forward_reads_host -> libccsm_bam -> file; the next chunk is inflated / parsed and the
         # previous one deflated / written by two helper threads while the GPU works on the current one.
-        # Multi-GPU (torch.distributed.run, one process per GPU): every rank parses the whole stream, takes the
-        # hole-batches with index = rank (mod world) and writes them as block-aligned runs into its own part file; the Philox
-        # counter of a batch is the number of sites in all earlier batches, so every probability equals the single-GPU run's;
-        # rank 0 stitches the runs back into input order.  The only communication is the gather of the run index and counters.
+        # Multi-GPU (torch.distributed.run, one process per GPU; ccsmeth_amd/sharding.py): rank 0 scans the input once
+        # in a background thread and publishes every hole-batch's place in the file and the running site index of its first site;
+        # every rank claims the next unclaimed batch (the reference's shared queue, call_modifications.py:561-578), seeks to it,
+        # and writes it as a block-aligned run into its own part file; the Philox counter of a batch is its published site index,
+        # so every probability equals the single-GPU run's; rank 0 stitches the runs back into input order.
         from concurrent.futures import ThreadPoolExecutor
         from .bamnative import NativeBamReader, NativeBamWriter, stitch_runs
-        dist = None
+
+        def filters(b):
+            """(skip mask or None, site window or None, sites of the batch that will be called)"""
+            skip, window = None, None
+            if name_filter:
+                skip = np.array([_skip_by_name(nm, holeids_e, holeids_ne) for nm in _batch_names(b)], bool)
+            if align:
+                from .bamnative import align_info
+                mq, qs, qe, ident = align_info(b)
+                askip, window = _align_skip_and_window(b.flag, mq, ident, qs, qe, b.length, args)
+                skip = askip if skip is None else (skip | askip)
+            sites = int(np.where((b.length > 0) & (~skip if skip is not None else True), b.n_sites, 0).sum())
+            return skip, window, sites
+
+        dist = board = scan = None
         if world > 1:
             import torch.distributed as dist
+            from . import sharding
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if not dist.is_initialized():
                 dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side bookkeeping only
+            board = sharding.BatchBoard(sharding.open_board_store(world, rank), world, rank, dispatch=args.dispatch)
+            if rank == 0:       # the scan gets the host cores the other ranks' readers do not need
+                scan_threads = max(args.threads, (os.cpu_count() or 1) // 2)
+                scan = sharding.start_scan_thread(lambda: NativeBamReader(args.input, threads=scan_threads), args.holes_batch,
+                                                  lambda b: filters(b)[2], board)
         part_path = out_path if world == 1 else "%s.part%d" % (out_path, rank)
         runs = []
-        # every rank inflates the whole input (it needs the site counts of the batches it skips): give the scan the rank's share of
-        # the host cores when that is more than --threads
-        scan_threads = max(args.threads, (os.cpu_count() or 1) // max(world, 1)) if world > 1 else args.threads
-        with NativeBamReader(args.input, threads=scan_threads) as rd:
+        with NativeBamReader(args.input, threads=args.threads) as rd:
             header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
             if not args.no_sort and rd.n_ref == 0:
                 header = _set_coordinate_order(header)             # no reference: every record sorts equal, input order is kept
+            header_inflated = rd.inflated_bytes
             with NativeBamWriter(part_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
                     ThreadPoolExecutor(1) as rpool, ThreadPoolExecutor(1) as wpool:
                 header_end = wr.flush()
-                nxt = rpool.submit(rd.next_batch, args.holes_batch)
+                seq_state = {"bi": 0, "site_base": 0}
+
+                def fetch():
+                    """next (batch, index, site index of its first site) of this rank, or None"""
+                    if board is None:
+                        b = rd.next_batch(args.holes_batch)
+                        if b is None:
+                            return None
+                        item = (b, seq_state["bi"], seq_state["site_base"])
+                        seq_state["bi"] += 1
+                        seq_state["site_base"] += filters(b)[2]
+                        return item
+                    c = board.claim()
+                    if c is None:
+                        return None
+                    index, vstart, vend, n_reads, site_base = c
+                    rd.seek(vstart, vend)
+                    b = rd.next_batch(n_reads)
+                    if b is None or b.n_reads != n_reads:
+                        raise IOError("hole-batch %d: expected %d records at its published offset" % (index, n_reads))
+                    return b, index, site_base
+                nxt = rpool.submit(fetch)
                 pending = None
-                site_base = 0
-                bi = 0
 
                 def write(b, first, locs, prob1, tagged, index):
                     n = wr.write_batch(b, first, locs, prob1, tagged, rm_pulse)
@@ -302,40 +346,39 @@ def call_mods(args, log=sys.stderr):
                         runs.append((index, wr.flush()))
                     return n
                 while True:
-                    b = nxt.result()
-                    if b is None:
+                    item = nxt.result()
+                    if item is None:
                         break
-                    nxt = rpool.submit(rd.next_batch, args.holes_batch)
-                    skip, window = None, None
-                    if name_filter:
-                        skip = np.array([_skip_by_name(nm, holeids_e, holeids_ne) for nm in _batch_names(b)], bool)
-                    if align:
-                        from .bamnative import align_info
-                        mq, qs, qe, ident = align_info(b)
-                        askip, window = _align_skip_and_window(b.flag, mq, ident, qs, qe, b.length, args)
-                        skip = askip if skip is None else (skip | askip)
-                    batch_sites = int(np.where((b.length > 0) & (~skip if skip is not None else True), b.n_sites, 0).sum())
-                    if bi % world == rank:
-                        pipe._site_counter = site_base
-                        first, locs, prob1, tagged, failed = pipe.run_native_batch(b, skip)
-                        if window is not None:
-                            first, locs, prob1, tagged = _filter_sites_by_window(first, locs, prob1, tagged, window)
-                        if pending is not None:
-                            cnt_mm += pending.result()
-                        pending = wpool.submit(write, b, first, locs, prob1, tagged, bi)
-                        cnt_w += b.n_reads
-                        cnt_failed += failed
-                    else:
-                        b.close()
-                    site_base += batch_sites
-                    bi += 1
+                    b, bi, site_base = item
+                    nxt = rpool.submit(fetch)
+                    skip, window, _ = filters(b)
+                    pipe._site_counter = site_base
+                    first, locs, prob1, tagged, failed = pipe.run_native_batch(b, skip)
+                    if window is not None:
+                        first, locs, prob1, tagged = _filter_sites_by_window(first, locs, prob1, tagged, window)
+                    if pending is not None:
+                        cnt_mm += pending.result()
+                    pending = wpool.submit(write, b, first, locs, prob1, tagged, bi)
+                    cnt_w += b.n_reads
+                    cnt_sites += len(locs)
+                    cnt_failed += failed
                 if pending is not None:
                     cnt_mm += pending.result()
+            work_inflated = rd.inflated_bytes - header_inflated
         pipe.close()
+        stats = dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, output=out_path, inflated_bytes=work_inflated, batches=len(runs))
         if world > 1:
+            if scan is not None:
+                scan[0].join()
+                if "error" in scan[1]:
+                    raise scan[1]["error"]
+                stats["scan_inflated_bytes"] = scan[1]["inflated_bytes"]
             gathered = [None] * world
-            dist.all_gather_object(gathered, dict(rank=rank, header_end=header_end, runs=runs, counts=(cnt_w, cnt_mm, cnt_failed)))
-            cnt_w, cnt_mm, cnt_failed = (sum(g["counts"][k] for g in gathered) for k in range(3))
+            dist.all_gather_object(gathered, dict(rank=rank, header_end=header_end, runs=runs, counts=(cnt_w, cnt_mm, cnt_failed, cnt_sites),
+                                                  inflated=work_inflated))
+            cnt_w, cnt_mm, cnt_failed, cnt_sites = (sum(g["counts"][k] for g in gathered) for k in range(4))
+            stats.update(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, rank_inflated_bytes=[g["inflated"] for g in gathered],
+                         rank_batches=[len(g["runs"]) for g in gathered])
             if rank == 0:
                 spans = []
                 for g in gathered:
@@ -352,7 +395,7 @@ def call_mods(args, log=sys.stderr):
             print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
             print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d GPU(s); ccsmeth_amd %s)" %
                   (time.time() - t0, cnt_failed, world, __version__), file=log)
-        return dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, output=out_path)
+        return stats
     with BamReader(args.input) as rd:
         header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
         if not args.no_sort and not rd.references:

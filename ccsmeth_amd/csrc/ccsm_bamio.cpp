@@ -316,6 +316,8 @@ struct ccsm_bam_reader {
     std::deque<BlockPos> bpos;
     uint64_t erased = 0;           // bytes dropped from the front of `stream` so far
     uint64_t next_coffset = 0;
+    uint64_t limit_coffset = ~0ull; // blocks starting beyond this file offset are not read (ccsm_bam_seek with an end offset)
+    uint64_t inflated = 0;         // bytes inflated so far (ccsm_bam_inflated_bytes)
     uint64_t abs_pos() const { return erased + pos; }
     // voffset of absolute inflated position p; at a block boundary: the start of the following block when there is one
     uint64_t voffset(uint64_t p) {
@@ -332,6 +334,7 @@ struct ccsm_bam_reader {
     bool read_block(RawBlock& b, std::string& err) {
         uint8_t head[12];
         b.coffset = next_coffset;
+        if (next_coffset > limit_coffset) return false;               // a seek's range ends here: treated as end of file
         const size_t got = std::fread(head, 1, 12, fh);
         if (got == 0) return false;
         if (got < 12 || head[0] != 0x1f || head[1] != 0x8b || head[2] != 8 || head[3] != 4) {
@@ -358,6 +361,7 @@ struct ccsm_bam_reader {
         }
         b.crc = rd32(tail);
         b.isize = rd32(tail + 4);
+        if (b.isize > 65536) { err = "corrupt BGZF block (ISIZE > 64 KiB)"; return false; }
         next_coffset += (uint64_t)bsize + 1;
         return true;
     }
@@ -373,7 +377,10 @@ struct ccsm_bam_reader {
             std::vector<RawBlock> blocks;
             blocks.reserve(kBlocksPerRound);
             std::string err;
-            for (int i = 0; i < kBlocksPerRound; ++i) {
+            // sequential reading inflates whole rounds of blocks; inside a seek range only what the request needs (+ one block)
+            int round = kBlocksPerRound;
+            if (limit_coffset != ~0ull) round = (int)std::min<size_t>(kBlocksPerRound, (need - (stream.size() - pos)) / 65280 + 2);
+            for (int i = 0; i < round; ++i) {
                 RawBlock b;
                 if (!read_block(b, err)) {
                     if (!err.empty()) return fail(err);
@@ -402,6 +409,7 @@ struct ccsm_bam_reader {
                 if (!b.ok) return fail("BGZF block failed its CRC / size check");
                 if (b.isize) bpos.push_back({erased + stream.size(), b.coffset, b.isize});
                 stream.insert(stream.end(), b.data.begin(), b.data.end());
+                inflated += b.isize;
             }
         }
         return 0;
@@ -518,6 +526,8 @@ int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) {
     OwnedBatch* ob = new (std::nothrow) OwnedBatch();
     if (!ob) return fail("out of memory");
     ob->rec_offset.push_back(0);
+    if (r->fill(4)) { delete ob; return 1; }
+    ob->view.voffset_start = r->voffset(r->abs_pos());
     for (int n = 0; n < max_reads; ++n) {
         if (r->fill(4)) { delete ob; return 1; }
         if (r->avail() == 0) break;
@@ -566,8 +576,8 @@ int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) {
         ob->rec_offset.push_back((int64_t)ob->records.size());
         ob->flag.push_back((int32_t)flag);
         ob->offset.push_back((int64_t)ob->seq.size());
-        ob->fn.push_back(has_fn ? fn : 0.f);
-        ob->rn.push_back(has_rn ? rn : 0.f);
+        ob->fn.push_back(has_fn && has_rn ? fn : 0.f);     // extract_features.py:115-119: a KeyError on either tag zeroes both
+        ob->rn.push_back(has_fn && has_rn ? rn : 0.f);
         int32_t nsites = 0;
         if (usable) {
             const size_t o = ob->seq.size(), L = l_seq;
@@ -615,9 +625,38 @@ int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) {
     ob->view.fn = ob->fn.data();
     ob->view.rn = ob->rn.data();
     ob->view.total_bases = (int64_t)ob->seq.size();
+    ob->view.voffset_end = r->voffset(r->abs_pos());
     *out = &ob->view;
     return 0;
 }
+
+int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_end) {
+    if (!r) return fail("reader must be non-NULL");
+    const uint64_t coff = voffset_start >> 16, uoff = voffset_start & 0xffffu;
+    if (std::fseek(r->fh, (long)coff, SEEK_SET) != 0) return fail("seek failed");
+    r->erased += r->stream.size();          // absolute positions stay monotonic (the virtual-offset bookkeeping keys on them)
+    r->stream.clear();
+    r->pos = 0;
+    r->bpos.clear();
+    r->next_coffset = coff;
+    r->file_eof = false;
+    r->limit_coffset = voffset_end == 0 ? ~0ull : (voffset_end >> 16);
+    if (uoff) {
+        if (r->fill((size_t)uoff)) return 1;
+        if (r->avail() < (size_t)uoff) return fail("seek beyond the end of the BGZF block");
+        r->pos += (size_t)uoff;
+    }
+    return 0;
+}
+
+int ccsm_bam_tell(ccsm_bam_reader* r, uint64_t* voffset) {
+    if (!r || !voffset) return fail("arguments must be non-NULL");
+    if (r->fill(1)) return 1;
+    *voffset = r->voffset(r->abs_pos());
+    return 0;
+}
+
+int64_t ccsm_bam_inflated_bytes(const ccsm_bam_reader* r) { return r ? (int64_t)r->inflated : 0; }
 
 int ccsm_bam_writer_open(const char* path, const char* header_text, int64_t text_len, const uint8_t* refs, int64_t refs_len,
                          int32_t n_ref, int threads, int level, ccsm_bam_writer** out) {

@@ -1,0 +1,93 @@
+"""Synthetic inputs and drivers of bench.py's secondary measurements (BASELINE.json configs[2] scaled down, configs[4])."""
+import os
+import tempfile
+import time
+
+import numpy as np
+
+
+def write_synthetic_hifi_bam(path, n_reads, read_len, cpg=0.012, seed=3):
+    """Unaligned HiFi reads with kinetics tags (fi/fp/ri/rp uint8 per base, fn/rn passes): SURVEY.md 8(d)'s configs[2] shape,
+    ~600 CpG sites per 15 kb read after the window filter.  Returns (seconds, bytes)."""
+    from .. import bamio
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    with bamio.BamWriter(path, "@HD\tVN:1.5\tSO:unknown\n", [], level=1) as w:
+        for i in range(n_reads):
+            seq = acgt[rng.choice(4, size=read_len, p=[0.3, 0.2, 0.2, 0.3])]
+            pos = rng.integers(0, read_len - 1, int(read_len * cpg))
+            seq[pos], seq[pos + 1] = ord("C"), ord("G")
+            kin = np.clip(rng.gamma(2.0, 20.0, size=(4, read_len)), 0, 255).astype(np.uint8)
+            tags = [("fi", "BC", kin[0]), ("fp", "BC", kin[1]), ("ri", "BC", kin[2]), ("rp", "BC", kin[3]), ("fn", "C", 12), ("rn", "C", 13),
+                    ("np", "C", 25)]
+            w.write(bamio.BamRecord("m/%d/ccs" % i, flag=4, ref_id=-1, seq=seq.tobytes().decode(), qual=np.full(read_len, 40, np.uint8), tags=tags))
+    return time.time() - t0, os.path.getsize(path)
+
+
+def call_mods_end_to_end(n_reads=1500, read_len=15000):
+    """`call_mods --io native` on a synthetic BAM (BGZF inflate, parse, feature extraction + model on the GPU, MM/ML, BGZF deflate);
+    second of two runs (the first pays page-ins and library loads)."""
+    import torch
+    from collections import OrderedDict
+    from ..call_mods import build_parser, call_mods
+    from . import synth
+    tmp = tempfile.mkdtemp(prefix="ccsm_bench_")
+    inp = os.path.join(tmp, "in.bam")
+    gen_s, nbytes = write_synthetic_hifi_bam(inp, n_reads, read_len)
+    ckpt = os.path.join(tmp, "m.ckpt")
+    torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
+    res, dt = None, None
+    for _ in range(2):
+        args = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", os.path.join(tmp, "out"), "--batch_size", "12288", "--holes_batch", "64",
+                                          "--no_sort"])
+        t0 = time.time()
+        res = call_mods(args, log=open(os.devnull, "w"))
+        dt = time.time() - t0
+    sites = int(res.get("sites", 0))
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
+    return {"value": sites / dt, "unit": "sites/s", "reads": int(res["reads"]), "sites": sites, "seconds": dt, "input_MB": nbytes / 1e6,
+            "what": "python -m ccsmeth_amd call_mods --io native --no_sort, wall time incl. model set-up; BASELINE configs[2] scaled from "
+                    "10 M reads to %d synthetic %d-base reads (input generated in %.1f s)" % (n_reads, read_len, gen_s)}
+
+
+def aggregate_50m(dev, regions=500, region_sites=100000):
+    """BASELINE configs[4]: aggregate attbigru_b11 over 50 M pile-up sites, device-resident tables, per-region seeded h0 stream."""
+    import ctypes as C  # noqa: F401
+    import torch
+    from .. import _lib
+    from ..call_mods_freq_bam import AggrModel
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    w = dict(np.load(os.path.join(root, "tests", "golden", "aggr_ckpt_weights.npz")))
+    model = AggrModel(w, device=dev.index or 0, stream_sites=region_sites)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    m = region_sites
+    pos = torch.cumsum(torch.randint(2, 401, (m,), device=dev, generator=g), 0).to(torch.int64)
+    cov = torch.randint(4, 61, (m, 1), device=dev, generator=g)
+    # histogram of cov_i Beta(0.3, 0.3)-like calls per site: a U-shaped multinomial over 20 bins, L2-normalised, 6 decimals
+    pbin = torch.tensor(np.diff(np.clip(np.linspace(0, 1, 21), 0, 1) ** 0.3) + np.diff(1 - (1 - np.linspace(0, 1, 21)) ** 0.3), device=dev, dtype=torch.float32)
+    pbin = pbin / pbin.sum()
+    draws = torch.multinomial(pbin.expand(m, -1), 60, replacement=True, generator=g)
+    keep = (torch.arange(60, device=dev).expand(m, -1) < cov)
+    hist = torch.zeros((m, 20), device=dev).scatter_add_(1, draws, keep.float())
+    hist = torch.round(hist / hist.norm(dim=1, keepdim=True) * 1e6) / 1e6
+    hist = hist.contiguous()
+    out = torch.empty(m, dtype=torch.float32, device=dev)
+    lib = model._lib
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(3):
+        _lib.check(lib.ccsm_aggr_forward_device(model.handle, m, pos.data_ptr(), hist.data_ptr(), 0, out.data_ptr(), st))
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(regions):
+        _lib.check(lib.ccsm_aggr_forward_device(model.handle, m, pos.data_ptr(), hist.data_ptr(), 0, out.data_ptr(), st))
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    sites = regions * m
+    ok = bool(torch.isfinite(out).all())
+    return {"value": sites / dt, "unit": "sites/s", "sites": sites, "seconds": dt, "TFLOPs": sites / dt * 275.3e3 / 1e12,
+            "algorithmic_GBps": sites / dt * 88 / 1e9, "finite": ok,
+            "what": "aggregate attbigru_b11 (real checkpoint) over %d regions x %d sites, device-resident histograms and positions" % (regions, m)}

@@ -42,6 +42,8 @@ typedef struct ccsm_bam_batch {
     const float* fn;            /* (n_reads) */
     const float* rn;
     int64_t total_bases;        /* bytes used in seq / fi / ri / fp / rp */
+    uint64_t voffset_start;     /* BGZF virtual file offset (block file offset << 16 | offset in the block) of the first record */
+    uint64_t voffset_end;       /* ... and of the byte behind the last one */
 } ccsm_bam_batch;
 
 const char* ccsm_bam_last_error(void);
@@ -56,6 +58,13 @@ int ccsm_bam_header(const ccsm_bam_reader* r, const char** text, int64_t* text_l
 int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out);
 void ccsm_bam_batch_free(ccsm_bam_batch* b);
 void ccsm_bam_close(ccsm_bam_reader* r);
+/* Random access for the multi-GPU call_mods (one scanning rank publishes the virtual offsets of the hole-batches, the others seek
+ * instead of inflating the whole file): continue reading at voffset_start; with voffset_end != 0 no BGZF block behind the one
+ * holding voffset_end is read or inflated (the range then ends like a file), so a rank inflates what it processes plus at most
+ * one block per range.  ccsm_bam_tell = virtual offset of the next record; ccsm_bam_inflated_bytes = bytes inflated so far. */
+int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_end);
+int ccsm_bam_tell(ccsm_bam_reader* r, uint64_t* voffset);
+int64_t ccsm_bam_inflated_bytes(const ccsm_bam_reader* r);
 
 /* level = zlib level of the BGZF blocks (1..9), threads = deflate workers. */
 int ccsm_bam_writer_open(const char* path, const char* header_text, int64_t text_len, const uint8_t* refs, int64_t refs_len,

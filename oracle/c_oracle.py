@@ -15,6 +15,7 @@ class _W(C.Structure):
 
 
 _lib = None
+DESCRIPTION = "oracle/attbigru2s_oracle.c fp32, OpenMP over sites"
 
 
 def load():

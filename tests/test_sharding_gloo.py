@@ -1,13 +1,57 @@
-"""N>1 path on CPU: world_size 2, gloo — shard assignment covers every unit exactly once and the end-of-run
-reduction (sum of counters, max of time) is what bench.py / a sharded call_mods run rely on."""
+"""N > 1 path of `call_mods` on CPU (gloo, no GPU): the hole-batch board of ccsmeth_amd/sharding.py — one scanning rank, every
+rank seeking to the batches it claims — with the model replaced by a stand-in whose "probabilities" are a function of the running
+site index only (what the Philox counter of the real initial states is): the stitched 8-rank output must be identical to the
+single-process output, and no rank may inflate more than its share of the file."""
+import gzip
 import os
 import socket
+import sys
 
-import torch
-import torch.distributed as dist
+import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
-from ccsmeth_amd.sharding import reduce_run_stats, shard_indices
+from ccsmeth_amd.extract_features import motif_locs_cg
+from ccsmeth_amd.sharding import shard_indices
+
+ARGV = ["ccsmeth_amd", "call_mods", "--test"]      # the @PG line quotes sys.argv: pinned so that both runs write the same header
+
+
+class StubPipe:
+    """CallModsPipeline's native-batch interface without a GPU: site locations from the sequence, prob = f(running site index)."""
+
+    def __init__(self):
+        self._site_counter = 0
+
+    def run_native_batch(self, batch, skip=None):
+        nr = batch.n_reads
+        cnt = np.where(batch.length > 0, batch.n_sites, 0).astype(np.int64)
+        if skip is not None:
+            cnt[np.asarray(skip, bool)] = 0
+        first = np.zeros(nr + 1, np.int32)
+        np.cumsum(cnt, out=first[1:])
+        locs = np.empty(int(first[-1]), np.int32)
+        for r in np.flatnonzero(cnt > 0):
+            n = int(batch.length[r])
+            sb = batch.seq[int(batch.offset[r]):int(batch.offset[r]) + n]
+            lc = motif_locs_cg(sb)
+            rl = n - 1 - (lc + 1)
+            lc = lc[(lc >= 10) & (lc < n - 10) & (rl >= 10) & (rl < n - 10)]
+            assert len(lc) == cnt[r]
+            locs[first[r]:first[r + 1]] = lc
+        idx = (self._site_counter + np.arange(len(locs), dtype=np.uint64)) * np.uint64(2654435761) % np.uint64(2 ** 32)
+        prob1 = np.round(idx.astype(np.float64) / 2 ** 32, 6).astype(np.float32)
+        self._site_counter += len(locs)
+        return first, locs, prob1, (cnt > 0).astype(np.uint8), 0
+
+    def close(self):
+        pass
+
+
+def _args(inp, out, dispatch="dynamic"):
+    from ccsmeth_amd.call_mods import build_parser
+    return build_parser().parse_args(["-i", inp, "-m", "unused.ckpt", "-o", out, "--holes_batch", "10", "--threads", "2", "--no_sort",
+                                      "--dispatch", dispatch])
 
 
 def _free_port():
@@ -18,35 +62,66 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_units, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    mine = list(shard_indices(n_units, rank, world))
-    sites = sum(100 + u for u in mine)          # unit u carries 100 + u sites
-    total_sites, total_reads, tmax = reduce_run_stats(sites, len(mine), 1.0 + rank)
-    dist.barrier()
-    q.put((rank, mine, total_sites, total_reads, tmax))
-    dist.destroy_process_group()
+def _worker(rank, world, ports, inp, out, dispatch, q):
+    from ccsmeth_amd.call_mods import call_mods
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[0]),
+                      **({"CCSM_BOARD_PORT": str(ports[1])} if dispatch == "static" else {}))
+    sys.argv = list(ARGV)
+    res = call_mods(_args(inp, out, dispatch), log=open(os.devnull, "w"), pipe=StubPipe())
+    q.put((rank, res))
 
 
-def test_two_rank_sharding_and_reduction():
-    world, n_units = 2, 11
+def _payload(path):
+    """inflated BAM stream (BGZF members concatenated): header and records, independent of the block boundaries"""
+    with open(path, "rb") as fh:
+        return gzip.decompress(fh.read())
+
+
+@pytest.fixture(scope="module")
+def bam(tmp_path_factory):
+    from ccsmeth_amd.utils.benchdata import write_synthetic_hifi_bam
+    d = tmp_path_factory.mktemp("shard")
+    path = str(d / "in.bam")
+    write_synthetic_hifi_bam(path, n_reads=203, read_len=6000, cpg=0.02, seed=11)
+    return str(d), path
+
+
+@pytest.mark.parametrize("dispatch", ["static", "dynamic"])
+def test_eight_ranks_equal_single_process(bam, dispatch, monkeypatch):
+    from ccsmeth_amd.call_mods import call_mods
+    d, inp = bam
+    monkeypatch.setattr(sys, "argv", list(ARGV))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    one = call_mods(_args(inp, os.path.join(d, "one")), log=open(os.devnull, "w"), pipe=StubPipe())
+    assert one["reads"] == 203 and one["tagged"] > 150
+    world = 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_units, q)) for r in range(world)]
+    ports = (_free_port(), _free_port())
+    out = os.path.join(d, "eight_" + dispatch)
+    procs = [ctx.Process(target=_worker, args=(r, world, ports, inp, out, dispatch, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    covered = sorted(u for _, mine, *_ in res for u in mine)
-    assert covered == list(range(n_units))
-    exp_sites = sum(100 + u for u in range(n_units))
-    for _, _, ts, tr, tmax in res:
-        assert ts == exp_sites and tr == n_units and tmax == 2.0
+    r0 = res[0]
+    assert (r0["reads"], r0["tagged"], r0["failed"]) == (one["reads"], one["tagged"], one["failed"])
+    assert _payload(r0["output"]) == _payload(one["output"])              # every record, tag and probability byte
+    n_batches = -(-203 // 10)
+    assert sum(r0["rank_batches"]) == n_batches
+    total = len(_payload(inp))                                             # inflated size of the input
+    block = 65536                                                          # a range starts and ends inside BGZF blocks: <= one extra block each side
+    shares = r0["rank_inflated_bytes"]
+    assert sum(shares) <= total + n_batches * 2 * block                    # the workers together inflate the file once
+    assert r0["scan_inflated_bytes"] <= total + block                      # the scan: one pass
+    if dispatch == "static":
+        mine = [len(shard_indices(n_batches, r, world)) for r in range(world)]
+        assert r0["rank_batches"] == mine
+        for r in range(world):                                             # a rank's share of the file (3 of 21 batches ~ 1/8) + epsilon
+            assert shares[r] <= total * mine[r] / n_batches * 1.1 + mine[r] * 2 * block
 
 
 def test_shard_indices_edges():
@@ -54,3 +129,14 @@ def test_shard_indices_edges():
     assert list(shard_indices(3, 2, 8)) == [2]
     assert list(shard_indices(3, 5, 8)) == []
     assert sorted(sum((list(shard_indices(17, r, 8)) for r in range(8)), [])) == list(range(17))
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """python bench.py --gpus 2 without torch.distributed.run must not fall back to fewer devices (here: none)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "6"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "refusing" in p.stderr and "{" not in p.stdout
