@@ -7,8 +7,9 @@
 A step = one forward of the hot path over one batch of 2048 synthetic CpG sites (both strands, 21-mers), features already
 resident in HBM, initial states drawn on the device (Philox) as SURVEY.md 8(d) prescribes for the timed run.  `--coalesce`
 steps are bound to one workspace and the heavy kernels run once over them (6 x 2048 sites = 512 workgroups of 96 strand rows
-= two full rounds of the 256 CUs); a ragged last group (steps not a multiple of the group size) runs on a second stream next to
-the last full group, so that its partial round fills up.  Exactly K steps are timed between barrier + synchronize on both
+= two full rounds of the 256 CUs); a ragged last group (steps not a multiple of the group size) runs last, from its own workspace,
+so that the per-kernel timers of the full groups describe full launches (running it on a second stream next to the last full
+group was measured: no gain in wall time, inflated kernel durations).  Exactly K steps are timed between barrier + synchronize on both
 sides, MAX over ranks is taken and rank 0 prints ONE JSON line.  Reads are sharded across GPUs with no collective on the data
 path (weak scaling).  With --gpus N > 1 and no torch.distributed environment, this script re-executes itself under
 torch.distributed.run with N ranks; it refuses to run if fewer than N GPUs are visible.
@@ -42,11 +43,12 @@ PEAK_HBM = 8.0e12
 # HBM/fabric bytes of ONE launch of the dominant kernel per site, from rocprofv3 PMC passes on the launch shape timed here
 # (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
 # read from inside this process)
-TRAFFIC = {4: ((2 * 1252400 + 518150) * 1024 / 6144.0, "profiles/r01_l_pmc_coalesced.md"),
+TRAFFIC = {4: ((2 * 1204200 + 516100) * 1024 / 6144.0, "profiles/r02_d_pmc_coalesced.md"),
            3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
-ARITH = {4: ("f16 + MX(fp4 x fp6) split operands, f32 accumulate",
-             "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: fp4 e2m1 weight blobs with "
-             "per-(row, 32-k) E8M0 scales x fp6 e2m3 activation blobs; attention pool: fp8 e4m3 x fp8), one fp32 accumulator", 99.0 / 64.0),
+ARITH = {4: ("f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate",
+             "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp6 e2m3 for the "
+             "input part, fp4 e2m1 for the recurrent part, per-(row, 32-k) E8M0 scales, x fp6 e2m3 activation blobs; attention pool: "
+             "fp8 e4m3 x fp8), one fp32 accumulator", 99.0 / 64.0),
          3: ("f16x3 split operands, f32 accumulate", "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate", 3.0)}
 
 
@@ -59,7 +61,7 @@ def parse():
                     help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
                          "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds)")
     ap.add_argument("--precision", type=int, default=4, choices=(3, 4),
-                    help="4 = split-mx (default: fp16 main product + MX correction product, max |dprob| 7-8e-6); 3 = split-fp16 x3\n"
+                    help="4 = split-mx (default: fp16 main product + MX correction product, max |dprob| ~5e-6); 3 = split-fp16 x3\n"
                          "(fp32-class, ~2e-7)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--extras", default="all", choices=("all", "none"), help="the secondary measurements (rank 0 at N = 1)")
@@ -118,22 +120,20 @@ def cpu_baseline(weights, target_s, device_model):
 
 
 class Runner:
-    """K steps of one DeviceModel: full groups on stream 0, a ragged last group on stream 1 next to the last full group."""
+    """K steps of one DeviceModel on one stream: full groups from workspace 0, a ragged last group from workspace 1."""
 
     def __init__(self, dm, pool, dev, grp, rank):
         import torch
         self.torch, self.dm, self.pool, self.dev, self.grp, self.rank = torch, dm, pool, dev, grp, rank
         self.ws = [dm.workspace(BATCH * grp) for _ in range(2)]
-        self.streams = [torch.cuda.Stream(dev) for _ in range(2)]
+        self.streams = [torch.cuda.Stream(dev)] * 2
         self.outs = [[(torch.empty((BATCH, 2), device=dev), torch.empty((BATCH, 2), device=dev)) for _ in range(grp)] for _ in range(2)]
         self.step0 = 0
 
     def run(self, steps):
         """Enqueue `steps` steps (no synchronisation)."""
         full, rag = divmod(steps, self.grp)
-        plan = [(0, self.grp)] * full
-        if rag:
-            plan.insert(max(len(plan) - 1, 0), (1, rag))      # the ragged group is enqueued just before the last full one, on stream 1
+        plan = [(0, self.grp)] * full + ([(1, rag)] if rag else [])
         i = self.step0
         for k, nb in plan:
             for j in range(nb):
@@ -153,10 +153,15 @@ class Runner:
             w.close()
 
 
+MIN_WARM_GROUPS = int(os.environ.get("CCSM_BENCH_MIN_WARM_GROUPS", "10"))
+
+
 def timed(runner, steps, warmup, fence):
     grp = runner.grp
-    # warm-up: at least W steps, at least one full group, and one group of the ragged shape if the timed region has one
-    w_steps = max(-(-warmup // grp), 1) * grp + steps % grp
+    # warm-up: at least W steps and at least MIN_WARM_GROUPS full groups (the chip reaches its power-capped steady state after a few
+    # tens of milliseconds: a timed region that starts on a cool, boosting chip does not describe sustained throughput), plus one group
+    # of the ragged shape if the timed region has one
+    w_steps = max(-(-warmup // grp), MIN_WARM_GROUPS) * grp + steps % grp
     runner.run(w_steps)
     fence()
     runner.arm()                 # average only the timed region's launches
@@ -301,8 +306,8 @@ def main():
         elapsed = float(t.item())
 
     # ---- per-kernel launch durations: mean over the FULL groups of the timed region (HIP events recorded on the stream each
-    # kernel was launched on; the warm-up runs were dropped by re-arming the timers after the warm-up fence).  With a ragged group
-    # the last full group shares the chip with it: its durations are in the mean (slightly inflated: the figure is conservative).
+    # kernel was launched on; the warm-up runs were dropped by re-arming the timers after the warm-up fence); a ragged group has
+    # its own workspace and timers
     kt, nruns = runner.ws[0].timing_mean() if full else runner.ws[1].timing_mean()
     kt = np.array(kt)
     dom_ms = float(kt[1:3].mean())

@@ -103,7 +103,7 @@ def load():
     lib.ccsm_workspace_last_timing.argtypes = [vp, _FP]
     lib.ccsm_selftest_mfma.argtypes = [ci, _FP]
     lib.ccsm_selftest_split_f8.argtypes = [ci, _FP, _FP]
-    lib.ccsm_selftest_split_mx.argtypes = [ci, _FP, _FP, C.POINTER(C.c_int)]
+    lib.ccsm_selftest_split_mx.argtypes = [ci, ci, _FP, _FP, C.POINTER(C.c_int)]
     lib.ccsm_debug_read.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ccsm_debug_rows_padded.argtypes = [ci]
     lib.ccsm_debug_fp8_e4m3.argtypes = [C.c_float]

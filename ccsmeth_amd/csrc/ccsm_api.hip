@@ -241,32 +241,39 @@ float mx_value(uint8_t code, int fmt) {
 inline int mx_perm(int j) { return 8 * ((j & 15) >> 2) + (j & 3) + 4 * (j >> 4); }   // blob position -> k within the pair (kMxPerm)
 
 // One lane's weight blob of 32 values `val[j]` (already in blob order): E8M0 scale from the block's largest magnitude (max |val| s
-// <= top of the format), fp4 codes packed little-endian (element j in nibble j & 1 of byte j >> 1) into 16 bytes; *scale = the
-// scale byte of the TRUE value (exp_bias = -11 for the W_lo lanes, which carry W_lo 2^11).  Returns the block's largest
-// quantisation error relative to its largest magnitude (a-priori accuracy figure, see ccsm_create).
-float emit_blob(uint8_t* dst16, uint8_t* scale, const float (&val)[32], int exp_bias) {
+// <= top of the format), codes packed little-endian (fp4: element j in nibble j & 1 of byte j >> 1; fp6: element j at bit 6 j) into
+// dst[0..15] (+ dst8[0..7] for fp6); *scale = the scale byte of the TRUE value (exp_bias = -11 for the W_lo lanes, which carry
+// W_lo 2^11).  err2 / ref2 accumulate the squared quantisation error and the squared values (in true units).
+void emit_blob(uint8_t* dst16, uint8_t* dst8, uint8_t* scale, const float (&val)[32], int fmt, int exp_bias, double* err2, double* ref2) {
     float mx = 0.f;
     for (int j = 0; j < 32; ++j) mx = std::fmax(mx, std::fabs(val[j]));
+    const float top = fmt == 2 ? 7.5f : 6.0f;
     int lg = 0;
-    if (mx > 0.f && std::isfinite(mx)) lg = (int)std::floor(std::log2(6.0f / mx));
+    if (mx > 0.f && std::isfinite(mx)) lg = (int)std::floor(std::log2(top / mx));
     lg = std::max(-100, std::min(100, lg));
-    std::memset(dst16, 0, 16);
-    float worst = 0.f;
+    uint8_t bits[24] = {0};
+    const int w = fmt == 2 ? 6 : 4;
     for (int j = 0; j < 32; ++j) {
         const float sv = std::ldexp(val[j], lg);
-        const uint8_t code = mx_code(sv, 4);
-        worst = std::fmax(worst, std::fabs(mx_value(code, 4) - sv));
-        dst16[j >> 1] |= (uint8_t)(code << (4 * (j & 1)));
+        const uint8_t code = mx_code(sv, fmt);
+        const double e = std::ldexp((double)mx_value(code, fmt) - (double)sv, -lg);
+        *err2 += e * e;
+        *ref2 += (double)val[j] * (double)val[j];
+        const int bit = j * w;
+        bits[bit >> 3] |= (uint8_t)(code << (bit & 7));
+        if ((bit & 7) + w > 8) bits[(bit >> 3) + 1] |= (uint8_t)(code >> (8 - (bit & 7)));
     }
+    std::memcpy(dst16, bits, 16);
+    if (fmt == 2) std::memcpy(dst8, bits + 16, 8);
     *scale = (uint8_t)std::max(0, std::min(254, 127 + exp_bias - lg));
-    return mx > 0.f ? worst / std::ldexp(mx, lg) : 0.f;
 }
 
-// blob fragment (1 KiB) of one (32-row block, pair of k-blocks) and its scale bytes: lane (i, g = 0) <- W_lo 2^11, (i, 1) <- W_hi;
-// scales = the pair's 256-byte scale block (lane * 4 + gate); get(i, k) = fp32 weight of row i of the block, k in [0, 32) of the pair
+// blob of one (32-row block, pair of k-blocks) and its scale bytes: lane (i, g = 0) <- W_lo 2^11, (i, 1) <- W_hi.  c0 = 1 KiB
+// fragment (lane * 16), c1 = 512 B (lane * 8; fp6 only), scales = the pair's 256-byte scale block (lane * 4 + gate);
+// get(i, k) = fp32 weight of row i of the block, k in [0, 32) of the pair.  Returns the blob's relative RMS quantisation error.
+struct BlobErr { double e2[2] = {0, 0}, r2[2] = {0, 0}; };
 template <typename Get>
-float emit_blob_frag(uint8_t* blob, uint8_t* scales, int gate, Get get) {
-    float worst = 0.f;
+void emit_blob_frag(uint8_t* c0, uint8_t* c1, uint8_t* scales, int gate, int fmt, Get get, BlobErr* be) {
     for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 31, g = lane >> 5;
         float val[32];
@@ -275,21 +282,21 @@ float emit_blob_frag(uint8_t* blob, uint8_t* scales, int gate, Get get) {
             const float hi = (float)(_Float16)v;
             val[j] = g ? hi : std::ldexp(v - hi, 11);
         }
-        worst = std::fmax(worst, emit_blob(blob + lane * 16, scales + lane * 4 + gate, val, g ? 0 : -11));
+        emit_blob(c0 + lane * 16, c1 ? c1 + lane * 8 : nullptr, scales + lane * 4 + gate, val, fmt, g ? 0 : -11, &be->e2[g], &be->r2[g]);
     }
-    return worst;
 }
 inline void emit_hi_frag(_Float16* dst, int kb, const std::function<float(int, int)>& get) {   // lane (i, g) <- hi of k = 16 kb + 8 g + j
     for (int lane = 0; lane < 64; ++lane)
         for (int j = 0; j < 8; ++j) dst[lane * 8 + j] = (_Float16)get(lane & 31, 16 * kb + 8 * (lane >> 5) + j);
 }
 
-// Split-mx weight stream of one layer (byte layouts: ccsm_gru_mx.hip).  Returns the largest relative blob quantisation error.
+// Split-mx weight stream of one layer (byte layouts: ccsm_gru_mx.hip).  Returns the relative RMS quantisation error of the layer's
+// correction blobs (the larger of the W_lo and W_hi halves).
 float pack_wstream_mx(int layer, const float* const wih[2], const float* const whh[2], std::vector<uint8_t>& out) {
     const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
     const size_t wbytes = layer == 0 ? kMx0WBytes : kMx12WBytes;
     out.assign((size_t)2 * kWaves * wbytes, 0);
-    float worst = 0.f;
+    BlobErr be;
     for (int dir = 0; dir < 2; ++dir)
         for (int wave = 0; wave < kWaves; ++wave) {
             uint8_t* base = out.data() + (size_t)(dir * kWaves + wave) * wbytes;
@@ -304,15 +311,15 @@ float pack_wstream_mx(int layer, const float* const wih[2], const float* const w
                         dst[lane * 8 + j] = (_Float16)(v - (float)(_Float16)v);
                     }
             };
-            auto blob_at = [&](size_t off, size_t sc_off, int gate_byte, const std::function<float(int, int)>& get, int pair) {
-                worst = std::fmax(worst, emit_blob_frag(base + off, base + sc_off, gate_byte, [&](int i, int k) { return get(i, 32 * pair + k); }));
+            auto blob_at = [&](size_t off, long off1, size_t sc_off, int gate_byte, int fmt, const std::function<float(int, int)>& get, int pair) {
+                emit_blob_frag(base + off, off1 >= 0 ? base + off1 : nullptr, base + sc_off, gate_byte, fmt, [&](int i, int k) { return get(i, 32 * pair + k); }, &be);
             };
             auto phase_b = [&](size_t off_b) {
                 for (int q = 0; q < kKBH / 2; ++q) {
                     const size_t pb = off_b + (size_t)q * kMxPairB;
                     for (int kbl = 0; kbl < 2; ++kbl)
                         for (int g = 0; g < 3; ++g) hi_at(pb + (size_t)(3 * kbl + g) * 1024, wh(g), 2 * q + kbl);
-                    for (int g = 0; g < 3; ++g) blob_at(pb + (size_t)(6 + g) * 1024, pb + 9 * 1024, g, wh(g), q);
+                    for (int g = 0; g < 3; ++g) blob_at(pb + (size_t)(6 + g) * 1024, -1, pb + 9 * 1024, g, kMxWFmtH, wh(g), q);
                 }
             };
             if (layer == 0) {
@@ -325,17 +332,18 @@ float pack_wstream_mx(int layer, const float* const wih[2], const float* const w
                     const size_t pa = (size_t)p * kMxPairA;
                     for (int kbl = 0; kbl < 2; ++kbl)
                         for (int g = 0; g < 2; ++g) hi_at(pa + (size_t)(2 * kbl + g) * 1024, wx(g), 2 * p + kbl);
-                    for (int g = 0; g < 2; ++g) blob_at(pa + (size_t)(4 + g) * 1024, pa + 6 * 1024, g, wx(g), p);
+                    for (int g = 0; g < 2; ++g) blob_at(pa + (size_t)(4 + g) * 1024, (long)(pa + 6 * 1024 + 512 * g), pa + 7 * 1024, g, kMxWFmtX, wx(g), p);
                 }
                 phase_b(kMx12OffB);
                 for (int p = 0; p < kKB12 / 2; ++p) {
                     const size_t pc = kMx12OffC + (size_t)p * kMxPairC;
                     hi_at(pc, wx(2), 2 * p); hi_at(pc + 1024, wx(2), 2 * p + 1);
-                    blob_at(pc + 2 * 1024, pc + 3 * 1024, 0, wx(2), p);
+                    blob_at(pc + 2 * 1024, (long)(pc + 3 * 1024), pc + 3 * 1024 + 512, 0, kMxWFmtX, wx(2), p);
                 }
             }
         }
-    return worst;
+    const double a = be.r2[0] > 0 ? std::sqrt(be.e2[0] / be.r2[0]) : 0.0, b = be.r2[1] > 0 ? std::sqrt(be.e2[1] / be.r2[1]) : 0.0;
+    return (float)std::fmax(a, b);
 }
 
 void pack_bias(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
@@ -1105,7 +1113,8 @@ ccsm_status ccsm_selftest_split_f8(int device, float* err_corr, float* err_main_
     return CCSM_OK;
 }
 
-ccsm_status ccsm_selftest_split_mx(int device, float* err_corr, float* err_main_only, int* blob_mismatch) {
+ccsm_status ccsm_selftest_split_mx(int device, int fmt, float* err_corr, float* err_main_only, int* blob_mismatch) {
+    if (fmt != 2 && fmt != 4) return fail(CCSM_ERR_INVALID_ARG, "fmt must be 2 (fp6 weight blob) or 4 (fp4)");
     if (!err_corr || !err_main_only || !blob_mismatch) return fail(CCSM_ERR_INVALID_ARG, "outputs must be non-NULL");
     HIP_TRY(hipSetDevice(device));
     // W: 32 units x 32 k, X: 32 rows x 32 k, deterministic, non-symmetric, weights ~ U(-0.07, 0.07), activations in (-1, 1)
@@ -1118,7 +1127,9 @@ ccsm_status ccsm_selftest_split_mx(int device, float* err_corr, float* err_main_
     auto get = [&](int i, int k) { return w[i * 32 + k]; };
     emit_hi_frag(frag.data(), 0, get);
     emit_hi_frag(frag.data() + 512, 1, get);
-    (void)emit_blob_frag(reinterpret_cast<uint8_t*>(frag.data()) + 2048, reinterpret_cast<uint8_t*>(frag.data()) + 3072, 0, get);
+    BlobErr be;
+    emit_blob_frag(reinterpret_cast<uint8_t*>(frag.data()) + 2048, reinterpret_cast<uint8_t*>(frag.data()) + 3072 + 256,
+                   reinterpret_cast<uint8_t*>(frag.data()) + 3072, 0, fmt, get, &be);
     uint4* dw = nullptr;
     float *dx = nullptr, *dc = nullptr;
     uint32_t* db = nullptr;
@@ -1130,7 +1141,7 @@ ccsm_status ccsm_selftest_split_mx(int device, float* err_corr, float* err_main_
     HIP_TRY(hipMemcpy(dx, x.data(), 4096, hipMemcpyHostToDevice));
     float* outs[2] = {err_corr, err_main_only};
     for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(mx_selftest_kernel, dim3(1), dim3(64), 0, 0, dw, dx, dc, db, pass == 0 ? 1 : 0, 0.25f, kMxScaleHi, kMxScaleLo);
+        hipLaunchKernelGGL(mx_selftest_kernel, dim3(1), dim3(64), 0, 0, dw, dx, dc, db, pass == 0 ? fmt : 0, 0.25f, kMxScaleHi, kMxScaleLo);
         HIP_TRY(hipGetLastError());
         std::vector<float> c(1024);
         HIP_TRY(hipMemcpy(c.data(), dc, 4096, hipMemcpyDeviceToHost));

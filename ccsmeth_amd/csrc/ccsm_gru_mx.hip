@@ -30,7 +30,8 @@
 
 namespace ccsm {
 
-constexpr int kMxWFmt = 4;                         // A (weight) operand format of the correction MFMA: fp4 e2m1
+constexpr int kMxWFmtH = 4;                        // A (weight) operand format of the correction MFMA, recurrent part (phase B): fp4 e2m1
+constexpr int kMxWFmtX = 2;                        // ... input part (phases A, C): fp6 e2m3 (fp4 there biases every site the same way: ~1e-5)
 constexpr int kMxBFmt = 2;                         // B (activation) operand: fp6 e2m3
 constexpr int kMxScaleHi = 127 - 2;                // x_hi blob holds x_hi * 4
 constexpr int kMxScaleLo = 127 - 14;               // x_lo blob holds x_lo * 2^14
@@ -40,12 +41,19 @@ constexpr int kMxScaleLo0 = 127 - 11;              //                 x_lo * 2^1
 typedef _Float16 half32 __attribute__((ext_vector_type(32)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
-// correction MFMA of one pair: weight blob w (fp4, 16 bytes per lane), its scale = byte G of ws, activation blob (x0, x1)
+// correction MFMA of one pair: fp4 weight blob w (16 bytes per lane), its scale = byte G of ws, activation blob (x0, x1)
 template <int G>
 __device__ __forceinline__ f32x16 mfma_corr_mx(uint4 w, uint32_t ws, uint4 x0, uint2 x1, f32x16 c, int scale_b) {
     const i32x8 a = {(int)w.x, (int)w.y, (int)w.z, (int)w.w, 0, 0, 0, 0};
     const i32x8 b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, 0, 0};
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, kMxWFmt, kMxBFmt, G, (int)ws, 0, scale_b);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, kMxWFmtH, kMxBFmt, G, (int)ws, 0, scale_b);
+}
+// the same with an fp6 weight blob (24 bytes per lane: w0 | w1)
+template <int G>
+__device__ __forceinline__ f32x16 mfma_corr_mx6(uint4 w0, uint2 w1, uint32_t ws, uint4 x0, uint2 x1, f32x16 c, int scale_b) {
+    const i32x8 a = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, 0, 0};
+    const i32x8 b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, kMxWFmtX, kMxBFmt, G, (int)ws, 0, scale_b);
 }
 
 // 32 fp16 values (16 packed registers) / scale -> one fp6 blob
@@ -208,10 +216,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // Weight streams, per (direction, wave), in bytes.  hi / lo fragments and blobs are 1 KiB (lane * 16), the scale dwords of a pair
 // 256 B (lane * 4; byte g = gate g):
-//   phase-A pair (r, z)    : hi (kbl, g) at (2 kbl + g) KiB | blob (g) at (4 + g) KiB | scales at 6 KiB           = 6400 B
-//   phase-B pair (r, z, n) : hi (kbl, g) at (3 kbl + g) KiB | blob (g) at (6 + g) KiB | scales at 9 KiB           = 9472 B
-//   phase-C pair (n)       : hi (kbl) at kbl KiB            | blob at 2 KiB           | scales at 3 KiB (byte 0)  = 3328 B
-constexpr int kMxPairA = 6 * 1024 + 256, kMxPairB = 9 * 1024 + 256, kMxPairC = 3 * 1024 + 256;
+//   phase-A pair (r, z)    : hi (kbl, g) at (2 kbl + g) KiB | fp6 blob (g): bytes 0-15 at (4 + g) KiB, bytes 16-23 (lane * 8) at
+//                            6 KiB + 512 g | scales at 7 KiB                                                                  = 7424 B
+//   phase-B pair (r, z, n) : hi (kbl, g) at (3 kbl + g) KiB | fp4 blob (g) at (6 + g) KiB | scales at 9 KiB                  = 9472 B
+//   phase-C pair (n)       : hi (kbl) at kbl KiB | fp6 blob: bytes 0-15 at 2 KiB, 16-23 at 3 KiB | scales at 3.5 KiB (byte 0) = 3840 B
+constexpr int kMxPairA = 7 * 1024 + 256, kMxPairB = 9 * 1024 + 256, kMxPairC = 3 * 1024 + 512 + 256;
 constexpr int kMx0WBytes = 4 * 1024 + (kKBH / 2) * kMxPairB + 2 * 1024;       // layer 0: [r hi, r lo, z hi, z lo] [B] [n hi, n lo]
 constexpr int kMx12OffB = (kKB12 / 2) * kMxPairA, kMx12OffC = kMx12OffB + (kKBH / 2) * kMxPairB;
 constexpr int kMx12WBytes = kMx12OffC + (kKB12 / 2) * kMxPairC;
@@ -450,8 +459,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 // Iterations ("consumptions") per step: 16 pairs of phase A, then 16 of phase C; phase B touches no x.  The pair code is
 // straight-line (static_for over compile-time pair indices): a rolled pair loop with peeled ends made the compiler shuffle weight
 // slots between register sets at the loop exits, each shuffle behind an s_waitcnt vmcnt(0).  s_waitcnt immediates count the
-// vector-memory operations a wave issues between a transfer and the barrier that needs it: per phase-A pair 7 weight requests
-// (2 + 2 hi fragments, 2 blobs + 1 scale dword) + d transfer instructions, per phase-C pair 4 + d, d = 2 for waves 0-3
+// vector-memory operations a wave issues between a transfer and the barrier that needs it: per phase-A pair 9 weight requests
+// (2 + 2 hi fragments, 2 x 2 blob pieces + 1 scale dword) + d transfer instructions, per phase-C pair 5 + d, d = 2 for waves 0-3
 // (fragments w and w + 8 of the pair) and 1 for waves 4-7; every load below is therefore UNCONDITIONAL.
 //   xin : [tile][t][32 kb][hi | corr][64] uint4      out : the same (OUT_FP8: fp8 corr fragments for the attention kernel)
 // LDS : h fragments 96 KiB | x ring 4 x 12 KiB | residuals 12 KiB | biases 4 KiB = 160 KiB
@@ -514,25 +523,32 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     const int bias_off = kMx12BiasOff + wave * 4 * 32 * 4;
     auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
     auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
+    auto w8_at = [&](int off) -> uint2 {            // bytes 16-23 of an fp6 blob: lane * 8
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, off, 0);
+        return make_uint2(v[0], v[1]);
+    };
 
-    // weight registers: phase A three pair slots: [slot][kb in pair][gate r,z] hi, [slot][gate] blobs, [slot] scale bytes; phase B one
-    // resident pair; phase C four pair slots of the n gate: [slot][kb in pair] hi, [slot] blob, [slot] scale byte
+    // weight registers: phase A three pair slots: [slot][kb in pair][gate r,z] hi, [slot][gate] fp6 blobs (16 + 8 bytes), [slot] scale
+    // bytes; phase B one resident pair (fp4 blobs); phase C four pair slots of the n gate: [slot][kb in pair] hi, [slot] fp6 blob, scale
     uint4 wah[3][2][2], wab[3][2];
+    uint2 wab1[3][2];
     uint32_t was[3];
     uint4 wbh[2][3], wbb[3];
     uint32_t wbs;
     uint4 wch[4][2], wcb[4];
+    uint2 wcb1[4];
     uint32_t wcs[4];
     auto ldAh = [&](uint4 (&d)[2], int p, int kbl) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) d[g] = w_at(p * PA + ((2 * kbl + g) << 10));
     };
-    auto ldAb = [&](int ws, int p) {
+    auto ldAb = [&](int ws, int p) {                // 5 requests
 #pragma unroll
-        for (int g = 0; g < 2; ++g) wab[ws][g] = w_at(p * PA + ((4 + g) << 10));
-        was[ws] = ws_at(p * PA + (6 << 10));
+        for (int g = 0; g < 2; ++g) { wab[ws][g] = w_at(p * PA + ((4 + g) << 10)); wab1[ws][g] = w8_at(p * PA + (6 << 10) + 512 * g); }
+        was[ws] = ws_at(p * PA + (7 << 10));
     };
-    auto ldA_slot = [&](int ws, int p) { ldAh(wah[ws][0], p, 0); ldAh(wah[ws][1], p, 1); ldAb(ws, p); };   // 7 requests
+    auto ldA_slot = [&](int ws, int p) { ldAh(wah[ws][0], p, 0); ldAh(wah[ws][1], p, 1); ldAb(ws, p); };   // 9 requests
 
     // ---- prologue: the ring's first pairs, the first three weight slots
 #pragma unroll
@@ -540,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     ldA_slot(0, 0);
     ldA_slot(1, 1);
     ldA_slot(2, 2);
-    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");               // all ring transfers (older than the 21 weight requests)
+    asm volatile("s_waitcnt vmcnt(27)" ::: "memory");               // all ring transfers (older than the 27 weight requests)
     __syncthreads();                                                // ring, h0 fragments and biases are in LDS
 
     int slot = 0;                                                   // ring slot of the next consumption (wave-uniform)
@@ -597,8 +613,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     } while (0)
 
         // ---------------- phase A: R, Z += W_i{r,z} x_t, pairs 0..15 ---------------------------------------------------------
-        // pair P lives in weight slot P % 3; behind its three MFMA groups its slot is refilled with pair P + 3 (2 + 2 + 3
-        // requests); pairs 13 and 14 take phase B's first pair instead (7 + 3 requests), pair 15 has nothing left to request and
+        // pair P lives in weight slot P % 3; behind its three MFMA groups its slot is refilled with pair P + 3 (2 + 2 + 5
+        // requests); pairs 13 and 14 take phase B's first pair instead (9 + 1 requests), pair 15 has nothing left to request and
         // its ring refill is deferred to the end of phase B: issued here it would sit in front of phase B's one-pair-ahead
         // weight requests.
         rdx(xh, slot_off(slot), 0, 0);
@@ -612,22 +628,28 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             CCSM_MAIN(wah[WS][0], xh, 2, 0);
             if constexpr (P + 3 < NPAIR) ldAh(wah[WS][0], P + 3, 0);
             else if constexpr (P == 13) { wbh[0][0] = w_at(OFF_B + (0 << 10)); wbh[0][1] = w_at(OFF_B + (1 << 10)); }
-            else if constexpr (P == 14) { wbb[1] = w_at(OFF_B + (7 << 10)); wbb[2] = w_at(OFF_B + (8 << 10)); }
+            else if constexpr (P == 14) { wbs = ws_at(OFF_B + (9 << 10)); }
             rdx_blob(xs);
             CCSM_MAIN(wah[WS][1], xh1, 2, 0);
             if constexpr (P + 3 < NPAIR) ldAh(wah[WS][1], P + 3, 1);
             else if constexpr (P == 13) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); }
-            else if constexpr (P == 14) { wbs = ws_at(OFF_B + (9 << 10)); }
-            // this wave's part of the next pair's transfer has landed: younger than it are RS - 2 pairs of 7 + d operations and 4 of
-            // this pair (pair 14: 3 of its own; pair 15: pair 13 with 7 + d, pair 14 with 3 + d, none of its own)
+            // this wave's part of the next pair's transfer has landed: younger than it are RS - 2 pairs of 9 + d operations and 4 of
+            // this pair (pair 14: 1 of its own; pair 15: pair 13 with 9 + d, pair 14 with 1 + d, none of its own)
             if constexpr (P == NPAIR - 1) CCSM_WAIT_XFER(12, 14);
-            else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(19, 21);
-            else CCSM_WAIT_XFER(20, 22);
+            else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(21, 23);
+            else CCSM_WAIT_XFER(24, 26);
             __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
-            CCSM_CORR_G(2, wab[WS], was[WS], sb);
+            CCSM_FENCE;
+#pragma unroll
+            for (int bt = 0; bt < NB; ++bt) {
+                acc[0][bt] = mfma_corr_mx6<0>(wab[WS][0], wab1[WS][0], was[WS], xc0[bt], xc1[bt], acc[0][bt], sb);
+                acc[1][bt] = mfma_corr_mx6<1>(wab[WS][1], wab1[WS][1], was[WS], xc0[bt], xc1[bt], acc[1][bt], sb);
+            }
+            CCSM_FENCE;
             if constexpr (P + 3 < NPAIR) ldAb(WS, P + 3);
-            else if constexpr (P == 13) { wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10)); wbb[0] = w_at(OFF_B + (6 << 10)); }
+            else if constexpr (P == 13) { wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10)); wbb[0] = w_at(OFF_B + (6 << 10));
+                                          wbb[1] = w_at(OFF_B + (7 << 10)); wbb[2] = w_at(OFF_B + (8 << 10)); }
             CCSM_FENCE;
             if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;
             slot = slot_n;
@@ -667,7 +689,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbh[1][g] = w_at(NXT + ((3 + g) << 10));
             } else {
-                wcs[0] = ws_at(OFF_C + 0 * PC + (3 << 10)); wch[1][0] = w_at(OFF_C + 1 * PC + (0 << 10)); wch[1][1] = w_at(OFF_C + 1 * PC + (1 << 10));
+                wcb1[0] = w8_at(OFF_C + 0 * PC + (3 << 10)); wcs[0] = ws_at(OFF_C + 0 * PC + (3 << 10) + 512); wch[1][0] = w_at(OFF_C + 1 * PC + (0 << 10));
             }
             CCSM_CORR_G(3, wbb, wbs, sbh);
             if constexpr (!LAST) {
@@ -675,8 +697,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 for (int g = 0; g < 3; ++g) wbb[g] = w_at(NXT + ((6 + g) << 10));
                 wbs = ws_at(NXT + (9 << 10));
             } else {
-                wcb[1] = w_at(OFF_C + 1 * PC + (2 << 10)); wcs[1] = ws_at(OFF_C + 1 * PC + (3 << 10));
-                wch[2][0] = w_at(OFF_C + 2 * PC + (0 << 10)); wch[2][1] = w_at(OFF_C + 2 * PC + (1 << 10));
+                wch[1][1] = w_at(OFF_C + 1 * PC + (1 << 10)); wcb[1] = w_at(OFF_C + 1 * PC + (2 << 10));
+                wcb1[1] = w8_at(OFF_C + 1 * PC + (3 << 10)); wcs[1] = ws_at(OFF_C + 1 * PC + (3 << 10) + 512);
             }
             CCSM_FENCE;
         });
@@ -689,11 +711,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
         }
-        // the rest of phase C's first four pair slots: requested once R is dead (the accumulators drop from 144 to 96 registers)
+        // phase C's pair slots 2 and 3: requested once R is dead (the accumulators drop from 144 to 96 registers)
         CCSM_FENCE;
-        wcb[2] = w_at(OFF_C + 2 * PC + (2 << 10)); wcs[2] = ws_at(OFF_C + 2 * PC + (3 << 10));
-        wch[3][0] = w_at(OFF_C + 3 * PC + (0 << 10)); wch[3][1] = w_at(OFF_C + 3 * PC + (1 << 10));
-        wcb[3] = w_at(OFF_C + 3 * PC + (2 << 10)); wcs[3] = ws_at(OFF_C + 3 * PC + (3 << 10));
+#pragma unroll
+        for (int q = 2; q < 4; ++q) {
+            wch[q][0] = w_at(OFF_C + q * PC + (0 << 10)); wch[q][1] = w_at(OFF_C + q * PC + (1 << 10)); wcb[q] = w_at(OFF_C + q * PC + (2 << 10));
+            wcb1[q] = w8_at(OFF_C + q * PC + (3 << 10)); wcs[q] = ws_at(OFF_C + q * PC + (3 << 10) + 512);
+        }
         CCSM_FENCE;
         auto zwork = [&](int bt) {                                  // z = sigmoid(Z) in place, inside phase C (vector ALU otherwise idle)
 #pragma unroll
@@ -702,8 +726,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 
         stamp(2);
         // ---------------- phase C: N += W_in x_t, pairs 0..15 (consumptions 16..31) ------------------------------------------
-        // pair P lives in slot P % 4 of the n-gate weights, refilled with pair P + 4 (1 + 1 + 2 requests); the last four pairs take
-        // the next step's phase-A slots 0 and 1 instead (4, 3, 4, 3 requests; slot 2 follows behind the tail)
+        // pair P lives in slot P % 4 of the n-gate weights, refilled with pair P + 4 (1 + 1 + 3 requests); the last four pairs take
+        // the next step's phase-A slots 0 and 1 instead (5, 4, 5, 4 requests; slot 2 follows behind the tail)
         rdx(xh, slot_off(slot), 0, 0);
         static_for<0, NPAIR>([&](auto PC_) {
             constexpr int P = decltype(PC_)::value;
@@ -717,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][0], xh[bt], acc[2][bt]);
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) wch[WS][0] = w_at(OFF_C + (P + 4) * PC + (0 << 10));
-            else if constexpr (AF == 0) wah[AS][0][0] = w_at(AS * PA + (0 << 10)); else wab[AS][0] = w_at(AS * PA + (4 << 10));
+            else if constexpr (AF == 0) wah[AS][0][0] = w_at(AS * PA + (0 << 10)); else wab1[AS][0] = w8_at(AS * PA + (6 << 10));
             rdx_blob(xs);
             CCSM_FENCE;
 #pragma unroll
@@ -725,17 +749,18 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) wch[WS][1] = w_at(OFF_C + (P + 4) * PC + (1 << 10));
             else if constexpr (AF == 0) wah[AS][0][1] = w_at(AS * PA + (1 << 10)); else wab[AS][1] = w_at(AS * PA + (5 << 10));
-            // RS - 2 pairs of 4 + d operations and 2 of this pair (pairs 14, 15 look back on a blob pair with 3 + d)
-            if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(11, 13); else CCSM_WAIT_XFER(12, 14);
+            // RS - 2 pairs of 5 + d operations and 2 of this pair (pairs 14, 15 look back on a pair with 4 + d)
+            if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(13, 15); else CCSM_WAIT_XFER(14, 16);
             __syncthreads();
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
             CCSM_FENCE;
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma_corr_mx<0>(wcb[WS], wcs[WS], xc0[bt], xc1[bt], acc[2][bt], sb);
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma_corr_mx6<0>(wcb[WS], wcb1[WS], wcs[WS], xc0[bt], xc1[bt], acc[2][bt], sb);
             CCSM_FENCE;
-            if constexpr (P + 4 < NPAIR) { wcb[WS] = w_at(OFF_C + (P + 4) * PC + (2 << 10)); wcs[WS] = ws_at(OFF_C + (P + 4) * PC + (3 << 10)); }
-            else if constexpr (AF == 0) { wah[AS][1][0] = w_at(AS * PA + (2 << 10)); wah[AS][1][1] = w_at(AS * PA + (3 << 10)); }
-            else { was[AS] = ws_at(AS * PA + (6 << 10)); }
+            if constexpr (P + 4 < NPAIR) { wcb[WS] = w_at(OFF_C + (P + 4) * PC + (2 << 10)); wcb1[WS] = w8_at(OFF_C + (P + 4) * PC + (3 << 10));
+                                           wcs[WS] = ws_at(OFF_C + (P + 4) * PC + (3 << 10) + 512); }
+            else if constexpr (AF == 0) { wah[AS][1][0] = w_at(AS * PA + (2 << 10)); wah[AS][1][1] = w_at(AS * PA + (3 << 10)); wab[AS][0] = w_at(AS * PA + (4 << 10)); }
+            else { wab1[AS][1] = w8_at(AS * PA + (6 << 10) + 512); was[AS] = ws_at(AS * PA + (7 << 10)); }
             CCSM_FENCE;
             dma_ahead(slot, s, NPAIR + P);
             slot = slot_n;
@@ -758,7 +783,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 #undef CCSM_FENCE
 
 // Self-test of the split-mx product: C[unit][row] = sum_k W[unit][k] X[row][k] over one pair (32 k).  W fragments packed by the
-// host (hi kb0, hi kb1, blob, scale dwords with the scale in byte 0), X given in fp32 as an MFMA-C-layout image and packed on the device with pack_pair_mx;
+// host (hi kb0, hi kb1, blob bytes 0-15, [scale dwords with the scale in byte 0 (256 B) | blob bytes 16-23 (512 B)]); with_corr =
+// the blob's format (2 fp6, 4 fp4; 0 = main product only).  X given in fp32 as an MFMA-C-layout image and packed on the device with pack_pair_mx;
 // blob_out receives the activation blobs (24 bytes per lane) so the host can check its own fp6 encoder against the instruction's.
 __global__ void mx_selftest_kernel(const uint4* __restrict__ wfrag, const float* __restrict__ x /* [row 32][k 32] */,
                                    float* __restrict__ c /* [unit 32][row 32] */, uint32_t* __restrict__ blob_out, int with_corr, float scale, int sb_hi, int sb_lo) {
@@ -779,7 +805,11 @@ __global__ void mx_selftest_kernel(const uint4* __restrict__ wfrag, const float*
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     acc = mfma16(wfrag[0 * 64 + lane], hi0, acc);
     acc = mfma16(wfrag[1 * 64 + lane], hi1, acc);
-    if (with_corr) acc = mfma_corr_mx<0>(wfrag[2 * 64 + lane], reinterpret_cast<const uint32_t*>(wfrag + 3 * 64)[lane], c0, c1, acc, hh ? sb_lo : sb_hi);
+    const uint32_t ws = reinterpret_cast<const uint32_t*>(wfrag + 3 * 64)[lane];
+    if (with_corr == 4) acc = mfma_corr_mx<0>(wfrag[2 * 64 + lane], ws, c0, c1, acc, hh ? sb_lo : sb_hi);
+    if (with_corr == 2)
+        acc = mfma_corr_mx6<0>(wfrag[2 * 64 + lane], reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(wfrag + 3 * 64) + 256)[lane], ws, c0, c1, acc,
+                               hh ? sb_lo : sb_hi);
 #pragma unroll
     for (int r = 0; r < 16; ++r) c[((r & 3) + 8 * (r >> 2) + 4 * hh) * 32 + n] = acc[r];
 }

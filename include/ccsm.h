@@ -214,7 +214,8 @@ ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err);
 ccsm_status ccsm_selftest_split_f8(int device, float* err_corr, float* err_main_only);
 /* The same for the split-mx product of the GRU layers (fp6 / fp4 correction blobs, host-packed weights, device-packed
  * activations); blob_mismatch = bytes in which the host's fp6 encoder and v_cvt_scalef32_pk32_fp6_f16 disagree (0 expected). */
-ccsm_status ccsm_selftest_split_mx(int device, float* err_corr, float* err_main_only, int* blob_mismatch);
+ccsm_status ccsm_selftest_split_mx(int device, int weight_fmt /* 2 = fp6 blob, 4 = fp4 blob */, float* err_corr, float* err_main_only,
+                                   int* blob_mismatch);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Aggregate mode (`ccsmeth call_freqb --call_mode aggregate`, BASELINE config 5).

@@ -5,9 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ccsmeth_amd import _lib
 lib = _lib.load()
-a, b, m = C.c_float(), C.c_float(), C.c_int()
-_lib.check(lib.ccsm_selftest_split_mx(0, C.byref(a), C.byref(b), C.byref(m)))
-print("split-mx selftest: max err with corr %.3e, main only %.3e, blob mismatching bytes %d" % (a.value, b.value, m.value))
+for fmt in (2, 4):
+    a, b, m = C.c_float(), C.c_float(), C.c_int()
+    _lib.check(lib.ccsm_selftest_split_mx(0, fmt, C.byref(a), C.byref(b), C.byref(m)))
+    print("split-mx selftest (weight blob fmt %d): max err with corr %.3e, main only %.3e, blob mismatching bytes %d" % (fmt, a.value, b.value, m.value))
 a2, b2 = C.c_float(), C.c_float()
 _lib.check(lib.ccsm_selftest_split_f8(0, C.byref(a2), C.byref(b2)))
 print("split-f8 selftest: max err with corr %.3e, main only %.3e" % (a2.value, b2.value))
