@@ -300,11 +300,12 @@ def call_mods(args, log=sys.stderr, pipe=None):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if not dist.is_initialized():
                 dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side bookkeeping only
-            board = sharding.BatchBoard(sharding.open_board_store(world, rank), world, rank, dispatch=args.dispatch)
-            if rank == 0:       # the scan gets the host cores the other ranks' readers do not need
+            store, connect = sharding.open_board_store(world, rank)
+            board = sharding.BatchBoard(store, world, rank, dispatch=args.dispatch)
+            if rank == 0:       # the scan gets the host cores the other ranks' readers do not need, and its own connection to the board
                 scan_threads = max(args.threads, (os.cpu_count() or 1) // 2)
                 scan = sharding.start_scan_thread(lambda: NativeBamReader(args.input, threads=scan_threads), args.holes_batch,
-                                                  lambda b: filters(b)[2], board)
+                                                  lambda b: filters(b)[2], sharding.BatchBoard(connect(), world, rank, dispatch=args.dispatch))
         part_path = out_path if world == 1 else "%s.part%d" % (out_path, rank)
         runs = []
         with NativeBamReader(args.input, threads=args.threads) as rd:

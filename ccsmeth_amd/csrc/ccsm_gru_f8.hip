@@ -84,8 +84,20 @@ __device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint
         lf[j] = v[j] - (float)h[0];
         lf[j + 1] = v[j + 1] - (float)h[1];
     }
-    uint32_t h0 = cvt4_fp8_h(hp[0], hp[1]);
-    uint32_t h1 = cvt4_fp8_h(hp[2], hp[3]);
+    // The fp8 conversions do not saturate (an overflow is a NaN in the product), and the GRU state is only bounded by max(1, |h0|):
+    // the values that go into the CORRECTION operands are clamped to the e4m3 range (|x_hi| <= 7, |x_lo| <= 448 / 2^17) first.
+    uint32_t hc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const half2p lim = {(_Float16)(kF8Clamp / kCorrActHi), (_Float16)(kF8Clamp / kCorrActHi)};
+        half2p t = __builtin_bit_cast(half2p, hp[j]);
+        t = __builtin_elementwise_min(__builtin_elementwise_max(t, -lim), lim);
+        hc[j] = __builtin_bit_cast(uint32_t, t);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lf[j] = __builtin_amdgcn_fmed3f(lf[j], -kF8Clamp / kCorrActLo, kF8Clamp / kCorrActLo);
+    uint32_t h0 = cvt4_fp8_h(hc[0], hc[1]);
+    uint32_t h1 = cvt4_fp8_h(hc[2], hc[3]);
     uint32_t l0 = cvt4_fp8_l(hp[0], lf[0], lf[1], lf[2], lf[3]);
     uint32_t l1 = cvt4_fp8_l(hp[2], lf[4], lf[5], lf[6], lf[7]);
     uint32_t a0 = hp[0], a1 = hp[1], b0 = hp[2], b1 = hp[3];

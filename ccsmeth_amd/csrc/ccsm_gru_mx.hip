@@ -35,8 +35,11 @@ constexpr int kMxWFmtX = 2;                        // ... input part (phases A, 
 constexpr int kMxBFmt = 2;                         // B (activation) operand: fp6 e2m3
 constexpr int kMxScaleHi = 127 - 2;                // x_hi blob holds x_hi * 4
 constexpr int kMxScaleLo = 127 - 14;               // x_lo blob holds x_lo * 2^14
-constexpr int kMxScaleHi0 = 127 + 1;               // initial states: x_hi / 2 (|h0| < 15)
-constexpr int kMxScaleLo0 = 127 - 11;              //                 x_lo * 2^11
+constexpr int kMxScaleHi0 = 127 + 2;               // initial states: x_hi / 4 (clamped to |h0| <= 30)
+constexpr int kMxScaleLo0 = 127 - 10;              //                 x_lo * 2^10
+constexpr float kMxH0Div = 4.0f;                   // what the initial-state blobs are divided by (GRU outputs: 0.25)
+constexpr float kMxLoScale = 65536.0f;             // a wave's private fp8 residuals carry lo * 2^16: |lo| <= 2^-8 (|h| < 16) stays below e4m3's 448.
+                                                   // |h_t| <= max(1, |h0|): the state is NOT confined to (-1, 1) when the initial states are not
 
 typedef _Float16 half32 __attribute__((ext_vector_type(32)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
@@ -68,12 +71,12 @@ __device__ __forceinline__ void blob_of(const uint32_t (&p)[16], float scale, ui
 // The wave's 32 units of one batch row in MFMA C layout, as lane (n, hh) holds them: v[4q + e] = unit 8q + 4hh + e.
 //   hi0, hi1 : this lane's 16 bytes of the hi fragments of the wave's two k-blocks
 //   c0, c1   : this lane's activation blob (lower lanes: x_hi of all 32 units, upper lanes: x_lo)
-//   lo8      : fp8 (x 2^17) residuals of this lane's own 16 values, C-layout order (the wave's private copy)
-// SCALE = what the blob's values are divided by (0.25 for GRU outputs; 2 for initial states).
+//   lo8      : fp8 (x 2^16) residuals of this lane's own 16 values, C-layout order (the wave's private copy)
+// SCALE = what the blob's values are divided by (0.25 for GRU outputs; kMxH0Div for initial states).
 template <bool CLAMP>
 __device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, uint4& hi0, uint4& hi1, uint4& c0, uint2& c1, uint4& lo8) {
     typedef _Float16 half2p __attribute__((ext_vector_type(2)));
-    uint32_t hp[8], lp[8];
+    uint32_t hp[8], hq[8], lp[8];     // hi (fragments), hi as it goes into the blob, lo * 2^12
     float lf[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -81,21 +84,31 @@ __device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, 
         hp[j] = __builtin_bit_cast(uint32_t, h);
         lf[2 * j] = v[2 * j] - (float)h[0];
         lf[2 * j + 1] = v[2 * j + 1] - (float)h[1];
-        lp[j] = pack2((_Float16)(lf[2 * j] * 4096.0f), (_Float16)(lf[2 * j + 1] * 4096.0f));    // |lo| <= 2^-12 |v|: no fp16 underflow
+        float l0 = lf[2 * j] * 4096.0f, l1 = lf[2 * j + 1] * 4096.0f;                            // |lo| <= 2^-12 |v|: no fp16 underflow
+        if constexpr (CLAMP) {      // nothing may exceed the fp6 range after the division by `scale`: an overflowing conversion poisons the
+                                    // product (NaN probabilities were observed for |h0| >= 8 with the residual at the top of its range)
+            const float top = 7.5f * scale;
+            const half2p hc = {(_Float16)fminf(fmaxf(v[2 * j], -top), top), (_Float16)fminf(fmaxf(v[2 * j + 1], -top), top)};
+            hq[j] = __builtin_bit_cast(uint32_t, hc);
+            l0 = fminf(fmaxf(l0, -top), top);
+            l1 = fminf(fmaxf(l1, -top), top);
+        } else {
+            hq[j] = hp[j];
+        }
+        lp[j] = pack2((_Float16)l0, (_Float16)l1);
     }
-    if constexpr (CLAMP) {      // initial states of any magnitude: v_cvt_pk_fp8_f32 does not saturate
+    {   // residuals as fp8: clamped first (the conversion does not saturate: an overflow is a NaN that would stay in the state)
         uint32_t r[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float c[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) c[e] = fminf(fmaxf(lf[4 * q + e] * kCorrActLo, -kF8Clamp), kF8Clamp);
-            r[q] = cvt4_fp8(c[0], c[1], c[2], c[3]);
+            for (int e = 0; e < 4; ++e) c[e] = __builtin_amdgcn_fmed3f(lf[4 * q + e], -kF8Clamp / kMxLoScale, kF8Clamp / kMxLoScale);
+            short2v t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(short2v, hp[2 * q]), c[0], c[1], 1.0f / kMxLoScale, false);
+            t = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(t, c[2], c[3], 1.0f / kMxLoScale, true);
+            r[q] = __builtin_bit_cast(uint32_t, t);
         }
         lo8 = make_uint4(r[0], r[1], r[2], r[3]);
-    } else {                    // GRU outputs: |lo| 2^17 <= 32
-        lo8 = make_uint4(cvt4_fp8_l(hp[0], lf[0], lf[1], lf[2], lf[3]), cvt4_fp8_l(hp[2], lf[4], lf[5], lf[6], lf[7]),
-                         cvt4_fp8_l(hp[4], lf[8], lf[9], lf[10], lf[11]), cvt4_fp8_l(hp[6], lf[12], lf[13], lf[14], lf[15]));
     }
     {   // hi fragments: lane (n, g) <- k = 16 kb + 8 g + j
         uint32_t a0 = hp[0], a1 = hp[1], b0 = hp[2], b1 = hp[3];
@@ -109,8 +122,8 @@ __device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, 
     }
     // blob: lower lanes end up with (own hi | partner's hi), upper lanes with (partner's lo | own lo): kMxPerm order
 #pragma unroll
-    for (int j = 0; j < 8; ++j) swap32(hp[j], lp[j]);
-    const uint32_t p[16] = {hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7], lp[0], lp[1], lp[2], lp[3], lp[4], lp[5], lp[6], lp[7]};
+    for (int j = 0; j < 8; ++j) swap32(hq[j], lp[j]);
+    const uint32_t p[16] = {hq[0], hq[1], hq[2], hq[3], hq[4], hq[5], hq[6], hq[7], lp[0], lp[1], lp[2], lp[3], lp[4], lp[5], lp[6], lp[7]};
     blob_of(p, scale, c0, c1);
 }
 
@@ -135,7 +148,7 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
         }
         uint4 hi0, hi1, c0, lo8;
         uint2 c1;
-        pack_pair_mx<true>(v, 2.0f, hi0, hi1, c0, c1, lo8);
+        pack_pair_mx<true>(v, kMxH0Div, hi0, hi1, c0, c1, lo8);
         *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 0) + lane * 16) = hi0;
         *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 0) + lane * 16) = hi1;
         *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 1) + lane * 16) = c0;
@@ -165,10 +178,10 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
         for (int q = 0; q < 4; ++q) {
             const half4 hi = as_half4(*reinterpret_cast<const uint2*>(t_rd + own_frag(q >> 1, bt, 0) + 512 * (q & 1)));
             const int lo4 = (int)l8[q];
-            const float hp[4] = {(float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo4, 0) * (1.0f / kCorrActLo),
-                                 (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo4, 1) * (1.0f / kCorrActLo),
-                                 (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo4, 2) * (1.0f / kCorrActLo),
-                                 (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo4, 3) * (1.0f / kCorrActLo)};
+            const float hp[4] = {(float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo4, 0) * (1.0f / kMxLoScale),
+                                 (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo4, 1) * (1.0f / kMxLoScale),
+                                 (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo4, 2) * (1.0f / kMxLoScale),
+                                 (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo4, 3) * (1.0f / kMxLoScale)};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float nn = tanh_fold(accn[bt][4 * q + e]);

@@ -44,7 +44,9 @@ class DeviceModel:
         _lib.check(lib.ccsm_create(C.byref(cfg), C.byref(w), int(device), C.byref(handle)))
         self.handle = handle
         self.device = int(device)
-        self.precision = lib.ccsm_model_precision(handle)
+        self.precision = lib.ccsm_model_precision(handle)      # the arithmetic in use (3 after a fallback from the default)
+        self.probe_error = float(lib.ccsm_model_probe_error(handle))
+        self.quant_error = float(lib.ccsm_model_quant_error(handle))
         self._workspaces = []
 
     def workspace(self, max_sites):

@@ -104,7 +104,9 @@ def start_scan_thread(make_reader, holes_batch, sites_of_batch, board):
 
 def open_board_store(world, rank, port=None, host=None, timeout_s=1800):
     """The board's store: a TCPStore on MASTER_ADDR hosted by rank 0, on CCSM_BOARD_PORT or, by default, a free port that rank 0
-    picks and broadcasts through the (already initialised) process group."""
+    picks and broadcasts through the (already initialised) process group.  Returns (store, connect): `connect()` opens one more
+    client connection — a store client serialises its calls, so the scanning thread must not share the connection on which the
+    same process's claimer blocks in get() (observed: the scan's set() waits behind that get() forever)."""
     import datetime
     import os
     import socket
@@ -120,5 +122,9 @@ def open_board_store(world, rank, port=None, host=None, timeout_s=1800):
                 box[0] = s.getsockname()[1]
         dist.broadcast_object_list(box, src=0)
         port = box[0]
-    return dist.TCPStore(host, int(port), int(world), is_master=(rank == 0), timeout=datetime.timedelta(seconds=timeout_s),
-                         wait_for_workers=True)
+    tmo = datetime.timedelta(seconds=timeout_s)
+    store = dist.TCPStore(host, int(port), int(world), is_master=(rank == 0), timeout=tmo, wait_for_workers=True)
+
+    def connect():
+        return dist.TCPStore(host, int(port), None, is_master=False, timeout=tmo, wait_for_workers=False)
+    return store, connect

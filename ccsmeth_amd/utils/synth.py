@@ -55,6 +55,26 @@ def synth_weights(seed, num_layers=3, hidden=256, fc_bias=True):
     return out
 
 
+def synth_weights_heavy(seed, outliers=8, outlier_scale=50.0, bias_shift=6.0):
+    """A deliberately hostile checkpoint for the split-operand arithmetic: GRU matrices with Student-t (3 dof) entries at the
+    synthetic scale, a few entries per matrix blown up by `outlier_scale`, and biases shifted by +-`bias_shift` on half of the units
+    (gates driven into saturation).  Everything else as synth_weights."""
+    w = synth_weights(seed)
+    rng = np.random.default_rng(seed + 1000003)
+    out = {}
+    for k, v in w.items():
+        if k.startswith("rnn.weight"):
+            t = rng.standard_t(3, size=v.shape).astype(np.float32) * np.abs(v).mean()
+            idx = rng.integers(0, t.size, size=outliers)
+            t.reshape(-1)[idx] *= outlier_scale
+            out[k] = t
+        elif k.startswith("rnn.bias"):
+            out[k] = (v + rng.choice([-bias_shift, 0.0, 0.0, bias_shift], size=v.shape)).astype(np.float32)
+        else:
+            out[k] = v
+    return out
+
+
 def synth_sites(n, seed, pseudo_read=15000):
     """n CpG sites of synthetic 21-mer features, both strands (SURVEY.md §8d recipe).
 

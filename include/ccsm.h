@@ -188,6 +188,12 @@ ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, con
 const char* ccsm_last_error(void);
 const char* ccsm_version(void);
 int ccsm_model_precision(const ccsm_model* m);
+/* precision 0 (default) picks the arithmetic by measurement: ccsm_create runs a 192-site probe batch through SPLIT_F8 (split-mx)
+ * and SPLIT3 and keeps split-mx only when every probability agrees to 1.5e-5; ccsm_model_probe_error = that max |dprob| (-1 when
+ * the precision was requested explicitly), ccsm_model_precision = the arithmetic in use.  ccsm_model_quant_error = relative RMS
+ * quantisation error of the weight correction blobs (worst layer). */
+float ccsm_model_probe_error(const ccsm_model* m);
+float ccsm_model_quant_error(const ccsm_model* m);
 size_t ccsm_workspace_bytes(const ccsm_workspace* ws);
 /* Times (ms, HIP events on `stream`) of the kernels of the LAST forward issued on this workspace with timing
  * enabled: out[0..2] = GRU layers 0..2, out[3] = attention+FC, out[4] = logits/softmax finalize.  Blocks. */

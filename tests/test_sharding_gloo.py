@@ -124,6 +124,49 @@ def test_eight_ranks_equal_single_process(bam, dispatch, monkeypatch):
             assert shares[r] <= total * mine[r] / n_batches * 1.1 + mine[r] * 2 * block
 
 
+def test_two_ranks_many_small_batches_per_block(tmp_path, monkeypatch):
+    """Hole-batches much smaller than a BGZF block (several per block, claimed faster than the scan publishes them): the claimers block
+    on the board while the scan is still publishing — on its own connection, or nobody moves."""
+    from ccsmeth_amd import bamio
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    rng = np.random.default_rng(77)
+    inp = str(tmp_path / "small.bam")
+    with bamio.BamWriter(inp, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
+        for i in range(23):
+            n = int(rng.integers(200, 3000))
+            seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n)
+            pos = rng.integers(0, n - 1, n // 40)
+            seq[pos], seq[pos + 1] = ord("C"), ord("G")
+            kin = lambda: rng.integers(0, 256, n).astype(np.uint8)  # noqa: E731
+            tags = [("fi", "BC", kin()), ("fp", "BC", kin()), ("ri", "BC", kin()), ("rp", "BC", kin()), ("fn", "C", 9), ("rn", "C", 11)]
+            w.write(bamio.BamRecord("z/%d/ccs" % i, flag=16 if i % 5 == 0 else 4, seq=seq.tobytes().decode(), tags=tags[1:] if i == 7 else tags))
+    monkeypatch.setattr(sys, "argv", list(ARGV))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    mk = lambda out: build_parser().parse_args(["-i", inp, "-m", "x", "-o", out, "--holes_batch", "3", "--threads", "2", "--no_sort"])  # noqa: E731
+    one = call_mods(mk(str(tmp_path / "one")), log=open(os.devnull, "w"), pipe=StubPipe())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ports = (_free_port(), _free_port())
+    procs = [ctx.Process(target=_worker_small, args=(r, 2, ports, inp, str(tmp_path / "two"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert _payload(res[0]["output"]) == _payload(one["output"])
+    assert sum(res[0]["rank_batches"]) == 8 and res[0]["sites"] == one["sites"]
+
+
+def _worker_small(rank, world, ports, inp, out, q):
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[0]))
+    sys.argv = list(ARGV)
+    a = build_parser().parse_args(["-i", inp, "-m", "x", "-o", out, "--holes_batch", "3", "--threads", "2", "--no_sort"])
+    q.put((rank, call_mods(a, log=open(os.devnull, "w"), pipe=StubPipe())))
+
+
 def test_shard_indices_edges():
     assert list(shard_indices(0, 0, 8)) == []
     assert list(shard_indices(3, 2, 8)) == [2]
