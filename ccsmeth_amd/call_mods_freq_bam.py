@@ -420,49 +420,80 @@ def call_mods_frequency_from_bamfile(args, log=sys.stderr, model=None):
         model = AggrModel(torch.load(args.aggre_model, map_location="cpu"), device=getattr(args, "device", 0), tseed=args.tseed)
     tables = _CountTables(args.prob_cf)
 
+    # The input is coordinate-sorted (the reference fetches its regions through the BAM index, which needs that order), so a contig is
+    # complete as soon as a record of a later one shows up: its rows are turned into bed lines right then and dropped, and the lines
+    # go to per-contig spool files that are concatenated in contig-name order at the end (the order of the reference's region list).
+    # Host memory is bounded by the largest contig instead of the whole file.
+    import shutil
+    import tempfile
     rows_of = {}
-    n_rec = n_used = 0
-    with bamnative.NativeBamReader(args.input_bam, threads=max(1, args.threads)) as rd:
-        names = _bam_ref_names(rd.raw_refs, rd.n_ref)
-        if rd.n_ref == 0:
-            raise ValueError("file has no sequences defined - please make sure that the reads are aligned to the genome reference!")
-        masks = None
-        if args.refsites_all:
-            masks = [(_motif_site_mask(dnacontigs[nm], [(r[1], r[2]) for r in regions_of[nm]], motifs, args.mod_loc)
-                      if nm in regions_of else None) for nm in names]
-        while True:
-            batch = rd.next_batch(4096)
-            if batch is None:
-                break
-            tid, pos, strand, ml, hap, seen, used = bamnative.modcalls_of_batch(
-                batch, mapq=args.mapq, identity=args.identity, no_supplementary=args.no_supplementary, base_clip=args.base_clip,
-                refsites_all=args.refsites_all, hap_tag=args.hap_tag, site_masks=masks, threads=max(1, args.threads))
-            batch.close()
-            n_rec += seen
-            n_used += used
-            if len(tid):
-                for t in np.unique(tid).tolist():
-                    if 0 <= t < len(names) and names[t] in regions_of:
-                        m = tid == t
-                        rows_of.setdefault(t, []).append((pos[m], strand[m], ml[m], hap[m]))
-    tid_of = {nm: t for t, nm in reversed(list(enumerate(names)))}
+    done = set()
+    n_rec = n_used = n_sites = 0
     fext = "bed" if args.bed else "freq.txt"
     paths = [args.output + ".{}.{}.{}".format(args.call_mode, w, fext) for w in ("all", "hp1", "hp2")]
-    files = [open(p, "w") for p in paths]
-    n_sites = 0
-    for name in sorted(regions_of.keys()):
-        t = tid_of.get(name)
-        if t is None or t not in rows_of:
-            continue
-        parts = rows_of.pop(t)
+    spool_dir = tempfile.mkdtemp(prefix="ccsm_freqb_", dir=out_dir)
+    spooled = {}
+
+    def finish(t, names):
+        nonlocal n_sites
+        done.add(t)
+        parts = rows_of.pop(t, None)
+        name = names[t]
+        if parts is None or name not in regions_of:
+            return
         rows = tuple(np.concatenate([p[k] for p in parts]) for k in range(4))
         beds = _bed_of_contig(name, dnacontigs[name], regions_of[name], rows, motifs_filter, args, tables, model)
         n_sites += len(beds[0])
-        for wf, bed in zip(files, beds):
-            for item in bed:
-                _write_one_line(item, wf, args.bed)
-    for wf in files:
-        wf.close()
+        files = [os.path.join(spool_dir, "%d.%d" % (t, k)) for k in range(3)]
+        for fp, bed in zip(files, beds):
+            with open(fp, "w") as wf:
+                for item in bed:
+                    _write_one_line(item, wf, args.bed)
+        spooled[name] = files
+
+    try:
+        with bamnative.NativeBamReader(args.input_bam, threads=max(1, args.threads)) as rd:
+            names = _bam_ref_names(rd.raw_refs, rd.n_ref)
+            if rd.n_ref == 0:
+                raise ValueError("file has no sequences defined - please make sure that the reads are aligned to the genome reference!")
+            masks = None
+            if args.refsites_all:
+                masks = [(_motif_site_mask(dnacontigs[nm], [(r[1], r[2]) for r in regions_of[nm]], motifs, args.mod_loc)
+                          if nm in regions_of else None) for nm in names]
+            while True:
+                batch = rd.next_batch(4096)
+                if batch is None:
+                    break
+                tid, pos, strand, ml, hap, seen, used = bamnative.modcalls_of_batch(
+                    batch, mapq=args.mapq, identity=args.identity, no_supplementary=args.no_supplementary, base_clip=args.base_clip,
+                    refsites_all=args.refsites_all, hap_tag=args.hap_tag, site_masks=masks, threads=max(1, args.threads))
+                batch.close()
+                n_rec += seen
+                n_used += used
+                if len(tid):
+                    uniq = np.unique(tid).tolist()
+                    for t in uniq:
+                        if t in done:
+                            raise ValueError("--input_bam is not coordinate-sorted (records of %s after a later contig): sort and index it first, "
+                                             "as the reference's region fetches require" % names[t])
+                        if 0 <= t < len(names) and names[t] in regions_of:
+                            m = tid == t
+                            rows_of.setdefault(t, []).append((pos[m], strand[m], ml[m], hap[m]))
+                    last = int(tid[-1])
+                    for t in [t for t in list(rows_of) if t < last] + [t for t in uniq if t < last and t not in rows_of]:
+                        if t not in done:
+                            finish(t, names)
+            for t in sorted(rows_of):
+                finish(t, names)
+        files = [open(p, "w") for p in paths]
+        for name in sorted(spooled):
+            for wf, fp in zip(files, spooled[name]):
+                with open(fp, "r") as rf:
+                    shutil.copyfileobj(rf, wf)
+        for wf in files:
+            wf.close()
+    finally:
+        shutil.rmtree(spool_dir, ignore_errors=True)
     for p in paths:
         if os.path.getsize(p) == 0:
             os.remove(p)

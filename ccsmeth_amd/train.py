@@ -166,13 +166,16 @@ class Trainer:
             h.h0[0], h.h0[1] = a.ctypes.data, b.ctypes.data
         return h, keep
 
-    def forward_backward(self, sites, labels, h0=None, pos_weight=1.0, dropout_rate=0.0, seed=0, step=0, want_logits=False):
-        """-> (loss, logits or None); the flat gradient buffer then holds this batch's gradients."""
+    def forward_backward(self, sites, labels, h0=None, pos_weight=1.0, dropout_rate=0.0, seed=0, step=0, want_logits=False, h0_offset=None):
+        """-> (loss, logits or None); the flat gradient buffer then holds this batch's gradients.
+        h0_offset: running SITE index of the batch's first site in the device-drawn initial states (the generator's counter advances
+        by 3072 per site); default step * N, so that consecutive steps draw disjoint windows (the reference draws a fresh
+        torch.randn(6, N, 256) per forward: models.py:77-87)."""
         b, keep, n = self._batch(sites)
         lab = np.ascontiguousarray(labels, dtype=np.int32)
         if lab.shape != (n,):
             raise ValueError("labels must be (N,)")
-        h, keep2 = self._h0(h0, n, seed, step)
+        h, keep2 = self._h0(h0, n, seed, int(step) * n if h0_offset is None else int(h0_offset))
         loss = C.c_float()
         logits = np.empty((n, 2), np.float32) if want_logits else None
         _check(self._lib.ccsm_train_forward_backward(self.handle, n, C.byref(b), lab.ctypes.data, C.byref(h), float(pos_weight),
@@ -180,10 +183,10 @@ class Trainer:
                                                      logits.ctypes.data if want_logits else None))
         return float(loss.value), logits
 
-    def evaluate(self, sites, labels=None, h0=None, pos_weight=1.0, seed=0, step=0):
+    def evaluate(self, sites, labels=None, h0=None, pos_weight=1.0, seed=0, step=0, h0_offset=None):
         b, keep, n = self._batch(sites)
         lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32)
-        h, keep2 = self._h0(h0, n, seed, step)
+        h, keep2 = self._h0(h0, n, seed, int(step) * n if h0_offset is None else int(h0_offset))
         loss = C.c_float()
         logits = np.empty((n, 2), np.float32)
         _check(self._lib.ccsm_train_eval(self.handle, n, C.byref(b), None if lab is None else lab.ctypes.data, C.byref(h),

@@ -275,8 +275,11 @@ def train(args, log=sys.stderr):
         for i in range(total_step):
             b = idx[i * args.batch_size:(i + 1) * args.batch_size]
             sites = {k: train_data[k][b] for k in feats}
+            # device-drawn initial states: the generator's counter is the running site index of this rank, so every forward draws fresh
+            # values as the reference's torch.randn does (a per-step offset of 1 made consecutive steps share all but one site's window)
             loss, _ = trainer.forward_backward(sites, train_data["labels"][b], h0=None, pos_weight=args.pos_weight,
-                                               dropout_rate=args.dropout_rate, seed=args.tseed * 1009 + rank, step=gstep)
+                                               dropout_rate=args.dropout_rate, seed=args.tseed * 1009 + rank, step=gstep,
+                                               h0_offset=gstep * args.batch_size)
             average_gradients(grads, world)
             trainer.step(sched.lr, max_norm=0.5)
             gstep += 1
@@ -291,7 +294,8 @@ def train(args, log=sys.stderr):
         for i in range(-(-len(vidx) // args.batch_size)):
             b = vidx[i * args.batch_size:(i + 1) * args.batch_size]
             vloss, logits = trainer.evaluate({k: valid_data[k][b] for k in feats}, valid_data["labels"][b], h0=None,
-                                             pos_weight=args.pos_weight, seed=args.tseed * 1009 + rank, step=10 ** 9 + gstep + i)
+                                             pos_weight=args.pos_weight, seed=args.tseed * 1009 + rank + 500009,      # validation: its own stream
+                                             h0_offset=(gstep + i) * args.batch_size)
             if world > 1:
                 t = torch.tensor([vloss], device="cuda:%d" % local_rank)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)

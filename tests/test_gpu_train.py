@@ -126,6 +126,27 @@ def test_dropout_and_device_rng_h0_train_and_reduce_loss():
     assert np.mean(a[-10:]) < 0.45 and eva < 0.45 and acca > 0.85, (a[:3], a[-10:], eva, acca)
 
 
+def test_device_drawn_initial_states_advance_by_sites():
+    """The h0 generator's counter is the running SITE index (trainm: step * batch_size): site j of a batch drawn at offset o + 1
+    gets the window site j + 1 gets at offset o, and two consecutive steps of N sites share no window at all (the defect this
+    pins: an offset that advanced by 1 per STEP made consecutive steps reuse all but one site's initial states)."""
+    from ccsmeth_amd.train import Trainer
+    n = 40
+    tr = Trainer(synth.synth_weights(3), device=0, max_sites=n)
+    sites = synth.synth_sites(n, 12)
+    shifted = {k: v[1:] for k, v in sites.items()}
+    _, l0 = tr.evaluate(sites, h0=None, seed=5, h0_offset=1000)
+    _, l1 = tr.evaluate(shifted, h0=None, seed=5, h0_offset=1001)
+    assert np.array_equal(l0[1:], l1)                                   # same site, same counter window -> identical logits
+    _, a = tr.evaluate(sites, h0=None, seed=5, step=7)                  # default: offset = step * N
+    _, b = tr.evaluate(sites, h0=None, seed=5, step=8)
+    _, c = tr.evaluate(sites, h0=None, seed=5, h0_offset=8 * n)
+    assert np.array_equal(b, c)
+    assert not np.isclose(a, b, atol=1e-6).all(axis=1).any()             # no site sees the same initial states in consecutive steps
+    for shift in range(1, n):                                           # ... nor a neighbour's
+        assert not np.isclose(a[shift:], b[:n - shift], atol=1e-7).all(axis=1).any()
+
+
 def _write_features(path, sites, labels):
     code2base = "ACGTN"
     with open(path, "w") as wf:
