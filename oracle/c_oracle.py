@@ -15,7 +15,7 @@ class _W(C.Structure):
 
 
 _lib = None
-DESCRIPTION = "oracle/attbigru2s_oracle.c fp32, OpenMP over sites"
+DESCRIPTION = "oracle/attbigru2s_oracle.c fp32, blocked packed-panel GEMM + vectorised exp, OpenMP over 48-site blocks"
 
 
 def load():
@@ -25,11 +25,22 @@ def load():
             raise ImportError("oracle/_build/liboracle.so missing: run `make -C oracle`")
         _lib = C.CDLL(_PATH)
         _lib.oracle_forward.restype = C.c_int
+        _lib.oracle_isa_name.restype = C.c_char_p
     return _lib
 
 
 def max_threads():
     return int(load().oracle_max_threads())
+
+
+def block_sites():
+    """Sites per OpenMP work item: size timing samples as a multiple of block_sites() * threads."""
+    return int(load().oracle_block_sites())
+
+
+def isa_name():
+    """The instruction-set clone the library picks on this host ("avx512", "avx2+fma", "generic"; ORACLE_ISA overrides)."""
+    return load().oracle_isa_name().decode()
 
 
 def forward(weights, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0_1, h0_2, threads=0):

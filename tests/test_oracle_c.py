@@ -38,3 +38,23 @@ def test_c_oracle_thread_count_invariant(corc):
     a = corc.forward(w, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2, threads=1)
     b = corc.forward(w, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2, threads=4)
     assert np.array_equal(a[1], b[1])
+
+
+def test_c_oracle_instruction_set_clones_agree(corc, monkeypatch):
+    """The AVX-512 / AVX2 / generic clones are the same arithmetic up to fused-multiply-add rounding."""
+    w = synth.synth_weights(9)
+    s = synth.synth_sites(50, 10)
+    h1, h2 = synth.synth_h0(50, 11)
+    args = (w, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2)
+    monkeypatch.delenv("ORACLE_ISA", raising=False)
+    best = corc.forward(*args)[1]
+    for isa in ("generic", "avx2"):
+        monkeypatch.setenv("ORACLE_ISA", isa)
+        if isa == "avx2" and " avx2 " not in open("/proc/cpuinfo").read():
+            continue
+        try:
+            got = corc.forward(*args)[1]
+        finally:
+            monkeypatch.delenv("ORACLE_ISA", raising=False)
+        assert np.abs(got - best).max() < 2e-6, isa
+    assert corc.block_sites() % 12 == 0
