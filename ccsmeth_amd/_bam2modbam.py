@@ -38,21 +38,25 @@ def _convert_locs_to_mmtag(locs, seq_fwseq):
 
 
 def _convert_probs_to_mltag(probs):
-    """floor(p * 256), 255 when p >= 1 (_bam2modbam.py:206-208); p may be Python floats or NumPy float32 scalars."""
-    return [math.floor(prob * 256) if prob < 1 else 255 for prob in probs]
+    """ML bytes of the called probabilities (_bam2modbam.py:206-208): p falls into bin floor(256 p) of [0, 1) cut into 256 bins and
+    p >= 1 into the last one; computed on the values as given (Python floats or NumPy float32 scalars)."""
+    ml = []
+    for p in probs:
+        ml.append(255 if not p < 1 else math.floor(p * 256))
+    return ml
+
+
+_PULSE_TAGS = frozenset(("fi", "fp", "ri", "rp"))
+_MOD_TAGS = frozenset(("MM", "ML"))
 
 
 def _refill_tags(all_tags, mm_values, ml_values, rm_pulse=True):
-    """Drop old MM/ML (and fi/fp/ri/rp unless keep_pulse), append 'C+m?,<deltas>;' and the ML list
-    (_bam2modbam.py:211-226)."""
-    new_tags = []
-    for tagtuple in all_tags:
-        if tagtuple[0] in {"MM", "ML"}:
-            continue
-        if rm_pulse and tagtuple[0] in {"fi", "fp", "ri", "rp"}:
-            continue
-        new_tags.append((tagtuple[0], tagtuple[1]))
-    if mm_values is not None:
-        new_tags.append(("MM", "C+m?," + ",".join(map(str, mm_values)) + ";"))
-        new_tags.append(("ML", ml_values))
-    return new_tags
+    """The tag list of the output record (_bam2modbam.py:211-226): the input's (tag, value) pairs in order without any earlier
+    MM/ML and — unless the kinetics are kept — without fi/fp/ri/rp, followed by MM = 'C+m?,<deltas>;' and ML when the read was
+    called.  Value types are left to the writer, as the reference leaves them to pysam."""
+    dropped = _MOD_TAGS | _PULSE_TAGS if rm_pulse else _MOD_TAGS
+    out = [(t[0], t[1]) for t in all_tags if t[0] not in dropped]
+    if mm_values is None:
+        return out
+    deltas = ",".join(str(v) for v in mm_values)
+    return out + [("MM", "C+m?,%s;" % deltas), ("ML", ml_values)]

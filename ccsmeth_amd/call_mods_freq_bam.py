@@ -114,6 +114,7 @@ def _cal_modfreq_in_aggregate_mode(refposes, refposes_histos, model, seq_len=11,
 # MM/ML, CIGAR walk) is libccsm_bam's ccsm_bam_modcalls_of_batch; no pysam, no BAM index: the file is streamed once and the
 # calls are grouped by region afterwards, which gives the same per-region lists as the reference's fetch() per region.
 # ---------------------------------------------------------------------------------------------------------------------------
+import math
 import os
 import sys
 import time
@@ -217,34 +218,16 @@ def _motif_site_mask(seq, regions, motifs, mod_loc):
     return mask
 
 
-def _cal_modfreq_in_count_mode(modprobs, prob_cf=0, no_amb_cov=False):
-    """call_mods_freq_bam.py:209-230 -> (coverage, modified count, frequency)."""
-    cnt_all_filtered, cnt_mod = 0, 0
-    for modprob in modprobs:
-        if abs(modprob - (1 - modprob)) < prob_cf:
-            continue
-        cnt_all_filtered += 1
-        if modprob > 0.5:
-            cnt_mod += 1
-    modfreq = cnt_mod / float(cnt_all_filtered) if cnt_all_filtered > 0 else 0.
-    if no_amb_cov:
-        return cnt_all_filtered, cnt_mod, modfreq
-    if cnt_all_filtered != len(modprobs):
-        cnt_mod = np.round(len(modprobs) * modfreq, 2)
-    return len(modprobs), cnt_mod, modfreq
-
-
 def discretize_score(modprob, coverage):
-    """call_mods_freq_bam.py:244-262."""
-    if modprob > 0.66:
-        mod_reads = int(np.ceil(modprob * float(coverage)))
-    elif modprob <= 0.33:
-        mod_reads = int(np.floor(modprob * float(coverage)))
-    else:
-        mod_reads = round(coverage * modprob, 2)
-    unmod_reads = int(coverage) - mod_reads
-    adjusted_score = 0.0 if mod_reads == 0 else float(mod_reads) / (mod_reads + unmod_reads)
-    return mod_reads, unmod_reads, adjusted_score
+    """A site frequency pushed towards whole reads (call_mods_freq_bam.py:244-262; the idea is pb-CpG-tools'): above 0.66 the
+    expected number of modified reads is rounded up, at or below 0.33 down, in between it is kept to two decimals.
+    -> (modified reads, unmodified reads, modified / (modified + unmodified))."""
+    n_reads = int(coverage)
+    expected = modprob * float(coverage)
+    snap = math.ceil if modprob > 0.66 else math.floor if modprob <= 0.33 else None
+    modified = int(snap(expected)) if snap is not None else round(coverage * modprob, 2)
+    unmodified = n_reads - modified
+    return modified, unmodified, (float(modified) / (modified + unmodified) if modified != 0 else 0.0)
 
 
 def _write_one_line(beditem, wf, is_bed):

@@ -88,7 +88,7 @@ struct ccsm_workspace {
     uint4* act[2] = {nullptr, nullptr};
     float* h0buf = nullptr;
     float* part = nullptr;
-    unsigned long long* dbg = nullptr;   // phase timestamps of GRU layer 1, workgroup 0 (CCSM_PHASE_DEBUG=1)
+    unsigned long long* dbg = nullptr;   // phase time stamps of one GRU layer's workgroup 0: only in a -DCCSM_PHASE_STAMPS build
     // device staging for the host-pointer path
     uint8_t* d_in = nullptr;   // features of both strands
     float* d_h0 = nullptr;     // explicit h0 (2 x 6 x max_sites x 256), allocated on first explicit use
@@ -415,20 +415,22 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
     return CCSM_OK;
 }
 
-// One GRU layer in split-f8 arithmetic; the DBG instantiation (phase time stamps, tools/gpu_phases.py) only when asked for.
-// GRU layers in split-mx arithmetic; the DBG instantiations (phase time stamps, tools/gpu_phases.py) only when asked for
+// GRU layers in split-mx arithmetic.  A build with -DCCSM_PHASE_STAMPS also holds the instantiations that record the cycle counter
+// at the phase boundaries of workgroup 0 (tools/gpu_phases.py); the product library is built without it.
 void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4* out, const uint4* wst, const float* bias, const float* h0,
                    int rows_p, unsigned long long* dbg) {
-    if (layer == 0) {
-        if (dbg) hipLaunchKernelGGL((gru_layer0_mx_kernel<true>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
-        else hipLaunchKernelGGL((gru_layer0_mx_kernel<false>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
-    } else if (layer == 1) {
-        if (dbg) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
-        else hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
-    } else {        // the last layer feeds the attention kernel: fp8 corr fragments
-        if (dbg) hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
-        else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+#ifdef CCSM_PHASE_STAMPS
+    if (dbg) {
+        if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<true>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        return;
     }
+#endif
+    (void)dbg;
+    if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);   // fp8 corr fragments for the attention kernel
 }
 
 // Heavy kernels, once over every row used by the current slices, then the per-slice logits/softmax.
@@ -441,7 +443,11 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     if (tm) HIP_TRY(hipEventRecord(ws->ev[1], st));
     const size_t slab = (size_t)2 * ws->rows_p * kHidden;  // floats per layer (two directions)
     const dim3 ggrid(2 * (tiles / kNBGru2));
+#ifdef CCSM_PHASE_STAMPS
     static const int dbg_layer = std::getenv("CCSM_PHASE_LAYER") ? std::atoi(std::getenv("CCSM_PHASE_LAYER")) : 1;
+#else
+    constexpr int dbg_layer = -1;
+#endif
     if constexpr (F8) {
         launch_gru_mx(0, ggrid, st, ws->x0, ws->act[0], m->wstmx[0], m->bias[0], ws->h0buf, ws->rows_p, dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
@@ -450,13 +456,13 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         launch_gru_mx(2, ggrid, st, ws->act[1], ws->act[0], m->wstmx[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, dbg_layer == 2 ? ws->dbg : nullptr);
     } else {
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
-                           m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p, nullptr);
+                           m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[0], ws->act[1],
-                           m->wst2[1], m->bias[1], ws->h0buf + slab, ws->rows_p, ws->dbg);
+                           m->wst2[1], m->bias[1], ws->h0buf + slab, ws->rows_p);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
-                           m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, nullptr);
+                           m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p);
     }
     if (tm) HIP_TRY(hipEventRecord(ws->ev[4], st));
     SliceTable tab;
@@ -467,7 +473,7 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     }
     if constexpr (F8)
         hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fcw,
-                           ws->part, tab, m->att_scale[0], m->att_scale[1], dbg_layer == 3 ? ws->dbg : nullptr);
+                           ws->part, tab, m->att_scale[0], m->att_scale[1]);
     else
         hipLaunchKernelGGL(attn_fc_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
                            ws->part, tab);
@@ -675,11 +681,13 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         set_lds(reinterpret_cast<const void*>(&attn_fc_kernel), kAttLds);
         if (prec == CCSM_PRECISION_SPLIT_F8) {
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false>), kMx0Lds);
-            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false>), kMx12Lds);
-            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false>), kMx12Lds);
+#ifdef CCSM_PHASE_STAMPS
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true>), kMx12Lds);
+#endif
             set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttLds);
         }
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
@@ -743,7 +751,9 @@ ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_works
     if (st == CCSM_OK) st = dmalloc((void**)&ws->act[1], act_b);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->h0buf, h0_b);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->part, part_b);
+#ifdef CCSM_PHASE_STAMPS
     if (st == CCSM_OK && std::getenv("CCSM_PHASE_DEBUG")) st = dmalloc((void**)&ws->dbg, (kSeqLen * kWaves * 5 + 2 * kSeqLen * kWaves * 8 * 6) * 8);
+#endif
     if (st == CCSM_OK) st = dmalloc((void**)&ws->d_in, ws->in_bytes);
     if (st == CCSM_OK) st = dmalloc((void**)&ws->d_out, out_b);
     if (st == CCSM_OK) {   // padding rows are computed (and ignored): give them finite contents once

@@ -119,8 +119,7 @@ __device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint
 __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
                                                              const uint4* __restrict__ ua, const float* __restrict__ va,
                                                              const float* __restrict__ fcw, float* __restrict__ part,
-                                                             SliceTable slices, int sa_wa, int sa_ua,
-                                                             unsigned long long* __restrict__ dbg) {
+                                                             SliceTable slices, int sa_wa, int sa_ua) {
     constexpr int TG = 7;                      // timesteps per Ua pass (21 = 3 * 7)
     constexpr int CK = 2;                      // k-blocks per staged chunk = one pair
     constexpr int NCHUNK = kKB12 / CK;
@@ -139,12 +138,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
 
     for (int i = threadIdx.x; i < kClasses * 4 * kHidden; i += blockDim.x) s_fcw[i] = fcw[i];
     if (threadIdx.x < kHidden) s_va[threadIdx.x] = va[threadIdx.x];
-    // dbg (normally NULL): workgroup 0 records the cycle counter per wave: [wave][0 start, 1 q done, 2+2g chunks of group g done,
-    // 3+2g epilogue of group g done, 8 end]
-    auto stamp = [&](int i) {
-        if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[wave * 16 + i] = __builtin_readcyclecounter();
-    };
-    stamp(0);
 
     const uint4* wap = wa + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
     const uint4* uap = ua + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
@@ -202,7 +195,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
         }
     };
 
-    stamp(1);
     uint4 wu[CK][2];       // Ua fragments of the next chunk, requested one chunk ahead
 #pragma unroll
     for (int kbl = 0; kbl < CK; ++kbl) { wu[kbl][0] = uap[(kbl * 2 + 0) * kFragU4]; wu[kbl][1] = uap[(kbl * 2 + 1) * kFragU4]; }
@@ -283,7 +275,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                 }
             }
         }
-        stamp(2 + 2 * tg);
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             float e = 0.f;
@@ -301,7 +292,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             }
         }
         __syncthreads();   // all waves are done with both staging buffers before the next group restages buffer 0
-        stamp(3 + 2 * tg);
     }
 
     // ---- softmax over t and the strand-half of the logits (fixed summation order: deterministic)
@@ -332,7 +322,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
         part[(size_t)row * 2 + 0] = l0;
         part[(size_t)row * 2 + 1] = l1;
     }
-    stamp(8);
 }
 
 // Self-test of the split-f8 product: C[unit][row] = sum_k W[unit][k] X[row][k] over 32 k, W fragments packed by the host

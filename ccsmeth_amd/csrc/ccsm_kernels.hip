@@ -231,9 +231,7 @@ __global__ void pack_x0_kernel(uint4* __restrict__ x0, StrandDev s1, StrandDev s
 template <int KX>
 __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                const uint4* __restrict__ wst, const float* __restrict__ bias,
-                                                               const float* __restrict__ h0, int rows_p,
-                                                               unsigned long long* __restrict__ dbg) {
-    // dbg (normally NULL): workgroup 0 records s_memtime at the phase boundaries of every step, [step][wave][5]
+                                                               const float* __restrict__ h0, int rows_p) {
     constexpr int NB = 3;
     constexpr int CK = KX >= 4 ? 4 : KX;       // k-blocks per staged chunk
     constexpr int NCH = KX / CK;               // chunks per pass over x_t
@@ -315,10 +313,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
 
     for (int s = 0; s < kSeqLen; ++s) {
         const int t = dir ? (kSeqLen - 1 - s) : s;
-        auto stamp = [&](int k) {
-            if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
-        };
-        stamp(0);
         const int tn = s + 1 < kSeqLen ? (dir ? t - 1 : t + 1) : t;   // next step's timestep (last step: harmless reload)
         f32x16 acc[3][NB];                            // R, Z, N
         auto bias_set = [&](int set) {                // from LDS
@@ -430,7 +424,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
             stage_store((s + 1) & 1);
         }
 
-        stamp(1);
         // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------
         // entering: recurrent k-block 0 is in wq[0]
         {
@@ -457,7 +450,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
                 for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
         }
 
-        stamp(2);
         // ---------------- phase C: N += W_in x_t.  Only 9 MFMAs per k-block: the n-gate weights of a whole chunk are
         // fetched one chunk (four k-blocks) ahead.
 #define CCSM_MMC(WKB, X)                                                                                             \
@@ -497,7 +489,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
 #undef CCSM_MM
 #undef CCSM_FENCE
 
-        stamp(3);
         // ---------------- h_{t-1} of this wave's own units (C layout), then the gate epilogue -------------------
         float hprev[NB][16];
 #pragma unroll
@@ -553,7 +544,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
                 o[kFragU4 + lane] = v[1];
             }
         }
-        stamp(4);
     }
 }
 

@@ -1,4 +1,4 @@
-"""Run a few single-stream forwards (for rocprofv3 counter collection).  env: PREC, CCSM_GRU_VERSION, NSITES, REPS"""
+"""Run a few single-stream forwards (for rocprofv3 counter collection).  env: PREC, NSITES, REPS"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

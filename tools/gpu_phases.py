@@ -1,4 +1,5 @@
-"""Phase timeline of GRU layer 1 (workgroup 0, all 8 waves): s_memtime at step start / after phase A / B / C / epilogue."""
+"""Phase timeline of one split-mx GRU layer (workgroup 0, all 8 waves): cycle counter at step start / after phase A / B / C / tail.
+Needs a library built with -DCCSM_PHASE_STAMPS (tools/ab_build.sh stamps -DCCSM_PHASE_STAMPS) named by CCSM_LIB_PATH."""
 import os, sys
 os.environ["CCSM_PHASE_DEBUG"] = "1"
 import numpy as np
