@@ -96,11 +96,17 @@ __global__ void build_x0_kernel(const uint8_t* kmer, const float* ipd, const flo
     o[10] = npass[m * T + t];
 }
 
-// h0 from the counter-based generator (DEVICE_RNG): N(0,1) by Box-Muller
-__global__ void h0_rng_kernel(float* h0, int64_t n, uint64_t seed, uint64_t offset) {
+// h0 from the counter-based generator (DEVICE_RNG): N(0,1) by Box-Muller.  The counter is keyed by the GLOBAL site index
+// (offset + site), then (layer-direction, strand, unit): a site draws the same states wherever it stands in a batch, and batches whose
+// site ranges [offset, offset + N) do not overlap share no counter.  h0 layout: [2L][2N rows: strand-major][H].
+__global__ void h0_rng_kernel(float* h0, int64_t n, int n_sites, uint64_t seed, uint64_t offset) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float u1 = fmaxf(uniform01(seed, 0x68300, offset + 2 * i), 1e-7f), u2 = uniform01(seed, 0x68300, offset + 2 * i + 1);
+    const int h = (int)(i % H);
+    const int64_t row = (i / H) % (2 * (int64_t)n_sites), k = i / ((int64_t)H * 2 * n_sites);
+    const uint64_t site = offset + (uint64_t)(row % n_sites), strand = (uint64_t)(row / n_sites);
+    const uint64_t c = 2 * ((((site * (2 * L) + (uint64_t)k) * 2 + strand) * H) + (uint64_t)h);
+    const float u1 = fmaxf(uniform01(seed, 0x68300, c), 1e-7f), u2 = uniform01(seed, 0x68300, c + 1);
     h0[i] = sqrtf(-2.0f * __logf(u1)) * __cosf(6.283185307179586f * u2);
 }
 
@@ -451,7 +457,7 @@ ccsm_status upload_batch(ccsm_trainer* t, int N, const ccsm_batch* batch, const 
     } else if (mode == CCSM_H0_ZERO) {
         HIPCHK(hipMemsetAsync(t->h0, 0, sizeof(float) * nh0, t->stream));
     } else if (mode == CCSM_H0_DEVICE_RNG) {
-        h0_rng_kernel<<<blocks(nh0), 256, 0, t->stream>>>(t->h0, nh0, h0->seed, h0->offset * (uint64_t)(2 * L * 2 * H));
+        h0_rng_kernel<<<blocks(nh0), 256, 0, t->stream>>>(t->h0, nh0, N, h0->seed, h0->offset);
     } else {
         return fail(CCSM_ERR_INVALID_ARG, "unknown h0 mode");
     }

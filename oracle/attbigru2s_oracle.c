@@ -125,14 +125,15 @@ static int packed_build(const oracle_isa* isa, const oracle_weights* w, packed_w
 static void gru_dir(const oracle_isa* isa, const float* x, int K, const float* h0, size_t h0_stride, const float* wp_ih,
                     const float* wp_hh, const float* b_ih, const float* b_hh, int reverse, float* out, int col0, int B, float* gi,
                     float* gh, float* h) {
-    isa->gemm(x, K, wp_ih, b_ih, gi, 3 * H, B * L, 3 * H, K);
     for (int b = 0; b < B; ++b) memcpy(h + (size_t)b * H, h0 + (size_t)b * h0_stride, sizeof(float) * H);
     for (int s = 0; s < L; ++s) {
         const int t = reverse ? L - 1 - s : s;
+        /* the input projection of THIS step only (rows b*L + t of x): the per-thread working set stays at the two layer buffers, which
+         * is what lets all hardware threads of a many-core host run at once without streaming a (B*L, 3H) buffer through DRAM */
+        isa->gemm(x + (size_t)t * K, L * K, wp_ih, b_ih, gi, 3 * H, B, 3 * H, K);
         isa->gemm(h, H, wp_hh, b_hh, gh, 3 * H, B, 3 * H, H);
         for (int b = 0; b < B; ++b)
-            isa->gates(gi + ((size_t)b * L + t) * 3 * H, gh + (size_t)b * 3 * H, h + (size_t)b * H,
-                       out + ((size_t)b * L + t) * 2 * H + col0);
+            isa->gates(gi + (size_t)b * 3 * H, gh + (size_t)b * 3 * H, h + (size_t)b * H, out + ((size_t)b * L + t) * 2 * H + col0);
     }
 }
 
@@ -149,7 +150,7 @@ static int scratch_alloc(scratch* s) {
     s->x0 = zalloc((size_t)BS * L * F0);
     s->bufa = zalloc((size_t)BS * L * 2 * H);
     s->bufb = zalloc((size_t)BS * L * 2 * H);
-    s->gi = zalloc((size_t)BS * L * 3 * H);
+    s->gi = zalloc((size_t)BS * 3 * H);
     s->gh = zalloc((size_t)BS * 3 * H);
     s->h = zalloc((size_t)BS * H);
     s->hn = zalloc((size_t)BS * 2 * H);
