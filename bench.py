@@ -92,15 +92,16 @@ def cpu_baseline(weights, target_s, device_model):
     the "prob delta vs ref" half of BASELINE.json's metric."""
     from ccsmeth_amd.utils import synth
     from oracle import c_oracle
-    threads = c_oracle.max_threads()
+    omp_default = c_oracle.max_threads()
+    threads = c_oracle.usable_threads()          # OpenMP default capped by affinity and the cgroup CPU quota
     unit = c_oracle.block_sites() * threads          # one block per thread
     probe_n = unit
     s = synth.synth_sites(probe_n, 777)
     h1, h2 = synth.synth_h0(probe_n, 778)
     args = (s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2)
-    c_oracle.forward(weights, *args)            # warm-up (thread pool, page faults)
+    c_oracle.forward(weights, *args, threads=threads)            # warm-up (thread pool, page faults)
     t0 = time.perf_counter()
-    _, ref_probs = c_oracle.forward(weights, *args)
+    _, ref_probs = c_oracle.forward(weights, *args, threads=threads)
     rate = probe_n / (time.perf_counter() - t0)
     ws = device_model.workspace(probe_n)
     _, gpu_probs = ws.forward_host(s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"],
@@ -114,12 +115,13 @@ def cpu_baseline(weights, target_s, device_model):
     h1, h2 = synth.synth_h0(n, 780)
     t0 = time.perf_counter()
     for _ in range(reps):
-        c_oracle.forward(weights, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2)
+        c_oracle.forward(weights, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2, threads=threads)
     dt = time.perf_counter() - t0
     n_total = n * reps
-    return {"value": n / dt, "unit": "sites/s", "cores": threads, "kind": "port",
-            "GFLOPs": n / dt * FLOP_PER_SITE / 1e9,
-            "sample": "%d synthetic sites (same generator as the GPU run), explicit h0, %s, %.1f s" % (n, c_oracle.DESCRIPTION, dt),
+    return {"value": n_total / dt, "unit": "sites/s", "cores": threads, "kind": "port",
+            "sites_per_s_per_core": n_total / dt / threads, "GFLOPs": n_total / dt * FLOP_PER_SITE / 1e9,
+            "sample": "%d x %d synthetic sites (same generator as the GPU run), explicit h0, %s [%s], %d threads (OpenMP default %d, capped by "
+                      "affinity / cgroup CPU quota), %.1f s" % (reps, n, c_oracle.DESCRIPTION, c_oracle.isa_name(), threads, omp_default, dt),
             "gpu_prob_max_abs_err": prob_err, "gpu_prob_err_sites": probe_n}
 
 

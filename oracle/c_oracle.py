@@ -33,6 +33,24 @@ def max_threads():
     return int(load().oracle_max_threads())
 
 
+def usable_threads():
+    """Threads worth starting on this host: the OpenMP default capped by the scheduler affinity and by the cgroup CPU quota
+    (a container that sees 256 CPUs but may use 16 CPU-seconds per second runs 16 threads at full speed and 128 at a fraction)."""
+    import math
+    n = max_threads()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def block_sites():
     """Sites per OpenMP work item: size timing samples as a multiple of block_sites() * threads."""
     return int(load().oracle_block_sites())
