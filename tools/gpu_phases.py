@@ -22,11 +22,10 @@ _lib.check(dm._lib.ccsm_debug_read(ws.handle, 5, buf.ctypes.data, buf.nbytes))
 d = buf[:21 * 8 * 5].reshape(21, 8, 5).astype(np.int64)
 ph = np.diff(d, axis=2)                       # [step][wave][A, B, C, epilogue]
 gap = d[1:, :, 0] - d[:-1, :, 4]
+names = os.environ.get("PHASE_NAMES", "X,H,sigm,tail").split(",")      # one-pass kernel; two-pass build: A,B,C,tail
 print("cycles per phase (mean over steps 1..19, per wave):")
-print("  A   ", np.round(ph[1:20, :, 0].mean(0)))
-print("  B   ", np.round(ph[1:20, :, 1].mean(0)))
-print("  C   ", np.round(ph[1:20, :, 2].mean(0)))
-print("  epi ", np.round(ph[1:20, :, 3].mean(0)))
-print("  step", np.round((d[2:20, :, 0] - d[1:19, :, 0]).mean(0)))
-print("ideal MFMA cycles per wave: A 18432, B 13824, C 9216 (x2 waves per SIMD)")
-
+for k, nm in enumerate(names):
+    print("  %-5s" % nm, np.round(ph[1:20, :, k].mean(0)))
+print("  gap  ", np.round(gap[1:19].mean(0)))
+print("  step ", np.round((d[2:20, :, 0] - d[1:19, :, 0]).mean(0)))
+print("ideal MFMA cycles per wave and step (x2 waves per SIMD): 64-row one-pass kernel X 16 x (12 x 32 + 6 x 32) = 9216, H 8 x 576 = 4608")
