@@ -126,33 +126,54 @@ def cpu_baseline(weights, target_s, device_model):
 
 
 class Runner:
-    """K steps of one DeviceModel on one stream: full groups from workspace 0, a ragged last group from workspace 1."""
+    """K steps of one DeviceModel.  Two workspaces on two streams take the groups in turn: the small per-batch kernels of a group (initial
+    states, input packing: ccsm_group_add) run on their stream while the previous group's four heavy kernels run on the other; the
+    heavy kernels themselves are chained by events, so exactly one of them runs at a time (their HIP-event times stay per-launch times)."""
 
     def __init__(self, dm, pool, dev, grp, rank):
         import torch
         self.torch, self.dm, self.pool, self.dev, self.grp, self.rank = torch, dm, pool, dev, grp, rank
-        self.ws = [dm.workspace(BATCH * grp) for _ in range(2)]
-        self.streams = [torch.cuda.Stream(dev)] * 2
-        self.outs = [[(torch.empty((BATCH, 2), device=dev), torch.empty((BATCH, 2), device=dev)) for _ in range(grp)] for _ in range(2)]
+        self.ws = [dm.workspace(BATCH * grp) for _ in range(3)]      # 0, 1: full groups in turn; 2: a ragged last group (own timers)
+        self.overlap = os.environ.get("CCSM_BENCH_OVERLAP", "1") != "0"
+        s0 = torch.cuda.Stream(dev)
+        self.streams = [s0, torch.cuda.Stream(dev) if self.overlap else s0]
+        self.outs = [[(torch.empty((BATCH, 2), device=dev), torch.empty((BATCH, 2), device=dev)) for _ in range(grp)] for _ in range(3)]
         self.step0 = 0
+        self.k = 0
+        self.last_run = None
 
     def run(self, steps):
         """Enqueue `steps` steps (no synchronisation)."""
         full, rag = divmod(steps, self.grp)
-        plan = [(0, self.grp)] * full + ([(1, rag)] if rag else [])
         i = self.step0
-        for k, nb in plan:
+        for nb in [self.grp] * full + ([rag] if rag else []):
+            st = self.streams[self.k]
+            k = self.k if nb == self.grp else 2
             for j in range(nb):
-                self.ws[k].group_add_torch(*self.pool[i % len(self.pool)], stream=self.streams[k].cuda_stream, out=self.outs[k][j], seed=1234,
+                self.ws[k].group_add_torch(*self.pool[i % len(self.pool)], stream=st.cuda_stream, out=self.outs[k][j], seed=1234,
                                            offset=(self.rank * 10**9 + i * BATCH))
                 i += 1
-            self.ws[k].group_run(stream=self.streams[k].cuda_stream)
+            if self.overlap and self.last_run is not None:
+                st.wait_event(self.last_run)
+            self.ws[k].group_run(stream=st.cuda_stream)
+            if self.overlap:
+                self.last_run = self.torch.cuda.Event()
+                self.last_run.record(st)
+            self.k ^= 1
         self.step0 = i
         return full, rag
 
     def arm(self):
         for w in self.ws:
             w.set_timing(True)
+
+    def kernel_times(self, full_groups=True):
+        """Mean per-launch kernel times (ms) of the full groups (both workspaces) or of the ragged group, and the launches averaged."""
+        parts = [w.timing_mean() for w in (self.ws[:2] if full_groups else self.ws[2:])]
+        n = sum(nr for _, nr in parts)
+        if n == 0:
+            return None, 0
+        return sum(np.array(kt) * nr for kt, nr in parts if nr) / n, n
 
     def close(self):
         for w in self.ws:
@@ -197,7 +218,7 @@ def extras(weights, dm, dev, pool, grp):
         r = Runner(dm3, pool, dev, grp, 0)
         steps = 4 * grp
         dt, full, _, _ = timed(r, steps, grp, fence)
-        kt, nr = r.ws[0].timing_mean()
+        kt, nr = r.kernel_times()
         r.close(); dm3.close()
         ach = 2.0 * MAC_GRU12 * BATCH * grp / (float(np.mean(kt[1:3])) * 1e-3)
         return {"value": steps * BATCH / dt, "unit": "sites/s", "dtype": ARITH[3][0], "steps": steps,
@@ -314,7 +335,7 @@ def main():
     # ---- per-kernel launch durations: mean over the FULL groups of the timed region (HIP events recorded on the stream each
     # kernel was launched on; the warm-up runs were dropped by re-arming the timers after the warm-up fence); a ragged group has
     # its own workspace and timers
-    kt, nruns = runner.ws[0].timing_mean() if full else runner.ws[1].timing_mean()
+    kt, nruns = runner.kernel_times(full_groups=bool(full))
     kt = np.array(kt)
     dom_ms = float(kt[1:3].mean())
     sites_per_launch = BATCH * (grp if full else rag)
@@ -331,7 +352,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": "attbigru2s_b21 forward on synthetic 21-mer CpG batches (BASELINE.json configs[1])",
-                       "batch": BATCH, "sites_per_step": BATCH, "coalesce": grp, "full_groups": full, "ragged_group_batches": rag,
+                       "batch": BATCH, "sites_per_step": BATCH, "coalesce": grp, "streams": 2 if runner.overlap else 1, "full_groups": full, "ragged_group_batches": rag,
                        "warmup_steps_run": w_steps, "h0": "device Philox N(0,1)", "arithmetic": arith,
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if a.precision == 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",

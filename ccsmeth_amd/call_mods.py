@@ -125,7 +125,12 @@ def _post_sort_index(out_path, args, log):
         print("[post_process] bam_sort_index costs %.2f seconds (%s)" % (time.time() - t, "sorted + indexed" if did else "already in order: indexed"),
               file=log)
     except Exception as e:  # noqa: BLE001
-        print("[post_process] failed sorting / indexing modbam file: %s" % e, file=log)
+        # the modbam itself is complete; tell the user exactly what is missing (the sort spills to disk above its memory limit, so this
+        # is a full disk, an unreadable file or the like)
+        print("[post_process] WARNING: sorting / indexing %s FAILED (%s): the file is unsorted and has no index; run "
+              "`samtools sort` + `samtools index` on it before call_freqb" % (out_path, e), file=log)
+        return False
+    return True
 
 
 def _sort_limit():

@@ -11,6 +11,7 @@
 #include <deque>
 #include <map>
 #include <new>
+#include <queue>
 #include <string>
 #include <thread>
 #include <vector>
@@ -465,11 +466,16 @@ struct ccsm_bam_writer {
     }
 };
 
+// No exception may cross the C boundary: allocation failures and the like become an error code + ccsm_bam_last_error().
+#define CCSM_BAM_CATCH                                                                        \
+    catch (const std::bad_alloc&) { return fail("out of host memory"); }                      \
+    catch (const std::exception& e) { return fail(std::string("unexpected: ") + e.what()); }
+
 extern "C" {
 
 const char* ccsm_bam_last_error(void) { return g_err.c_str(); }
 
-int ccsm_bam_open(const char* path, int threads, ccsm_bam_reader** out) {
+int ccsm_bam_open(const char* path, int threads, ccsm_bam_reader** out) try {
     if (!path || !out) return fail("path and out must be non-NULL");
     *out = nullptr;
     ccsm_bam_reader* r = new (std::nothrow) ccsm_bam_reader();
@@ -498,7 +504,7 @@ int ccsm_bam_open(const char* path, int threads, ccsm_bam_reader** out) {
     }
     *out = r;
     return 0;
-}
+} CCSM_BAM_CATCH
 
 int ccsm_bam_header(const ccsm_bam_reader* r, const char** text, int64_t* text_len, const uint8_t** refs, int64_t* refs_len,
                     int32_t* n_ref) {
@@ -519,7 +525,7 @@ void ccsm_bam_close(ccsm_bam_reader* r) {
 
 void ccsm_bam_batch_free(ccsm_bam_batch* b) { delete reinterpret_cast<OwnedBatch*>(b); }
 
-int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) {
+int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) try {
     if (!r || !out) return fail("reader and out must be non-NULL");
     *out = nullptr;
     if (max_reads <= 0) return fail("max_reads must be > 0");
@@ -628,9 +634,9 @@ int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) {
     ob->view.voffset_end = r->voffset(r->abs_pos());
     *out = &ob->view;
     return 0;
-}
+} CCSM_BAM_CATCH
 
-int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_end) {
+int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_end) try {
     if (!r) return fail("reader must be non-NULL");
     const uint64_t coff = voffset_start >> 16, uoff = voffset_start & 0xffffu;
     if (std::fseek(r->fh, (long)coff, SEEK_SET) != 0) return fail("seek failed");
@@ -647,7 +653,7 @@ int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_e
         r->pos += (size_t)uoff;
     }
     return 0;
-}
+} CCSM_BAM_CATCH
 
 int ccsm_bam_tell(ccsm_bam_reader* r, uint64_t* voffset) {
     if (!r || !voffset) return fail("arguments must be non-NULL");
@@ -659,7 +665,7 @@ int ccsm_bam_tell(ccsm_bam_reader* r, uint64_t* voffset) {
 int64_t ccsm_bam_inflated_bytes(const ccsm_bam_reader* r) { return r ? (int64_t)r->inflated : 0; }
 
 int ccsm_bam_writer_open(const char* path, const char* header_text, int64_t text_len, const uint8_t* refs, int64_t refs_len,
-                         int32_t n_ref, int threads, int level, ccsm_bam_writer** out) {
+                         int32_t n_ref, int threads, int level, ccsm_bam_writer** out) try {
     if (!path || !out || (text_len > 0 && !header_text) || (refs_len > 0 && !refs)) return fail("bad arguments");
     *out = nullptr;
     if (level < 1 || level > 9) return fail("level must be in [1, 9]");
@@ -679,10 +685,10 @@ int ccsm_bam_writer_open(const char* path, const char* header_text, int64_t text
     if (refs_len > 0) w->put(refs, (size_t)refs_len);
     *out = w;
     return 0;
-}
+} CCSM_BAM_CATCH
 
 int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int32_t* first_site, const int32_t* locs,
-                         const float* prob1, const uint8_t* tagged, int rm_pulse, int32_t* n_tagged) {
+                         const float* prob1, const uint8_t* tagged, int rm_pulse, int32_t* n_tagged) try {
     if (!w || !b) return fail("writer and batch must be non-NULL");
     int32_t cnt = 0;
     std::vector<uint8_t> rec;
@@ -739,27 +745,27 @@ int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int3
     }
     if (n_tagged) *n_tagged = cnt;
     return 0;
-}
+} CCSM_BAM_CATCH
 
-int ccsm_bam_writer_flush(ccsm_bam_writer* w, int64_t* file_offset) {
+int ccsm_bam_writer_flush(ccsm_bam_writer* w, int64_t* file_offset) try {
     if (!w) return fail("writer must be non-NULL");
     if (w->flush_blocks(true)) return 1;
     if (std::fflush(w->fh) != 0) return fail("write failed");
     if (file_offset) *file_offset = (int64_t)std::ftell(w->fh);
     return 0;
-}
+} CCSM_BAM_CATCH
 
-int ccsm_bam_writer_close(ccsm_bam_writer* w) {
+int ccsm_bam_writer_close(ccsm_bam_writer* w) try {
     if (!w) return 0;
     int rc = w->flush_blocks(true);
     if (rc == 0 && std::fwrite(kBgzfEof, 1, sizeof(kBgzfEof), w->fh) != sizeof(kBgzfEof)) rc = fail("write failed");
     if (std::fclose(w->fh) != 0 && rc == 0) rc = fail("close failed");
     delete w;
     return rc;
-}
+} CCSM_BAM_CATCH
 
 int ccsm_bam_modcalls_of_batch(const ccsm_bam_batch* b, const ccsm_bam_modcall_opts* opts, const uint8_t* const* site_mask,
-                               const int64_t* mask_len, int32_t n_ref, int threads, ccsm_bam_modcalls** out) {
+                               const int64_t* mask_len, int32_t n_ref, int threads, ccsm_bam_modcalls** out) try {
     if (!b || !opts || !out) return fail("batch, opts and out must be non-NULL");
     *out = nullptr;
     if (opts->refsites_all && (!site_mask || !mask_len)) return fail("refsites_all needs the reference site masks");
@@ -793,7 +799,7 @@ int ccsm_bam_modcalls_of_batch(const ccsm_bam_batch* b, const ccsm_bam_modcall_o
     oc->view.n_used = used;
     *out = &oc->view;
     return 0;
-}
+} CCSM_BAM_CATCH
 
 void ccsm_bam_modcalls_free(ccsm_bam_modcalls* c) { delete reinterpret_cast<OwnedCalls*>(c); }
 
@@ -826,7 +832,7 @@ struct RefIndex {
 
 }  // namespace
 
-int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads, int* sorted, int64_t* n_records) {
+int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads, int* sorted, int64_t* n_records) try {
     if (!bam_path || !bai_path) return fail("paths must be non-NULL");
     ccsm_bam_reader* r = nullptr;
     if (ccsm_bam_open(bam_path, threads, &r)) return 1;
@@ -932,33 +938,60 @@ int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads
     const bool okw = std::fwrite(out.data(), 1, out.size(), f) == out.size();
     if (std::fclose(f) != 0 || !okw) return fail("write failed");
     return 0;
-}
+} CCSM_BAM_CATCH
 
-int ccsm_bam_sort(const char* in_path, const char* out_path, int threads, int level, int64_t max_bytes) {
-    if (!in_path || !out_path) return fail("paths must be non-NULL");
-    ccsm_bam_reader* r = nullptr;
-    if (ccsm_bam_open(in_path, threads, &r)) return 1;
+// Coordinate sort (samtools sort order: reference id with unplaced reads last, position, reverse-strand flag; stable).  Records are
+// collected up to max_bytes (0 = no limit); when the input is larger, each full collection is sorted and spilled as a run
+// (<out_path>.sorttmp.<k>.bam, BGZF level 1) and the runs are merged k-way at the end, like samtools sort's temporary files — host
+// memory stays bounded by max_bytes plus one decode window per run.
+namespace {
+struct SortChunk {
     std::vector<uint8_t> data;
     std::vector<uint64_t> off, k1;
     std::vector<uint32_t> k2;
-    int rc = 0;
-    for (;;) {
-        if (r->fill(4)) { rc = 1; break; }
-        if (r->avail() == 0) break;
-        if (r->avail() < 4) { rc = fail("truncated BAM record"); break; }
-        const uint32_t bs = rd32(r->stream.data() + r->pos);
-        if (bs < 32) { rc = fail("corrupt BAM record (block_size < 32)"); break; }
-        if (r->fill(4 + (size_t)bs)) { rc = 1; break; }
-        if (r->avail() < 4 + (size_t)bs) { rc = fail("truncated BAM record"); break; }
-        if (max_bytes > 0 && (int64_t)(data.size() + 4 + bs) > max_bytes) { rc = fail("the records do not fit the in-memory sort limit"); break; }
-        const uint8_t* rec = r->stream.data() + r->pos;
-        uint64_t a; uint32_t b;
-        sort_key(rec + 4, a, b);
-        off.push_back(data.size()); k1.push_back(a); k2.push_back(b);
-        data.insert(data.end(), rec, rec + 4 + bs);
-        r->pos += 4 + bs;
+    void clear() { data.clear(); off.clear(); k1.clear(); k2.clear(); }
+    // records in sorted order to w
+    int write_sorted(ccsm_bam_writer* w) {
+        const size_t n = k1.size();
+        if (n > 0xfffffffeull) return fail("too many records in one sort run");
+        std::vector<uint32_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return k1[x] < k1[y] || (k1[x] == k1[y] && k2[x] < k2[y]); });
+        off.push_back(data.size());
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t j = order[i];
+            if (w->put(data.data() + off[j], (size_t)(off[j + 1] - off[j]))) return 1;
+        }
+        off.pop_back();
+        return 0;
     }
-    off.push_back(data.size());
+};
+// one record at a time from a run file
+struct RunCursor {
+    ccsm_bam_reader* r = nullptr;
+    uint64_t k1 = 0;
+    uint32_t k2 = 0, bs = 0;
+    bool done = false;
+    int advance(bool consume) {             // 0 ok (or done set), 1 error
+        if (consume) r->pos += 4 + (size_t)bs;
+        if (r->fill(4)) return 1;
+        if (r->avail() == 0) { done = true; return 0; }
+        if (r->avail() < 4) return fail("truncated sort run");
+        bs = rd32(r->stream.data() + r->pos);
+        if (bs < 32) return fail("corrupt sort run");
+        if (r->fill(4 + (size_t)bs)) return 1;
+        if (r->avail() < 4 + (size_t)bs) return fail("truncated sort run");
+        sort_key(r->stream.data() + r->pos + 4, k1, k2);
+        return 0;
+    }
+    const uint8_t* rec() const { return r->stream.data() + r->pos; }
+};
+}  // namespace
+
+int ccsm_bam_sort(const char* in_path, const char* out_path, int threads, int level, int64_t max_bytes) try {
+    if (!in_path || !out_path) return fail("paths must be non-NULL");
+    ccsm_bam_reader* r = nullptr;
+    if (ccsm_bam_open(in_path, threads, &r)) return 1;
     // header: @HD ... SO:coordinate as samtools sort leaves it
     std::string text = r->text;
     {
@@ -980,23 +1013,77 @@ int ccsm_bam_sort(const char* in_path, const char* out_path, int threads, int le
     }
     const std::vector<uint8_t> refs = r->refs;
     const int32_t n_ref = r->n_ref;
-    ccsm_bam_close(r);
-    if (rc) return rc;
-    const size_t n = k1.size();
-    std::vector<uint32_t> order(n);
-    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-    if (n > 0xfffffffeull) return fail("too many records for the in-memory sort");
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return k1[x] < k1[y] || (k1[x] == k1[y] && k2[x] < k2[y]); });
-    ccsm_bam_writer* w = nullptr;
-    if (ccsm_bam_writer_open(out_path, text.data(), (int64_t)text.size(), refs.data(), (int64_t)refs.size(), n_ref, threads, level, &w)) return 1;
-    for (size_t i = 0; i < n; ++i) {
-        const uint32_t j = order[i];
-        if (w->put(data.data() + off[j], (size_t)(off[j + 1] - off[j]))) { ccsm_bam_writer_close(w); return 1; }
+    std::vector<std::string> runs;
+    auto remove_runs = [&]() { for (const std::string& p : runs) std::remove(p.c_str()); };
+    SortChunk ch;
+    auto spill = [&]() -> int {
+        const std::string path = std::string(out_path) + ".sorttmp." + std::to_string(runs.size()) + ".bam";
+        ccsm_bam_writer* w = nullptr;
+        if (ccsm_bam_writer_open(path.c_str(), text.data(), (int64_t)text.size(), refs.data(), (int64_t)refs.size(), n_ref, threads, 1, &w)) return 1;
+        runs.push_back(path);
+        if (ch.write_sorted(w)) { ccsm_bam_writer_close(w); return 1; }
+        ch.clear();
+        return ccsm_bam_writer_close(w);
+    };
+    int rc = 0;
+    for (;;) {
+        if (r->fill(4)) { rc = 1; break; }
+        if (r->avail() == 0) break;
+        if (r->avail() < 4) { rc = fail("truncated BAM record"); break; }
+        const uint32_t bs = rd32(r->stream.data() + r->pos);
+        if (bs < 32) { rc = fail("corrupt BAM record (block_size < 32)"); break; }
+        if (r->fill(4 + (size_t)bs)) { rc = 1; break; }
+        if (r->avail() < 4 + (size_t)bs) { rc = fail("truncated BAM record"); break; }
+        if (max_bytes > 0 && !ch.k1.empty() && (int64_t)(ch.data.size() + 4 + bs) > max_bytes && (rc = spill()) != 0) break;
+        const uint8_t* rec = r->stream.data() + r->pos;
+        uint64_t a; uint32_t b;
+        sort_key(rec + 4, a, b);
+        ch.off.push_back(ch.data.size()); ch.k1.push_back(a); ch.k2.push_back(b);
+        ch.data.insert(ch.data.end(), rec, rec + 4 + bs);
+        r->pos += 4 + bs;
     }
-    return ccsm_bam_writer_close(w);
+    ccsm_bam_close(r);
+    if (rc == 0 && !runs.empty() && !ch.k1.empty()) rc = spill();      // the last partial collection becomes a run too
+    if (rc) { remove_runs(); return rc; }
+    ccsm_bam_writer* w = nullptr;
+    if (ccsm_bam_writer_open(out_path, text.data(), (int64_t)text.size(), refs.data(), (int64_t)refs.size(), n_ref, threads, level, &w)) { remove_runs(); return 1; }
+    if (runs.empty()) {
+        if (ch.write_sorted(w)) { ccsm_bam_writer_close(w); return 1; }
+        return ccsm_bam_writer_close(w);
+    }
+    // k-way merge; ties go to the earlier run (= earlier in the input: the sort stays stable)
+    std::vector<RunCursor> cur(runs.size());
+    for (size_t i = 0; i < runs.size() && rc == 0; ++i) {
+        if (ccsm_bam_open(runs[i].c_str(), 1, &cur[i].r)) { rc = 1; break; }
+        rc = cur[i].advance(false);
+    }
+    auto later = [&](size_t x, size_t y) {       // priority_queue keeps the LARGEST on top: order by "comes later"
+        if (cur[x].k1 != cur[y].k1) return cur[x].k1 > cur[y].k1;
+        if (cur[x].k2 != cur[y].k2) return cur[x].k2 > cur[y].k2;
+        return x > y;
+    };
+    std::priority_queue<size_t, std::vector<size_t>, decltype(later)> heap(later);
+    for (size_t i = 0; i < cur.size() && rc == 0; ++i)
+        if (!cur[i].done) heap.push(i);
+    while (rc == 0 && !heap.empty()) {
+        const size_t i = heap.top();
+        heap.pop();
+        if (w->put(cur[i].rec(), 4 + (size_t)cur[i].bs)) { rc = 1; break; }
+        rc = cur[i].advance(true);
+        if (rc == 0 && !cur[i].done) heap.push(i);
+    }
+    for (RunCursor& c : cur)
+        if (c.r) ccsm_bam_close(c.r);
+    remove_runs();
+    const int rc2 = ccsm_bam_writer_close(w);
+    return rc ? rc : rc2;
+} catch (const std::bad_alloc&) {
+    return fail("out of host memory while sorting (lower the sort memory limit: the sort then spills runs to disk)");
+} catch (const std::exception& e) {
+    return fail(std::string("sort: ") + e.what());
 }
 
-int ccsm_bam_align_info(const ccsm_bam_batch* b, int32_t* mapq, int32_t* qstart, int32_t* qend, double* identity) {
+int ccsm_bam_align_info(const ccsm_bam_batch* b, int32_t* mapq, int32_t* qstart, int32_t* qend, double* identity) try {
     if (!b || !mapq || !qstart || !qend || !identity) return fail("arguments must be non-NULL");
     for (int32_t r = 0; r < b->n_reads; ++r) {
         const uint8_t* body = b->records + b->rec_offset[r] + 4;
@@ -1024,6 +1111,6 @@ int ccsm_bam_align_info(const ccsm_bam_batch* b, int32_t* mapq, int32_t* qstart,
         identity[r] = nalign > 0 ? (double)(cnt[0] + cnt[7]) / (double)nalign : 0.0;
     }
     return 0;
-}
+} CCSM_BAM_CATCH
 
 }  // extern "C"

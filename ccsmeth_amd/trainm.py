@@ -210,8 +210,13 @@ def average_gradients(flat, world):
     """DDP's gradient averaging as one collective: sum over ranks (RCCL all_reduce on the flat buffer), divide by world."""
     import torch.distributed as dist
     if world > 1:
+        import torch
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world)
+        if flat.is_cuda:
+            # libccsm_train runs on its own stream and does not know torch's: the averaged gradients must be complete before
+            # trainer.step() reads them
+            torch.cuda.current_stream(flat.device).synchronize()
     return flat
 
 

@@ -366,6 +366,31 @@ def test_sort_and_index_aligned_bam(tmp_path):
                 assert v >= min_off
 
 
+def test_sort_spills_runs_and_merges_to_the_same_file(tmp_path):
+    """A sort memory limit far below the input: sorted runs go to temporary files and are merged; the result is record for record
+    what the in-memory sort gives (stable: equal keys keep their input order across runs), and no temporary file is left."""
+    rng = np.random.default_rng(8)
+    recs = _aligned_records(rng, 600)
+    for i in range(0, len(recs) - 6, 7):                              # runs of equal keys across the file
+        recs[i].ref_id, recs[i].pos, recs[i].flag = 1, 4242, 0
+    order = rng.permutation(len(recs))
+    refs = [("c%d" % i, 300000) for i in range(3)]
+    paths = [str(tmp_path / ("s%d.bam" % k)) for k in range(2)]
+    for p in paths:
+        with bamio.BamWriter(p, "@HD\tVN:1.5\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs), refs, level=1) as w:
+            for i in order:
+                w.write(recs[i])
+    assert bamnative.sort_and_index(paths[0], threads=2) is True
+    assert bamnative.sort_and_index(paths[1], threads=2, max_bytes=200000) is True      # ~6 MB of records: dozens of runs
+    with bamio.BamReader(paths[0]) as a, bamio.BamReader(paths[1]) as b:
+        assert a.header_text == b.header_text
+        ra, rb = list(a), list(b)
+    assert len(ra) == len(rb) == len(recs)
+    assert [(x.query_name, x.ref_id, x.pos, x.flag) for x in ra] == [(x.query_name, x.ref_id, x.pos, x.flag) for x in rb]
+    assert not [f for f in os.listdir(tmp_path) if "sorttmp" in f]
+    assert open(paths[0] + ".bai", "rb").read()[:4] == b"BAI\x01" and os.path.getsize(paths[1] + ".bai") > 0
+
+
 def test_index_of_unaligned_bam_and_errors(tmp_path):
     path = str(tmp_path / "u.bam")
     with bamio.BamWriter(path, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
@@ -375,13 +400,16 @@ def test_index_of_unaligned_bam_and_errors(tmp_path):
     assert open(path + ".bai", "rb").read() == b"BAI\x01" + (0).to_bytes(4, "little") + (7).to_bytes(8, "little")
     with pytest.raises(IOError):
         bamnative.index_build(str(tmp_path / "missing.bam"))
-    with pytest.raises(IOError, match="in-memory sort limit"):
-        p2 = str(tmp_path / "b.bam")
-        with bamio.BamWriter(p2, "", [("c", 1000)]) as w:
-            w.write(bamio.BamRecord("a", flag=0, ref_id=0, pos=500, cigar=[(0, 4)], seq="ACGT"))
-            w.write(bamio.BamRecord("b", flag=0, ref_id=0, pos=100, cigar=[(0, 4)], seq="ACGT"))
-        bamnative.load().ccsm_bam_sort  # noqa: B018
-        bamnative._check(bamnative.load().ccsm_bam_sort(p2.encode(), (p2 + ".s").encode(), 1, 6, 10))
+    # a memory limit below a single record: every record becomes its own run, the merge still sorts
+    p2 = str(tmp_path / "b.bam")
+    with bamio.BamWriter(p2, "", [("c", 1000)]) as w:
+        w.write(bamio.BamRecord("a", flag=0, ref_id=0, pos=500, cigar=[(0, 4)], seq="ACGT"))
+        w.write(bamio.BamRecord("b", flag=0, ref_id=0, pos=100, cigar=[(0, 4)], seq="ACGT"))
+    bamnative._check(bamnative.load().ccsm_bam_sort(p2.encode(), (p2 + ".s").encode(), 1, 6, 10))
+    with bamio.BamReader(p2 + ".s") as rd:
+        assert [r.query_name for r in rd] == ["b", "a"]
+    with pytest.raises(IOError):                                        # an output path that cannot be created
+        bamnative._check(bamnative.load().ccsm_bam_sort(p2.encode(), str(tmp_path / "no_dir" / "x.bam").encode(), 1, 6, 0))
 
 
 def test_modcalls_index_sort_survive_corrupted_records(tmp_path):
