@@ -12,6 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_plain.json 2> $O/bench_plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --extras none --cpu-seconds 0 > $O/bench_under_rocprof.json 2> $O/rocprof.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+python $R/tools/kernel_trace_by_shape.py $(find /tmp/prof_stats -name "*kernel_trace.csv" | head -1) $O/bench_kernel_by_shape.md 3 > /dev/null
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   name=${pass%%:*}; ctrs=${pass#*:}
   PREC=${PREC:-4} REPS=6 rocprofv3 --kernel-trace --output-format csv --pmc $ctrs -d /tmp/pmc/$name -- python $R/tools/gpu_group.py > /dev/null 2>> $O/pmc.err
@@ -19,3 +20,4 @@ done
 python $R/tools/pmc_summary.py /tmp/pmc $O/pmc.md "$TAG PMC - coalesced launch (3 x 2048 sites = 256 workgroups), precision ${PREC:-4}"
 tail -1 $O/bench_plain.json
 head -8 $O/bench_kernel_stats.csv
+cat $O/bench_kernel_by_shape.md
