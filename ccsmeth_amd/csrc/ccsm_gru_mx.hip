@@ -734,7 +734,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         CCSM_FENCE;
         auto zwork = [&](int bt) {                                  // z = sigmoid(Z) in place, inside phase C (vector ALU otherwise idle)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
+            for (int r = 0; r < 16; ++r) {
+                float v = sigmoid_f(acc[1][bt][r]);
+#ifndef CCSM_ZWORK_FREE
+                asm volatile("" : "+v"(v));                         // pins the evaluation HERE: the compiler otherwise sinks it to its first use, the tail
+#endif
+                acc[1][bt][r] = v;
+            }
         };
 
         stamp(2);
