@@ -25,7 +25,7 @@ def write_synthetic_hifi_bam(path, n_reads, read_len, cpg=0.012, seed=3):
     return time.time() - t0, os.path.getsize(path)
 
 
-def call_mods_end_to_end(n_reads=1500, read_len=15000):
+def call_mods_end_to_end(n_reads=4000, read_len=15000):
     """`call_mods --io native` on a synthetic BAM (BGZF inflate, parse, feature extraction + model on the GPU, MM/ML, BGZF deflate);
     second of two runs (the first pays page-ins and library loads)."""
     import torch
@@ -39,7 +39,7 @@ def call_mods_end_to_end(n_reads=1500, read_len=15000):
     torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
     res, dt = None, None
     for _ in range(2):
-        args = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", os.path.join(tmp, "out"), "--batch_size", "12288", "--holes_batch", "64",
+        args = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", os.path.join(tmp, "out"), "--batch_size", "12288", "--holes_batch", "128",
                                           "--no_sort"])
         t0 = time.time()
         res = call_mods(args, log=open(os.devnull, "w"))
