@@ -364,6 +364,8 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, int64_
 
 inline dim3 blocks(int64_t n, int per = 256) { return dim3((unsigned)((n + per - 1) / per)); }
 
+#include "ccsm_train_seq.hip"
+
 }  // namespace
 
 struct ccsm_trainer {
@@ -397,6 +399,8 @@ struct ccsm_trainer {
     std::vector<StepGraph> graphs;
     bool use_graph = false;
     int sp20 = 0, sp21 = 0;            // timesteps per batched weight-gradient product (divisors of 20 / 21); 0 = by batch size
+    uint4* whh_frag = nullptr;         // split fp16 B-operand fragments of every W_hh (ccsm_train_seq.hip), repacked every forward
+    bool stepwise = false;             // CCSM_TRAIN_STEPWISE=1: one rocBLAS product + gate kernel per timestep (the pre-fusion path, A/B runs)
 };
 
 namespace {
@@ -484,6 +488,13 @@ ccsm_status forward_dir(ccsm_trainer* t, int M, int l, int d, const float* X, in
     rocblas_handle blas = d == 0 ? t->blas : t->blas1;
     hipStream_t st = d == 0 ? t->stream : t->stream1;
     BLASCHK(rm_gemm(blas, false, true, T * M, G, in, 1.f, X, in, P + kOff.w_ih[l][d], in, 0.f, t->gi[d], G));
+    if (!t->stepwise) {     // all 21 steps in one launch (ccsm_train_seq.hip)
+        gru_seq_fwd_kernel<<<(M + 31) / 32, 512, kSqLds, st>>>(t->gi[d], t->h0 + (size_t)(2 * l + d) * M * H, t->whh_frag + (size_t)(2 * l + d) * kSqFragPerDir,
+                                                               P + kOff.b_ih[l][d], P + kOff.b_hh[l][d], t->out[l] + d * H, t->sav[l][d][0], t->sav[l][d][1],
+                                                               t->sav[l][d][2], t->sav[l][d][3], M, d, train ? 1 : 0);
+        HIPCHK(hipGetLastError());
+        return CCSM_OK;
+    }
     for (int s = 0; s < T; ++s) {
         const int tt = d == 0 ? s : T - 1 - s;
         const float* hprev;
@@ -504,6 +515,10 @@ ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, bool have_la
     const float* P = t->params;
     hipStream_t st = t->stream;
     build_x0_kernel<<<blocks((int64_t)T * M), 256, 0, st>>>(t->kmer, t->ipd, t->pw, t->npass, P + kOff.embed, t->x0, M);
+    if (!t->stepwise)
+        for (int l = 0; l < L; ++l)
+            for (int d = 0; d < 2; ++d)
+                pack_whh_kernel<<<blocks(8 * (H / 16) * 3 * 64), 256, 0, st>>>(P + kOff.w_hh[l][d], t->whh_frag + (size_t)(2 * l + d) * kSqFragPerDir);
     const bool drop = train && rate > 0.f;
     for (int l = 0; l < L; ++l) {
         const float* X = l == 0 ? t->x0 : (drop ? t->xdrop[l - 1] : t->out[l - 1]);
@@ -684,7 +699,8 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
             for (int k = 0; k < 4; ++k) { t->sav[l][d][k] = nullptr; TRY(dalloc(&t->sav[l][d][k], T * M * H)); }
     }
     for (int d = 0; d < 2; ++d) {
-        TRY(dalloc(&t->gi[d], T * M * G)); TRY(dalloc(&t->gh[d], M * G)); TRY(dalloc(&t->dgi[d], T * M * G)); TRY(dalloc(&t->dgh[d], T * M * G));
+        TRY(dalloc(&t->gi[d], T * M * G + 32 * G));     // + 32 rows of slack: gru_seq_fwd_kernel reads whole 32-row tiles
+        TRY(dalloc(&t->gh[d], M * G)); TRY(dalloc(&t->dgi[d], T * M * G)); TRY(dalloc(&t->dgh[d], T * M * G));
         TRY(dalloc(&t->carry[d], M * H)); TRY(dalloc(&t->cpart[d], 3 * M * H)); TRY(dalloc(&t->part[d], (size_t)T * G * H2));
     }
     TRY(dalloc(&t->hn, M * H2)); TRY(dalloc(&t->q, M * H)); TRY(dalloc(&t->KS, T * M * H)); TRY(dalloc(&t->e, T * M)); TRY(dalloc(&t->a, T * M));
@@ -694,6 +710,9 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
       if (t->sp20 < 0 || (t->sp20 && (T - 1) % t->sp20)) t->sp20 = 0;
       if (t->sp21 < 0 || (t->sp21 && T % t->sp21)) t->sp21 = 0; }
     { const char* e = std::getenv("CCSM_TRAIN_GRAPH"); t->use_graph = e && e[0] == '1'; }   // opt-in: measured +1.5 % (the step is not launch-bound)
+    { const char* e = std::getenv("CCSM_TRAIN_STEPWISE"); t->stepwise = e && e[0] == '1'; }
+    TRY(dalloc(&t->whh_frag, (size_t)2 * L * kSqFragPerDir));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSqLds));
     TRY(dalloc(&t->dc, M * H2)); TRY(dalloc(&t->dq, M * H)); TRY(dalloc(&t->dhn, M * H2)); TRY(dalloc(&t->dA, T * M * H2)); TRY(dalloc(&t->dB, T * M * H2));
     // parameters: host tensors -> flat order
     std::vector<float> flat((size_t)kOff.total);
@@ -730,6 +749,7 @@ void ccsm_train_destroy(ccsm_trainer* t) {
     for (float* p : fl) if (p) (void)hipFree(p);
     for (auto& c : t->graphs) if (c.exec) (void)hipGraphExecDestroy(c.exec);
     if (t->ctl) (void)hipFree(t->ctl);
+    if (t->whh_frag) (void)hipFree(t->whh_frag);
     if (t->kmer) (void)hipFree(t->kmer);
     if (t->labels) (void)hipFree(t->labels);
     for (int l = 0; l < L; ++l) {

@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libccsm_train.so")
+LIB_PATH = os.environ.get("CCSM_TRAIN_LIB_PATH") or os.path.join(_HERE, "lib", "libccsm_train.so")   # the variable: A/B builds (tools/)
 EXPORTS = ("ccsm_train_last_error", "ccsm_train_num_params", "ccsm_train_param_offsets", "ccsm_train_create", "ccsm_train_destroy",
            "ccsm_train_forward_backward", "ccsm_train_eval", "ccsm_train_step", "ccsm_train_grad_ptr", "ccsm_train_get_params",
            "ccsm_train_set_params", "ccsm_train_get_grads")
