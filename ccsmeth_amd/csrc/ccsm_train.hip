@@ -400,7 +400,11 @@ struct ccsm_trainer {
     bool use_graph = false;
     int sp20 = 0, sp21 = 0;            // timesteps per batched weight-gradient product (divisors of 20 / 21); 0 = by batch size
     uint4* whh_frag = nullptr;         // split fp16 B-operand fragments of every W_hh (ccsm_train_seq.hip), repacked every forward
-    bool stepwise = false;             // CCSM_TRAIN_STEPWISE=1: one rocBLAS product + gate kernel per timestep (the pre-fusion path, A/B runs)
+    uint4* whh_t_frag = nullptr;       // ... and of every W_hh^T (the backward kernel's product dgh W_hh)
+    int seq_mode = -1;                 // recurrent part: 1 = one fused launch per layer and direction (ccsm_train_seq.hip), 0 = one rocBLAS
+                                       // product + gate kernel per timestep, -1 = by batch size (fused from 768 rows up: measured 4.13 vs
+                                       // 3.92 ms per step at 256 sites, 5.73 vs 6.40 at 512, 13.6 vs 18.4 at 2048); CCSM_TRAIN_STEPWISE=0|1 forces
+    bool stepwise_for(int M) const { return seq_mode == 0 || (seq_mode < 0 && M < 768); }
 };
 
 namespace {
@@ -488,7 +492,7 @@ ccsm_status forward_dir(ccsm_trainer* t, int M, int l, int d, const float* X, in
     rocblas_handle blas = d == 0 ? t->blas : t->blas1;
     hipStream_t st = d == 0 ? t->stream : t->stream1;
     BLASCHK(rm_gemm(blas, false, true, T * M, G, in, 1.f, X, in, P + kOff.w_ih[l][d], in, 0.f, t->gi[d], G));
-    if (!t->stepwise) {     // all 21 steps in one launch (ccsm_train_seq.hip)
+    if (!t->stepwise_for(M)) {     // all 21 steps in one launch (ccsm_train_seq.hip)
         gru_seq_fwd_kernel<<<(M + 31) / 32, 512, kSqLds, st>>>(t->gi[d], t->h0 + (size_t)(2 * l + d) * M * H, t->whh_frag + (size_t)(2 * l + d) * kSqFragPerDir,
                                                                P + kOff.b_ih[l][d], P + kOff.b_hh[l][d], t->out[l] + d * H, t->sav[l][d][0], t->sav[l][d][1],
                                                                t->sav[l][d][2], t->sav[l][d][3], M, d, train ? 1 : 0);
@@ -515,10 +519,13 @@ ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, bool have_la
     const float* P = t->params;
     hipStream_t st = t->stream;
     build_x0_kernel<<<blocks((int64_t)T * M), 256, 0, st>>>(t->kmer, t->ipd, t->pw, t->npass, P + kOff.embed, t->x0, M);
-    if (!t->stepwise)
+    if (!t->stepwise_for(M))
         for (int l = 0; l < L; ++l)
             for (int d = 0; d < 2; ++d)
-                pack_whh_kernel<<<blocks(8 * (H / 16) * 3 * 64), 256, 0, st>>>(P + kOff.w_hh[l][d], t->whh_frag + (size_t)(2 * l + d) * kSqFragPerDir);
+                {
+                    pack_whh_kernel<<<blocks(8 * (H / 16) * 3 * 64), 256, 0, st>>>(P + kOff.w_hh[l][d], t->whh_frag + (size_t)(2 * l + d) * kSqFragPerDir);
+                    if (train) pack_whh_t_kernel<<<blocks(8 * (G / 16) * 64), 256, 0, st>>>(P + kOff.w_hh[l][d], t->whh_t_frag + (size_t)(2 * l + d) * kSqFragPerDir);
+                }
     const bool drop = train && rate > 0.f;
     for (int l = 0; l < L; ++l) {
         const float* X = l == 0 ? t->x0 : (drop ? t->xdrop[l - 1] : t->out[l - 1]);
@@ -557,23 +564,30 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
     // timesteps per batched weight-gradient product: measured best 2 / 3 up to 1024 sites per step (6.98 vs 8.30 ms at 512), 4 / 3 above
     const int sp20 = t->sp20 ? t->sp20 : (M <= 2048 ? 2 : 4), sp21 = t->sp21 ? t->sp21 : 3;
     float* cpart = t->cpart[d];
-    HIPCHK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)M * H, st));
-    HIPCHK(hipMemsetAsync(cpart, 0, sizeof(float) * (size_t)3 * M * H, st));
-    for (int s = T - 1; s >= 0; --s) {
-        const int tt = d == 0 ? s : T - 1 - s;
-        const float* hprev;
-        int ld;
-        if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
-        else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
-        const size_t so = (size_t)tt * M * H;
-        gru_gate_bwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(dO + (size_t)tt * M * H2 + d * H, carry, cpart, t->sav[l][d][0] + so,
-                                                                   t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, hprev, ld,
-                                                                   dgi + (size_t)tt * M * G, dgh + (size_t)tt * M * G, M);
-        if (s > 0) {
-            const float one = 1.f, zero = 0.f;      // cpart[g] (M x 256) = dgh_t[:, g*256 : (g+1)*256] W_hh[g*256 : (g+1)*256, :]
-            BLASCHK(rocblas_sgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, H, M, H, &one, P + kOff.w_hh[l][d], H,
-                                                  (rocblas_stride)H * H, dgh + (size_t)tt * M * G, G, (rocblas_stride)H, &zero, cpart, H,
-                                                  (rocblas_stride)M * H, 3));
+    if (!t->stepwise_for(M)) {     // all 21 steps in one launch (ccsm_train_seq.hip)
+        gru_seq_bwd_kernel<<<(M + 31) / 32, 512, kSbLds, st>>>(dO + d * H, t->out[l] + d * H, t->h0 + (size_t)(2 * l + d) * M * H,
+                                                               t->whh_t_frag + (size_t)(2 * l + d) * kSqFragPerDir, t->sav[l][d][0], t->sav[l][d][1],
+                                                               t->sav[l][d][2], t->sav[l][d][3], dgi, dgh, Gd + kOff.b_ih[l][d], Gd + kOff.b_hh[l][d], M, d);
+        HIPCHK(hipGetLastError());
+    } else {
+        HIPCHK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)M * H, st));
+        HIPCHK(hipMemsetAsync(cpart, 0, sizeof(float) * (size_t)3 * M * H, st));
+        for (int s = T - 1; s >= 0; --s) {
+            const int tt = d == 0 ? s : T - 1 - s;
+            const float* hprev;
+            int ld;
+            if (s == 0) { hprev = t->h0 + (size_t)(2 * l + d) * M * H; ld = H; }
+            else { hprev = t->out[l] + (size_t)(d == 0 ? tt - 1 : tt + 1) * M * H2 + d * H; ld = H2; }
+            const size_t so = (size_t)tt * M * H;
+            gru_gate_bwd_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(dO + (size_t)tt * M * H2 + d * H, carry, cpart, t->sav[l][d][0] + so,
+                                                                       t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, hprev, ld,
+                                                                       dgi + (size_t)tt * M * G, dgh + (size_t)tt * M * G, M);
+            if (s > 0) {
+                const float one = 1.f, zero = 0.f;      // cpart[g] (M x 256) = dgh_t[:, g*256 : (g+1)*256] W_hh[g*256 : (g+1)*256, :]
+                BLASCHK(rocblas_sgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, H, M, H, &one, P + kOff.w_hh[l][d], H,
+                                                      (rocblas_stride)H * H, dgh + (size_t)tt * M * G, G, (rocblas_stride)H, &zero, cpart, H,
+                                                      (rocblas_stride)M * H, 3));
+            }
         }
     }
     // weight gradients over all steps at once
@@ -587,8 +601,10 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
         BLASCHK(atb_split(blas, st, G, H, M * sp20, (T - 1) / sp20, dgh, G, t->out[l] + (size_t)M * H2 + H, H2, part, 1, dWhh));
     }
     BLASCHK(atb_split(blas, st, G, in, M * sp21, T / sp21, dgi, G, X, in, part, 0, Gd + kOff.w_ih[l][d]));
-    colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgi, Gd + kOff.b_ih[l][d], T * M, G);
-    colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgh, Gd + kOff.b_hh[l][d], T * M, G);
+    if (t->stepwise_for(M)) {      // (the fused backward kernel has accumulated the bias gradients already)
+        colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgi, Gd + kOff.b_ih[l][d], T * M, G);
+        colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgh, Gd + kOff.b_hh[l][d], T * M, G);
+    }
     return CCSM_OK;
 }
 
@@ -690,13 +706,13 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
     TRY(dalloc(&t->kmer, M * T));
     TRY(dalloc(&t->ipd, M * T)); TRY(dalloc(&t->pw, M * T)); TRY(dalloc(&t->npass, M * T));
     TRY(dalloc(&t->labels, (size_t)max_sites));
-    TRY(dalloc(&t->h0, 2 * L * M * H));
+    TRY(dalloc(&t->h0, 2 * L * M * H + 32 * H));      // + 32 rows of slack everywhere the fused recurrent kernels read whole 32-row tiles
     TRY(dalloc(&t->x0, T * M * F0));
     for (int l = 0; l < L; ++l) {
-        TRY(dalloc(&t->out[l], T * M * H2));
+        TRY(dalloc(&t->out[l], T * M * H2 + 32 * H2));
         if (l + 1 < L) TRY(dalloc(&t->xdrop[l], T * M * H2));
         for (int d = 0; d < 2; ++d)
-            for (int k = 0; k < 4; ++k) { t->sav[l][d][k] = nullptr; TRY(dalloc(&t->sav[l][d][k], T * M * H)); }
+            for (int k = 0; k < 4; ++k) { t->sav[l][d][k] = nullptr; TRY(dalloc(&t->sav[l][d][k], T * M * H + 32 * H)); }
     }
     for (int d = 0; d < 2; ++d) {
         TRY(dalloc(&t->gi[d], T * M * G + 32 * G));     // + 32 rows of slack: gru_seq_fwd_kernel reads whole 32-row tiles
@@ -710,10 +726,12 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
       if (t->sp20 < 0 || (t->sp20 && (T - 1) % t->sp20)) t->sp20 = 0;
       if (t->sp21 < 0 || (t->sp21 && T % t->sp21)) t->sp21 = 0; }
     { const char* e = std::getenv("CCSM_TRAIN_GRAPH"); t->use_graph = e && e[0] == '1'; }   // opt-in: measured +1.5 % (the step is not launch-bound)
-    { const char* e = std::getenv("CCSM_TRAIN_STEPWISE"); t->stepwise = e && e[0] == '1'; }
+    { const char* e = std::getenv("CCSM_TRAIN_STEPWISE"); if (e && (e[0] == '0' || e[0] == '1')) t->seq_mode = e[0] == '1' ? 0 : 1; }
     TRY(dalloc(&t->whh_frag, (size_t)2 * L * kSqFragPerDir));
+    TRY(dalloc(&t->whh_t_frag, (size_t)2 * L * kSqFragPerDir));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSbLds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSqLds));
-    TRY(dalloc(&t->dc, M * H2)); TRY(dalloc(&t->dq, M * H)); TRY(dalloc(&t->dhn, M * H2)); TRY(dalloc(&t->dA, T * M * H2)); TRY(dalloc(&t->dB, T * M * H2));
+    TRY(dalloc(&t->dc, M * H2)); TRY(dalloc(&t->dq, M * H)); TRY(dalloc(&t->dhn, M * H2)); TRY(dalloc(&t->dA, T * M * H2 + 32 * H2)); TRY(dalloc(&t->dB, T * M * H2 + 32 * H2));
     // parameters: host tensors -> flat order
     std::vector<float> flat((size_t)kOff.total);
     auto put = [&](int64_t off, const float* src, int64_t n) { if (src) std::memcpy(flat.data() + off, src, sizeof(float) * (size_t)n); };
@@ -750,6 +768,7 @@ void ccsm_train_destroy(ccsm_trainer* t) {
     for (auto& c : t->graphs) if (c.exec) (void)hipGraphExecDestroy(c.exec);
     if (t->ctl) (void)hipFree(t->ctl);
     if (t->whh_frag) (void)hipFree(t->whh_frag);
+    if (t->whh_t_frag) (void)hipFree(t->whh_t_frag);
     if (t->kmer) (void)hipFree(t->kmer);
     if (t->labels) (void)hipFree(t->labels);
     for (int l = 0; l < L; ++l) {

@@ -115,10 +115,10 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
         for (int r = 0; r < 16; ++r) { acc[0][r] = nr[r] + bir; acc[1][r] = nz[r] + biz; acc[2][r] = bhn; gn[r] = nn_[r] + bin; }
         const _Float16* hi = sq_lds + (size_t)cur * 2 * kSqBufHalfs + j * kSqRowHalfs + 8 * hh;
         const _Float16* lo = hi + kSqBufHalfs;
-        // weight fragments two k-blocks ahead (three register sets; a fourth spills: the stream is latency-bound, 768 KiB per step and
-        // workgroup from L2); the k-block loop stays rolled: fully unrolled, the compiler hoists all 96 fragment loads to the top of the
+        // weight fragments three k-blocks ahead (four register sets: the stream is latency-bound, 768 KiB per step and workgroup from
+        // L2); the k-block loop stays rolled: fully unrolled, the compiler hoists all 96 fragment loads to the top of the
         // step and spills them
-        uint4 wq[3][6];
+        uint4 wq[4][6];
         auto wload = [&](uint4 (&w)[6], int kb) {
 #pragma unroll
             for (int f = 0; f < 6; ++f) w[f] = wf[(size_t)(kb * 6 + f) * 64];
@@ -136,17 +136,19 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
             }
         };
         asm volatile("" ::: "memory");
-        wload(wq[0], 0); wload(wq[1], 1);
+        wload(wq[0], 0); wload(wq[1], 1); wload(wq[2], 2);
 #pragma unroll 1
-        for (int kb = 0; kb + 3 <= H / 16; kb += 3) {                  // k-blocks 0..14, three per trip, loads two k-blocks ahead
-            wload(wq[2], kb + 2);
+        for (int kb = 0; kb < H / 16; kb += 4) {                       // four k-blocks per trip, loads three k-blocks ahead
+            constexpr int last = H / 16 - 1;
+            wload(wq[3], kb + 3);
             kblock(kb, wq[0]);
-            wload(wq[0], kb + 3);
+            wload(wq[0], kb + 4 < last ? kb + 4 : last);               // past the end: a harmless reload
             kblock(kb + 1, wq[1]);
-            wload(wq[1], kb + 4 < H / 16 ? kb + 4 : H / 16 - 1);       // past the end: a harmless reload
+            wload(wq[1], kb + 5 < last ? kb + 5 : last);
             kblock(kb + 2, wq[2]);
+            wload(wq[2], kb + 6 < last ? kb + 6 : last);
+            kblock(kb + 3, wq[3]);
         }
-        kblock(H / 16 - 1, wq[0]);
         asm volatile("" ::: "memory");                                 // memory operations stay on their side: the compiler otherwise hoists the
         if (s + 1 < T) gi_load(s + 1);                                 // next step's 48 loads above the k-block loop and spills
         asm volatile("" ::: "memory");
@@ -162,11 +164,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
             const float rr = sigmoidf_(acc[0][r]);
             const float zz = sigmoidf_(acc[1][r]);
             const float hp = acc[2][r];
-#ifdef CCSM_SEQ_FAST_TANH
-            const float nn = 1.0f - 2.0f / (__expf(2.0f * (gn[r] + rr * hp)) + 1.0f);
-#else
             const float nn = tanhf(gn[r] + rr * hp);
-#endif
             h[r] = (1.0f - zz) * nn + zz * h[r];
             if (c < rows_left) {
                 ot[oo + (unsigned)c * H2] = h[r];
@@ -178,5 +176,165 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
         }
         publish(cur ^ 1);
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward.  Per timestep (in the reverse of the forward order) and lane, for its 16 (row, unit) pairs:
+//   dh = d out_t + dh_{t+1} z_{t+1} + (dgh_{t+1} W_hh)            (the product of the step before, straight from the accumulator)
+//   dn = dh (1 - z)(1 - n^2); dz = dh (h_{t-1} - n) z (1 - z); dr = dn hp r (1 - r)
+//   dgi_t = [dr, dz, dn], dgh_t = [dr, dz, dn r] -> global (the weight-gradient products read them), dgh_t also as fp16 hi / lo into
+//   LDS = the A operand (32 rows x 768) of this step's product with W_hh (K = 768: 48 k-blocks, wave w owns units [32w, 32w + 32)).
+// One accumulator tile per wave leaves room for eleven k-blocks of weight fragments in flight (the forward kernel: three); the next
+// step's 96 input values per lane are requested behind the product loop, in the registers the fragments vacate.
+// The bias gradients (column sums of dgi / dgh over rows and steps) are accumulated in registers on the way: no separate pass.
+//   dO, hout: (T, M, 512) with the direction's column offset applied; hout = the layer's outputs (h_{t-1} of a step);
+//   wt: B-operand fragments of W_hh^T: [wave][kb 48][hi | lo][lane], lane (j, g) = split(W_hh[16 kb + 8 g + 0..7][32 wave + j]).
+constexpr int kSbRowHalfs = G + 8;                               // 1552 B rows: 16-byte aligned, conflict-free
+constexpr int kSbLds = 2 * 32 * kSbRowHalfs * 2;                 // [hi | lo][32 rows][776] halfs = 99328 B
+constexpr float kSbScale = 4096.0f;
+
+__global__ void pack_whh_t_kernel(const float* __restrict__ w, uint4* __restrict__ frag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (wave * 48 + kb) * 64 + lane
+    if (i >= 8 * (G / 16) * 64) return;
+    const int lane = i & 63, kb = (i >> 6) % (G / 16), wave = (i >> 6) / (G / 16);
+    const float* src = w + (size_t)(16 * kb + 8 * (lane >> 5)) * H + 32 * wave + (lane & 31);
+    sq_half8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float v = src[(size_t)k * H];
+        hi[k] = (_Float16)v;
+        lo[k] = (_Float16)(v - (float)hi[k]);
+    }
+    const size_t o = (size_t)(i >> 6) * 2 * 64 + lane;
+    frag[o] = __builtin_bit_cast(uint4, hi);
+    frag[o + 64] = __builtin_bit_cast(uint4, lo);
+}
+
+__global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __restrict__ dO, const float* __restrict__ hout,
+                                                            const float* __restrict__ h0, const uint4* __restrict__ wt,
+                                                            const float* __restrict__ R, const float* __restrict__ Z,
+                                                            const float* __restrict__ Nn, const float* __restrict__ HP,
+                                                            float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ db_ih,
+                                                            float* __restrict__ db_hh, int M, int reverse) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 sb_lds[];
+    _Float16* t_hi = sb_lds;
+    _Float16* t_lo = sb_lds + 32 * kSbRowHalfs;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, hh = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    const int u = 32 * wave + j;
+    const int lrow = row0 + 4 * hh;                                 // the lane's rows are lrow + c, c = 8 q + e
+    const int rows_left = M - lrow;
+    auto opaque = [](unsigned v) { asm volatile("" : "+v"(v)); return v; };
+    const uint4* wf = wt + (size_t)wave * (G / 16) * 2 * 64 + lane;
+
+    float carry[16], mm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { carry[r] = 0.f; mm[r] = 0.f; }
+    float s_dr = 0.f, s_dz = 0.f, s_dn = 0.f, s_dnr = 0.f;          // bias gradients = column sums of dgi / dgh over rows and steps
+    // inputs of one step: requested ahead (behind the previous step's first weight requests), all unguarded (32 rows of slack)
+    float xd[16], xr[16], xz[16], xn[16], xp[16], xh[16];
+    auto in_load = [&](int s) {
+        const int tt = reverse ? T - 1 - s : s;
+        const unsigned o2 = opaque((unsigned)lrow * H2 + u), o1 = opaque((unsigned)lrow * H + u);
+        const float* dt = dO + (size_t)tt * M * H2;
+        const size_t so = (size_t)tt * M * H;
+        const float* hp_ = s == 0 ? h0 : hout + (size_t)(reverse ? tt + 1 : tt - 1) * M * H2;
+        const unsigned oh = s == 0 ? o1 : o2, sh = s == 0 ? H : H2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned c = (unsigned)(8 * (r >> 2) + (r & 3));
+            xd[r] = dt[o2 + c * H2];
+            xr[r] = (R + so)[o1 + c * H];
+            xz[r] = (Z + so)[o1 + c * H];
+            xn[r] = (Nn + so)[o1 + c * H];
+            xp[r] = (HP + so)[o1 + c * H];
+            xh[r] = hp_[oh + c * sh];
+        }
+    };
+    in_load(T - 1);
+    for (int s = T - 1; s >= 0; --s) {
+        const int tt = reverse ? T - 1 - s : s;
+        // ---- gates of this lane's 16 elements
+        {
+            float* gi_t = dgi + (size_t)tt * M * G;
+            float* gh_t = dgh + (size_t)tt * M * G;
+            const unsigned og = opaque((unsigned)lrow * G + u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = 8 * (r >> 2) + (r & 3);
+                const float dh = xd[r] + carry[r] + mm[r];
+                const float rr = xr[r], zz = xz[r], nn = xn[r];
+                const float dn = dh * (1.0f - zz) * (1.0f - nn * nn);
+                const float dz = dh * (xh[r] - nn) * zz * (1.0f - zz);
+                const float dr = dn * xp[r] * rr * (1.0f - rr);
+                const float dnr = dn * rr;
+                carry[r] = dh * zz;
+                if (c < rows_left) {
+                    const unsigned o = og + (unsigned)c * G;
+                    gi_t[o] = dr; gi_t[o + H] = dz; gi_t[o + 2 * H] = dn;
+                    gh_t[o] = dr; gh_t[o + H] = dz; gh_t[o + 2 * H] = dnr;
+                    s_dr += dr; s_dz += dz; s_dn += dn; s_dnr += dnr;
+                }
+                const int row = 4 * hh + c;
+                // gradients are small (a mean over the batch): scaled by 2^12 into fp16's normal range before the split (a value of 1e-7
+                // would otherwise be a subnormal hi with no lo), saturated instead of overflowing; the product is scaled back
+                const float v3[3] = {dr, dz, dnr};
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const float v = fminf(fmaxf(v3[g] * kSbScale, -60000.f), 60000.f);
+                    const _Float16 x = (_Float16)v;
+                    t_hi[row * kSbRowHalfs + g * H + u] = x;
+                    t_lo[row * kSbRowHalfs + g * H + u] = (_Float16)(v - (float)x);
+                }
+            }
+        }
+        if (s == 0) break;                                          // d h0 is not a parameter gradient
+        __syncthreads();                                            // the dgh tile is complete
+        // ---- mm = dgh_t W_hh for this wave's 32 units: 48 k-blocks, fragments eleven k-blocks ahead (22 KiB per wave in flight: the stream is latency-bound)
+        sq_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const _Float16* ph = t_hi + j * kSbRowHalfs + 8 * hh;
+        const _Float16* pl = t_lo + j * kSbRowHalfs + 8 * hh;
+        uint4 wq[12][2];
+        auto wload = [&](uint4 (&w)[2], int kb) { w[0] = wf[(size_t)(kb * 2) * 64]; w[1] = wf[(size_t)(kb * 2 + 1) * 64]; };
+        auto kblock = [&](int kb, const uint4 (&w)[2]) {
+            const sq_half8 a_hi = *reinterpret_cast<const sq_half8*>(ph + 16 * kb);
+            const sq_half8 a_lo = *reinterpret_cast<const sq_half8*>(pl + 16 * kb);
+            const sq_half8 w_hi = __builtin_bit_cast(sq_half8, w[0]);
+            const sq_half8 w_lo = __builtin_bit_cast(sq_half8, w[1]);
+            acc = sq_mfma(a_hi, w_hi, acc);
+            acc = sq_mfma(a_lo, w_hi, acc);
+            acc = sq_mfma(a_hi, w_lo, acc);
+        };
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < 11; ++b) wload(wq[b], b);
+        asm volatile("" ::: "memory");
+#pragma unroll 1
+        for (int kb = 0; kb < G / 16; kb += 12) {
+            constexpr int last = G / 16 - 1;
+#pragma unroll
+            for (int b = 0; b < 12; ++b) {
+                const int nx = kb + b + 11;
+                wload(wq[(b + 11) % 12], nx < last ? nx : last);    // past the end: a harmless reload
+                kblock(kb + b, wq[b]);
+            }
+        }
+        asm volatile("" ::: "memory");
+        in_load(s - 1);                                             // the next step's inputs (their registers held weight fragments until here)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mm[r] = acc[r] * (1.0f / kSbScale);
+        __syncthreads();                                            // every wave has read the tile before the next step overwrites it
+    }
+    // bias gradients (pre-zeroed by the caller): both half-waves hold the same unit
+    s_dr += __shfl_xor(s_dr, 32, 64); s_dz += __shfl_xor(s_dz, 32, 64); s_dn += __shfl_xor(s_dn, 32, 64); s_dnr += __shfl_xor(s_dnr, 32, 64);
+    if (hh == 0) {
+        atomicAdd(db_ih + u, s_dr); atomicAdd(db_ih + H + u, s_dz); atomicAdd(db_ih + 2 * H + u, s_dn);
+        atomicAdd(db_hh + u, s_dr); atomicAdd(db_hh + H + u, s_dz); atomicAdd(db_hh + 2 * H + u, s_dnr);
     }
 }
