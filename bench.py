@@ -268,7 +268,7 @@ def extras(weights, dm, dev, pool, grp):
 
     def call_mods_e2e():
         from ccsmeth_amd.utils import benchdata
-        return benchdata.call_mods_end_to_end(n_reads=int(os.environ.get("CCSM_BENCH_READS", "1500")), read_len=15000)
+        return benchdata.call_mods_end_to_end(n_reads=int(os.environ.get("CCSM_BENCH_READS", "4000")), read_len=15000)
 
     def aggregate():
         from ccsmeth_amd.utils import benchdata
@@ -296,10 +296,13 @@ def main():
     if torch.cuda.device_count() <= local_rank:
         sys.stderr.write("bench.py: rank %d has no GPU (device_count %d)\n" % (local_rank, torch.cuda.device_count()))
         sys.exit(2)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CCSM_BENCH_FORCE_DIST") == "1"     # the variable: exercise the RCCL path on a one-GPU box
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.barrier()              # pays the communicator's lazy set-up (hundreds of ms of idle GPU) HERE, not in the fence in front of the timed region
     n_gpus = world
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -322,12 +325,12 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     elapsed, full, rag, w_steps = timed(runner, a.steps, a.warmup, fence)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -380,7 +383,7 @@ def main():
         print(json.dumps(line), flush=True)
     runner.close()
     dm.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
