@@ -274,7 +274,58 @@ def extras(weights, dm, dev, pool, grp):
         from ccsmeth_amd.utils import benchdata
         return benchdata.aggregate_50m(dev)
 
+    def torch_cpu():
+        # The same model assembled from stock PyTorch modules (nn.Embedding, nn.GRU, nn.Linear: what the reference's CPU path executes,
+        # models.py:89-150 / utils/attention.py:48-70) on the host cores this container may use; neither oracle/ nor the reference is
+        # involved.  Also a second, independent check of the HIP path's probabilities.
+        import math
+        from ccsmeth_amd.utils import synth
+        threads = len(os.sched_getaffinity(0))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                threads = min(threads, max(1, math.ceil(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+        torch.set_num_threads(threads)
+        tw = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
+        gru = torch.nn.GRU(11, 256, 3, batch_first=True, bidirectional=True)
+        gru.load_state_dict({k[4:]: v for k, v in tw.items() if k.startswith("rnn.")})
+        gru.eval()
+
+        def strand(kmer, ipd, pw, npass, h0):
+            x = torch.cat([tw["embed.weight"][kmer.long()], ipd[..., None], pw[..., None], npass[:, None, None].expand(-1, 21, 1)], 2)
+            out, hn = gru(x, h0)
+            q = torch.cat([hn[-2], hn[-1]], 1) @ tw["_att3.Wa.weight"].T
+            e = torch.tanh(q[:, None, :] + out @ tw["_att3.Ua.weight"].T) @ tw["_att3.va.weight"].T
+            return (torch.softmax(e, 1) * out).sum(1)
+
+        def forward(s, h1, h2):
+            t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in s.items()}
+            with torch.no_grad():
+                c = torch.cat([strand(t["kmer1"], t["ipd1"], t["pw1"], t["npass1"], torch.from_numpy(h1)),
+                               strand(t["kmer2"], t["ipd2"], t["pw2"], t["npass2"], torch.from_numpy(h2))], 1)
+                return torch.softmax(c @ tw["fc1.weight"].T + tw["fc1.bias"], 1).numpy()
+        n = 512 * max(1, threads // 4)
+        s = synth.synth_sites(n, 991)
+        h1, h2 = synth.synth_h0(n, 992)
+        forward(s, h1, h2)
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 6.0:
+            probs = forward(s, h1, h2)
+            reps += 1
+        dt = time.perf_counter() - t0
+        ws = dm.workspace(n)
+        _, gpu = ws.forward_host(s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h0=(h1, h2))
+        ws.close()
+        return {"value": reps * n / dt, "unit": "sites/s", "cores": threads, "sites_per_call": n, "calls": reps,
+                "gpu_prob_max_abs_err_vs_torch_cpu": float(np.abs(gpu - probs).max()),
+                "what": "stock PyTorch %s CPU modules (nn.GRU 3 x bidirectional + attention + fc), fp32, torch.set_num_threads(%d), explicit h0"
+                        % (torch.__version__, threads)}
+
     leg("split3", split3)
+    leg("torch_cpu_path", torch_cpu)
     leg("pcie_inclusive", pcie)
     leg("call_mods_end_to_end", call_mods_e2e)
     leg("aggregate_50M", aggregate)
