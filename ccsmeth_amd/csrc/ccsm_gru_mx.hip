@@ -648,10 +648,19 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             else if constexpr (P == 13) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); }
             // this wave's part of the next pair's transfer has landed: younger than it are RS - 2 pairs of 9 + d operations and 4 of
             // this pair (pair 14: 1 of its own; pair 15: pair 13 with 9 + d, pair 14 with 1 + d, none of its own)
+#ifdef CCSM_DMA_LATE
             if constexpr (P == NPAIR - 1) CCSM_WAIT_XFER(12, 14);
             else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(21, 23);
             else CCSM_WAIT_XFER(24, 26);
             __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
+#else
+            // (with the refill issued right behind the barrier, the 5 blob / scale requests of that pair are younger than it as well)
+            if constexpr (P == NPAIR - 1) CCSM_WAIT_XFER(17, 19);
+            else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(26, 28);
+            else CCSM_WAIT_XFER(29, 31);
+            __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
+            if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once: 0.4 pair more lead
+#endif
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
             CCSM_FENCE;
 #pragma unroll
@@ -664,7 +673,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             else if constexpr (P == 13) { wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10)); wbb[0] = w_at(OFF_B + (6 << 10));
                                           wbb[1] = w_at(OFF_B + (7 << 10)); wbb[2] = w_at(OFF_B + (8 << 10)); }
             CCSM_FENCE;
+#ifdef CCSM_DMA_LATE
             if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;
+#endif
             slot = slot_n;
         });
 
@@ -769,8 +780,14 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             if constexpr (P + 4 < NPAIR) wch[WS][1] = w_at(OFF_C + (P + 4) * PC + (1 << 10));
             else if constexpr (AF == 0) wah[AS][0][1] = w_at(AS * PA + (1 << 10)); else wab[AS][1] = w_at(AS * PA + (5 << 10));
             // RS - 2 pairs of 5 + d operations and 2 of this pair (pairs 14, 15 look back on a pair with 4 + d)
+#ifdef CCSM_DMA_LATE
             if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(13, 15); else CCSM_WAIT_XFER(14, 16);
             __syncthreads();
+#else
+            if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(16, 18); else CCSM_WAIT_XFER(17, 19);     // + the 3 requests behind that pair's refill
+            __syncthreads();
+            dma_ahead(slot, s, NPAIR + P);
+#endif
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
             CCSM_FENCE;
 #pragma unroll
@@ -781,7 +798,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             else if constexpr (AF == 0) { wah[AS][1][0] = w_at(AS * PA + (2 << 10)); wah[AS][1][1] = w_at(AS * PA + (3 << 10)); wab[AS][0] = w_at(AS * PA + (4 << 10)); }
             else { wab1[AS][1] = w8_at(AS * PA + (6 << 10) + 512); was[AS] = ws_at(AS * PA + (7 << 10)); }
             CCSM_FENCE;
+#ifdef CCSM_DMA_LATE
             dma_ahead(slot, s, NPAIR + P);
+#endif
             slot = slot_n;
             if constexpr (P == 1) zwork(0);
             if constexpr (P == 5) zwork(1);
