@@ -46,9 +46,9 @@ PEAK_HBM = 8.0e12
 TRAFFIC = {4: ((2 * 1220000 + 516100) * 1024 / 6144.0, "profiles/r02_m_pmc_coalesced.md"),
            3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
 ARITH = {4: ("f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate",
-             "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp6 e2m3 for the "
-             "input part, fp4 e2m1 for the recurrent part, per-(row, 32-k) E8M0 scales, x fp6 e2m3 activation blobs; attention pool: "
-             "fp8 e4m3 x fp8), one fp32 accumulator", 99.0 / 64.0),
+             "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp4 e2m1 for the "
+             "recurrent part and the r, z gates' input part, fp6 e2m3 for the n gate's input part, per-(row, 32-k) E8M0 scales, fp6 e2m3 "
+             "activation blobs; attention pool: fp8 e4m3 x fp8), one fp32 accumulator", 99.0 / 64.0),
          3: ("f16x3 split operands, f32 accumulate", "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate", 3.0)}
 
 

@@ -334,7 +334,7 @@ float pack_wstream_mx(int layer, const float* const wih[2], const float* const w
                     const size_t pa = (size_t)p * kMxPairA;
                     for (int kbl = 0; kbl < 2; ++kbl)
                         for (int g = 0; g < 2; ++g) hi_at(pa + (size_t)(2 * kbl + g) * 1024, wx(g), 2 * p + kbl);
-                    for (int g = 0; g < 2; ++g) blob_at(pa + (size_t)(4 + g) * 1024, (long)(pa + 6 * 1024 + 512 * g), pa + 7 * 1024, g, kMxWFmtX, wx(g), p);
+                    for (int g = 0; g < 2; ++g) blob_at(pa + (size_t)(4 + g) * 1024, -1, pa + 6 * 1024, g, kMxWFmtH, wx(g), p);     // r, z: fp4 (see ccsm_gru_mx.hip)
                 }
                 phase_b(kMx12OffB);
                 for (int p = 0; p < kKB12 / 2; ++p) {

@@ -6,7 +6,8 @@
 // is issued per pair of k-blocks (32 k) as
 //     main : 2 x v_mfma_f32_32x32x16_f16 on (W_hi, x_hi)
 //     corr : 1 x v_mfma_scale_f32_32x32x64_f8f6f4, K = 64 = [32 k of W_lo x_hi | 32 k of W_hi x_lo], activations (B) in
-//            fp6 e2m3, weights (A) in fp4 e2m1, fp32 accumulation into the SAME accumulator.
+//            fp6 e2m3, weights (A) in fp4 e2m1 (recurrent part; input part of the r and z gates) or fp6 e2m3 (input part of the n
+//            gate: fp4 there shifts every site the same way, ~1e-5), fp32 accumulation into the SAME accumulator.
 // Why not fp8 operands (round 1): the GRU kernels run at the 1400 W package power cap (profiles/r02_c_power_attribution.md), so
 // their time is their energy; the fp8 x fp8 correction MFMAs cost 16 % of it, fp6 x fp6 half of that, fp4 weights x fp6
 // activations almost none, at 4-7e-6 max |dprob| (tests/diag/emulate_corr_formats.py; fp8: 4e-6, bar 1e-4).
@@ -31,7 +32,9 @@
 namespace ccsm {
 
 constexpr int kMxWFmtH = 4;                        // A (weight) operand format of the correction MFMA, recurrent part (phase B): fp4 e2m1
-constexpr int kMxWFmtX = 2;                        // ... input part (phases A, C): fp6 e2m3 (fp4 there biases every site the same way: ~1e-5)
+constexpr int kMxWFmtX = 2;                        // ... input part of the n gate (phase C): fp6 e2m3 — fp4 THERE biases every site the same way (~1e-5);
+                                                   // the input part of the r and z gates (phase A) takes fp4 like the recurrent part
+                                                   // (tests/diag/emulate_corr_formats.py: 4.9-6.4e-6 max |dprob| either way)
 constexpr int kMxBFmt = 2;                         // B (activation) operand: fp6 e2m3
 constexpr int kMxScaleHi = 127 - 2;                // x_hi blob holds x_hi * 4
 constexpr int kMxScaleLo = 127 - 14;               // x_lo blob holds x_lo * 2^14
@@ -229,11 +232,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // Weight streams, per (direction, wave), in bytes.  hi / lo fragments and blobs are 1 KiB (lane * 16), the scale dwords of a pair
 // 256 B (lane * 4; byte g = gate g):
-//   phase-A pair (r, z)    : hi (kbl, g) at (2 kbl + g) KiB | fp6 blob (g): bytes 0-15 at (4 + g) KiB, bytes 16-23 (lane * 8) at
-//                            6 KiB + 512 g | scales at 7 KiB                                                                  = 7424 B
+//   phase-A pair (r, z)    : hi (kbl, g) at (2 kbl + g) KiB | fp4 blob (g) at (4 + g) KiB | scales at 6 KiB                      = 6400 B
 //   phase-B pair (r, z, n) : hi (kbl, g) at (3 kbl + g) KiB | fp4 blob (g) at (6 + g) KiB | scales at 9 KiB                  = 9472 B
 //   phase-C pair (n)       : hi (kbl) at kbl KiB | fp6 blob: bytes 0-15 at 2 KiB, 16-23 at 3 KiB | scales at 3.5 KiB (byte 0) = 3840 B
-constexpr int kMxPairA = 7 * 1024 + 256, kMxPairB = 9 * 1024 + 256, kMxPairC = 3 * 1024 + 512 + 256;
+constexpr int kMxPairA = 6 * 1024 + 256, kMxPairB = 9 * 1024 + 256, kMxPairC = 3 * 1024 + 512 + 256;
 constexpr int kMx0WBytes = 4 * 1024 + (kKBH / 2) * kMxPairB + 2 * 1024;       // layer 0: [r hi, r lo, z hi, z lo] [B] [n hi, n lo]
 constexpr int kMx12OffB = (kKB12 / 2) * kMxPairA, kMx12OffC = kMx12OffB + (kKBH / 2) * kMxPairB;
 constexpr int kMx12WBytes = kMx12OffC + (kKB12 / 2) * kMxPairC;
@@ -461,8 +463,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 // Layers 1-2 (KX = 32 k-blocks of input = 16 pairs), on a schedule built around two facts measured on the chunked round-1 kernel
 // (DESIGN.md 7): (i) x_t comes from HBM and a transfer takes ~3.5-4 k cycles to land, (ii) a wave's vector-memory operations
 // retire IN ORDER, so a weight fragment requested after a transfer cannot be used before that transfer has landed.  Hence
-//   * the x ring holds FOUR pairs of k-blocks (4 x 12 KiB); the pair consumed by iteration g is refilled at the END of
-//     iteration g with the pair of iteration g + 4, as the YOUNGEST vector-memory operation of the iteration;
+//   * the x ring holds FOUR pairs of k-blocks (4 x 12 KiB); the slot of the pair consumed by iteration g is refilled with the pair of
+//     iteration g + 4 right behind iteration g's barrier (measured +1.4 % against refilling it as the iteration's youngest operation);
 //   * weights are requested three pairs ahead in phase A (three register slots), one pair ahead in phase B, four pairs ahead
 //     in phase C (four slots of the n gate);
 //   * ONE barrier per pair, in the middle of the pair (after the main MFMAs, before the correction MFMAs whose operands are
@@ -472,8 +474,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 // Iterations ("consumptions") per step: 16 pairs of phase A, then 16 of phase C; phase B touches no x.  The pair code is
 // straight-line (static_for over compile-time pair indices): a rolled pair loop with peeled ends made the compiler shuffle weight
 // slots between register sets at the loop exits, each shuffle behind an s_waitcnt vmcnt(0).  s_waitcnt immediates count the
-// vector-memory operations a wave issues between a transfer and the barrier that needs it: per phase-A pair 9 weight requests
-// (2 + 2 hi fragments, 2 x 2 blob pieces + 1 scale dword) + d transfer instructions, per phase-C pair 5 + d, d = 2 for waves 0-3
+// vector-memory operations a wave issues between a transfer and the barrier that needs it: per phase-A pair 7 weight requests
+// (2 + 2 hi fragments, 2 fp4 blobs + 1 scale dword) + d transfer instructions, per phase-C pair 5 + d, d = 2 for waves 0-3
 // (fragments w and w + 8 of the pair) and 1 for waves 4-7; every load below is therefore UNCONDITIONAL.
 //   xin : [tile][t][32 kb][hi | corr][64] uint4      out : the same (OUT_FP8: fp8 corr fragments for the attention kernel)
 // LDS : h fragments 96 KiB | x ring 4 x 12 KiB | residuals 12 KiB | biases 4 KiB = 160 KiB
@@ -545,7 +547,6 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     // weight registers: phase A three pair slots: [slot][kb in pair][gate r,z] hi, [slot][gate] fp6 blobs (16 + 8 bytes), [slot] scale
     // bytes; phase B one resident pair (fp4 blobs); phase C four pair slots of the n gate: [slot][kb in pair] hi, [slot] fp6 blob, scale
     uint4 wah[3][2][2], wab[3][2];
-    uint2 wab1[3][2];
     uint32_t was[3];
     uint4 wbh[2][3], wbb[3];
     uint32_t wbs;
@@ -556,12 +557,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 #pragma unroll
         for (int g = 0; g < 2; ++g) d[g] = w_at(p * PA + ((2 * kbl + g) << 10));
     };
-    auto ldAb = [&](int ws, int p) {                // 5 requests
+    auto ldAb = [&](int ws, int p) {                // 3 requests
 #pragma unroll
-        for (int g = 0; g < 2; ++g) { wab[ws][g] = w_at(p * PA + ((4 + g) << 10)); wab1[ws][g] = w8_at(p * PA + (6 << 10) + 512 * g); }
-        was[ws] = ws_at(p * PA + (7 << 10));
+        for (int g = 0; g < 2; ++g) wab[ws][g] = w_at(p * PA + ((4 + g) << 10));
+        was[ws] = ws_at(p * PA + (6 << 10));
     };
-    auto ldA_slot = [&](int ws, int p) { ldAh(wah[ws][0], p, 0); ldAh(wah[ws][1], p, 1); ldAb(ws, p); };   // 9 requests
+    auto ldA_slot = [&](int ws, int p) { ldAh(wah[ws][0], p, 0); ldAh(wah[ws][1], p, 1); ldAb(ws, p); };   // 7 requests
 
     // ---- prologue: the ring's first pairs, the first three weight slots
 #pragma unroll
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     ldA_slot(0, 0);
     ldA_slot(1, 1);
     ldA_slot(2, 2);
-    asm volatile("s_waitcnt vmcnt(27)" ::: "memory");               // all ring transfers (older than the 27 weight requests)
+    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");               // all ring transfers (older than the 21 weight requests)
     __syncthreads();                                                // ring, h0 fragments and biases are in LDS
 
     int slot = 0;                                                   // ring slot of the next consumption (wave-uniform)
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     } while (0)
 
         // ---------------- phase A: R, Z += W_i{r,z} x_t, pairs 0..15 ---------------------------------------------------------
-        // pair P lives in weight slot P % 3; behind its three MFMA groups its slot is refilled with pair P + 3 (2 + 2 + 5
+        // pair P lives in weight slot P % 3; behind its three MFMA groups its slot is refilled with pair P + 3 (2 + 2 + 3
         // requests); pairs 13 and 14 take phase B's first pair instead (9 + 1 requests), pair 15 has nothing left to request and
         // its ring refill is deferred to the end of phase B: issued here it would sit in front of phase B's one-pair-ahead
         // weight requests.
@@ -646,36 +647,27 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             CCSM_MAIN(wah[WS][1], xh1, 2, 0);
             if constexpr (P + 3 < NPAIR) ldAh(wah[WS][1], P + 3, 1);
             else if constexpr (P == 13) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); }
-            // this wave's part of the next pair's transfer has landed: younger than it are RS - 2 pairs of 9 + d operations and 4 of
-            // this pair (pair 14: 1 of its own; pair 15: pair 13 with 9 + d, pair 14 with 1 + d, none of its own)
-#ifdef CCSM_DMA_LATE
-            if constexpr (P == NPAIR - 1) CCSM_WAIT_XFER(12, 14);
-            else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(21, 23);
-            else CCSM_WAIT_XFER(24, 26);
+            // this wave's part of the next pair's transfer has landed.  Operations the wave has issued since that refill (it sits right
+            // behind its pair's barrier): the 3 blob / scale requests of that pair, two pairs of 7 + d, 4 of this pair; pair 13 requests
+            // phase B's first pair instead (9), pair 14 one more of it, pair 15 nothing
+            if constexpr (P == NPAIR - 1) CCSM_WAIT_XFER(15, 17);
+            else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(22, 24);
+            else CCSM_WAIT_XFER(23, 25);
             __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
-#else
-            // (with the refill issued right behind the barrier, the 5 blob / scale requests of that pair are younger than it as well)
-            if constexpr (P == NPAIR - 1) CCSM_WAIT_XFER(17, 19);
-            else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(26, 28);
-            else CCSM_WAIT_XFER(29, 31);
-            __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
-            if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once: 0.4 pair more lead
-#endif
+            if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once (0.4 pair more
+                                                                                      // lead than as the pair's youngest operation: +1.4 %)
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
             CCSM_FENCE;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
-                acc[0][bt] = mfma_corr_mx6<0>(wab[WS][0], wab1[WS][0], was[WS], xc0[bt], xc1[bt], acc[0][bt], sb);
-                acc[1][bt] = mfma_corr_mx6<1>(wab[WS][1], wab1[WS][1], was[WS], xc0[bt], xc1[bt], acc[1][bt], sb);
+                acc[0][bt] = mfma_corr_mx<0>(wab[WS][0], was[WS], xc0[bt], xc1[bt], acc[0][bt], sb);
+                acc[1][bt] = mfma_corr_mx<1>(wab[WS][1], was[WS], xc0[bt], xc1[bt], acc[1][bt], sb);
             }
             CCSM_FENCE;
             if constexpr (P + 3 < NPAIR) ldAb(WS, P + 3);
             else if constexpr (P == 13) { wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10)); wbb[0] = w_at(OFF_B + (6 << 10));
                                           wbb[1] = w_at(OFF_B + (7 << 10)); wbb[2] = w_at(OFF_B + (8 << 10)); }
             CCSM_FENCE;
-#ifdef CCSM_DMA_LATE
-            if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;
-#endif
             slot = slot_n;
         });
 
@@ -688,7 +680,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         }
         const int sbh = sb + (s == 0 ? kMxScaleHi0 - kMxScaleHi : 0);
         // pair Q = k-blocks 2Q, 2Q + 1: one pair resident, refilled with the next pair behind each MFMA group (3 + 3 + 4
-        // requests); the last pair's positions take phase C's first pair slots
+        // requests); the last pair's positions take phase C's first pair slot
         static_for<0, kKBH / 2>([&](auto QC) {
             constexpr int Q = decltype(QC)::value;
             constexpr bool LAST = Q == kKBH / 2 - 1;
@@ -721,8 +713,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 for (int g = 0; g < 3; ++g) wbb[g] = w_at(NXT + ((6 + g) << 10));
                 wbs = ws_at(NXT + (9 << 10));
             } else {
-                wch[1][1] = w_at(OFF_C + 1 * PC + (1 << 10)); wcb[1] = w_at(OFF_C + 1 * PC + (2 << 10));
-                wcb1[1] = w8_at(OFF_C + 1 * PC + (3 << 10)); wcs[1] = ws_at(OFF_C + 1 * PC + (3 << 10) + 512);
+                wch[1][1] = w_at(OFF_C + 1 * PC + (1 << 10));
             }
             CCSM_FENCE;
         });
@@ -735,8 +726,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
         }
-        // phase C's pair slots 2 and 3: requested once R is dead (the accumulators drop from 144 to 96 registers)
+        // the blob of phase C's pair slot 1 and its slots 2 and 3: requested once R is dead (the accumulators drop from 144 to 96
+        // registers; slot 0 and the hi fragments of slot 1 came with phase B's last pair)
         CCSM_FENCE;
+        wcb[1] = w_at(OFF_C + 1 * PC + (2 << 10)); wcb1[1] = w8_at(OFF_C + 1 * PC + (3 << 10)); wcs[1] = ws_at(OFF_C + 1 * PC + (3 << 10) + 512);
 #pragma unroll
         for (int q = 2; q < 4; ++q) {
             wch[q][0] = w_at(OFF_C + q * PC + (0 << 10)); wch[q][1] = w_at(OFF_C + q * PC + (1 << 10)); wcb[q] = w_at(OFF_C + q * PC + (2 << 10));
@@ -757,7 +750,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         stamp(2);
         // ---------------- phase C: N += W_in x_t, pairs 0..15 (consumptions 16..31) ------------------------------------------
         // pair P lives in slot P % 4 of the n-gate weights, refilled with pair P + 4 (1 + 1 + 3 requests); the last four pairs take
-        // the next step's phase-A slots 0 and 1 instead (5, 4, 5, 4 requests; slot 2 follows behind the tail)
+        // the next step's phase-A slots 0 and 1 instead (5, 2, 5, 2 requests; slot 2 follows behind the tail)
         rdx(xh, slot_off(slot), 0, 0);
         static_for<0, NPAIR>([&](auto PC_) {
             constexpr int P = decltype(PC_)::value;
@@ -771,7 +764,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][0], xh[bt], acc[2][bt]);
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) wch[WS][0] = w_at(OFF_C + (P + 4) * PC + (0 << 10));
-            else if constexpr (AF == 0) wah[AS][0][0] = w_at(AS * PA + (0 << 10)); else wab1[AS][0] = w8_at(AS * PA + (6 << 10));
+            else if constexpr (AF == 0) wah[AS][0][0] = w_at(AS * PA + (0 << 10)); else was[AS] = ws_at(AS * PA + (6 << 10));
             rdx_blob(xs);
             CCSM_FENCE;
 #pragma unroll
@@ -779,15 +772,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) wch[WS][1] = w_at(OFF_C + (P + 4) * PC + (1 << 10));
             else if constexpr (AF == 0) wah[AS][0][1] = w_at(AS * PA + (1 << 10)); else wab[AS][1] = w_at(AS * PA + (5 << 10));
-            // RS - 2 pairs of 5 + d operations and 2 of this pair (pairs 14, 15 look back on a pair with 4 + d)
-#ifdef CCSM_DMA_LATE
-            if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(13, 15); else CCSM_WAIT_XFER(14, 16);
+            // operations since the awaited refill: the 3 requests behind it, two pairs of 5 + d (pairs 13 and 15: 2 + d), 2 of this pair
+            if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(14, 16); else CCSM_WAIT_XFER(17, 19);
             __syncthreads();
-#else
-            if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(16, 18); else CCSM_WAIT_XFER(17, 19);     // + the 3 requests behind that pair's refill
-            __syncthreads();
-            dma_ahead(slot, s, NPAIR + P);
-#endif
+            dma_ahead(slot, s, NPAIR + P);                              // the vacated slot is refilled at once
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
             CCSM_FENCE;
 #pragma unroll
@@ -796,11 +784,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             if constexpr (P + 4 < NPAIR) { wcb[WS] = w_at(OFF_C + (P + 4) * PC + (2 << 10)); wcb1[WS] = w8_at(OFF_C + (P + 4) * PC + (3 << 10));
                                            wcs[WS] = ws_at(OFF_C + (P + 4) * PC + (3 << 10) + 512); }
             else if constexpr (AF == 0) { wah[AS][1][0] = w_at(AS * PA + (2 << 10)); wah[AS][1][1] = w_at(AS * PA + (3 << 10)); wab[AS][0] = w_at(AS * PA + (4 << 10)); }
-            else { wab1[AS][1] = w8_at(AS * PA + (6 << 10) + 512); was[AS] = ws_at(AS * PA + (7 << 10)); }
             CCSM_FENCE;
-#ifdef CCSM_DMA_LATE
-            dma_ahead(slot, s, NPAIR + P);
-#endif
             slot = slot_n;
             if constexpr (P == 1) zwork(0);
             if constexpr (P == 5) zwork(1);

@@ -47,6 +47,9 @@ def corr(xh, xl, wh, wl, fa, fb, act_dyn):
 
 
 def mm(x, w, mode):
+    if isinstance(mode, dict):      # input part with per-gate weight formats: rows [0, 2H) = r, z gates, rows [2H, 3H) = n gate
+        hid = w.shape[0] // 3
+        return np.concatenate([mm(x, w[:2 * hid], mode["rz"]), mm(x, w[2 * hid:], mode["n"])], axis=1)
     xh, xl, wh, wl = hi16(x), lo32(x), hi16(w), lo32(w)
     if mode == "full": return xh @ wh.T + xh @ wl.T + xl @ wh.T
     if mode == "fp16": return xh @ wh.T
@@ -93,6 +96,10 @@ if __name__ == "__main__":
     orig = orc.gru_direction
     modes = [("full", 0), ("fp16", 0), (("fp8", "fp8", 0), 1), (("fp6", "fp6", 0), 1), (("fp6", "fp4", 0), 1), (("fp6", "fp4", 1), 1),
              (("fp4", "fp6", 0), 1), (("fp4", "fp4", 0), 1), (("fp4", "fp4", 1), 1)]
+    # the product's choice: recurrent part fp4 weights; input part fp4 for the r and z gates, fp6 for the n gate (fp4 THERE is what
+    # biases every site the same way), fp6 activations everywhere
+    PRODUCT = ({"rz": ("fp4", "fp6", 0), "n": ("fp6", "fp6", 0)}, ("fp4", "fp6", 0))
+    XN_FP4 = ({"rz": ("fp6", "fp6", 0), "n": ("fp4", "fp6", 0)}, ("fp4", "fp6", 0))
     for wseed in (7, 11):
         w = synth.synth_weights(wseed)
         if heavy: w = heavy_tailed(w, wseed)
@@ -106,3 +113,8 @@ if __name__ == "__main__":
             print("wseed %d %s%s  A=%s B=%s act_scale=%s : max |dprob| %.2e  99.9%% %.2e  mean %.2e" % (
                 wseed, "heavy " if heavy else "", "hq" if hq else "  ", m if isinstance(m, str) else m[0], "" if isinstance(m, str) else m[1],
                 "" if isinstance(m, str) else ("dyn" if m[2] else "fixed"), d.max(), np.quantile(d, 0.999), d.mean()), flush=True)
+        for name, (xm, hm) in (("product (x: r,z fp4 | n fp6; h fp4)", PRODUCT), ("x: r,z fp6 | n fp4; h fp4", XN_FP4)):
+            MODE["x"], MODE["h"], MODE["hq"] = xm, hm, 1
+            d = f() - ref
+            print("wseed %d %shq  %s : max |dprob| %.2e  mean |d| %.2e  mean d %+.2e" % (wseed, "heavy " if heavy else "", name, np.abs(d).max(),
+                                                                                      np.abs(d).mean(), d[:, 1].mean()), flush=True)
