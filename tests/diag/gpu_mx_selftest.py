@@ -1,7 +1,7 @@
 """Split-mx self-test on the GPU box: one pair product end to end + host vs device fp6 encoders, then a small forward vs the oracle."""
 import ctypes as C, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from ccsmeth_amd import _lib
 lib = _lib.load()
