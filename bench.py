@@ -60,9 +60,9 @@ def parse():
     ap.add_argument("--coalesce", type=int, default=6,
                     help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
                          "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds)")
-    ap.add_argument("--precision", type=int, default=4, choices=(3, 4),
-                    help="4 = split-mx (default: fp16 main product + MX correction product, max |dprob| ~5e-6); 3 = split-fp16 x3\n"
-                         "(fp32-class, ~2e-7)")
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 3, 4),
+                    help="0 = the library's default: split-mx (fp16 main product + MX correction product) if ccsm_create's probe batch keeps it\n"
+                         "within 1.5e-5 of split3 on these weights, split3 otherwise; 4 = split-mx forced; 3 = split-fp16 x3 (fp32-class)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--extras", default="all", choices=("all", "none"), help="the secondary measurements (rank 0 at N = 1)")
     return ap.parse_args()
@@ -397,9 +397,9 @@ def main():
 
     if rank == 0:
         value = n_gpus * a.steps * BATCH / elapsed
-        dtype, arith, passes = ARITH[a.precision]
+        dtype, arith, passes = ARITH[dm.precision]
         achieved = 2.0 * MAC_GRU12 * sites_per_launch / (dom_ms * 1e-3)
-        traffic, traffic_src = TRAFFIC[a.precision]
+        traffic, traffic_src = TRAFFIC[dm.precision]
         line = {
             "metric": "CpG sites/sec (call_mods, attbigru2s b21)", "value": value, "unit": "sites/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -408,8 +408,11 @@ def main():
             "config": {"workload": "attbigru2s_b21 forward on synthetic 21-mer CpG batches (BASELINE.json configs[1])",
                        "batch": BATCH, "sites_per_step": BATCH, "coalesce": grp, "streams": 2 if runner.overlap else 1, "full_groups": full, "ragged_group_batches": rag,
                        "warmup_steps_run": w_steps, "h0": "device Philox N(0,1)", "arithmetic": arith,
+                       "arithmetic_selected": {3: "split3", 4: "split-mx"}.get(dm.precision, dm.precision), "probe_max_abs_dprob": dm.probe_error,
+                       "weights": "synthetic random initialisation (seed 20260928); a TRAINED checkpoint typically makes the probe of ccsm_create "
+                                  "select split3 (extras.split3): DESIGN.md section 2",
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if a.precision == 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
+            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision == 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
                          "traffic": traffic * sites_per_launch, "traffic_source": traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled per site)",

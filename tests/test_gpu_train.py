@@ -116,14 +116,34 @@ def test_dropout_and_device_rng_h0_train_and_reduce_loss():
             out.append(loss)
         ev, logits = tr.evaluate(val, lab(val), h0=None, seed=seed, step=10 ** 6)
         acc = float((logits.argmax(1) == lab(val)).mean())
+        trained.append(tr.state_dict())
         tr.close()
         return out, ev, acc
+    trained = []
     a, eva, acca = run(0.5, 7, 320)
     b, _, _ = run(0.5, 7, 4)
     c, _, _ = run(0.0, 7, 4)
     assert np.allclose(a[:4], b, rtol=1e-4)            # same masks and h0 (the float atomics of the reductions are not ordered)
     assert not np.allclose(a[1:4], c[1:4], rtol=1e-3)
     assert np.mean(a[-10:]) < 0.45 and eva < 0.45 and acca > 0.85, (a[:3], a[-10:], eva, acca)
+    # the TRAINED parameters (not the synthetic initialisation the other parity tests use) through the inference library's default
+    # arithmetic: whatever the probe batch selects for THIS checkpoint (a trained model is more sensitive: split-mx leaves a tail of
+    # ~0.1 % of the sites beyond 1e-4, the probe sees 2e-5 and selects the three-pass arithmetic), the probabilities stay within 1e-5
+    # of the oracle (h0 pinned)
+    from ccsmeth_amd.models import DeviceModel
+    from oracle import attbigru2s_oracle as orc
+    wt = trained[0]
+    dm = DeviceModel(wt, device=0)
+    assert dm.precision in (3, 4) and (dm.precision == 3) == (dm.probe_error > 1.5e-5)
+    m = 256
+    sv = {k: v[:m] for k, v in val.items()}
+    h1, h2 = synth.synth_h0(m, 99)
+    ws = dm.workspace(m)
+    _, probs = ws.forward_host(sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"], h0=(h1, h2))
+    ws.close(); dm.close()
+    _, ref = orc.attbigru2s_forward(wt, sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"], h1, h2)
+    assert np.abs(probs - ref).max() < 1e-5
+    assert 0.05 < float((ref[:, 1] > 0.5).mean()) < 0.95                # a model that actually discriminates
 
 
 def test_device_drawn_initial_states_advance_by_sites():
