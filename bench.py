@@ -14,8 +14,8 @@ sides, MAX over ranks is taken and rank 0 prints ONE JSON line.  Reads are shard
 path (weak scaling).  With --gpus N > 1 and no torch.distributed environment, this script re-executes itself under
 torch.distributed.run with N ranks; it refuses to run if fewer than N GPUs are visible.
 
-Besides BASELINE's metric the line carries (rank 0, N = 1; `--extras none` skips them): the same forward in the fp32-class
-split3 arithmetic, the PCIe-inclusive rate through ccsm_submit_host / ccsm_wait_host, `call_mods` end to end on a scaled-down
+Besides BASELINE's metric the line carries (rank 0, N = 1; `--extras none` skips them): the same forward in the arithmetics
+the probe did not select (hybrid: what a trained checkpoint gets; split3: fp32-class), the PCIe-inclusive rate through ccsm_submit_host / ccsm_wait_host, `call_mods` end to end on a scaled-down
 configs[2] BAM, and the aggregate kernel on configs[4]'s 50 M sites.
 """
 import argparse
@@ -44,11 +44,16 @@ PEAK_HBM = 8.0e12
 # (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
 # read from inside this process)
 TRAFFIC = {4: ((2 * 1209000 + 516100) * 1024 / 6144.0, "profiles/r02_p_pmc_coalesced.md"),
+           5: ((2 * 1209000 + 516100) * 1024 / 6144.0, "profiles/r02_p_pmc_coalesced.md (split-mx; the hybrid moves the same activation bytes)"),
            3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
 ARITH = {4: ("f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate",
              "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp4 e2m1 for the "
              "recurrent part and the r, z gates' input part, fp6 e2m3 for the n gate's input part, per-(row, 32-k) E8M0 scales, fp6 e2m3 "
              "activation blobs; attention pool: fp8 e4m3 x fp8), one fp32 accumulator", 99.0 / 64.0),
+         5: ("f16 + MX(fp6|fp4 x fp6) input part, f16x3 recurrent part, f32 accumulate",
+             "GRU layers: the input part as in split-mx (hi*hi on v_mfma_f32_32x32x16_f16 + one block-scaled fp6/fp4 x fp6 correction MFMA per "
+             "32 k), the recurrent part in three fp16 passes (hi*hi+hi*lo+lo*hi) on an fp16 hi + lo state; attention pool: fp8 e4m3 x fp8 "
+             "correction; one fp32 accumulator", (512 * 99.0 / 64.0 + 256 * 3.0) / 768.0),
          3: ("f16x3 split operands, f32 accumulate", "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate", 3.0)}
 
 
@@ -60,9 +65,10 @@ def parse():
     ap.add_argument("--coalesce", type=int, default=6,
                     help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
                          "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds)")
-    ap.add_argument("--precision", type=int, default=0, choices=(0, 3, 4),
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 3, 4, 5),
                     help="0 = the library's default: split-mx (fp16 main product + MX correction product) if ccsm_create's probe batch keeps it\n"
-                         "within 1.5e-5 of split3 on these weights, split3 otherwise; 4 = split-mx forced; 3 = split-fp16 x3 (fp32-class)")
+                         "within 1.5e-5 of split3 on these weights, else the hybrid (split-mx input part, three-pass recurrent part) under the same\n"
+                         "condition, else split3; 4 = split-mx forced; 5 = hybrid forced; 3 = split-fp16 x3 (fp32-class)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--extras", default="all", choices=("all", "none"), help="the secondary measurements (rank 0 at N = 1)")
     return ap.parse_args()
@@ -212,17 +218,19 @@ def extras(weights, dm, dev, pool, grp):
     def fence():
         torch.cuda.synchronize(dev)
 
-    def split3():
-        from ccsmeth_amd.models import DeviceModel
-        dm3 = DeviceModel(weights, device=dev.index, precision=3)
-        r = Runner(dm3, pool, dev, grp, 0)
-        steps = 4 * grp
-        dt, full, _, _ = timed(r, steps, grp, fence)
-        kt, nr = r.kernel_times()
-        r.close(); dm3.close()
-        ach = 2.0 * MAC_GRU12 * BATCH * grp / (float(np.mean(kt[1:3])) * 1e-3)
-        return {"value": steps * BATCH / dt, "unit": "sites/s", "dtype": ARITH[3][0], "steps": steps,
-                "roofline_frac": ach / PEAK_F16_MFMA, "launch_ms": float(np.mean(kt[1:3])), "mfma_passes_per_flop": 3}
+    def other_arithmetic(prec):
+        def run():
+            from ccsmeth_amd.models import DeviceModel
+            dmo = DeviceModel(weights, device=dev.index, precision=prec)
+            r = Runner(dmo, pool, dev, grp, 0)
+            steps = 4 * grp
+            dt, full, _, _ = timed(r, steps, grp, fence)
+            kt, nr = r.kernel_times()
+            r.close(); dmo.close()
+            ach = 2.0 * MAC_GRU12 * BATCH * grp / (float(np.mean(kt[1:3])) * 1e-3)
+            return {"value": steps * BATCH / dt, "unit": "sites/s", "dtype": ARITH[prec][0], "steps": steps,
+                    "roofline_frac": ach / PEAK_F16_MFMA, "launch_ms": float(np.mean(kt[1:3])), "mfma_passes_per_flop": ARITH[prec][2]}
+        return run
 
     def pcie():
         # features in host memory every step, logits/probs back to host memory: ccsm_submit_host / ccsm_wait_host on two workspaces
@@ -324,7 +332,9 @@ def extras(weights, dm, dev, pool, grp):
                 "what": "stock PyTorch %s CPU modules (nn.GRU 3 x bidirectional + attention + fc), fp32, torch.set_num_threads(%d), explicit h0"
                         % (torch.__version__, threads)}
 
-    leg("split3", split3)
+    for prec, name in ((5, "hybrid"), (3, "split3"), (4, "split-mx")):     # the arithmetics the probe did not select for these weights
+        if prec != dm.precision:
+            leg(name, other_arithmetic(prec))
     leg("torch_cpu_path", torch_cpu)
     leg("pcie_inclusive", pcie)
     leg("call_mods_end_to_end", call_mods_e2e)
@@ -408,11 +418,12 @@ def main():
             "config": {"workload": "attbigru2s_b21 forward on synthetic 21-mer CpG batches (BASELINE.json configs[1])",
                        "batch": BATCH, "sites_per_step": BATCH, "coalesce": grp, "streams": 2 if runner.overlap else 1, "full_groups": full, "ragged_group_batches": rag,
                        "warmup_steps_run": w_steps, "h0": "device Philox N(0,1)", "arithmetic": arith,
-                       "arithmetic_selected": {3: "split3", 4: "split-mx"}.get(dm.precision, dm.precision), "probe_max_abs_dprob": dm.probe_error,
+                       "arithmetic_selected": {3: "split3", 4: "split-mx", 5: "hybrid"}.get(dm.precision, dm.precision), "probe_max_abs_dprob": dm.probe_error,
+                       "probe_max_abs_dprob_hybrid": dm.probe_error_hybrid,
                        "weights": "synthetic random initialisation (seed 20260928); a TRAINED checkpoint typically makes the probe of ccsm_create "
-                                  "select split3 (extras.split3): DESIGN.md section 2",
+                                  "select the hybrid arithmetic (extras.hybrid): DESIGN.md section 2",
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision == 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
+            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
                          "traffic": traffic * sites_per_launch, "traffic_source": traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled per site)",

@@ -75,11 +75,12 @@ def build_parser():
     p.add_argument("--io", default="native", choices=["native", "python"],
                    help="BAM reader/writer: libccsm_bam (threaded BGZF, whole read chunks straight to the GPU; implies --extract\n"
                         "device) or the pure-Python record-by-record implementation")
-    p.add_argument("--arithmetic", default="auto", choices=["auto", "split3", "split-mx"],
-                   help="MFMA arithmetic of the model: auto (default) = split-mx (fp16 main product + one block-scaled fp6/fp4 correction\n"
-                        "product) if a probe batch through THIS checkpoint stays within 1.5e-5 of the three-fp16-pass arithmetic, split3\n"
-                        "otherwise (trained checkpoints usually end there: split-mx leaves ~0.1 %% of their sites beyond 1e-4);\n"
-                        "split3 = fp32-class (max abs error < 1e-6), 1.45x slower; split-mx = forced")
+    p.add_argument("--arithmetic", default="auto", choices=["auto", "split3", "hybrid", "split-mx"],
+                   help="MFMA arithmetic of the model: auto (default) = the fastest of split-mx (fp16 main product + one block-scaled\n"
+                        "fp6/fp4 correction product), hybrid (split-mx for the GRUs' input part, three fp16 passes for their recurrent\n"
+                        "part) and split3 (three fp16 passes everywhere: fp32-class, max abs error < 1e-6) that keeps a probe batch\n"
+                        "through THIS checkpoint within 1.5e-5 of split3.  Trained checkpoints usually end at hybrid: split-mx leaves\n"
+                        "~0.1 %% of their sites beyond 1e-4.  The other values force one")
     p.add_argument("--extract", default="device", choices=["device", "host"],
                    help="where the 21-mer features are built: on the GPU from the raw read arrays (default) or NumPy on the host")
     return p
@@ -258,7 +259,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
             args.device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)    # one process per GPU
         model = ModelAttRNN(args.seq_len, args.layer_rnn, args.class_num, args.dropout_rate, args.hid_rnn, is_npass=True,
                             model_type=args.model_type, device=args.device, seed=args.tseed, max_batch=args.batch_size,
-                            precision={"auto": 0, "split3": 3, "split-mx": 4}[getattr(args, "arithmetic", "auto")])
+                            precision={"auto": 0, "split3": 3, "split-mx": 4, "hybrid": 5}[getattr(args, "arithmetic", "auto")])
         para = _load_state_dict(args.model_file)
         try:
             model.load_state_dict(para)
@@ -266,9 +267,11 @@ def call_mods(args, log=sys.stderr, pipe=None):
             model.load_state_dict(OrderedDict((k[7:], v) for k, v in para.items()))
         model.cuda(args.device).eval()
         if int(os.environ.get("RANK", "0")) == 0:
-            print("[main]arithmetic: %s%s" % ({3: "split3 (three fp16 passes)", 4: "split-mx"}.get(model._dev.precision, model._dev.precision),
-                                             "" if model._dev.probe_error < 0 else " (probe batch: max abs dprob %.1e between the two)" % model._dev.probe_error),
-                  file=log)
+            dm = model._dev
+            probe = "" if dm.probe_error < 0 else " (probe batch, max abs dprob against split3: split-mx %.1e%s)" % (
+                dm.probe_error, "" if dm.probe_error_hybrid < 0 else ", hybrid %.1e" % dm.probe_error_hybrid)
+            print("[main]arithmetic: %s%s" % ({3: "split3 (three fp16 passes)", 4: "split-mx", 5: "hybrid (split-mx input part, three-pass "
+                                               "recurrent part)"}.get(dm.precision, dm.precision), probe), file=log)
         # --batch_size (reference default 512) is the reference's sites per model call.  On the GPU-extraction paths a launch wants
         # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
         # (every site's initial state is a function of the seed and its running index), so the flag is only a lower bound there.

@@ -65,8 +65,11 @@ struct ccsm_model {
     int precision = 3;
     uint4* wst2[kLayers] = {nullptr, nullptr, nullptr}; // split3: [dir][wave][A: KX x (r,z) | B: 16 x (r,z,n) | C: KX x (n)][hl][64]
     float mx_quant_err = 0.f;                            // relative RMS quantisation error of the weight correction blobs (worst layer)
+    float probe_err_hybrid = -1.f;                       // ... of the hybrid arithmetic (-1: not run: split-mx was accepted)
+    float probe_tail = -1.f, probe_tail_hybrid = -1.f;   // fraction of the probe sites beyond kProbeTailAt
     float probe_err = -1.f;                              // max |dprob| split-mx vs split-fp16 on the probe batch of ccsm_create (-1: not run)
     uint4* wstmx[kLayers] = {nullptr, nullptr, nullptr};// split-mx weight streams (ccsm_gru_mx.hip: hi fragments + MX correction blobs)
+    uint4* wsthy[kLayers] = {nullptr, nullptr, nullptr};// hybrid weight streams (the same with fp16 lo fragments for the recurrent part)
     uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
     uint4* ua3 = nullptr;
     int att_scale[2] = {127, 127};                       // E8M0 scales of the Wa / Ua corr operands
@@ -294,9 +297,10 @@ inline void emit_hi_frag(_Float16* dst, int kb, const std::function<float(int, i
 
 // Split-mx weight stream of one layer (byte layouts: ccsm_gru_mx.hip).  Returns the relative RMS quantisation error of the layer's
 // correction blobs (the larger of the W_lo and W_hi halves).
-float pack_wstream_mx(int layer, const float* const wih[2], const float* const whh[2], std::vector<uint8_t>& out) {
+float pack_wstream_mx(int layer, const float* const wih[2], const float* const whh[2], bool hs3, std::vector<uint8_t>& out) {
     const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
-    const size_t wbytes = layer == 0 ? kMx0WBytes : kMx12WBytes;
+    const size_t wbytes = layer == 0 ? mx0_wbytes(hs3) : mx12_wbytes(hs3);
+    const size_t pair_b = mx_pair_b(hs3);
     out.assign((size_t)2 * kWaves * wbytes, 0);
     BlobErr be;
     for (int dir = 0; dir < 2; ++dir)
@@ -318,16 +322,20 @@ float pack_wstream_mx(int layer, const float* const wih[2], const float* const w
             };
             auto phase_b = [&](size_t off_b) {
                 for (int q = 0; q < kKBH / 2; ++q) {
-                    const size_t pb = off_b + (size_t)q * kMxPairB;
+                    const size_t pb = off_b + (size_t)q * pair_b;
                     for (int kbl = 0; kbl < 2; ++kbl)
-                        for (int g = 0; g < 3; ++g) hi_at(pb + (size_t)(3 * kbl + g) * 1024, wh(g), 2 * q + kbl);
-                    for (int g = 0; g < 3; ++g) blob_at(pb + (size_t)(6 + g) * 1024, -1, pb + 9 * 1024, g, kMxWFmtH, wh(g), q);
+                        for (int g = 0; g < 3; ++g) {
+                            hi_at(pb + (size_t)(3 * kbl + g) * 1024, wh(g), 2 * q + kbl);
+                            if (hs3) lo_at(pb + (size_t)(6 + 3 * kbl + g) * 1024, wh(g), 2 * q + kbl);      // hybrid: fp16 residual fragments
+                        }
+                    if (!hs3)
+                        for (int g = 0; g < 3; ++g) blob_at(pb + (size_t)(6 + g) * 1024, -1, pb + 9 * 1024, g, kMxWFmtH, wh(g), q);
                 }
             };
             if (layer == 0) {
                 for (int g = 0; g < 2; ++g) { hi_at((size_t)(2 * g) * 1024, wx(g), 0); lo_at((size_t)(2 * g + 1) * 1024, wx(g), 0); }
                 phase_b(4 * 1024);
-                const size_t oc = 4 * 1024 + (size_t)(kKBH / 2) * kMxPairB;
+                const size_t oc = 4 * 1024 + (size_t)(kKBH / 2) * pair_b;
                 hi_at(oc, wx(2), 0); lo_at(oc + 1024, wx(2), 0);
             } else {
                 for (int p = 0; p < kKB12 / 2; ++p) {
@@ -338,7 +346,7 @@ float pack_wstream_mx(int layer, const float* const wih[2], const float* const w
                 }
                 phase_b(kMx12OffB);
                 for (int p = 0; p < kKB12 / 2; ++p) {
-                    const size_t pc = kMx12OffC + (size_t)p * kMxPairC;
+                    const size_t pc = mx12_off_c(hs3) + (size_t)p * kMxPairC;
                     hi_at(pc, wx(2), 2 * p); hi_at(pc + 1024, wx(2), 2 * p + 1);
                     blob_at(pc + 2 * 1024, (long)(pc + 3 * 1024), pc + 3 * 1024 + 512, 0, kMxWFmtX, wx(2), p);
                 }
@@ -417,24 +425,26 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
 
 // GRU layers in split-mx arithmetic.  A build with -DCCSM_PHASE_STAMPS also holds the instantiations that record the cycle counter
 // at the phase boundaries of workgroup 0 (tools/gpu_phases.py); the product library is built without it.
+template <bool HS3>
 void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4* out, const uint4* wst, const float* bias, const float* h0,
                    int rows_p, unsigned long long* dbg) {
 #ifdef CCSM_PHASE_STAMPS
     if (dbg) {
-        if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<true>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
-        else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
-        else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<true, HS3>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true, HS3>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true, HS3>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
         return;
     }
 #endif
     (void)dbg;
-    if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
-    else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
-    else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);   // fp8 corr fragments for the attention kernel
+    if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, HS3>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false, HS3>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false, HS3>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);   // fp8 corr fragments for the attention kernel
 }
 
 // Heavy kernels, once over every row used by the current slices, then the per-slice logits/softmax.
-template <bool F8>
+// F8: the split-mx family (activations as [hi | blob] fragments); HS3: its hybrid member (recurrent part in three fp16 passes)
+template <bool F8, bool HS3 = false>
 ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
     const int rows_run = ((ws->rows_used + kRowPad - 1) / kRowPad) * kRowPad;
     const int tiles = rows_run / 32;
@@ -449,11 +459,12 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     constexpr int dbg_layer = -1;
 #endif
     if constexpr (F8) {
-        launch_gru_mx(0, ggrid, st, ws->x0, ws->act[0], m->wstmx[0], m->bias[0], ws->h0buf, ws->rows_p, dbg_layer == 0 ? ws->dbg : nullptr);
+        uint4* const* wst = HS3 ? m->wsthy : m->wstmx;
+        launch_gru_mx<HS3>(0, ggrid, st, ws->x0, ws->act[0], wst[0], m->bias[0], ws->h0buf, ws->rows_p, dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
-        launch_gru_mx(1, ggrid, st, ws->act[0], ws->act[1], m->wstmx[1], m->bias[1], ws->h0buf + slab, ws->rows_p, dbg_layer == 1 ? ws->dbg : nullptr);
+        launch_gru_mx<HS3>(1, ggrid, st, ws->act[0], ws->act[1], wst[1], m->bias[1], ws->h0buf + slab, ws->rows_p, dbg_layer == 1 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-        launch_gru_mx(2, ggrid, st, ws->act[1], ws->act[0], m->wstmx[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, dbg_layer == 2 ? ws->dbg : nullptr);
+        launch_gru_mx<HS3>(2, ggrid, st, ws->act[1], ws->act[0], wst[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, dbg_layer == 2 ? ws->dbg : nullptr);
     } else {
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
                            m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p);
@@ -499,9 +510,10 @@ ccsm_status dispatch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st
     }
     switch (m->precision) {
         case CCSM_PRECISION_SPLIT_F8: return launch_run<true>(m, ws, st);
+        case CCSM_PRECISION_HYBRID: return launch_run<true, true>(m, ws, st);
         case CCSM_PRECISION_SPLIT3: return launch_run<false>(m, ws, st);
     }
-    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 3 (split-fp16) or 4 (split-f8)");
+    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 3 (split-fp16), 4 (split-mx) or 5 (hybrid)");
 }
 
 // add one slice (device pointers) to the workspace
@@ -560,13 +572,19 @@ size_t ccsm_workspace_bytes(const ccsm_workspace* ws) { return ws ? ws->bytes : 
 }  // extern "C"
 
 namespace {
-// The default arithmetic is chosen by MEASUREMENT: ccsm_create runs one probe batch (192 synthetic sites, z-scores with a heavy
-// tail, device-drawn initial states) through split-mx and through the fp32-class split-fp16 arithmetic on the new model and keeps
-// split-mx only if the two agree to kMxProbeMargin on every probability.  Checkpoints whose weights make the model unusually
-// sensitive to operand rounding (heavy-tailed matrices, gate-saturating biases: tests/test_gpu_parity.py) fall back to split-fp16.
-constexpr float kMxProbeMargin = 1.5e-5f;
+// The default arithmetic is chosen by MEASUREMENT: ccsm_create runs one probe batch (2048 synthetic sites, z-scores with a heavy
+// tail, device-drawn initial states) through the fp32-class split-fp16 arithmetic and through the candidates in order of speed
+// (split-mx, then the hybrid) and keeps the first one whose probabilities agree with split-fp16's like this: at most kProbeTailFrac
+// of the sites differ by more than kProbeTailAt and none by more than kProbeMaxErr (half of the 1e-4 parity bar).  The quantile is
+// what discriminates: on a TRAINED checkpoint split-mx leaves ~2 % of the sites beyond 1e-5 with a heavy tail (max over 8192 sites
+// 0.9-1.8e-4) where the hybrid leaves 0.2 % and a light one (max 1.8e-5); a max over a few hundred sites misses that one time in
+// six (profiles/r02_q_trained_weights_parity.log).  Checkpoints that make the model unusually sensitive to operand rounding
+// (heavy-tailed matrices, gate-saturating biases: tests/test_gpu_parity.py) end at split-fp16.
+constexpr float kProbeTailAt = 1.0e-5f;
+constexpr float kProbeTailFrac = 0.005f;
+constexpr float kProbeMaxErr = 5.0e-5f;
 constexpr float kMxH0Limit = 6.0f;
-constexpr int kProbeSites = 192;
+constexpr int kProbeSites = 2048;
 
 ccsm_status probe_arithmetic(ccsm_model* m) {
     ccsm_workspace* ws = nullptr;
@@ -599,19 +617,32 @@ ccsm_status probe_arithmetic(ccsm_model* m) {
     std::memset(&h0, 0, sizeof(h0));
     h0.mode = CCSM_H0_DEVICE_RNG;
     h0.seed = 20260928;
+    // reference = three fp16 passes; candidates in order of speed: split-mx, then the hybrid (recurrent part in three passes)
     std::vector<float> lg((size_t)kProbeSites * 2), pa(lg.size()), pb(lg.size());
-    st = ccsm_forward_host(m, ws, kProbeSites, &b, &h0, lg.data(), pa.data(), nullptr);
-    if (st == CCSM_OK) {
-        m->precision = CCSM_PRECISION_SPLIT3;
-        st = ccsm_forward_host(m, ws, kProbeSites, &b, &h0, lg.data(), pb.data(), nullptr);
-        m->precision = CCSM_PRECISION_SPLIT_F8;
+    const int wanted = m->precision;
+    m->precision = CCSM_PRECISION_SPLIT3;
+    st = ccsm_forward_host(m, ws, kProbeSites, &b, &h0, lg.data(), pb.data(), nullptr);
+    int chosen = CCSM_PRECISION_SPLIT3;
+    for (int cand : {(int)CCSM_PRECISION_SPLIT_F8, (int)CCSM_PRECISION_HYBRID}) {
+        if (st != CCSM_OK) break;
+        m->precision = cand;
+        st = ccsm_forward_host(m, ws, kProbeSites, &b, &h0, lg.data(), pa.data(), nullptr);
+        if (st != CCSM_OK) break;
+        float err = 0.f;
+        int beyond = 0;
+        for (int i = 0; i < kProbeSites; ++i) {
+            const float d = std::isfinite(pa[2 * i + 1]) ? std::fabs(pa[2 * i + 1] - pb[2 * i + 1]) : 1.0f;
+            err = std::fmax(err, d);
+            beyond += d > kProbeTailAt;
+        }
+        const float tail = (float)beyond / (float)kProbeSites;
+        (cand == CCSM_PRECISION_SPLIT_F8 ? m->probe_err : m->probe_err_hybrid) = err;
+        (cand == CCSM_PRECISION_SPLIT_F8 ? m->probe_tail : m->probe_tail_hybrid) = tail;
+        if ((tail <= kProbeTailFrac && err <= kProbeMaxErr) || std::getenv("CCSM_NO_PRECISION_FALLBACK") != nullptr) { chosen = cand; break; }
     }
+    m->precision = st == CCSM_OK ? chosen : wanted;
     ccsm_workspace_destroy(ws);
-    if (st != CCSM_OK) return st;
-    float err = 0.f;
-    for (size_t i = 0; i < pa.size(); ++i) err = std::fmax(err, std::isfinite(pa[i]) ? std::fabs(pa[i] - pb[i]) : 1.0f);
-    m->probe_err = err;
-    return CCSM_OK;
+    return st;
 }
 }  // namespace
 
@@ -628,8 +659,8 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         return fail(CCSM_ERR_UNSUPPORTED, "this build implements is_npass=yes, is_sn=no, is_map=no, is_stds=no");
     const int prec = cfg->precision == 0 ? 4 : cfg->precision;
     const bool auto_prec = cfg->precision == 0;
-    if (prec != CCSM_PRECISION_SPLIT3 && prec != CCSM_PRECISION_SPLIT_F8)
-        return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default), 3 (split-fp16) or 4 (split-f8)");
+    if (prec != CCSM_PRECISION_SPLIT3 && prec != CCSM_PRECISION_SPLIT_F8 && prec != CCSM_PRECISION_HYBRID)
+        return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default: chosen by a probe batch), 3 (split-fp16), 4 (split-mx) or 5 (hybrid)");
     if (!w->embed_weight || !w->att_wa || !w->att_ua || !w->att_va || !w->fc1_weight || !w->fc1_bias)
         return fail(CCSM_ERR_INVALID_ARG, "weights: NULL tensor");
     for (int l = 0; l < kLayers; ++l)
@@ -650,8 +681,15 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         if (st != CCSM_OK) break;
         if (prec == 4) {
             std::vector<uint8_t> bbuf;
-            m->mx_quant_err = std::fmax(m->mx_quant_err, pack_wstream_mx(l, w->weight_ih[l], w->weight_hh[l], bbuf));
+            m->mx_quant_err = std::fmax(m->mx_quant_err, pack_wstream_mx(l, w->weight_ih[l], w->weight_hh[l], false, bbuf));
             st = upload(&m->wstmx[l], bbuf.data(), bbuf.size());
+            if (st != CCSM_OK) break;
+        }
+        if (prec == 5 || auto_prec) {
+            std::vector<uint8_t> bbuf;
+            const float qe = pack_wstream_mx(l, w->weight_ih[l], w->weight_hh[l], true, bbuf);
+            if (prec == 5) m->mx_quant_err = std::fmax(m->mx_quant_err, qe);
+            st = upload(&m->wsthy[l], bbuf.data(), bbuf.size());
             if (st != CCSM_OK) break;
         }
         pack_bias(w->bias_ih[l], w->bias_hh[l], fbuf);
@@ -659,8 +697,8 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     }
     if (st == CCSM_OK) { pack_att(w->att_wa, hbuf); st = upload(&m->wa, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
     if (st == CCSM_OK) { pack_att(w->att_ua, hbuf); st = upload(&m->ua, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
-    if (st == CCSM_OK && prec == 4) { pack_att_v3(w->att_wa, hbuf, m->att_scale[0]); st = upload(&m->wa3, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
-    if (st == CCSM_OK && prec == 4) { pack_att_v3(w->att_ua, hbuf, m->att_scale[1]); st = upload(&m->ua3, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
+    if (st == CCSM_OK && prec >= 4) { pack_att_v3(w->att_wa, hbuf, m->att_scale[0]); st = upload(&m->wa3, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
+    if (st == CCSM_OK && prec >= 4) { pack_att_v3(w->att_ua, hbuf, m->att_scale[1]); st = upload(&m->ua3, hbuf.data(), hbuf.size() * sizeof(_Float16)); }
     if (st == CCSM_OK) {
         fbuf.assign((size_t)kWaves * 2 * 16, 0.f);
         for (int wave = 0; wave < kWaves; ++wave)
@@ -679,23 +717,27 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         set_lds(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB0>), gru2_lds(kKB0));
         set_lds(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB12>), gru2_lds(kKB12));
         set_lds(reinterpret_cast<const void*>(&attn_fc_kernel), kAttLds);
-        if (prec == CCSM_PRECISION_SPLIT_F8) {
-            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false>), kMx0Lds);
-            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false>), kMx12Lds);
-            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false>), kMx12Lds);
+        if (prec >= CCSM_PRECISION_SPLIT_F8) {
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, true>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, true>), kMx12Lds);
 #ifdef CCSM_PHASE_STAMPS
-            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true>), kMx0Lds);
-            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true>), kMx12Lds);
-            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, false>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, false>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true, false>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, true>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true, true>), kMx12Lds);
 #endif
             set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttLds);
         }
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }
     if (st == CCSM_OK && auto_prec) {
-        st = probe_arithmetic(m);
-        if (st == CCSM_OK && m->probe_err > kMxProbeMargin && std::getenv("CCSM_NO_PRECISION_FALLBACK") == nullptr)
-            m->precision = CCSM_PRECISION_SPLIT3;
+        st = probe_arithmetic(m);      // leaves the fastest arithmetic within the margin in m->precision
     }
     if (st != CCSM_OK) {
         ccsm_destroy(m);
@@ -706,6 +748,10 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
 }
 
 float ccsm_model_probe_error(const ccsm_model* m) { return m ? m->probe_err : -1.f; }
+float ccsm_model_probe_error_hybrid(const ccsm_model* m) { return m ? m->probe_err_hybrid : -1.f; }
+float ccsm_model_probe_tail(const ccsm_model* m, int precision) {
+    return !m ? -1.f : precision == CCSM_PRECISION_SPLIT_F8 ? m->probe_tail : precision == CCSM_PRECISION_HYBRID ? m->probe_tail_hybrid : -1.f;
+}
 float ccsm_model_quant_error(const ccsm_model* m) { return m ? m->mx_quant_err : -1.f; }
 
 void ccsm_destroy(ccsm_model* m) {
@@ -714,6 +760,7 @@ void ccsm_destroy(ccsm_model* m) {
     for (int l = 0; l < kLayers; ++l) {
         (void)hipFree(m->wst2[l]);
         (void)hipFree(m->wstmx[l]);
+        (void)hipFree(m->wsthy[l]);
         (void)hipFree(m->bias[l]);
     }
     (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);
@@ -884,7 +931,7 @@ ccsm_status ccsm_submit_host(const ccsm_model* m, ccsm_workspace* ws, int n_site
         std::memcpy(reinterpret_cast<uint8_t*>(ws->p_h0) + hb, h0->h0[1], hb);
         // split-mx's correction operands cover |h| up to ~8 (|h_t| <= max(1, |h0|)); a call with larger explicit initial states is
         // served in the split-fp16 arithmetic (host-pointer entry points only: device-resident initial states are not inspected)
-        if (m->precision == CCSM_PRECISION_SPLIT_F8) {
+        if (m->precision >= CCSM_PRECISION_SPLIT_F8) {       // split-mx and the hybrid (its activation blobs have the same range)
             float mx = 0.f;
             const float* p = ws->p_h0;
             for (size_t i = 0; i < 2 * hb / sizeof(float); ++i) mx = std::fmax(mx, std::fabs(p[i]));
@@ -1038,7 +1085,7 @@ ccsm_status ccsm_submit_reads_host(const ccsm_model* m, ccsm_workspace* ws, cons
         std::memcpy(reinterpret_cast<uint8_t*>(ws->p_h0) + hb, h0->h0[1], hb);
         // split-mx's correction operands cover |h| up to ~8 (|h_t| <= max(1, |h0|)); a call with larger explicit initial states is
         // served in the split-fp16 arithmetic (host-pointer entry points only: device-resident initial states are not inspected)
-        if (m->precision == CCSM_PRECISION_SPLIT_F8) {
+        if (m->precision >= CCSM_PRECISION_SPLIT_F8) {       // split-mx and the hybrid (its activation blobs have the same range)
             float mx = 0.f;
             const float* p = ws->p_h0;
             for (size_t i = 0; i < 2 * hb / sizeof(float); ++i) mx = std::fmax(mx, std::fabs(p[i]));

@@ -130,6 +130,27 @@ __device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, 
     blob_of(p, scale, c0, c1);
 }
 
+// The same 16 values as fp16 hi and fp16 lo fragments of the wave's two k-blocks (hybrid arithmetic: the recurrent operand).
+__device__ __forceinline__ void pack_pair_hl(const float (&v)[16], uint4& hi0, uint4& hi1, uint4& lo0, uint4& lo1) {
+    typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+    uint32_t hp[8], lp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const half2p h = {(_Float16)v[2 * j], (_Float16)v[2 * j + 1]};
+        hp[j] = __builtin_bit_cast(uint32_t, h);
+        lp[j] = pack2((_Float16)(v[2 * j] - (float)h[0]), (_Float16)(v[2 * j + 1] - (float)h[1]));
+    }
+    auto frag = [](uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1) {      // lane (n, g) <- k = 16 kb + 8 g + j
+        swap32(a0, b0);
+        swap32(a1, b1);
+        return make_uint4(a0, a1, b0, b1);
+    };
+    hi0 = frag(hp[0], hp[1], hp[2], hp[3]);
+    hi1 = frag(hp[4], hp[5], hp[6], hp[7]);
+    lo0 = frag(lp[0], lp[1], lp[2], lp[3]);
+    lo1 = frag(lp[4], lp[5], lp[6], lp[7]);
+}
+
 // LDS byte offsets shared by the two kernels: h fragments [kb 16][bt 3][hi | corr] x 1 KiB at 0 (96 KiB).  The fp8 residuals of a
 // wave's own units (16 B per lane and batch tile) live half in the unused second half of the lane's slot in the corr fragment
 // of the wave's second k-block (bytes 8-15) and half in a 12 KiB region at LO_OFF: [wave][bt][lane] x 8 B.
@@ -138,6 +159,7 @@ constexpr int kMxHBytes = kKBH * kMxNB * 2 * 1024;
 __device__ __forceinline__ int mx_hfrag(int kb, int bt, int f) { return ((kb * kMxNB + bt) * 2 + f) << 10; }
 
 // ---- h0 -> LDS: hi fragments, blobs (coarse scale) and residuals of this wave's own two k-blocks, every batch tile
+template <bool HS3>
 __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float* __restrict__ h0d, int tile0, int wave, int lane) {
     const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -148,6 +170,15 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
         for (int q = 0; q < 4; ++q) {
             const float4 t = *reinterpret_cast<const float4*>(src + 8 * q + 4 * hh);
             v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+        if constexpr (HS3) {            // exact: fp16 hi and fp16 lo fragments, any magnitude
+            uint4 hi0, hi1, lo0, lo1;
+            pack_pair_hl(v, hi0, hi1, lo0, lo1);
+            *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 0) + lane * 16) = hi0;
+            *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 0) + lane * 16) = hi1;
+            *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 1) + lane * 16) = lo0;
+            *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 1) + lane * 16) = lo1;
+            continue;
         }
         uint4 hi0, hi1, c0, lo8;
         uint2 c1;
@@ -163,7 +194,7 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
 // ---- step tail: n = tanh(N); h' = n + z (h_{t-1} - n) for this wave's own units; fragments and blobs for the next step (LDS)
 // and the next layer (HBM).  accz = sigmoid(Z) already, accn = N.  OUT_FP8: the layer feeding the attention kernel writes fp8 corr
 // fragments (attn_fc_f8_kernel's format) instead of blobs.  t16 = lane * 16 (an opaque copy: see lane16_here in the kernels).
-template <bool OUT_FP8>
+template <bool OUT_FP8, bool HS3>
 __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&accz)[kMxNB], const f32x16 (&accn)[kMxNB], uint4* __restrict__ out,
                                         int tile0, int t, int dir, int wave, int t16) {
     const int own_off = wave * (2 * kMxNB * 2 * 1024);                          // mx_hfrag(2 wave, 0, 0)
@@ -174,17 +205,27 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
 #pragma unroll
     for (int bt = 0; bt < kMxNB; ++bt) {
         float hn[16];
-        const uint2 la = *reinterpret_cast<const uint2*>(t_wr + own_frag(1, bt, 1) + 8);    // residuals of values 0..7
-        const uint2 lb = *reinterpret_cast<const uint2*>(t_lo + bt * (64 * 8));             // 8..15
+        uint2 la = make_uint2(0, 0), lb = make_uint2(0, 0);
+        if constexpr (!HS3) {
+            la = *reinterpret_cast<const uint2*>(t_wr + own_frag(1, bt, 1) + 8);            // residuals of values 0..7
+            lb = *reinterpret_cast<const uint2*>(t_lo + bt * (64 * 8));                     // 8..15
+        }
         const uint32_t l8[4] = {la.x, la.y, lb.x, lb.y};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const half4 hi = as_half4(*reinterpret_cast<const uint2*>(t_rd + own_frag(q >> 1, bt, 0) + 512 * (q & 1)));
-            const int lo4 = (int)l8[q];
-            const float hp[4] = {(float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo4, 0) * (1.0f / kMxLoScale),
-                                 (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo4, 1) * (1.0f / kMxLoScale),
-                                 (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo4, 2) * (1.0f / kMxLoScale),
-                                 (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo4, 3) * (1.0f / kMxLoScale)};
+            float hp[4];
+            if constexpr (HS3) {        // h_{t-1} = fp16 hi + fp16 lo, both from this wave's own fragments
+                const half4 lo = as_half4(*reinterpret_cast<const uint2*>(t_rd + own_frag(q >> 1, bt, 1) + 512 * (q & 1)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hp[e] = (float)hi[e] + (float)lo[e];
+            } else {
+                const int lo4 = (int)l8[q];
+                hp[0] = (float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo4, 0) * (1.0f / kMxLoScale);
+                hp[1] = (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo4, 1) * (1.0f / kMxLoScale);
+                hp[2] = (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo4, 2) * (1.0f / kMxLoScale);
+                hp[3] = (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo4, 3) * (1.0f / kMxLoScale);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float nn = tanh_fold(accn[bt][4 * q + e]);
@@ -197,9 +238,16 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
         const uint4 c1w = make_uint4(c1.x, c1.y, lo8.x, lo8.y);
         *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 0)) = hi0;
         *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 0)) = hi1;
-        *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = c0;
-        *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = c1w;
-        *reinterpret_cast<uint2*>(t_lo + bt * (64 * 8)) = make_uint2(lo8.z, lo8.w);
+        if constexpr (HS3) {            // the recurrent operand of the next step: fp16 lo fragments (the blob only travels to the next layer)
+            uint4 h0_, h1_, lo0, lo1;
+            pack_pair_hl(hn, h0_, h1_, lo0, lo1);
+            *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = lo0;
+            *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = lo1;
+        } else {
+            *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = c0;
+            *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = c1w;
+            *reinterpret_cast<uint2*>(t_lo + bt * (64 * 8)) = make_uint2(lo8.z, lo8.w);
+        }
         // streaming stores: the next reader is another kernel 0.5 GB later, keep the L2 for the weight stream
         char* o = reinterpret_cast<char*>(out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + 2 * wave)) * 2 * kFragU4) + t16;
         nt_store(hi0, reinterpret_cast<uint4*>(o));
@@ -236,9 +284,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   phase-B pair (r, z, n) : hi (kbl, g) at (3 kbl + g) KiB | fp4 blob (g) at (6 + g) KiB | scales at 9 KiB                  = 9472 B
 //   phase-C pair (n)       : hi (kbl) at kbl KiB | fp6 blob: bytes 0-15 at 2 KiB, 16-23 at 3 KiB | scales at 3.5 KiB (byte 0) = 3840 B
 constexpr int kMxPairA = 6 * 1024 + 256, kMxPairB = 9 * 1024 + 256, kMxPairC = 3 * 1024 + 512 + 256;
-constexpr int kMx0WBytes = 4 * 1024 + (kKBH / 2) * kMxPairB + 2 * 1024;       // layer 0: [r hi, r lo, z hi, z lo] [B] [n hi, n lo]
-constexpr int kMx12OffB = (kKB12 / 2) * kMxPairA, kMx12OffC = kMx12OffB + (kKBH / 2) * kMxPairB;
-constexpr int kMx12WBytes = kMx12OffC + (kKB12 / 2) * kMxPairC;
+// "hybrid" arithmetic (HS3): the recurrent part in three fp16 passes (hi*hi + lo*hi + hi*lo, the state carried as fp16 hi + fp16 lo),
+// the input part in split-mx.  On a TRAINED checkpoint the recurrent part is where the 4-bit corrections and the fp8 state residual cost
+// accuracy (it is applied 21 times per layer): emulated on trained weights, max |dprob| 1.8e-5 with the hybrid against 1.2e-4 with split-mx
+// throughout.  Its phase-B pair: hi (kbl, g) at (3 kbl + g) KiB | fp16 lo (kbl, g) at (6 + 3 kbl + g) KiB = 12 KiB.
+constexpr int kMxPairBH = 12 * 1024;
+constexpr int mx_pair_b(bool hs3) { return hs3 ? kMxPairBH : kMxPairB; }
+constexpr int mx0_wbytes(bool hs3) { return 4 * 1024 + (kKBH / 2) * mx_pair_b(hs3) + 2 * 1024; }   // layer 0: [r hi, r lo, z hi, z lo] [B] [n hi, n lo]
+constexpr int kMx12OffB = (kKB12 / 2) * kMxPairA;
+constexpr int mx12_off_c(bool hs3) { return kMx12OffB + (kKBH / 2) * mx_pair_b(hs3); }
+constexpr int mx12_wbytes(bool hs3) { return mx12_off_c(hs3) + (kKB12 / 2) * kMxPairC; }
 
 // G gates of the pair's correction product: weight blobs W[g] with scale bytes g of WS, activation blobs xc0 / xc1
 #define CCSM_CORR_G(G, W, WS, SB)                                                                             \
@@ -262,13 +317,14 @@ constexpr int kMx12WBytes = kMx12OffC + (kKB12 / 2) * kMxPairC;
 constexpr int kMx0XOff = kMxHBytes, kMx0LoOff = kMx0XOff + 2 * kMxNB * 2 * 1024, kMx0BiasOff = kMx0LoOff + kWaves * kMxNB * 64 * 8;
 constexpr int kMx0Lds = kMx0BiasOff + kWaves * 4 * 32 * 4;
 
-template <bool DBG>
+template <bool DBG, bool HS3>
 __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                 const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                 const float* __restrict__ h0, int rows_p,
                                                                 unsigned long long* __restrict__ dbg) {
     constexpr int NB = kMxNB;
-    constexpr int OFF_B = 4 * 1024, OFF_C = OFF_B + (kKBH / 2) * kMxPairB;
+    constexpr int PB = mx_pair_b(HS3);
+    constexpr int OFF_B = 4 * 1024, OFF_C = OFF_B + (kKBH / 2) * PB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -281,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 
     if (threadIdx.x < kWaves * 4 * 32 / 4)
         reinterpret_cast<float4*>(smem + kMx0BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
-    mx_h0_to_lds(smem, kMx0LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
+    mx_h0_to_lds<HS3>(smem, kMx0LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     // x staging: 6 fragments per step (bt x hi|lo), waves 0-5 move one each
     const u32x4_t xrs = dma_rsrc(xin);
@@ -292,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
         const int soff = ((((tile0 + bt) * kSeqLen + t) * 2 + hl) << 10);
         dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + ((buf * 6 + f) << 10))));
     };
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * kMx0WBytes);
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx0_wbytes(HS3));
     const int bias_off = kMx0BiasOff + wave * 4 * 32 * 4;
     auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
     auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
@@ -300,20 +356,23 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
     uint4 wxa[2][2];                                                // phase A: [gate r,z][hi, lo]
     uint4 wxc[2];                                                   // phase C: n gate [hi, lo]
     uint4 wbh[2][3], wbb[3];                                        // phase B resident pair: [kb in pair][gate] hi ; [gate] blob
-    uint32_t wbs;                                                   //                        scale bytes
-    auto ld_first = [&]() {                                         // everything a step needs before its second phase-B pair: 14 requests
+    uint32_t wbs = 0;                                               //                        scale bytes
+    uint4 wbl[2][3];                                                // hybrid arithmetic: [kb in pair][gate] fp16 lo instead of the blobs
+    auto ld_first = [&]() {                                         // everything a step needs before its second phase-B pair: 14 (16) requests
 #pragma unroll
         for (int g = 0; g < 2; ++g) { wxa[g][0] = w_at((2 * g) << 10); wxa[g][1] = w_at((2 * g + 1) << 10); }
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
             wbh[0][g] = w_at(OFF_B + (g << 10)); wbh[1][g] = w_at(OFF_B + ((3 + g) << 10));
-            wbb[g] = w_at(OFF_B + ((6 + g) << 10));
+            if constexpr (HS3) { wbl[0][g] = w_at(OFF_B + ((6 + g) << 10)); wbl[1][g] = w_at(OFF_B + ((9 + g) << 10)); }
+            else wbb[g] = w_at(OFF_B + ((6 + g) << 10));
         }
-        wbs = ws_at(OFF_B + (9 << 10));
+        if constexpr (!HS3) wbs = ws_at(OFF_B + (9 << 10));
     };
     stage_load(dir ? kSeqLen - 1 : 0, 0);
     ld_first();
-    asm volatile("s_waitcnt vmcnt(14)" ::: "memory");               // the first transfer (older than the 14 weight requests)
+    if constexpr (HS3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");          // the first transfer (older than the 14 weight requests)
 
     for (int s = 0; s < kSeqLen; ++s) {
         const int t = dir ? (kSeqLen - 1 - s) : s;
@@ -347,7 +406,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
         }
         // ---------------- phase A: R, Z += W_i{r,z} x_t (three fp16 passes) -------------------------------------------------
         // the transfer of this step's x (issued one step ago) is older than the 14 weight requests and 12 output stores of the tail
-        asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+        if constexpr (HS3) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // (16 weight requests there)
+        else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
         __syncthreads();                                            // x_t in LDS; everybody's h_{t-1} fragments written
         stage_load(tn, (s + 1) & 1);
         auto rd_x0 = [&](uint4 (&x0)[NB][2]) {
@@ -383,10 +443,40 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
         const int sbh = sb + (s == 0 ? kMxScaleHi0 - kMxScaleHi : 0);
         uint4 xh[NB], xc0[NB];
         uint2 xc1[NB];
+        if constexpr (HS3) {
+            // hybrid arithmetic: three fp16 passes per k-block (W_hi h_hi + W_lo h_hi + W_hi h_lo); one pair resident (hi and lo fragments
+            // of its two k-blocks), each k-block's six fragments refilled with the next pair's right behind its MFMAs
+            uint4 xl[NB];
+            static_for<0, kKBH>([&](auto KC) {
+                constexpr int KB = decltype(KC)::value;
+                constexpr int KBL = KB & 1, Q = KB >> 1;
+                constexpr int NXT = OFF_B + (Q + 1) * PB;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(KB, bt, 0) + lane * 16);
+                    xl[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(KB, bt, 1) + lane * 16);
+                }
+                CCSM_FENCE;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[g][bt] = mfma16(wbh[KBL][g], xh[bt], acc[g][bt]);
+                        acc[g][bt] = mfma16(wbl[KBL][g], xh[bt], acc[g][bt]);
+                        acc[g][bt] = mfma16(wbh[KBL][g], xl[bt], acc[g][bt]);
+                    }
+                CCSM_FENCE;
+                if constexpr (Q + 1 < kKBH / 2) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) { wbh[KBL][g] = w_at(NXT + ((3 * KBL + g) << 10)); wbl[KBL][g] = w_at(NXT + ((6 + 3 * KBL + g) << 10)); }
+                }
+                CCSM_FENCE;
+            });
+        } else
         static_for<0, kKBH / 2>([&](auto QC) {
             constexpr int Q = decltype(QC)::value;
             constexpr bool LAST = Q == kKBH / 2 - 1;
-            constexpr int NXT = OFF_B + (Q + 1) * kMxPairB;
+            constexpr int NXT = OFF_B + (Q + 1) * PB;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 0) + lane * 16);
@@ -453,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
         __syncthreads();                                            // every wave has read h_{t-1} (phase B) before anybody overwrites its fragments
-        mx_tail<false>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        mx_tail<false, HS3>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         stamp(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no transfer may still be writing LDS when the workgroup retires
@@ -485,13 +575,13 @@ constexpr int kMxSlotBytes = 2 * kMxNB * 2 * 1024;
 constexpr int kMx12XOff = kMxHBytes, kMx12LoOff = kMx12XOff + kMxRS * kMxSlotBytes, kMx12BiasOff = kMx12LoOff + kWaves * kMxNB * 64 * 8;
 constexpr int kMx12Lds = kMx12BiasOff + kWaves * 4 * 32 * 4;
 
-template <bool OUT_FP8, bool DBG>
+template <bool OUT_FP8, bool DBG, bool HS3>
 __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                  const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                  const float* __restrict__ h0, int rows_p,
                                                                  unsigned long long* __restrict__ dbg) {
     constexpr int NB = kMxNB, KX = kKB12, NPAIR = KX / 2, RS = kMxRS, SLOT_BYTES = kMxSlotBytes;
-    constexpr int PA = kMxPairA, PB = kMxPairB, PC = kMxPairC, OFF_B = kMx12OffB, OFF_C = kMx12OffC;
+    constexpr int PA = kMxPairA, PB = mx_pair_b(HS3), PC = kMxPairC, OFF_B = kMx12OffB, OFF_C = mx12_off_c(HS3);
     constexpr int X_OFF = kMx12XOff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -504,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 
     if (threadIdx.x < kWaves * 4 * 32 / 4)
         reinterpret_cast<float4*>(smem + kMx12BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
-    mx_h0_to_lds(smem, kMx12LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
+    mx_h0_to_lds<HS3>(smem, kMx12LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     // ---- x transfers: fragment f = (kbl * NB + bt) * 2 + hl of a ring slot; wave w moves fragment w, waves 0-3 also w + 8
     const u32x4_t xrs = dma_rsrc(xin);
@@ -534,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         else asm volatile("s_waitcnt vmcnt(" #NLO ")" ::: "memory");                     \
     } while (0)
 
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * kMx12WBytes);
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx12_wbytes(HS3));
     const int bias_off = kMx12BiasOff + wave * 4 * 32 * 4;
     auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
     auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
@@ -549,7 +639,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     uint4 wah[3][2][2], wab[3][2];
     uint32_t was[3];
     uint4 wbh[2][3], wbb[3];
-    uint32_t wbs;
+    uint32_t wbs = 0;
+    uint4 wbl[2][3];                                // hybrid arithmetic: fp16 lo fragments of the resident phase-B pair instead of the blobs
     uint4 wch[4][2], wcb[4];
     uint2 wcb1[4];
     uint32_t wcs[4];
@@ -642,16 +733,20 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             CCSM_MAIN(wah[WS][0], xh, 2, 0);
             if constexpr (P + 3 < NPAIR) ldAh(wah[WS][0], P + 3, 0);
             else if constexpr (P == 13) { wbh[0][0] = w_at(OFF_B + (0 << 10)); wbh[0][1] = w_at(OFF_B + (1 << 10)); }
-            else if constexpr (P == 14) { wbs = ws_at(OFF_B + (9 << 10)); }
+            else if constexpr (P == 14) {
+                if constexpr (HS3) wbl[1][0] = w_at(OFF_B + (9 << 10)); else wbs = ws_at(OFF_B + (9 << 10));
+            }
             rdx_blob(xs);
             CCSM_MAIN(wah[WS][1], xh1, 2, 0);
             if constexpr (P + 3 < NPAIR) ldAh(wah[WS][1], P + 3, 1);
             else if constexpr (P == 13) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); }
+            else if constexpr (P == 14 && HS3) { wbl[1][1] = w_at(OFF_B + (10 << 10)); wbl[1][2] = w_at(OFF_B + (11 << 10)); }
             // this wave's part of the next pair's transfer has landed.  Operations the wave has issued since that refill (it sits right
             // behind its pair's barrier): the 3 blob / scale requests of that pair, two pairs of 7 + d, 4 of this pair; pair 13 requests
             // phase B's first pair instead (9), pair 14 one more of it, pair 15 nothing
-            if constexpr (P == NPAIR - 1) CCSM_WAIT_XFER(15, 17);
-            else if constexpr (P == NPAIR - 2) CCSM_WAIT_XFER(22, 24);
+            // (hybrid arithmetic: pair 14 requests three fragments of phase B's first pair instead of one)
+            if constexpr (P == NPAIR - 1) { if constexpr (HS3) CCSM_WAIT_XFER(17, 19); else CCSM_WAIT_XFER(15, 17); }
+            else if constexpr (P == NPAIR - 2) { if constexpr (HS3) CCSM_WAIT_XFER(24, 26); else CCSM_WAIT_XFER(22, 24); }
             else CCSM_WAIT_XFER(23, 25);
             __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
             if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once (0.4 pair more
@@ -665,8 +760,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             }
             CCSM_FENCE;
             if constexpr (P + 3 < NPAIR) ldAb(WS, P + 3);
-            else if constexpr (P == 13) { wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10)); wbb[0] = w_at(OFF_B + (6 << 10));
-                                          wbb[1] = w_at(OFF_B + (7 << 10)); wbb[2] = w_at(OFF_B + (8 << 10)); }
+            else if constexpr (P == 13) {       // (hybrid: fragments 6-8 are the fp16 lo of the pair's first k-block)
+                wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10));
+                if constexpr (HS3) { wbl[0][0] = w_at(OFF_B + (6 << 10)); wbl[0][1] = w_at(OFF_B + (7 << 10)); wbl[0][2] = w_at(OFF_B + (8 << 10)); }
+                else { wbb[0] = w_at(OFF_B + (6 << 10)); wbb[1] = w_at(OFF_B + (7 << 10)); wbb[2] = w_at(OFF_B + (8 << 10)); }
+            }
             CCSM_FENCE;
             slot = slot_n;
         });
@@ -679,6 +777,42 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             for (int bt = 0; bt < NB; ++bt) acc[2][bt] = b3;
         }
         const int sbh = sb + (s == 0 ? kMxScaleHi0 - kMxScaleHi : 0);
+        if constexpr (HS3) {
+            // hybrid arithmetic: three fp16 passes per k-block (W_hi h_hi + W_lo h_hi + W_hi h_lo); one pair resident (hi and lo fragments
+            // of its two k-blocks), each k-block's six fragments refilled with the next pair's right behind its MFMAs; the last pair's
+            // positions take phase C's first pair slot and the hi fragments of its second
+            uint4 (&xl)[NB] = xc0;
+            static_for<0, kKBH>([&](auto KC) {
+                constexpr int KB = decltype(KC)::value;
+                constexpr int KBL = KB & 1, Q = KB >> 1;
+                constexpr int NXT = OFF_B + (Q + 1) * PB;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(KB, bt, 0) + lane * 16);
+                    xl[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(KB, bt, 1) + lane * 16);
+                }
+                CCSM_FENCE;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        acc[g][bt] = mfma16(wbh[KBL][g], xh[bt], acc[g][bt]);
+                        acc[g][bt] = mfma16(wbl[KBL][g], xh[bt], acc[g][bt]);
+                        acc[g][bt] = mfma16(wbh[KBL][g], xl[bt], acc[g][bt]);
+                    }
+                CCSM_FENCE;
+                if constexpr (Q + 1 < kKBH / 2) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) { wbh[KBL][g] = w_at(NXT + ((3 * KBL + g) << 10)); wbl[KBL][g] = w_at(NXT + ((6 + 3 * KBL + g) << 10)); }
+                } else if constexpr (KBL == 0) {
+                    wch[0][0] = w_at(OFF_C + 0 * PC + (0 << 10)); wch[0][1] = w_at(OFF_C + 0 * PC + (1 << 10)); wcb[0] = w_at(OFF_C + 0 * PC + (2 << 10));
+                } else {
+                    wcb1[0] = w8_at(OFF_C + 0 * PC + (3 << 10)); wcs[0] = ws_at(OFF_C + 0 * PC + (3 << 10) + 512);
+                    wch[1][0] = w_at(OFF_C + 1 * PC + (0 << 10)); wch[1][1] = w_at(OFF_C + 1 * PC + (1 << 10));
+                }
+                CCSM_FENCE;
+            });
+        } else
         // pair Q = k-blocks 2Q, 2Q + 1: one pair resident, refilled with the next pair behind each MFMA group (3 + 3 + 4
         // requests); the last pair's positions take phase C's first pair slot
         static_for<0, kKBH / 2>([&](auto QC) {
@@ -792,7 +926,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         });
 #undef CCSM_MAIN
         stamp(3);
-        mx_tail<OUT_FP8>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        mx_tail<OUT_FP8, HS3>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         CCSM_FENCE;
         ldA_slot(2, 2);                                             // the third weight slot of the next step (needed two pairs in): not live across the tail
         CCSM_FENCE;

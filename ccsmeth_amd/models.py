@@ -46,6 +46,9 @@ class DeviceModel:
         self.device = int(device)
         self.precision = lib.ccsm_model_precision(handle)      # the arithmetic in use (3 after a fallback from the default)
         self.probe_error = float(lib.ccsm_model_probe_error(handle))
+        self.probe_error_hybrid = float(lib.ccsm_model_probe_error_hybrid(handle))     # -1: split-mx was accepted (or a precision forced)
+        self.probe_tail = float(lib.ccsm_model_probe_tail(handle, 4))                  # fraction of the probe sites beyond 1e-5
+        self.probe_tail_hybrid = float(lib.ccsm_model_probe_tail(handle, 5))
         self.quant_error = float(lib.ccsm_model_quant_error(handle))
         self._workspaces = []
 

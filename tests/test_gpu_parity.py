@@ -26,13 +26,14 @@ DEFAULT_TOL = 1e-5   # what the default (split-mx) arithmetic has to hold on wel
 SPLIT3_TOL = 1e-6    # the fp32-class fallback (measured: 2-3e-7)
 
 
-@pytest.fixture(scope="module", params=[0, 3], ids=["default-split-mx", "split3"])
+@pytest.fixture(scope="module", params=[0, 5, 3], ids=["default-split-mx", "hybrid", "split3"])
 def model7(request):
-    """Every test on this fixture runs in the default arithmetic (split-mx, CCSM_PRECISION_SPLIT_F8) and in the three-pass fp16 split."""
+    """Every test on this fixture runs in the default arithmetic (split-mx, CCSM_PRECISION_SPLIT_F8), in the hybrid (split-mx input part,
+    three-pass recurrent part: what the probe selects for trained checkpoints) and in the three-pass fp16 split."""
     from ccsmeth_amd.models import DeviceModel
     w = synth.synth_weights(7)
     dm = DeviceModel(w, device=0, precision=request.param)
-    assert dm.precision == (4 if request.param == 0 else 3)
+    assert dm.precision == {0: 4, 5: 5, 3: 3}[request.param]
     yield w, dm
     dm.close()
 
@@ -81,11 +82,21 @@ def test_default_arithmetic_within_1e5_and_split3_within_1e6(model7):
     _, probs = _fwd(ws, s, (h1, h2))
     ws.close()
     err = np.abs(probs - _oracle(w, s, h1, h2)[1]).max()
-    assert err < (DEFAULT_TOL if dm.precision == 4 else SPLIT3_TOL), err
+    assert err < (DEFAULT_TOL if dm.precision >= 4 else SPLIT3_TOL), err
+
+
+def _cascade(dm):
+    """What ccsm_create's probe has to select: the fastest arithmetic that leaves <= 0.5 % of the probe sites beyond 1e-5 and none beyond
+    5e-5 of the three-pass one."""
+    ok = lambda err, tail: 0 <= err <= 5e-5 and 0 <= tail <= 0.005     # noqa: E731
+    if ok(dm.probe_error, dm.probe_tail):
+        assert dm.probe_error_hybrid < 0 and dm.probe_tail_hybrid < 0   # not run
+        return 4
+    return 5 if ok(dm.probe_error_hybrid, dm.probe_tail_hybrid) else 3
 
 
 def test_default_arithmetic_is_chosen_by_the_probe():
-    """precision 0: ccsm_create measures split-mx against split-fp16 on a probe batch; the synthetic checkpoint keeps split-mx, the
+    """precision 0: ccsm_create measures split-mx, then the hybrid, against split-fp16 on a probe batch; the synthetic checkpoint keeps split-mx, the
     hostile one (Student-t matrices with x50 outliers, gate-saturating biases) is served in whatever arithmetic the probe left, and
     in either case holds the tolerance that arithmetic promises.  An explicit precision is never overridden."""
     from ccsmeth_amd.models import DeviceModel
@@ -94,7 +105,7 @@ def test_default_arithmetic_is_chosen_by_the_probe():
     h1, h2 = synth.synth_h0(n, 98)
     w = synth.synth_weights(7)
     dm = DeviceModel(w, device=0)
-    assert dm.precision == 4 and 0 <= dm.probe_error < 1.5e-5 and 0 < dm.quant_error < 0.2
+    assert dm.precision == 4 and 0 <= dm.probe_error < 1.5e-5 and dm.probe_tail == 0 and 0 < dm.quant_error < 0.2
     dm.close()
     for seed in (7, 11):
         wh = synth.synth_weights_heavy(seed)
@@ -103,8 +114,8 @@ def test_default_arithmetic_is_chosen_by_the_probe():
         assert dm.probe_error >= 0
         ws = dm.workspace(n)
         err = np.abs(_fwd(ws, s, (h1, h2))[1] - ref).max()
-        assert (dm.precision == 3) == (dm.probe_error > 1.5e-5)
-        assert err < (3e-5 if dm.precision == 4 else SPLIT3_TOL), (seed, dm.precision, dm.probe_error, err)
+        assert dm.precision == _cascade(dm), (dm.precision, dm.probe_error, dm.probe_error_hybrid)
+        assert err < (5e-5 if dm.precision >= 4 else SPLIT3_TOL), (seed, dm.precision, dm.probe_error, err)
         dm.close()
         forced = DeviceModel(wh, device=0, precision=4)       # explicit split-mx on the hostile checkpoint: still inside the bar
         assert forced.precision == 4 and forced.probe_error < 0
@@ -129,7 +140,7 @@ def test_large_initial_states(model7, scale):
     _, again = _fwd(ws, s, (np.clip(h1, -1, 1), np.clip(h2, -1, 1)))          # the next call is back in the model's own arithmetic
     ws.close()
     assert np.abs(probs - _oracle(w, s, h1, h2)[1]).max() < 1e-5      # fp32 rounding of states up to 35 (measured: 3e-6)
-    assert np.abs(again - _oracle(w, s, np.clip(h1, -1, 1), np.clip(h2, -1, 1))[1]).max() < (DEFAULT_TOL if dm.precision == 4 else SPLIT3_TOL)
+    assert np.abs(again - _oracle(w, s, np.clip(h1, -1, 1), np.clip(h2, -1, 1))[1]).max() < (DEFAULT_TOL if dm.precision >= 4 else SPLIT3_TOL)
 
 
 def test_large_device_resident_initial_states_degrade_gracefully():
@@ -165,7 +176,7 @@ def test_forward_vs_oracle_ragged_sizes(model7, n):
     rl, rp = _oracle(w, s, h1, h2)
     ws.close()
     assert np.isfinite(logits).all() and np.isfinite(probs).all()
-    assert np.abs(probs - rp).max() < (DEFAULT_TOL if dm.precision == 4 else SPLIT3_TOL)
+    assert np.abs(probs - rp).max() < (DEFAULT_TOL if dm.precision >= 4 else SPLIT3_TOL)
     assert np.abs(logits - rl).max() < LOGIT_TOL
 
 
@@ -179,7 +190,7 @@ def test_forward_vs_reference_goldens():
         w = synth.synth_weights(m["weight_seed"])
         s = synth.synth_sites(m["n"], m["site_seed"])
         h1, h2 = synth.synth_h0(m["n"], m["h0_seed"])
-        for prec in (0, 3):
+        for prec in (0, 5, 3):
             dm = DeviceModel(w, device=0, precision=prec)
             ws = dm.workspace(m["n"])
             logits, probs = _fwd(ws, s, (h1, h2))

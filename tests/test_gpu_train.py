@@ -127,14 +127,16 @@ def test_dropout_and_device_rng_h0_train_and_reduce_loss():
     assert not np.allclose(a[1:4], c[1:4], rtol=1e-3)
     assert np.mean(a[-10:]) < 0.45 and eva < 0.45 and acca > 0.85, (a[:3], a[-10:], eva, acca)
     # the TRAINED parameters (not the synthetic initialisation the other parity tests use) through the inference library's default
-    # arithmetic: whatever the probe batch selects for THIS checkpoint (a trained model is more sensitive: split-mx leaves a tail of
-    # ~0.1 % of the sites beyond 1e-4, the probe sees 2e-5 and selects the three-pass arithmetic), the probabilities stay within 1e-5
-    # of the oracle (h0 pinned)
+    # arithmetic: whatever the probe batch selects for THIS checkpoint (a trained model is more sensitive: split-mx leaves ~2 % of the
+    # sites beyond 1e-5 and a heavy tail, the probe rejects it and accepts the hybrid arithmetic), the probabilities stay within the
+    # probe's own bound of the oracle (h0 pinned)
     from ccsmeth_amd.models import DeviceModel
     from oracle import attbigru2s_oracle as orc
     wt = trained[0]
     dm = DeviceModel(wt, device=0)
-    assert dm.precision in (3, 4) and (dm.precision == 3) == (dm.probe_error > 1.5e-5)
+    ok = lambda err, tail: 0 <= err <= 5e-5 and 0 <= tail <= 0.005     # noqa: E731  (ccsm_create's acceptance rule)
+    want = 4 if ok(dm.probe_error, dm.probe_tail) else 5 if ok(dm.probe_error_hybrid, dm.probe_tail_hybrid) else 3
+    assert dm.precision == want, (dm.precision, dm.probe_error, dm.probe_tail, dm.probe_error_hybrid, dm.probe_tail_hybrid)
     m = 256
     sv = {k: v[:m] for k, v in val.items()}
     h1, h2 = synth.synth_h0(m, 99)
@@ -142,7 +144,7 @@ def test_dropout_and_device_rng_h0_train_and_reduce_loss():
     _, probs = ws.forward_host(sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"], h0=(h1, h2))
     ws.close(); dm.close()
     _, ref = orc.attbigru2s_forward(wt, sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"], h1, h2)
-    assert np.abs(probs - ref).max() < 1e-5
+    assert np.abs(probs - ref).max() < (5e-5 if dm.precision >= 4 else 1e-5), dm.precision
     assert 0.05 < float((ref[:, 1] > 0.5).mean()) < 0.95                # a model that actually discriminates
 
 
