@@ -28,7 +28,8 @@ class Weights(C.Structure):
 
 
 class Strand(C.Structure):
-    _fields_ = [("kmer", C.c_void_p), ("ipd", C.c_void_p), ("pw", C.c_void_p), ("npass", C.c_void_p)]
+    _fields_ = [("kmer", C.c_void_p), ("ipd", C.c_void_p), ("pw", C.c_void_p), ("npass", C.c_void_p),
+                ("ipd_std", C.c_void_p), ("pw_std", C.c_void_p), ("sn", C.c_void_p), ("map", C.c_void_p)]   # is_stds / is_sn / is_map models only
 
 
 class Batch(C.Structure):

@@ -92,7 +92,8 @@ def _check_scope(args):
     if args.model_type != "attbigru2s":
         raise ValueError("--model_type not right!")                    # call_modifications.py:340
     if not yes(args.is_npass) or yes(args.is_stds) or yes(args.is_sn) or yes(args.is_map):
-        raise ValueError("this build implements --is_npass yes --is_stds no --is_sn no --is_map no")
+        raise ValueError("this command builds the default per-site features (--is_npass yes --is_stds no --is_sn no --is_map no); the model "
+                         "itself takes the other variants through ModelAttRNN.forward / ccsm_forward_host (include/ccsm.h)")
     if (args.layer_rnn, args.hid_rnn, args.class_num, args.seq_len) != (3, 256, 2, 21):
         if args.seq_len % 2 == 0:
             raise ValueError("--seq_len must be odd")                  # :500-501

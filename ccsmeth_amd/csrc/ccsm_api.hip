@@ -65,6 +65,8 @@ struct ccsm_model {
     int precision = 3;
     uint4* wst2[kLayers] = {nullptr, nullptr, nullptr}; // split3: [dir][wave][A: KX x (r,z) | B: 16 x (r,z,n) | C: KX x (n)][hl][64]
     float mx_quant_err = 0.f;                            // relative RMS quantisation error of the weight correction blobs (worst layer)
+    int feat = kFeatNpass;                               // optional input features of the variant (kFeat* bits); feat0 = columns of weight_ih_l0
+    int feat0 = kFeat0;
     float probe_err_hybrid = -1.f;                       // ... of the hybrid arithmetic (-1: not run: split-mx was accepted)
     float probe_tail = -1.f, probe_tail_hybrid = -1.f;   // fraction of the probe sites beyond kProbeTailAt
     float probe_err = -1.f;                              // max |dprob| split-mx vs split-fp16 on the probe batch of ccsm_create (-1: not run)
@@ -135,9 +137,9 @@ struct ccsm_workspace {
 namespace {
 
 // Split-fp16 weight stream: per (dir, wave) the [hi | lo] fragments in the order the three phases consume them.
-void pack_wstream_v2(int layer, const float* const wih[2], const float* const whh[2], std::vector<_Float16>& out) {
+void pack_wstream_v2(int layer, int feat0, const float* const wih[2], const float* const whh[2], std::vector<_Float16>& out) {
     const int kx = layer_kx(layer);
-    const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
+    const int k_in = layer == 0 ? feat0 : 2 * kHidden;
     const int nfrag = kx * 4 + kKBH * 6 + kx * 2;   // (gate, hl) fragments per wave
     out.assign((size_t)2 * kWaves * nfrag * 512, (_Float16)0.f);
     for (int dir = 0; dir < 2; ++dir)
@@ -297,8 +299,8 @@ inline void emit_hi_frag(_Float16* dst, int kb, const std::function<float(int, i
 
 // Split-mx weight stream of one layer (byte layouts: ccsm_gru_mx.hip).  Returns the relative RMS quantisation error of the layer's
 // correction blobs (the larger of the W_lo and W_hi halves).
-float pack_wstream_mx(int layer, const float* const wih[2], const float* const whh[2], bool hs3, std::vector<uint8_t>& out) {
-    const int k_in = layer == 0 ? kFeat0 : 2 * kHidden;
+float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const float* const whh[2], bool hs3, std::vector<uint8_t>& out) {
+    const int k_in = layer == 0 ? feat0 : 2 * kHidden;
     const size_t wbytes = layer == 0 ? mx0_wbytes(hs3) : mx12_wbytes(hs3);
     const size_t pair_b = mx_pair_b(hs3);
     out.assign((size_t)2 * kWaves * wbytes, 0);
@@ -418,7 +420,7 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
                        seed, offset);
     const int total = 2 * n_sites * kSeqLen * 2;
     hipLaunchKernelGGL(pack_x0_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws->x0, s1, s2, m->embed, n_sites, row_base,
-                       kmer_is_f32, npass_per_base);
+                       kmer_is_f32, npass_per_base, m->feat);
     HIP_TRY(hipGetLastError());
     return CCSM_OK;
 }
@@ -544,14 +546,24 @@ ccsm_status dispatch_forward(const ccsm_model* m, ccsm_workspace* ws, int n_site
     return dispatch_run(m, ws, st);
 }
 
+StrandDev strand_dev(const ccsm_strand& t) {
+    StrandDev d{t.kmer, t.ipd, t.pw, t.npass};
+    d.ipd_std = t.ipd_std; d.pw_std = t.pw_std; d.sn = t.sn; d.map = t.map;
+    return d;
+}
+
 ccsm_status check_call(const ccsm_model* m, const ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0) {
     if (!m || !ws || !b) return fail(CCSM_ERR_INVALID_ARG, "model, workspace and batch must be non-NULL");
     if (n_sites <= 0) return fail(CCSM_ERR_INVALID_ARG, "n_sites must be > 0");
     if (n_sites > ws->max_sites) return fail(CCSM_ERR_CAPACITY, "n_sites exceeds the workspace's max_sites");
     if (ws->device != m->device) return fail(CCSM_ERR_INVALID_ARG, "workspace and model live on different devices");
-    for (int s = 0; s < 2; ++s)
-        if (!b->strand[s].kmer || !b->strand[s].ipd || !b->strand[s].pw || !b->strand[s].npass)
+    for (int s = 0; s < 2; ++s) {
+        const ccsm_strand& t = b->strand[s];
+        if (!t.kmer || !t.ipd || !t.pw || ((m->feat & kFeatNpass) && !t.npass))
             return fail(CCSM_ERR_INVALID_ARG, "batch strand pointers must be non-NULL");
+        if (((m->feat & kFeatStds) && (!t.ipd_std || !t.pw_std)) || ((m->feat & kFeatSn) && !t.sn) || ((m->feat & kFeatMap) && !t.map))
+            return fail(CCSM_ERR_INVALID_ARG, "the model was created with is_stds / is_sn / is_map: the batch must carry ipd_std + pw_std / sn / map");
+    }
     if (h0) {
         if (h0->mode < 0 || h0->mode > 2) return fail(CCSM_ERR_INVALID_ARG, "unknown h0 mode");
         if (h0->mode == CCSM_H0_EXPLICIT && (!h0->h0[0] || !h0->h0[1]))
@@ -591,7 +603,7 @@ ccsm_status probe_arithmetic(ccsm_model* m) {
     ccsm_status st = ccsm_workspace_create(m, kProbeSites, &ws);
     if (st != CCSM_OK) return st;
     std::vector<uint8_t> kmer[2];
-    std::vector<float> ipd[2], pw[2], npass[2];
+    std::vector<float> ipd[2], pw[2], npass[2], isd[2], psd[2], sn[2], mp[2];
     uint32_t sd = 0x9e3779b9u;
     auto rnd = [&]() { sd = sd * 1664525u + 1013904223u; return (float)(sd >> 8) * (1.0f / 16777216.0f); };
     ccsm_batch b;
@@ -612,6 +624,17 @@ ccsm_status probe_arithmetic(ccsm_model* m) {
             }
         }
         b.strand[s].kmer = kmer[s].data(); b.strand[s].ipd = ipd[s].data(); b.strand[s].pw = pw[s].data(); b.strand[s].npass = npass[s].data();
+        auto fill = [&](std::vector<float>& v, size_t cnt, float lo, float hi) {
+            v.resize(cnt);
+            for (float& x : v) x = lo + (hi - lo) * rnd();
+            return v.data();
+        };
+        if (m->feat & kFeatStds) {
+            b.strand[s].ipd_std = fill(isd[s], kmer[s].size(), 0.f, 2.f);
+            b.strand[s].pw_std = fill(psd[s], kmer[s].size(), 0.f, 2.f);
+        }
+        if (m->feat & kFeatSn) b.strand[s].sn = fill(sn[s], (size_t)kProbeSites * 4, 3.f, 16.f);
+        if (m->feat & kFeatMap) b.strand[s].map = fill(mp[s], kmer[s].size(), 0.f, 1.f);
     }
     ccsm_h0 h0;
     std::memset(&h0, 0, sizeof(h0));
@@ -655,8 +678,12 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         return fail(CCSM_ERR_UNSUPPORTED, "--model_type not right! (this build implements attbigru2s)");
     if (cfg->seq_len != kSeqLen || cfg->num_layers != kLayers || cfg->num_classes != kClasses || cfg->hidden_size != kHidden)
         return fail(CCSM_ERR_UNSUPPORTED, "this build implements seq_len 21, layer_rnn 3, class_num 2, hid_rnn 256");
-    if (!cfg->is_npass || cfg->is_sn || cfg->is_map || cfg->is_stds)
-        return fail(CCSM_ERR_UNSUPPORTED, "this build implements is_npass=yes, is_sn=no, is_map=no, is_stds=no");
+    // [embedding(8) | ipd | pw | npass? | ipd_std, pw_std? | sn(4)? | map?] (models.py:39-47): the layer-0 kernels take one 16-wide
+    // k-block, which holds every variant except is_npass + is_stds + is_sn (17 or 18 columns)
+    const int feat = (cfg->is_npass ? kFeatNpass : 0) | (cfg->is_stds ? kFeatStds : 0) | (cfg->is_sn ? kFeatSn : 0) | (cfg->is_map ? kFeatMap : 0);
+    const int feat0 = kEmbed + 2 + (cfg->is_npass ? 1 : 0) + (cfg->is_stds ? 2 : 0) + (cfg->is_sn ? 4 : 0) + (cfg->is_map ? 1 : 0);
+    if (feat0 > 16)
+        return fail(CCSM_ERR_UNSUPPORTED, "this build takes at most 16 input columns (is_npass + is_stds + is_sn together need 17)");
     const int prec = cfg->precision == 0 ? 4 : cfg->precision;
     const bool auto_prec = cfg->precision == 0;
     if (prec != CCSM_PRECISION_SPLIT3 && prec != CCSM_PRECISION_SPLIT_F8 && prec != CCSM_PRECISION_HYBRID)
@@ -672,22 +699,24 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     if (!m) return fail(CCSM_ERR_NOMEM, "out of host memory");
     m->device = device;
     m->precision = prec;
+    m->feat = feat;
+    m->feat0 = feat0;
     ccsm_status st = CCSM_OK;
     std::vector<_Float16> hbuf;
     std::vector<float> fbuf;
     for (int l = 0; l < kLayers && st == CCSM_OK; ++l) {
-        pack_wstream_v2(l, w->weight_ih[l], w->weight_hh[l], hbuf);
+        pack_wstream_v2(l, m->feat0, w->weight_ih[l], w->weight_hh[l], hbuf);
         st = upload(&m->wst2[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
         if (st != CCSM_OK) break;
         if (prec == 4) {
             std::vector<uint8_t> bbuf;
-            m->mx_quant_err = std::fmax(m->mx_quant_err, pack_wstream_mx(l, w->weight_ih[l], w->weight_hh[l], false, bbuf));
+            m->mx_quant_err = std::fmax(m->mx_quant_err, pack_wstream_mx(l, m->feat0, w->weight_ih[l], w->weight_hh[l], false, bbuf));
             st = upload(&m->wstmx[l], bbuf.data(), bbuf.size());
             if (st != CCSM_OK) break;
         }
         if (prec == 5 || auto_prec) {
             std::vector<uint8_t> bbuf;
-            const float qe = pack_wstream_mx(l, w->weight_ih[l], w->weight_hh[l], true, bbuf);
+            const float qe = pack_wstream_mx(l, m->feat0, w->weight_ih[l], w->weight_hh[l], true, bbuf);
             if (prec == 5) m->mx_quant_err = std::fmax(m->mx_quant_err, qe);
             st = upload(&m->wsthy[l], bbuf.data(), bbuf.size());
             if (st != CCSM_OK) break;
@@ -786,6 +815,9 @@ ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_works
     const size_t part_b = (size_t)ws->rows_p * 2 * sizeof(float);
     // host-path staging: per strand kmer f32|u8 (N,21) + ipd + pw (N,21) f32 + npass (N,21) f32 worst case
     ws->in_bytes = (size_t)2 * ((size_t)max_sites * kSeqLen * 4 * sizeof(float) + 64);  // + alignment padding
+    if (m->feat & kFeatStds) ws->in_bytes += (size_t)2 * 2 * max_sites * kSeqLen * sizeof(float);
+    if (m->feat & kFeatSn) ws->in_bytes += (size_t)2 * max_sites * 4 * sizeof(float);
+    if (m->feat & kFeatMap) ws->in_bytes += (size_t)2 * max_sites * kSeqLen * sizeof(float);
     const size_t out_b = (size_t)max_sites * 4 * sizeof(float);
     ccsm_status st = CCSM_OK;
     auto dmalloc = [&](void** p, size_t b) -> ccsm_status {
@@ -854,8 +886,7 @@ ccsm_status ccsm_forward_device(const ccsm_model* m, ccsm_workspace* ws, int n_s
     if (st != CCSM_OK) return st;
     if (!logits || !probs) return fail(CCSM_ERR_INVALID_ARG, "logits and probs must be non-NULL");
     HIP_TRY(hipSetDevice(m->device));
-    StrandDev s1{b->strand[0].kmer, b->strand[0].ipd, b->strand[0].pw, b->strand[0].npass};
-    StrandDev s2{b->strand[1].kmer, b->strand[1].ipd, b->strand[1].pw, b->strand[1].npass};
+    const StrandDev s1 = strand_dev(b->strand[0]), s2 = strand_dev(b->strand[1]);
     const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
     return dispatch_forward(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
                             h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
@@ -870,8 +901,7 @@ ccsm_status ccsm_group_add_device(const ccsm_model* m, ccsm_workspace* ws, int n
     if (st != CCSM_OK) return st;
     if (!logits || !probs) return fail(CCSM_ERR_INVALID_ARG, "logits and probs must be non-NULL");
     HIP_TRY(hipSetDevice(m->device));
-    StrandDev s1{b->strand[0].kmer, b->strand[0].ipd, b->strand[0].pw, b->strand[0].npass};
-    StrandDev s2{b->strand[1].kmer, b->strand[1].ipd, b->strand[1].pw, b->strand[1].npass};
+    const StrandDev s1 = strand_dev(b->strand[0]), s2 = strand_dev(b->strand[1]);
     const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
     return add_slice(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
                      h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
@@ -900,7 +930,9 @@ ccsm_status ccsm_submit_host(const ccsm_model* m, ccsm_workspace* ws, int n_site
     const size_t kmer_pad = (kmer_b + 15) & ~(size_t)15;
     const size_t f_b = n * kSeqLen * sizeof(float);
     const size_t np_b = b->npass_per_base ? f_b : ((n * sizeof(float) + 15) & ~(size_t)15);
-    const size_t strand_b = kmer_pad + 2 * f_b + np_b;
+    const size_t sn_b = n * 4 * sizeof(float);
+    const size_t strand_b = kmer_pad + 2 * f_b + np_b + ((m->feat & kFeatStds) ? 2 * f_b : 0) + ((m->feat & kFeatSn) ? sn_b : 0) +
+                            ((m->feat & kFeatMap) ? f_b : 0);
     if (2 * strand_b > ws->in_bytes) return fail(CCSM_ERR_CAPACITY, "staging buffer too small");
     StrandDev sd[2];
     for (int s = 0; s < 2; ++s) {
@@ -909,11 +941,21 @@ ccsm_status ccsm_submit_host(const ccsm_model* m, ccsm_workspace* ws, int n_site
         std::memcpy(hp, b->strand[s].kmer, kmer_b);
         std::memcpy(hp + kmer_pad, b->strand[s].ipd, f_b);
         std::memcpy(hp + kmer_pad + f_b, b->strand[s].pw, f_b);
-        std::memcpy(hp + kmer_pad + 2 * f_b, b->strand[s].npass, b->npass_per_base ? f_b : n * sizeof(float));
+        if (m->feat & kFeatNpass) std::memcpy(hp + kmer_pad + 2 * f_b, b->strand[s].npass, b->npass_per_base ? f_b : n * sizeof(float));
         sd[s].kmer = dp;
         sd[s].ipd = reinterpret_cast<const float*>(dp + kmer_pad);
         sd[s].pw = reinterpret_cast<const float*>(dp + kmer_pad + f_b);
         sd[s].npass = reinterpret_cast<const float*>(dp + kmer_pad + 2 * f_b);
+        size_t o = kmer_pad + 2 * f_b + np_b;                       // the variant's optional planes
+        auto plane = [&](const float* src, size_t bytes) {
+            std::memcpy(hp + o, src, bytes);
+            const float* d = reinterpret_cast<const float*>(dp + o);
+            o += bytes;
+            return d;
+        };
+        if (m->feat & kFeatStds) { sd[s].ipd_std = plane(b->strand[s].ipd_std, f_b); sd[s].pw_std = plane(b->strand[s].pw_std, f_b); }
+        if (m->feat & kFeatSn) sd[s].sn = plane(b->strand[s].sn, sn_b);
+        if (m->feat & kFeatMap) sd[s].map = plane(b->strand[s].map, f_b);
     }
     HIP_TRY(hipMemcpyAsync(ws->d_in, ws->p_in, 2 * strand_b, hipMemcpyHostToDevice, hs));
     const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
@@ -980,6 +1022,9 @@ ccsm_status ccsm_submit_reads_host(const ccsm_model* m, ccsm_workspace* ws, cons
                                    const ccsm_h0* h0, void* stream) {
     if (!m || !ws || !rd) return fail(CCSM_ERR_INVALID_ARG, "model, workspace and reads must be non-NULL");
     if (rd->n_reads <= 0) return fail(CCSM_ERR_INVALID_ARG, "n_reads must be > 0");
+    if (m->feat != kFeatNpass)
+        return fail(CCSM_ERR_UNSUPPORTED, "the read-level entry points build the default features (is_npass only); a model with is_stds / "
+                                          "is_sn / is_map takes per-site features (ccsm_forward_host / _device)");
     if (!rd->offset || !rd->length || !rd->seq || !rd->fi || !rd->ri || !rd->fp || !rd->rp || !rd->fn || !rd->rn)
         return fail(CCSM_ERR_INVALID_ARG, "read arrays must be non-NULL");
     if (ws->device != m->device) return fail(CCSM_ERR_INVALID_ARG, "workspace and model live on different devices");

@@ -172,10 +172,18 @@ struct StrandDev {
     const float* ipd;   // (N,21)
     const float* pw;    // (N,21)
     const float* npass; // (N) or (N,21) if npass_per_base
+    const float* ipd_std = nullptr;  // (N,21)  is_stds
+    const float* pw_std = nullptr;   // (N,21)  is_stds
+    const float* sn = nullptr;       // (N,4)   is_sn
+    const float* map = nullptr;      // (N,21)  is_map
 };
 
+// feature flags of the model variant (ccsm_config.is_npass / is_stds / is_sn / is_map): which of the optional planes follow
+// [embedding(8) | ipd | pw] in a row of the layer-0 input, in the reference's concatenation order (models.py:100-123)
+constexpr int kFeatNpass = 1, kFeatStds = 2, kFeatSn = 4, kFeatMap = 8;
+
 __global__ void pack_x0_kernel(uint4* __restrict__ x0, StrandDev s1, StrandDev s2, const float* __restrict__ embed,
-                               int n_sites, int row_base, int kmer_is_f32, int npass_per_base) {
+                               int n_sites, int row_base, int kmer_is_f32, int npass_per_base, int feat) {
     const int total = 2 * n_sites * kSeqLen * 2;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int g = i & 1;
@@ -197,7 +205,12 @@ __global__ void pack_x0_kernel(uint4* __restrict__ x0, StrandDev s1, StrandDev s
         } else {
             v[0] = s.ipd[e];
             v[1] = s.pw[e];
-            v[2] = npass_per_base ? s.npass[e] : s.npass[site];
+            int k = 2;                                                  // at most 6 optional features (checked by ccsm_create)
+            if (feat & kFeatNpass) v[k++] = npass_per_base ? s.npass[e] : s.npass[site];
+            if (feat & kFeatStds) { v[k++] = s.ipd_std[e]; v[k++] = s.pw_std[e]; }
+            if (feat & kFeatSn)
+                for (int j = 0; j < 4; ++j) v[k++] = s.sn[(size_t)site * 4 + j];    // one signal-to-noise quadruple per site, every position
+            if (feat & kFeatMap) v[k++] = s.map[e];
         }
         _Float16 hi[8], lo[8];
 #pragma unroll

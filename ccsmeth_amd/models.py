@@ -27,6 +27,10 @@ class DeviceModel:
         lib = _lib.load()
         self._lib = lib
         self._keep = {k: _f32c(v) for k, v in state_dict.items()}
+        self.features = (bool(is_npass), bool(is_stds), bool(is_sn), bool(is_map))
+        k0 = 8 + 2 + int(bool(is_npass)) + 2 * int(bool(is_stds)) + 4 * int(bool(is_sn)) + int(bool(is_map))      # models.py:39-47
+        if self._keep["rnn.weight_ih_l0"].shape[1] != k0:
+            raise ValueError("rnn.weight_ih_l0 has %d columns, the feature flags need %d" % (self._keep["rnn.weight_ih_l0"].shape[1], k0))
         w = _lib.Weights()
         ptr = lambda k: self._keep[k].ctypes.data  # noqa: E731
         w.embed_weight = ptr("embed.weight")
@@ -86,8 +90,13 @@ class Workspace:
             self.model._lib.ccsm_workspace_destroy(self.handle)
             self.handle = None
 
-    @staticmethod
-    def _batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of):
+    def _batch(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of, extra=None):
+        """extra: for a model with is_stds / is_sn / is_map, one dict per strand with the keys "ipd_std", "pw_std" (N, 21), "sn" (N, 4),
+        "map" (N, 21) that the flags ask for; npass may be None without is_npass."""
+        has_npass, has_stds, has_sn, has_map = self.model.features
+        want = [k for k, on in (("ipd_std", has_stds), ("pw_std", has_stds), ("sn", has_sn), ("map", has_map)) if on]
+        if want and (extra is None or len(extra) != 2):
+            raise ValueError("this model variant needs extra=(strand1, strand2) dicts with %s" % want)
         b = _lib.Batch()
         n = None
         keep = []
@@ -97,7 +106,7 @@ class Workspace:
             kmer, kf = ptr_of(kmer, kmer=True)
             ipd, _ = ptr_of(ipd)
             pw, _ = ptr_of(pw)
-            npass, _ = ptr_of(npass)
+            npass, _ = ptr_of(npass if has_npass else np.zeros(kmer[1][0], np.float32))
             keep += [kmer, ipd, pw, npass]
             ns = kmer[1][0]
             if n is None:
@@ -111,6 +120,12 @@ class Workspace:
             if tuple(npass[1]) not in ((n,), (n, _lib.SEQ_LEN)):
                 raise ValueError("npass must have shape (N,) or (N, 21)")
             b.strand[s].kmer, b.strand[s].ipd, b.strand[s].pw, b.strand[s].npass = kmer[0], ipd[0], pw[0], npass[0]
+            for key in want:
+                t, _ = ptr_of(extra[s][key])
+                if tuple(t[1]) != ((n, 4) if key == "sn" else (n, _lib.SEQ_LEN)):
+                    raise ValueError("%s must have shape %s" % (key, "(N, 4)" if key == "sn" else "(N, 21)"))
+                keep.append(t)
+                setattr(b.strand[s], key, t[0])
         b.kmer_is_f32 = int(kmer_f32)
         b.npass_per_base = int(per_base)
         return b, n, keep
@@ -134,7 +149,7 @@ class Workspace:
         h.seed, h.offset = int(seed), int(offset)
         return h, keep
 
-    def forward_host(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None):
+    def forward_host(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None, extra=None):
         """NumPy in / NumPy out through the pinned staging ring (ccsm_forward_host)."""
         def ptr_of(a, kmer=False):
             a = np.asarray(a)
@@ -143,7 +158,7 @@ class Workspace:
                 return (a.ctypes.data, a.shape, a), False
             a = _f32c(a)
             return (a.ctypes.data, a.shape, a), True
-        b, n, keep = self._batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of)
+        b, n, keep = self._batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of, extra)
         h, keep2 = self._h0(h0, n, ptr_of, seed, offset)
         logits = np.empty((n, 2), np.float32)
         probs = np.empty((n, 2), np.float32)
@@ -295,7 +310,7 @@ class Workspace:
         return first, locs[:n], logits[:n], probs[:n]
 
     def forward_torch(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0=None, seed=0, offset=0, stream=None,
-                      out=None):
+                      out=None, extra=None):
         """torch CUDA tensors in / out, asynchronous on `stream` (default: torch's current stream)."""
         import torch
         dev = torch.device("cuda", self.model.device)
@@ -308,7 +323,7 @@ class Workspace:
                 return (a.data_ptr(), tuple(a.shape), a), False
             a = a.to(device=dev, dtype=torch.float32).contiguous()
             return (a.data_ptr(), tuple(a.shape), a), True
-        b, n, keep = self._batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of)
+        b, n, keep = self._batch(kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of, extra)
         h, keep2 = self._h0(h0, n, ptr_of, seed, offset)
         if out is None:
             logits = torch.empty((n, 2), dtype=torch.float32, device=dev)
@@ -391,7 +406,8 @@ class ModelAttRNN:
         self.is_npass, self.is_sn, self.is_map, self.is_stds = is_npass, is_sn, is_map, is_stds
         self.dropout_rate = dropout_rate   # identity at inference (model.eval())
         self.precision, self.seed, self.max_batch = precision, seed, max_batch
-        self._shapes = state_dict_shapes(seq_len, num_layers, num_classes, hidden_size)
+        feas_ccs = 2 + int(bool(is_npass)) + 2 * int(bool(is_stds)) + 4 * int(bool(is_sn)) + int(bool(is_map))      # models.py:39-47
+        self._shapes = state_dict_shapes(seq_len, num_layers, num_classes, hidden_size, feas_ccs=feas_ccs)
         self._state = OrderedDict((k, np.zeros(s, np.float32)) for k, s in self._shapes.items())
         self._dev = None
         self._ws = None
@@ -446,20 +462,24 @@ class ModelAttRNN:
 
     def forward(self, kmer, kpass, ipd_means, ipd_stds, pw_means, pw_stds, sns, maps,
                 kmer2, kpass2, ipd_means2, ipd_stds2, pw_means2, pw_stds2, sns2, maps2, *, h0=None):
-        """models.py:89-150.  ipd_stds/pw_stds/sns/maps are accepted and ignored exactly as the reference ignores
-        them when is_stds/is_sn/is_map are off."""
+        """models.py:89-150.  ipd_stds / pw_stds / sns / maps are read when the model was built with is_stds / is_sn / is_map and
+        ignored otherwise, exactly as in the reference."""
         import torch
         n = int(kmer.shape[0])
         self._ensure(n)
         is_torch = isinstance(kmer, torch.Tensor)
+        extra = None
+        if self.is_stds or self.is_sn or self.is_map:
+            extra = ({"ipd_std": ipd_stds, "pw_std": pw_stds, "sn": sns, "map": maps},
+                     {"ipd_std": ipd_stds2, "pw_std": pw_stds2, "sn": sns2, "map": maps2})
         if is_torch:
             logits, probs = self._ws.forward_torch(kmer, ipd_means, pw_means, kpass, kmer2, ipd_means2, pw_means2, kpass2,
-                                                   h0=h0, seed=self.seed, offset=self._calls)
+                                                   h0=h0, seed=self.seed, offset=self._calls, extra=extra)
             if not kmer.is_cuda:   # reference on a CPU-tensor call returns CPU tensors
                 logits, probs = logits.cpu(), probs.cpu()
         else:
             logits, probs = self._ws.forward_host(kmer, ipd_means, pw_means, kpass, kmer2, ipd_means2, pw_means2, kpass2,
-                                                  h0=h0, seed=self.seed, offset=self._calls)
+                                                  h0=h0, seed=self.seed, offset=self._calls, extra=extra)
         self._calls += n
         return logits, probs
 

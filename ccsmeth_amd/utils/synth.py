@@ -36,13 +36,36 @@ def state_dict_shapes(seq_len=21, num_layers=3, num_classes=2, hidden=256, n_emb
     return shapes
 
 
-def synth_weights(seed, num_layers=3, hidden=256, fc_bias=True):
+def feas_ccs_of(is_npass=True, is_stds=False, is_sn=False, is_map=False):
+    """Columns after the 8 embedding dims of a row of the layer-0 input (reference models.py:39-47)."""
+    return 2 + int(bool(is_npass)) + 2 * int(bool(is_stds)) + 4 * int(bool(is_sn)) + int(bool(is_map))
+
+
+def synth_extras(n, seed, is_stds=False, is_sn=False, is_map=False, seq_len=21):
+    """The optional feature planes of the is_stds / is_sn / is_map model variants, one dict per strand: ipd_std, pw_std (N, 21) >= 0,
+    sn (N, 4) signal-to-noise ratios, map (N, 21) in {0, 1}."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(2):
+        d = {}
+        if is_stds:
+            d["ipd_std"] = rng.gamma(2.0, 0.4, size=(n, seq_len)).astype(np.float32)
+            d["pw_std"] = rng.gamma(2.0, 0.4, size=(n, seq_len)).astype(np.float32)
+        if is_sn:
+            d["sn"] = np.round(rng.uniform(4.0, 18.0, size=(n, 4)), 6).astype(np.float32)
+        if is_map:
+            d["map"] = (rng.random(size=(n, seq_len)) < 0.9).astype(np.float32)
+        out.append(d)
+    return tuple(out)
+
+
+def synth_weights(seed, num_layers=3, hidden=256, fc_bias=True, feas_ccs=3):
     """Random-init weights with the reference's init ranges: GRU / Linear default U(-1/sqrt(fan), 1/sqrt(fan)),
     embed and fc1.weight U(-0.1, 0.1) (models.py:71-75).  fc_bias=True draws a small non-zero fc1.bias so
     that parity tests exercise it (the reference zero-inits it; trained checkpoints do not keep it zero)."""
     rng = np.random.default_rng(seed)
     out = {}
-    for key, shape in state_dict_shapes(num_layers=num_layers, hidden=hidden).items():
+    for key, shape in state_dict_shapes(num_layers=num_layers, hidden=hidden, feas_ccs=feas_ccs).items():
         if key.startswith("rnn."):
             bound = 1.0 / np.sqrt(hidden)
         elif key.startswith("_att3."):

@@ -53,8 +53,8 @@ typedef struct {
     int32_t num_classes; /* 2 */
     int32_t hidden_size; /* 256 */
     int32_t is_npass;    /* 1 */
-    int32_t is_sn;       /* 0 */
-    int32_t is_map;      /* 0 */
+    int32_t is_sn;       /* 0   the optional input features of models.py:39-47, 100-123: any combination with at most 16 input */
+    int32_t is_map;      /* 0   columns (8 + 2 + npass 1 + stds 2 + sn 4 + map 1), i.e. all but is_npass + is_stds + is_sn together */
     int32_t is_stds;     /* 0 */
     const char* model_type; /* "attbigru2s" */
     int32_t precision;   /* ccsm_precision; 0 = default (SPLIT_F8) */
@@ -75,14 +75,19 @@ typedef struct {
     const float* fc1_bias;                     /* fc1.bias (2) */
 } ccsm_weights;
 
-/* One strand's per-site 21-mer features = the tensors `kmer, kpass, ipd_means, pw_means` of
- * ModelAttRNN.forward (models.py:89-90); the unused placeholders (ipd_stds, pw_stds, sns, maps) are not passed. */
+/* One strand's per-site 21-mer features = the tensors `kmer, kpass, ipd_means, ipd_stds, pw_means, pw_stds, sns, maps` of
+ * ModelAttRNN.forward (models.py:89-90).  The last four are read only by a model created with is_stds / is_sn / is_map (NULL
+ * otherwise: the reference passes placeholders there), npass only with is_npass. */
 typedef struct {
     const void* kmer;   /* (N,21) base codes A0 C1 G2 T3 other4 (process_utils.py:26-29): uint8, or float32 when
                            ccsm_batch.kmer_is_f32 (the reference hands FloatTensors, truncated by .int(), models.py:91) */
     const float* ipd;   /* (N,21) normalised IPD */
     const float* pw;    /* (N,21) normalised PW */
     const float* npass; /* (N) subread passes, or (N,21) when ccsm_batch.npass_per_base (call_modifications.py:96) */
+    const float* ipd_std; /* (N,21) is_stds (models.py:105-111) */
+    const float* pw_std;  /* (N,21) is_stds */
+    const float* sn;      /* (N,4)  is_sn: one signal-to-noise quadruple per site, expanded over the 21 positions (models.py:112-116) */
+    const float* map;     /* (N,21) is_map (models.py:117-121) */
 } ccsm_strand;
 
 typedef struct {

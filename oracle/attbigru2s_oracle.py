@@ -86,28 +86,41 @@ def attention(last_hidden, enc_out, wa, ua, va):
     return ctx, a
 
 
-def strand_input(embed_w, kmer, ipd, pw, npass):
-    """models.py:91-106: x = cat(embed[kmer.int()], ipd, pw, npass) -> (N,L,11); feature order = 8 embedding dims,
-    ipd, pw, npass (is_npass=True, is_stds/is_sn/is_map False: call_modifications.py:652-663 defaults)."""
+def strand_input(embed_w, kmer, ipd, pw, npass, extra=None, features=(True, False, False, False)):
+    """models.py:91-123: x = cat(embed[kmer.int()], ipd, pw [, npass] [, ipd_std, pw_std] [, sn expanded over L] [, map]) -> (N, L, C);
+    features = (is_npass, is_stds, is_sn, is_map); the defaults (call_modifications.py:652-663) give C = 11."""
+    is_npass, is_stds, is_sn, is_map = features
     kmer = np.asarray(kmer)
     idx = kmer.astype(np.int32)                  # models.py:91  kmer.int()  (truncation toward zero)
     emb = embed_w[idx]
     n_b, seq_len = idx.shape
-    npass = np.asarray(npass, dtype=embed_w.dtype)
-    if npass.ndim == 1:
-        npass = np.repeat(npass[:, None], seq_len, axis=1)   # call_modifications.py:96  [npass]*len(kmer)
-    feats = [emb, np.asarray(ipd, embed_w.dtype)[..., None], np.asarray(pw, embed_w.dtype)[..., None], npass[..., None]]
+    dt = embed_w.dtype
+    feats = [emb, np.asarray(ipd, dt)[..., None], np.asarray(pw, dt)[..., None]]
+    if is_npass:                                 # models.py:100-104
+        npass = np.asarray(npass, dtype=dt)
+        if npass.ndim == 1:
+            npass = np.repeat(npass[:, None], seq_len, axis=1)   # call_modifications.py:96  [npass]*len(kmer)
+        feats.append(npass[..., None])
+    if is_stds:                                  # models.py:105-111
+        feats += [np.asarray(extra["ipd_std"], dt)[..., None], np.asarray(extra["pw_std"], dt)[..., None]]
+    if is_sn:                                    # models.py:112-116  sns.unsqueeze(1).expand(-1, L, -1)
+        feats.append(np.repeat(np.asarray(extra["sn"], dt)[:, None, :], seq_len, axis=1))
+    if is_map:                                   # models.py:117-121
+        feats.append(np.asarray(extra["map"], dt)[..., None])
     return np.concatenate(feats, axis=2)
 
 
 def attbigru2s_forward(weights, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, h0_1, h0_2,
-                       num_layers=3, dtype=np.float64):
+                       num_layers=3, dtype=np.float64, extra=None, features=(True, False, False, False)):
     """ModelAttRNN(model_type="attbigru2s").forward, models.py:89-150, with h0 pinned (the reference draws
-    torch.randn per strand, models.py:77-87,125-130 — strand 1 first).  Returns (logits (N,2), probs (N,2))."""
+    torch.randn per strand, models.py:77-87,125-130 — strand 1 first).  Returns (logits (N,2), probs (N,2)).
+    extra = (strand-1 dict, strand-2 dict) of the planes `features` = (is_npass, is_stds, is_sn, is_map) asks for."""
     w = {k: np.asarray(v, dtype=dtype) for k, v in weights.items()}
     ctxs = []
-    for kmer, ipd, pw, npass, h0 in ((kmer1, ipd1, pw1, npass1, h0_1), (kmer2, ipd2, pw2, npass2, h0_2)):
-        x = strand_input(w["embed.weight"], kmer, np.asarray(ipd, dtype), np.asarray(pw, dtype), np.asarray(npass, dtype))
+    extra = extra or (None, None)
+    for kmer, ipd, pw, npass, h0, ex in ((kmer1, ipd1, pw1, npass1, h0_1, extra[0]), (kmer2, ipd2, pw2, npass2, h0_2, extra[1])):
+        x = strand_input(w["embed.weight"], kmer, np.asarray(ipd, dtype), np.asarray(pw, dtype),
+                         None if npass is None else np.asarray(npass, dtype), ex, features)
         out, h_n = bigru(x, np.asarray(h0, dtype), w, num_layers)
         # models.py:135-137: last layer's (fwd, bwd) final states -> (N, 2H)
         q = np.concatenate([h_n[2 * (num_layers - 1)], h_n[2 * (num_layers - 1) + 1]], axis=1)

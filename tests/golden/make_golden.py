@@ -99,6 +99,44 @@ def gen_forward():
     json.dump(meta, open(os.path.join(HERE, "forward_golden.json"), "w"), indent=1, sort_keys=True)
 
 
+VARIANTS = [  # name, (is_npass, is_stds, is_sn, is_map): every combination with at most 16 input columns that differs from the default
+    ("sn", (True, False, True, False)), ("map", (True, False, False, True)), ("stds", (True, True, False, False)),
+    ("stds_map", (True, True, False, True)), ("sn_map", (True, False, True, True)), ("nonpass", (False, False, False, False)),
+    ("nonpass_stds_sn", (False, True, True, False)), ("nonpass_stds_sn_map", (False, True, True, True)),
+]
+
+
+def gen_forward_variants():
+    """ModelAttRNN built with is_stds / is_sn / is_map / without is_npass (models.py:39-47, 100-123): the optional feature planes."""
+    out, meta = {}, {}
+    n = 48
+    for k, (name, (is_npass, is_stds, is_sn, is_map)) in enumerate(VARIANTS):
+        ws, ss, hs, es = 31 + k, 301 + k, 401 + k, 501 + k
+        w = synth.synth_weights(ws, feas_ccs=synth.feas_ccs_of(is_npass, is_stds, is_sn, is_map))
+        sites = synth.synth_sites(n, ss)
+        h1, h2 = synth.synth_h0(n, hs)
+        ex = synth.synth_extras(n, es, is_stds, is_sn, is_map)
+        model = ref_models.ModelAttRNN(21, 3, 2, 0, 256, is_npass=is_npass, is_sn=is_sn, is_map=is_map, is_stds=is_stds,
+                                       model_type="attbigru2s", device=0)
+        model.load_state_dict({k2: torch.from_numpy(v.copy()) for k2, v in w.items()})
+        model.eval()
+        f = lambda a: torch.tensor(np.asarray(a), dtype=torch.float)  # noqa: E731
+        rep = lambda a: np.repeat(np.asarray(a)[:, None], 21, axis=1)  # noqa: E731
+        zeros = f(np.zeros(n))
+        args = []
+        for s_, e in (("1", ex[0]), ("2", ex[1])):
+            args += [f(sites["kmer" + s_]), f(rep(sites["npass" + s_])), f(sites["ipd" + s_]), f(e["ipd_std"]) if is_stds else zeros,
+                     f(sites["pw" + s_]), f(e["pw_std"]) if is_stds else zeros, f(e["sn"]) if is_sn else zeros, f(e["map"]) if is_map else zeros]
+        with PinnedRandn([h1, h2]):
+            logits, probs = model(*args)
+        out[name + "_logits"], out[name + "_probs"] = logits.detach().numpy(), probs.detach().numpy()
+        meta[name] = dict(weight_seed=ws, site_seed=ss, h0_seed=hs, extra_seed=es, n=n, is_npass=is_npass, is_stds=is_stds, is_sn=is_sn,
+                          is_map=is_map)
+        print(name, probs[:2])
+    np.savez_compressed(os.path.join(HERE, "forward_variants_golden.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "forward_variants_golden.json"), "w"), indent=1, sort_keys=True)
+
+
 class FakeRead:
     """Duck-typed pysam.AlignedSegment exposing what extract_features.py:88-126 reads."""
 
@@ -251,5 +289,9 @@ def _j(x):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["variants"]:          # only the model-variant fixtures
+        gen_forward_variants()
+        sys.exit(0)
     gen_forward()
+    gen_forward_variants()
     gen_extract_and_pipeline()

@@ -199,6 +199,46 @@ def test_forward_vs_reference_goldens():
             assert np.abs(logits - fwd[name + "_logits"]).max() < LOGIT_TOL, (name, prec)
 
 
+@pytest.mark.parametrize("prec", [0, 5, 3])
+def test_model_variants_vs_reference_goldens(prec):
+    """is_stds / is_sn / is_map / no is_npass (models.py:39-47, 100-123): every combination that fits the 16 input columns of the layer-0
+    kernels against the reference's own outputs, through the raw workspace and through ModelAttRNN.forward's 16-argument signature;
+    the 17-column combinations are rejected by ccsm_create."""
+    from ccsmeth_amd.models import DeviceModel, ModelAttRNN
+    from test_oracle_golden import VAR, VAR_META, variant_inputs
+    for name, meta in sorted(VAR_META.items()):
+        w, s, h1, h2, ex, feats = variant_inputs(meta)
+        kw = dict(is_npass=feats[0], is_stds=feats[1], is_sn=feats[2], is_map=feats[3])
+        if 8 + synth.feas_ccs_of(*feats) > 16:                      # is_stds + is_sn + one more: 17 columns
+            with pytest.raises(RuntimeError, match="16 input columns"):
+                DeviceModel(w, device=0, precision=prec, **kw)
+            continue
+        dm = DeviceModel(w, device=0, precision=prec, **kw)
+        ws = dm.workspace(meta["n"])
+        logits, probs = ws.forward_host(s["kmer1"], s["ipd1"], s["pw1"], s["npass1"] if feats[0] else None, s["kmer2"], s["ipd2"], s["pw2"],
+                                        s["npass2"] if feats[0] else None, h0=(h1, h2), extra=ex)
+        if any(feats[1:]):
+            with pytest.raises(ValueError):                          # the planes are required
+                _fwd(ws, s, (h1, h2))
+        ws.close(); dm.close()
+        assert np.abs(probs - VAR[name + "_probs"]).max() < (DEFAULT_TOL if prec != 3 else 2e-6), (name, prec)
+        assert np.abs(logits - VAR[name + "_logits"]).max() < LOGIT_TOL, (name, prec)
+        if prec == 0:
+            m = ModelAttRNN(21, 3, 2, 0, 256, model_type="attbigru2s", device=0, **kw)
+            m.load_state_dict(w)
+            z = np.zeros(meta["n"], np.float32)
+            g = lambda d, k: d.get(k, z)      # noqa: E731  (placeholders where a flag is off, as the reference's callers pass)
+            rep = lambda a: np.repeat(np.asarray(a, np.float32)[:, None], 21, axis=1)     # noqa: E731
+            _, p2 = m(s["kmer1"].astype(np.float32), rep(s["npass1"]), s["ipd1"], g(ex[0], "ipd_std"), s["pw1"], g(ex[0], "pw_std"),
+                      g(ex[0], "sn"), g(ex[0], "map"),
+                      s["kmer2"].astype(np.float32), rep(s["npass2"]), s["ipd2"], g(ex[1], "ipd_std"), s["pw2"], g(ex[1], "pw_std"),
+                      g(ex[1], "sn"), g(ex[1], "map"), h0=(h1, h2))
+            m._release()
+            assert np.abs(np.asarray(p2) - VAR[name + "_probs"]).max() < DEFAULT_TOL, name
+    with pytest.raises(RuntimeError, match="16 input columns"):
+        DeviceModel(synth.synth_weights(1, feas_ccs=9), device=0, is_npass=True, is_stds=True, is_sn=True)
+
+
 def test_input_layout_variants_agree(model7):
     """float32 k-mers and per-base npass (what the reference's FloatTensor call passes) == u8 k-mers + per-site npass."""
     w, dm = model7

@@ -33,6 +33,29 @@ def test_forward_matches_reference(name):
     assert np.abs(probs - FWD[name + "_probs"]).max() < 2e-6
 
 
+VAR = np.load(os.path.join(GOLDEN, "forward_variants_golden.npz"))
+VAR_META = json.load(open(os.path.join(GOLDEN, "forward_variants_golden.json")))
+
+
+def variant_inputs(meta):
+    feats = (meta["is_npass"], meta["is_stds"], meta["is_sn"], meta["is_map"])
+    w = synth.synth_weights(meta["weight_seed"], feas_ccs=synth.feas_ccs_of(*feats))
+    s = synth.synth_sites(meta["n"], meta["site_seed"])
+    h1, h2 = synth.synth_h0(meta["n"], meta["h0_seed"])
+    ex = synth.synth_extras(meta["n"], meta["extra_seed"], meta["is_stds"], meta["is_sn"], meta["is_map"])
+    return w, s, h1, h2, ex, feats
+
+
+@pytest.mark.parametrize("name", sorted(VAR_META))
+def test_forward_variants_match_reference(name):
+    """ModelAttRNN built with is_stds / is_sn / is_map / without is_npass (models.py:39-47, 100-123)."""
+    w, s, h1, h2, ex, feats = variant_inputs(VAR_META[name])
+    logits, probs = orc.attbigru2s_forward(w, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"],
+                                           h1, h2, extra=ex, features=feats)
+    assert np.abs(logits - VAR[name + "_logits"]).max() < 5e-6
+    assert np.abs(probs - VAR[name + "_probs"]).max() < 2e-6
+
+
 def test_forward_float32_oracle_close():
     meta = FWD_META["b21_n64"]
     w, s, h1, h2 = _case_inputs(meta)
