@@ -68,7 +68,7 @@ EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspa
            "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean",
            "ccsm_forward_reads_host", "ccsm_submit_reads_host", "ccsm_wait_reads_host", "ccsm_selftest_split_f8", "ccsm_selftest_split_mx",
            "ccsm_debug_fp8_e4m3",
-           "ccsm_aggr_create", "ccsm_aggr_destroy", "ccsm_aggr_forward_host", "ccsm_aggr_forward_device")
+           "ccsm_aggr_create", "ccsm_aggr_destroy", "ccsm_aggr_set_only_close", "ccsm_aggr_forward_host", "ccsm_aggr_forward_device")
 
 
 def load():
@@ -127,6 +127,7 @@ def load():
     lib.ccsm_aggr_create.argtypes = [C.POINTER(AggrWeights), ci, C.c_uint64, C.c_int64, C.POINTER(vp)]
     lib.ccsm_aggr_destroy.argtypes = [vp]
     lib.ccsm_aggr_destroy.restype = None
+    lib.ccsm_aggr_set_only_close.argtypes = [vp, ci]
     lib.ccsm_aggr_forward_host.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, vp, vp]
     lib.ccsm_aggr_forward_device.argtypes = [vp, C.c_int64, vp, vp, C.c_int64, vp, vp]
     _lib = lib

@@ -84,8 +84,11 @@ class AggrModel:
         except Exception:
             pass
 
-    def forward_raw(self, refposes, histos):
+    def forward_raw(self, refposes, histos, only_close=False):
         """fc1 outputs (M,) float32 for the sites of one call; advances the region's random stream by 64 values per site."""
+        if bool(only_close) != getattr(self, "_only_close", False):
+            _lib.check(self._lib.ccsm_aggr_set_only_close(self.handle, int(bool(only_close))))
+            self._only_close = bool(only_close)
         pos = np.ascontiguousarray(refposes, dtype=np.int64)
         h = np.ascontiguousarray(histos, dtype=np.float32)
         m = len(pos)
@@ -101,9 +104,7 @@ def _cal_modfreq_in_aggregate_mode(refposes, refposes_histos, model, seq_len=11,
     """call_mods_freq_bam.py:265-305: per-site probabilities round(clip(y, 0, 1), 6) (float32), or None for no sites."""
     if len(refposes) == 0:
         return None
-    if only_close:
-        raise ValueError("only_close is outside this build")
-    y = model.forward_raw(refposes, np.stack(refposes_histos))
+    y = model.forward_raw(refposes, np.stack(refposes_histos), only_close)
     return list(np.round(np.clip(y, 0, 1), 6))
 
 
@@ -384,9 +385,9 @@ def call_mods_frequency_from_bamfile(args, log=sys.stderr, model=None):
     if args.call_mode == "aggregate":
         if args.model_type != "attbigru":
             raise ValueError("--model_type not right!")
-        if (args.seq_len, args.layer_rnn, args.hid_rnn, args.bin_size, args.class_num) != (11, 1, 32, 20, 1) or args.only_close:
+        if (args.seq_len, args.layer_rnn, args.hid_rnn, args.bin_size, args.class_num) != (11, 1, 32, 20, 1):
             raise ValueError("this build implements the aggregate model attbigru_b11: --seq_len 11 --layer_rnn 1 --hid_rnn 32 "
-                             "--bin_size 20 --class_num 1, without --only_close")
+                             "--bin_size 20 --class_num 1")
     out_dir = os.path.dirname(os.path.abspath(args.output))
     os.makedirs(out_dir, exist_ok=True)
 

@@ -33,10 +33,12 @@ struct Weights {
 };
 
 // pos: (M) int64 sorted reference positions; hist: (M,20) fp32 normalised histograms; normals: the seeded randn stream;
-// stream_pos: index of the first value this call consumes; out: (M) fp32 raw fc1 output.
+// stream_pos: index of the first value this call consumes; out: (M) fp32 raw fc1 output.  only_close (--only_close,
+// call_mods_freq_bam.py:285-290): the position feature is 1 where the window's site lies exactly 2 bases after its predecessor
+// (the padded sequence first-1000, ..., positions, ..., last+1000), else 0, instead of the distance to the centre site.
 __global__ __launch_bounds__(256, 2) void aggr_kernel(Weights w, const long long* __restrict__ pos, const float* __restrict__ hist,
                                                        const float* __restrict__ normals, long long stream_pos, int m,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, int only_close) {
     __shared__ float s_wa[64 * H], s_ua[64 * H];
     __shared__ float s_h[WAVES][2 * H];         // current hidden state, [dir*32 + unit]
     __shared__ float s_o[WAVES][L][2 * H];      // layer output
@@ -89,8 +91,14 @@ __global__ __launch_bounds__(256, 2) void aggr_kernel(Weights w, const long long
                 for (int k = 0; k < NB; ++k) x[k] = 0.f;
             }
             const long long pn = in ? pos[nb] : (nb < 0 ? pos_lo : pos_hi);
-            const long long d = pn - pc;
-            x[NB] = (float)(d < 0 ? -d : d);
+            if (only_close) {
+                const int pb = nb - 1;
+                const long long pp = (pb >= 0 && pb < m) ? pos[pb] : (pb < 0 ? pos_lo : pos_hi);
+                x[NB] = pn - pp == 2 ? 1.f : 0.f;
+            } else {
+                const long long d = pn - pc;
+                x[NB] = (float)(d < 0 ? -d : d);
+            }
             s_h[wave][lane] = h;                       // wave-private LDS: in-order within the wave, no barrier needed
             float gi[3], gh[3];
 #pragma unroll

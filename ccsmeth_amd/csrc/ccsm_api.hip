@@ -1411,6 +1411,7 @@ struct ccsm_aggr_model {
           *fcw = nullptr, *fcb = nullptr;
     float* normals = nullptr;      // seeded torch.randn stream replica
     int64_t n_normals = 0;
+    bool only_close = false;       // --only_close: adjacency indicator instead of the distance feature
     // staging for the host-pointer path
     int64_t cap_sites = 0;
     long long* d_pos = nullptr;
@@ -1489,6 +1490,12 @@ void ccsm_aggr_destroy(ccsm_aggr_model* m) {
     delete m;
 }
 
+ccsm_status ccsm_aggr_set_only_close(ccsm_aggr_model* m, int only_close) {
+    if (!m) return fail(CCSM_ERR_INVALID_ARG, "model must be non-NULL");
+    m->only_close = only_close != 0;
+    return CCSM_OK;
+}
+
 ccsm_status ccsm_aggr_forward_device(ccsm_aggr_model* m, int64_t n_sites, const int64_t* refposes, const float* histos,
                                      int64_t stream_pos, float* out, void* stream) {
     if (!m || !refposes || !histos || !out) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");
@@ -1500,7 +1507,8 @@ ccsm_status ccsm_aggr_forward_device(ccsm_aggr_model* m, int64_t n_sites, const 
     const int waves = (int)std::min<int64_t>(n_sites, 256 * 8 * 2);
     const int grid = (waves + ccsm_aggr::WAVES - 1) / ccsm_aggr::WAVES;
     hipLaunchKernelGGL(ccsm_aggr::aggr_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                       reinterpret_cast<const long long*>(refposes), histos, m->normals, (long long)stream_pos, (int)n_sites, out);
+                       reinterpret_cast<const long long*>(refposes), histos, m->normals, (long long)stream_pos, (int)n_sites, out,
+                       m->only_close ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return CCSM_OK;
 }

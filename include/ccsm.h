@@ -258,6 +258,9 @@ typedef struct ccsm_aggr_model ccsm_aggr_model;
 
 ccsm_status ccsm_aggr_create(const ccsm_aggr_weights* w, int device, uint64_t seed, int64_t stream_sites, ccsm_aggr_model** out);
 void ccsm_aggr_destroy(ccsm_aggr_model* m);
+/* --only_close (call_mods_freq_bam.py:285-290): the 21st input becomes "this window site lies exactly 2 bases after its predecessor"
+ * (0/1, over the padded position sequence) instead of the distance to the centre site.  Applies to the following forward calls. */
+ccsm_status ccsm_aggr_set_only_close(ccsm_aggr_model* m, int only_close);
 /* refposes (M) int64 sorted positions, histos (M,20) fp32 normalised histograms (_get_normalized_histo), out (M) fp32 raw
  * fc1 outputs (the caller applies round(clip(y,0,1),6), call_mods_freq_bam.py:302).  Host pointers, synchronous. */
 ccsm_status ccsm_aggr_forward_host(ccsm_aggr_model* m, int64_t n_sites, const int64_t* refposes, const float* histos,

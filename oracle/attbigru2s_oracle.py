@@ -253,9 +253,9 @@ def normalized_histo(probs, cov_cf=4, binsize=20):
     return np.round(hist / np.linalg.norm(hist), 6)
 
 
-def aggregate_windows(refposes, histos, seq_len=11):
-    """call_mods_freq_bam.py:270-284 (only_close False): zero-padded histogram windows (M,L,20) and |pos - centre|
-    offsets (M,L) with pad positions first-1000 / last+1000."""
+def aggregate_windows(refposes, histos, seq_len=11, only_close=False):
+    """call_mods_freq_bam.py:270-290: zero-padded histogram windows (M,L,20) and the position feature (M,L): |pos - centre| with pad
+    positions first-1000 / last+1000, or with only_close (:285-290) 1 where a window site lies exactly 2 bases after its predecessor."""
     refposes = np.asarray(refposes, dtype=np.int64)
     histos = np.asarray(histos, dtype=np.float64)
     m, pad = len(refposes), seq_len // 2
@@ -263,6 +263,9 @@ def aggregate_windows(refposes, histos, seq_len=11):
     hp[pad:pad + m] = histos
     pp = np.concatenate([np.full(pad, refposes[0] - 1000), refposes, np.full(pad, refposes[-1] + 1000)])
     idx = np.arange(m)[:, None] + np.arange(seq_len)[None, :]
+    if only_close:
+        pq = np.concatenate([np.full(pad + 1, refposes[0] - 1000), refposes, np.full(pad, refposes[-1] + 1000)])
+        return hp[idx], (np.diff(pq) == 2).astype(np.int64)[idx]
     return hp[idx], np.abs(pp[idx] - refposes[:, None])
 
 
@@ -277,10 +280,10 @@ def aggr_attbigru_forward(weights, offsets, histos, h0, dtype=np.float64):
     return ctx @ w["fc1.weight"].T + w["fc1.bias"]
 
 
-def cal_modfreq_in_aggregate_mode(refposes, histos, weights, h0_normals, stream_pos=0, seq_len=11, batch_size=1024):
+def cal_modfreq_in_aggregate_mode(refposes, histos, weights, h0_normals, stream_pos=0, seq_len=11, batch_size=1024, only_close=False):
     """call_mods_freq_bam.py:265-305: batches of 1024, h0 = the next 64*B values of the seeded randn stream reshaped
     (2,B,32), output round(clip(y,0,1),6) as float32.  Returns (probs float32 (M,), new stream position)."""
-    histos_mat, pos_mat = aggregate_windows(refposes, histos, seq_len)
+    histos_mat, pos_mat = aggregate_windows(refposes, histos, seq_len, only_close)
     probs = []
     for s in range(0, len(histos_mat), batch_size):
         b_h = histos_mat[s:s + batch_size].astype(np.float32)

@@ -265,6 +265,7 @@ CASES = {
     "aggregate_bed_cov6": ns(call_mode="aggregate", bed=True, cov_cf=6),
     "aggregate_no_comb_discrete": ns(call_mode="aggregate", no_comb=True, discrete=True),
     "aggregate_nohap_refsites_only": ns(call_mode="aggregate", no_hap=True, refsites_only=True, chunk_len=4000),
+    "aggregate_only_close": ns(call_mode="aggregate", only_close=True),
 }
 
 

@@ -58,8 +58,9 @@ class OracleAggrModel:
     def new_region(self):
         self.pos = 0
 
-    def forward_raw(self, refposes, histos):
-        out, self.pos = self.orc.cal_modfreq_in_aggregate_mode(np.asarray(refposes), np.asarray(histos), self.w, self.normals, self.pos)
+    def forward_raw(self, refposes, histos, only_close=False):
+        out, self.pos = self.orc.cal_modfreq_in_aggregate_mode(np.asarray(refposes), np.asarray(histos), self.w, self.normals, self.pos,
+                                                               only_close=only_close)
         return out
 
 

@@ -543,7 +543,7 @@ def test_aggregate_mode_vs_reference_golden():
     model.close()
 
 
-@pytest.mark.parametrize("case", ["aggregate_default", "aggregate_bed_cov6", "aggregate_no_comb_discrete", "aggregate_nohap_refsites_only"])
+@pytest.mark.parametrize("case", ["aggregate_default", "aggregate_bed_cov6", "aggregate_no_comb_discrete", "aggregate_nohap_refsites_only", "aggregate_only_close"])
 def test_call_freqb_aggregate_on_gpu_vs_reference_text(case, tmp_path):
     """`call_freqb --call_mode aggregate` end to end (native pile-up -> per-region windows -> HIP aggregate model -> text)
     against what the reference's own functions wrote for the same modbam (tests/golden/make_freqb_golden.py)."""
