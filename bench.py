@@ -276,7 +276,7 @@ def extras(weights, dm, dev, pool, grp):
 
     def call_mods_e2e():
         from ccsmeth_amd.utils import benchdata
-        return benchdata.call_mods_end_to_end(n_reads=int(os.environ.get("CCSM_BENCH_READS", "4000")), read_len=15000)
+        return benchdata.call_mods_end_to_end(n_reads=int(os.environ.get("CCSM_BENCH_READS", "8000")), read_len=15000)
 
     def aggregate():
         from ccsmeth_amd.utils import benchdata
