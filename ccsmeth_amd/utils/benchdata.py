@@ -39,8 +39,7 @@ def call_mods_end_to_end(n_reads=4000, read_len=15000):
     torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
     res, dt = None, None
     for _ in range(2):
-        args = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", os.path.join(tmp, "out"), "--batch_size", "12288", "--holes_batch", "128",
-                                          "--no_sort"])
+        args = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", os.path.join(tmp, "out"), "--batch_size", "12288", "--no_sort"])
         t0 = time.time()
         res = call_mods(args, log=open(os.devnull, "w"))
         dt = time.time() - t0

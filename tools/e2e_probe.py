@@ -10,7 +10,7 @@ tmp = "/tmp"
 inp = os.path.join(tmp, "e2e_in.bam"); ckpt = os.path.join(tmp, "e2e.ckpt")
 print("gen", benchdata.write_synthetic_hifi_bam(inp, int(os.environ.get("NREADS", "6000")), 15000))
 torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
-for hb in (64, 128):
+for hb in (64, 128, 512, 2048):
     args = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", os.path.join(tmp, "e2e_out"), "--batch_size", "12288", "--holes_batch", str(hb), "--no_sort"])
     call_mods(args, log=open(os.devnull, "w"))
     t0 = time.time(); res = call_mods(args, log=open(os.devnull, "w")); dt = time.time() - t0
