@@ -121,14 +121,20 @@ def cpu_baseline(weights, target_s, device_model):
     h1, h2 = synth.synth_h0(n, 780)
     t0 = time.perf_counter()
     for _ in range(reps):
-        c_oracle.forward(weights, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2, threads=threads)
+        _, ref_probs = c_oracle.forward(weights, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2,
+                                        threads=threads)
     dt = time.perf_counter() - t0
     n_total = n * reps
+    # the HIP path against the oracle on the WHOLE timed sample (h0 pinned: 12 KiB per site from host memory, outside every timed region)
+    ws = device_model.workspace(n)
+    _, gpu_probs = ws.forward_host(s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h0=(h1, h2))
+    ws.close()
+    prob_err = max(prob_err, float(np.abs(gpu_probs - ref_probs).max()))
     return {"value": n_total / dt, "unit": "sites/s", "cores": threads, "kind": "port",
             "sites_per_s_per_core": n_total / dt / threads, "GFLOPs": n_total / dt * FLOP_PER_SITE / 1e9,
             "sample": "%d x %d synthetic sites (same generator as the GPU run), explicit h0, %s [%s], %d threads (OpenMP default %d, capped by "
                       "affinity / cgroup CPU quota), %.1f s" % (reps, n, c_oracle.DESCRIPTION, c_oracle.isa_name(), threads, omp_default, dt),
-            "gpu_prob_max_abs_err": prob_err, "gpu_prob_err_sites": probe_n}
+            "gpu_prob_max_abs_err": prob_err, "gpu_prob_err_sites": probe_n + n}
 
 
 class Runner:

@@ -340,12 +340,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
     mx_h0_to_lds<HS3>(smem, kMx0LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     // x staging: 6 fragments per step (bt x hi|lo), waves 0-5 move one each
-    const u32x4_t xrs = dma_rsrc(xin);
+    const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * 2 * kFragU4);     // per-workgroup base: see gru_layer12_mx_kernel
     const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + kMx0XOff);
     auto stage_load = [&](int t, int buf) {
         const int f = wave < 6 ? wave : 5;                          // waves 6, 7 re-stage fragment 5 (same bytes, same place)
         const int hl = f & 1, bt = f >> 1;
-        const int soff = ((((tile0 + bt) * kSeqLen + t) * 2 + hl) << 10);
+        const int soff = (((bt * kSeqLen + t) * 2 + hl) << 10);
         dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + ((buf * 6 + f) << 10))));
     };
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx0_wbytes(HS3));
@@ -597,14 +597,16 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     mx_h0_to_lds<HS3>(smem, kMx12LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     // ---- x transfers: fragment f = (kbl * NB + bt) * 2 + hl of a ring slot; wave w moves fragment w, waves 0-3 also w + 8
-    const u32x4_t xrs = dma_rsrc(xin);
+    // the descriptor starts at THIS workgroup's first tile (64-bit address arithmetic): its 2 GiB range and the 32-bit offsets below
+    // then never see more than three tiles, whatever the size of the launch (a layer output passes 2 GiB at 24960 sites)
+    const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * KX * 2 * kFragU4);
     const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + X_OFF);
     auto dma_pair = [&](int slot, int sd, int jd) {                 // wave-uniform: ring slot, step (clamped), pair of x_t(sd)
         const int sc_ = sd < kSeqLen ? sd : kSeqLen - 1;
         const int td = dir ? kSeqLen - 1 - sc_ : sc_;
         auto one = [&](int f) {
             const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
-            const int soff = (((((tile0 + bt) * kSeqLen + td) * KX + (2 * jd + kbl)) * 2 + hl) << 10);
+            const int soff = ((((bt * kSeqLen + td) * KX + (2 * jd + kbl)) * 2 + hl) << 10);
             dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff),
                       __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT_BYTES + (f << 10))));
         };

@@ -296,12 +296,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
     static_assert(SPW <= 3, "staging registers");
     uint4 sreg0, sreg1, sreg2;
     const int lane16 = lane * 16;
-    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xin);
+    // the descriptor starts at THIS workgroup's first tile: its 2 GiB range and the 32-bit offsets never see more than NB tiles
+    const __amdgpu_buffer_rsrc_t xrs = make_rsrc(xin + (size_t)tile0 * kSeqLen * KX * 2 * kFragU4);
     auto stage_off = [&](int t, int c, int i) -> int {      // wave-uniform byte offset of the fragment this wave stages
         // branch-free: a wave with nothing left to move re-stages the last fragment (same bytes, same place)
         const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);
         const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
-        return (((((tile0 + bt) * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) << 10);
+        return ((((bt * kSeqLen + t) * KX + (c * CK + kbl)) * 2 + hl) << 10);
     };
     auto stage_dst = [&](int buf, int i) -> uint4* {
         const int f = (CHF % kWaves == 0) ? wave + kWaves * i : min(wave + kWaves * i, CHF - 1);

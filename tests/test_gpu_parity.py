@@ -970,6 +970,13 @@ def test_config2_one_million_sites_properties():
     assert np.isfinite(p2048).all() and (p2048 >= 0).all() and (p2048 <= 1).all() and np.abs(p2048.sum(1) - 1).max() < 1e-6
     p8192 = run(8192)
     assert np.array_equal(p2048, p8192)
+    # launches of 30000 sites: a layer output of 2.6 GB, past the 2 GiB range of one buffer descriptor (the kernels rebase theirs per
+    # workgroup; a launch-wide descriptor returned zeros beyond 24960 sites)
+    ws.close()
+    ws = dm.workspace(30000)
+    assert np.array_equal(p2048, run(30000))
+    ws.close()
+    ws = dm.workspace(8192)
     assert np.array_equal(p2048, run(2048))
     whole = np.float64(p2048[:, 1].astype(np.float64).sum())
     parts = sum(np.float64(p2048[a:a + 2048, 1].astype(np.float64).sum()) for a in range(0, n, 2048))
@@ -980,8 +987,8 @@ def test_config2_one_million_sites_properties():
     dm.close()
     for prec, bound in ((3, 0.0), (5, 1e-5)):
         dm = DeviceModel(synth.synth_weights(20260928), device=0, precision=prec)
-        ws = dm.workspace(8192)
-        other = run(8192)
+        ws = dm.workspace(30000)                                               # these two in launches past 2 GiB as well
+        other = run(30000)
         ws.close()
         dm.close()
         if prec == 3:
