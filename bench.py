@@ -43,8 +43,8 @@ PEAK_HBM = 8.0e12
 # HBM/fabric bytes of ONE launch of the dominant kernel per site, from rocprofv3 PMC passes on the launch shape timed here
 # (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
 # read from inside this process)
-TRAFFIC = {4: ((2 * 1209000 + 516100) * 1024 / 6144.0, "profiles/r02_s_pmc_coalesced.md"),
-           5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_s_pmc_coalesced_hybrid.md"),
+TRAFFIC = {4: ((2 * 1209000 + 516100) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced.md"),
+           5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced_hybrid.md"),
            3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
 ARITH = {4: ("f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate",
              "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp4 e2m1 for the "
