@@ -69,6 +69,9 @@ def parse():
                     help="0 = the library's default: split-mx (fp16 main product + MX correction product) if ccsm_create's probe batch keeps it\n"
                          "within 1.5e-5 of split3 on these weights, else the hybrid (split-mx input part, three-pass recurrent part) under the same\n"
                          "condition, else split3; 4 = split-mx forced; 5 = hybrid forced; 3 = split-fp16 x3 (fp32-class)")
+    ap.add_argument("--weights", default=None,
+                    help="an .npz of state_dict arrays (e.g. SAVE_TRAINED=<file> python tests/diag/gpu_trained_weights_parity.py) instead of\n"
+                         "the contract's random initialisation: what the probe selects for THAT checkpoint, and its speed")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--extras", default="all", choices=("all", "none"), help="the secondary measurements (rank 0 at N = 1)")
     return ap.parse_args()
@@ -376,7 +379,7 @@ def main():
 
     from ccsmeth_amd.models import DeviceModel
     from ccsmeth_amd.utils import synth
-    weights = synth.synth_weights(20260928)
+    weights = dict(np.load(a.weights)) if a.weights else synth.synth_weights(20260928)
     dm = DeviceModel(weights, device=local_rank, precision=a.precision)
 
     # synthetic site pool resident in HBM: 8 distinct 2048-site batches per rank, cycled (SURVEY.md 8(d) generator)
@@ -426,7 +429,8 @@ def main():
                        "warmup_steps_run": w_steps, "h0": "device Philox N(0,1)", "arithmetic": arith,
                        "arithmetic_selected": {3: "split3", 4: "split-mx", 5: "hybrid"}.get(dm.precision, dm.precision), "probe_max_abs_dprob": dm.probe_error,
                        "probe_max_abs_dprob_hybrid": dm.probe_error_hybrid,
-                       "weights": "synthetic random initialisation (seed 20260928); a TRAINED checkpoint typically makes the probe of ccsm_create "
+                       "weights": ("state dict from %s" % a.weights) if a.weights else
+                                  "synthetic random initialisation (seed 20260928); a TRAINED checkpoint typically makes the probe of ccsm_create "
                                   "select the hybrid arithmetic (extras.hybrid): DESIGN.md section 2",
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
