@@ -66,13 +66,15 @@ def parse():
                     help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
                          "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds)")
     ap.add_argument("--precision", type=int, default=0, choices=(0, 3, 4, 5),
-                    help="0 = the library's default: split-mx (fp16 main product + MX correction product) if ccsm_create's probe batch keeps it\n"
-                         "within 1.5e-5 of split3 on these weights, else the hybrid (split-mx input part, three-pass recurrent part) under the same\n"
-                         "condition, else split3; 4 = split-mx forced; 5 = hybrid forced; 3 = split-fp16 x3 (fp32-class)")
+                    help="0 = the library's default: the fastest of split-mx (fp16 main product + MX correction product), the hybrid (split-mx input\n"
+                         "part, three-pass recurrent part) and split3 whose probe batch through ccsm_create on these weights leaves at most 0.5 %% of\n"
+                         "the sites beyond 1e-5 and none beyond 5e-5 of split3; 4 = split-mx forced; 5 = hybrid forced; 3 = split-fp16 x3 (fp32-class)")
     ap.add_argument("--weights", default=None,
                     help="an .npz of state_dict arrays (e.g. SAVE_TRAINED=<file> python tests/diag/gpu_trained_weights_parity.py) instead of\n"
                          "the contract's random initialisation: what the probe selects for THAT checkpoint, and its speed")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--ceiling-seconds", type=float, default=3.0,
+                    help="seconds per mode of the live power-capped MFMA ceiling probe behind roofline.peak_power_capped (0 = skip)")
     ap.add_argument("--extras", default="all", choices=("all", "none"), help="the secondary measurements (rank 0 at N = 1)")
     return ap.parse_args()
 
@@ -439,7 +441,7 @@ def main():
                          "traffic": traffic * sites_per_launch, "traffic_source": traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled per site)",
                          "launch_ms": dom_ms, "mfma_passes_per_flop": passes,
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,
-                         "power_note": "the kernel runs at the 1400 W package power cap (sclk ~1.65-1.75 GHz of 2.4): profiles/r02_c_power_attribution.md",
+                         "power_note": "the kernel runs at the package power cap (sclk ~1.65-1.75 GHz of 2.4): profiles/r02_c_power_attribution.md; see peak_power_capped",
                          "note": "achieved = algorithmic flops of one launch (%d sites x 99.09 MFLOP) / its HIP-event duration; one launch = "
                                  "%d workgroups of 96 strand rows on 256 CUs" % (sites_per_launch, 2 * ((2 * int(sites_per_launch) + 95) // 96)),
                          "hbm_algorithmic_GBps": value / n_gpus * BYTES_PER_SITE / 1e9,
@@ -448,6 +450,26 @@ def main():
                           "finalize": float(kt[4]), "launches_averaged": int(nruns)},
             "whole_path_TFLOPs": value / n_gpus * FLOP_PER_SITE / 1e12,
         }
+        # the same device's MFMA ceiling under its power cap, measured live (3 s each; after the timed region): the GRU kernels'
+        # instruction mix with random register-resident operands, and the same with the activations re-read from LDS
+        if a.ceiling_seconds > 0:
+            import ctypes as C
+            from ccsmeth_amd import _lib as L
+            capped = {}
+            for mode, key in ((1, "mix"), (2, "mix_lds")):
+                tf, gc = C.c_float(0), C.c_float(0)
+                L.check(dm._lib.ccsm_measure_mfma_ceiling(local_rank, mode, float(a.ceiling_seconds), C.byref(tf), C.byref(gc)))
+                capped[key] = (float(tf.value), float(gc.value))
+            rl = line["roofline"]
+            rl["peak_power_capped"] = capped["mix"][0]
+            rl["frac_of_capped"] = achieved / 1e12 / capped["mix"][0]
+            rl["peak_power_capped_lds_fed"] = capped["mix_lds"][0]
+            rl["frac_of_capped_lds_fed"] = achieved / 1e12 / capped["mix_lds"][0]
+            rl["power_capped_note"] = ("ccsm_measure_mfma_ceiling on this device, %.0f s per mode: one 512-thread workgroup per CU issuing the kernel's "
+                                       "MFMA mix (per two v_mfma_f32_32x32x16_f16 one fp4 x fp6 v_mfma_scale_f32_32x32x64_f8f6f4) on RANDOM register-"
+                                       "resident operands sustains %.0f TFLOP/s of fp16-MFMA flops at %.2f G issue cycles/s per SIMD (of 2.4), %.0f with "
+                                       "the B operands re-read from LDS; full sweep with sclk / W: profiles/r03_a_power_ceiling.log"
+                                       % (a.ceiling_seconds, capped["mix"][0], capped["mix"][1], capped["mix_lds"][0]))
         if n_gpus == 1 and a.cpu_seconds > 0:
             try:
                 line["cpu_baseline"] = cpu_baseline(weights, a.cpu_seconds, dm)

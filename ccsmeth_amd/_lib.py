@@ -67,7 +67,7 @@ EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspa
            "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded", "ccsm_debug_rows_capacity",
            "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean",
            "ccsm_forward_reads_host", "ccsm_submit_reads_host", "ccsm_wait_reads_host", "ccsm_selftest_split_f8", "ccsm_selftest_split_mx",
-           "ccsm_debug_fp8_e4m3",
+           "ccsm_debug_fp8_e4m3", "ccsm_measure_mfma_ceiling",
            "ccsm_aggr_create", "ccsm_aggr_destroy", "ccsm_aggr_set_only_close", "ccsm_aggr_forward_host", "ccsm_aggr_forward_device")
 
 
@@ -113,6 +113,7 @@ def load():
     lib.ccsm_selftest_mfma.argtypes = [ci, _FP]
     lib.ccsm_selftest_split_f8.argtypes = [ci, _FP, _FP]
     lib.ccsm_selftest_split_mx.argtypes = [ci, ci, _FP, _FP, C.POINTER(C.c_int)]
+    lib.ccsm_measure_mfma_ceiling.argtypes = [ci, ci, C.c_double, _FP, _FP]
     lib.ccsm_debug_read.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ccsm_debug_rows_padded.argtypes = [ci]
     lib.ccsm_debug_fp8_e4m3.argtypes = [C.c_float]

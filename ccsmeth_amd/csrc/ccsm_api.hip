@@ -1,6 +1,7 @@
 // libccsm host side: C-ABI (include/ccsm.h), weight fragment packing, workspaces, kernel sequencing.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +16,7 @@
 #include "ccsm_gru_mx.hip"
 #include "ccsm_aggr.hip"
 #include "ccsm_extract.hip"
+#include "ccsm_ceiling.hip"
 
 #include <cmath>
 #include <random>
@@ -1533,6 +1535,59 @@ ccsm_status ccsm_aggr_forward_host(ccsm_aggr_model* m, int64_t n_sites, const in
     if (st != CCSM_OK) return st;
     HIP_TRY(hipMemcpyAsync(out, m->d_out, n_sites * sizeof(float), hipMemcpyDeviceToHost, hs));
     HIP_TRY(hipStreamSynchronize(hs));
+    return CCSM_OK;
+}
+
+// See include/ccsm.h.  Launches run back to back for `seconds`; only the second half is averaged (the power governor needs
+// about a second to settle at the cap).
+ccsm_status ccsm_measure_mfma_ceiling(int device, int mode, double seconds, float* tflops, float* issue_gcycles) {
+    if (!tflops || mode < 0 || mode > 2 || !(seconds > 0.0) || seconds > 60.0)
+        return fail(CCSM_ERR_INVALID_ARG, "mode must be 0 (f16), 1 (mix) or 2 (mix, LDS-fed), 0 < seconds <= 60, tflops non-NULL");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int grid = prop.multiProcessorCount, iters = 20000;
+    const std::vector<uint4> h = ccsm_ceiling::random_operands();
+    uint4* rnd = nullptr;
+    float* out = nullptr;
+    HIP_TRY(hipMalloc((void**)&rnd, h.size() * sizeof(uint4)));
+    if (hipMalloc((void**)&out, (size_t)grid * 512 * sizeof(float)) != hipSuccess) { (void)hipFree(rnd); return fail(CCSM_ERR_NOMEM, "hipMalloc"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ccsm_status st = CCSM_OK;
+    auto launch = [&](int it) {
+        switch (mode) {
+            case 0: hipLaunchKernelGGL((ccsm_ceiling::k<512, 0>), dim3(grid), dim3(512), 0, 0, rnd, out, it); break;
+            case 1: hipLaunchKernelGGL((ccsm_ceiling::k<512, 1>), dim3(grid), dim3(512), 0, 0, rnd, out, it); break;
+            default: hipLaunchKernelGGL((ccsm_ceiling::k<512, 2>), dim3(grid), dim3(512), 0, 0, rnd, out, it); break;
+        }
+    };
+    double ms_sum = 0.0;
+    long launches = 0;
+    do {
+        if (hipMemcpy(rnd, h.data(), h.size() * sizeof(uint4), hipMemcpyHostToDevice) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+            hipEventCreate(&e1) != hipSuccess) { st = fail(CCSM_ERR_HIP, "ceiling probe set-up"); break; }
+        launch(200);
+        if (hipDeviceSynchronize() != hipSuccess) { st = fail(CCSM_ERR_HIP, "ceiling probe launch"); break; }
+        const auto t0 = std::chrono::steady_clock::now();
+        auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+        while (elapsed() < seconds) {
+            (void)hipEventRecord(e0, 0);
+            for (int r = 0; r < 4; ++r) launch(iters);
+            (void)hipEventRecord(e1, 0);
+            if (hipEventSynchronize(e1) != hipSuccess) { st = fail(CCSM_ERR_HIP, "ceiling probe run"); break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (elapsed() > 0.5 * seconds) { ms_sum += ms; launches += 4; }
+        }
+    } while (false);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(rnd); (void)hipFree(out);
+    if (st != CCSM_OK) return st;
+    if (launches == 0) return fail(CCSM_ERR_INVALID_ARG, "seconds too short for one averaged launch");
+    const double waves = (double)grid * 8, sec = ms_sum * 1e-3;
+    *tflops = (float)(launches * waves * iters * (8.0 * 2 * 32 * 32 * 16) / sec * 1e-12);
+    if (issue_gcycles) *issue_gcycles = (float)(launches * (waves / (grid * 4.0)) * iters * (8 * 32 + (mode ? 4 * 35 : 0)) / sec * 1e-9);
     return CCSM_OK;
 }
 
