@@ -37,13 +37,14 @@ class Batch(C.Structure):
 
 
 class H0(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("h0", C.c_void_p * 2), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+    _fields_ = [("mode", C.c_int32), ("h0", C.c_void_p * 2), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("site_key", C.c_void_p), ("site_sub", C.c_void_p)]
 
 
 class Reads(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("offset", C.c_void_p), ("length", C.c_void_p), ("seq", C.c_void_p),
                 ("fi", C.c_void_p), ("ri", C.c_void_p), ("fp", C.c_void_p), ("rp", C.c_void_p), ("fn", C.c_void_p),
-                ("rn", C.c_void_p)]
+                ("rn", C.c_void_p), ("h0_key", C.c_void_p)]
 
 
 class AggrWeights(C.Structure):

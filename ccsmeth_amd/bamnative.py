@@ -12,20 +12,31 @@ LIB_PATH = os.path.join(_HERE, "lib", "libccsm_bam.so")
 EXPORTS = ("ccsm_bam_last_error", "ccsm_bam_open", "ccsm_bam_header", "ccsm_bam_next", "ccsm_bam_batch_free", "ccsm_bam_close",
            "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_flush", "ccsm_bam_writer_close",
            "ccsm_bam_modcalls_of_batch", "ccsm_bam_modcalls_free", "ccsm_bam_index_build", "ccsm_bam_sort",
-           "ccsm_bam_align_info", "ccsm_bam_seek", "ccsm_bam_tell", "ccsm_bam_inflated_bytes")
+           "ccsm_bam_align_info", "ccsm_bam_seek", "ccsm_bam_tell", "ccsm_bam_inflated_bytes", "ccsm_bam_seek_chunk",
+           "ccsm_bam_writer_track_index", "ccsm_bam_writer_take_index", "ccsm_bam_index_write")
 
 
 class _Batch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("records", C.c_void_p), ("rec_offset", C.c_void_p), ("flag", C.c_void_p),
                 ("offset", C.c_void_p), ("length", C.c_void_p), ("n_sites", C.c_void_p), ("seq", C.c_void_p), ("fi", C.c_void_p),
                 ("ri", C.c_void_p), ("fp", C.c_void_p), ("rp", C.c_void_p), ("fn", C.c_void_p), ("rn", C.c_void_p),
-                ("total_bases", C.c_int64), ("voffset_start", C.c_uint64), ("voffset_end", C.c_uint64)]
+                ("name_hash", C.c_void_p), ("total_bases", C.c_int64), ("voffset_start", C.c_uint64), ("voffset_end", C.c_uint64)]
 
 
 class ModCallOpts(C.Structure):
     """ccsm_bam_modcall_opts: the per-record options of call_freqb (call_mods_freq_bam.py:486-537)."""
     _fields_ = [("identity", C.c_double), ("mapq", C.c_int32), ("no_supplementary", C.c_int32), ("base_clip", C.c_int32),
                 ("refsites_all", C.c_int32), ("hap_tag", C.c_char * 2), ("modbase", C.c_char), ("modification", C.c_char)]
+
+
+INDEX_ENTRY = np.dtype([("tid", "<i4"), ("pos", "<i4"), ("end", "<i4"), ("flag", "<u4"), ("vbeg", "<u8"), ("vend", "<u8")])
+
+
+class _IndexRun(C.Structure):
+    """ccsm_bam_index_run"""
+    _fields_ = [("n_records", C.c_int64), ("n_unplaced", C.c_int64), ("sorted", C.c_int32), ("first_k1", C.c_uint64), ("first_k2", C.c_uint32),
+                ("last_k1", C.c_uint64), ("last_k2", C.c_uint32), ("n_entries", C.c_int64), ("entries", C.c_void_p),
+                ("file_start", C.c_int64), ("file_end", C.c_int64)]
 
 
 class _ModCalls(C.Structure):
@@ -67,6 +78,10 @@ def load():
     lib.ccsm_bam_tell.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.ccsm_bam_inflated_bytes.argtypes = [vp]
     lib.ccsm_bam_inflated_bytes.restype = C.c_int64
+    lib.ccsm_bam_seek_chunk.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.ccsm_bam_writer_track_index.argtypes = [vp, C.c_int]
+    lib.ccsm_bam_writer_take_index.argtypes = [vp, C.POINTER(_IndexRun)]
+    lib.ccsm_bam_index_write.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_IndexRun), vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 
@@ -99,6 +114,7 @@ class Batch:
         self.seq, self.fi, self.ri, self.fp, self.rp = (_view(p, np.uint8, self.total_bases) for p in (b.seq, b.fi, b.ri, b.fp, b.rp))
         self.fn = _view(b.fn, np.float32, n)
         self.rn = _view(b.rn, np.float32, n)
+        self.name_hash = _view(b.name_hash, np.uint64, n)
         self.voffset_start, self.voffset_end = int(b.voffset_start), int(b.voffset_end)
 
     def close(self):
@@ -157,6 +173,13 @@ class NativeBamReader:
         """Continue at a BGZF virtual offset; with voffset_end the range ends like a file (nothing behind its block is inflated)."""
         _check(_lib.ccsm_bam_seek(self._h, int(voffset_start), int(voffset_end)))
 
+    def seek_chunk(self, coffset_lo, coffset_hi):
+        """Position at the first record that starts in a BGZF block of file range [coffset_lo, coffset_hi); next_batch then returns
+        the records starting there and None behind them.  -> that record's virtual offset, or 0 when the chunk holds no record start."""
+        v = C.c_uint64(0)
+        _check(_lib.ccsm_bam_seek_chunk(self._h, int(coffset_lo), int(coffset_hi), C.byref(v)))
+        return v.value
+
     def tell(self):
         v = C.c_uint64(0)
         _check(_lib.ccsm_bam_tell(self._h, C.byref(v)))
@@ -202,10 +225,24 @@ class NativeBamWriter:
         return n.value
 
     def flush(self):
-        """End the current BGZF block; returns the file size so far."""
+        """End the current BGZF block (= the current run); returns the file size so far."""
         off = C.c_int64(0)
         _check(_lib.ccsm_bam_writer_flush(self._h, C.byref(off)))
         return off.value
+
+    def track_index(self, enable=True):
+        """Keep the index bookkeeping of the records written from here on (call right after a flush)."""
+        _check(_lib.ccsm_bam_writer_track_index(self._h, int(bool(enable))))
+
+    def take_index(self):
+        """IndexRun of everything written since the previous take; call right after flush()."""
+        r = _IndexRun()
+        _check(_lib.ccsm_bam_writer_take_index(self._h, C.byref(r)))
+        ent = np.empty(0, INDEX_ENTRY)
+        if r.n_entries:
+            ent = np.ctypeslib.as_array(C.cast(r.entries, C.POINTER(C.c_uint8)), shape=(int(r.n_entries) * INDEX_ENTRY.itemsize,)).view(INDEX_ENTRY).copy()
+        return IndexRun(int(r.n_records), int(r.n_unplaced), bool(r.sorted), (int(r.first_k1), int(r.first_k2)), (int(r.last_k1), int(r.last_k2)),
+                        ent, int(r.file_start), int(r.file_end))
 
     def close(self):
         if self._h:
@@ -217,6 +254,39 @@ class NativeBamWriter:
 
     def __exit__(self, *a):
         self.close()
+
+
+class IndexRun:
+    """One run table of NativeBamWriter.take_index (include/ccsm_bam.h: ccsm_bam_index_run); picklable."""
+    __slots__ = ("n_records", "n_unplaced", "sorted", "first_key", "last_key", "entries", "file_start", "file_end")
+
+    def __init__(self, n_records, n_unplaced, is_sorted, first_key, last_key, entries, file_start, file_end):
+        self.n_records, self.n_unplaced, self.sorted, self.first_key, self.last_key = n_records, n_unplaced, is_sorted, first_key, last_key
+        self.entries, self.file_start, self.file_end = entries, file_start, file_end
+
+    def __getstate__(self):
+        return tuple(getattr(self, k) for k in self.__slots__)
+
+    def __setstate__(self, st):
+        for k, v in zip(self.__slots__, st):
+            setattr(self, k, v)
+
+
+def index_write(bai_path, n_ref, runs, shifts=None):
+    """Write <bai_path> from IndexRun tables given in final file order (shifts[i] = how far run i's bytes were moved when the part
+    files were stitched).  -> (sorted, n_records); nothing is written when the records are not in coordinate order."""
+    n = len(runs)
+    arr = (_IndexRun * max(n, 1))()
+    keep = []
+    for i, r in enumerate(runs):
+        ent = np.ascontiguousarray(r.entries, INDEX_ENTRY)
+        keep.append(ent)
+        arr[i] = _IndexRun(r.n_records, r.n_unplaced, int(r.sorted), r.first_key[0], r.first_key[1], r.last_key[0], r.last_key[1], len(ent),
+                           ent.ctypes.data if len(ent) else None, r.file_start, r.file_end)
+    sh = np.ascontiguousarray(shifts if shifts is not None else np.zeros(n), np.int64)
+    srt, cnt = C.c_int(), C.c_int64()
+    _check(load().ccsm_bam_index_write(os.fsencode(bai_path), int(n_ref), n, arr, sh.ctypes.data if n else None, C.byref(srt), C.byref(cnt)))
+    return bool(srt.value), int(cnt.value)
 
 
 BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
@@ -246,6 +316,72 @@ def stitch_runs(out_path, header_file, header_end, runs):
             for fh in handles.values():
                 fh.close()
         out.write(BGZF_EOF)
+
+
+def stitch_layout(header_end, spans):
+    """Final file offsets of the runs [(path, start, end)] laid back to back behind the header, and the file's total size."""
+    dst, off = [], int(header_end)
+    for _, a, e in spans:
+        dst.append(off)
+        off += int(e) - int(a)
+    return dst, off + len(BGZF_EOF)
+
+
+def stitch_create(out_path, header_file, header_end, total_size):
+    """The output file with its header blocks in place, sized for every run, the BGZF end-of-file block at its end."""
+    with open(out_path, "wb") as out:
+        with open(header_file, "rb") as fh:
+            out.write(fh.read(header_end))
+        out.truncate(total_size)
+        out.seek(total_size - len(BGZF_EOF))
+        out.write(BGZF_EOF)
+
+
+def stitch_copy(out_path, spans, dst):
+    """Copy the runs [(path, start, end)] to their offsets `dst` of the (existing, sized) output: in the kernel where the file
+    system allows it (copy_file_range), else through a buffer.  Every rank copies its own runs at the same time; no byte is
+    touched twice and nothing is recompressed."""
+    fds = {}
+    out = os.open(out_path, os.O_WRONLY)
+    use_cfr = hasattr(os, "copy_file_range")
+    try:
+        for (path, start, end), d in zip(spans, dst):
+            fd = fds.get(path)
+            if fd is None:
+                fd = fds[path] = os.open(path, os.O_RDONLY)
+            src, left = int(start), int(end) - int(start)
+            while left > 0:
+                n = 0
+                if use_cfr:
+                    try:
+                        n = os.copy_file_range(fd, out, min(left, 1 << 30), src, d)
+                    except OSError:
+                        use_cfr = False
+                if not use_cfr:
+                    buf = os.pread(fd, min(left, 1 << 24), src)
+                    if not buf:
+                        raise IOError("short read while stitching %s" % path)
+                    n = os.pwrite(out, buf, d)
+                elif n == 0:
+                    raise IOError("short read while stitching %s" % path)
+                src += n
+                d += n
+                left -= n
+    finally:
+        os.close(out)
+        for fd in fds.values():
+            os.close(fd)
+
+
+def stitch_runs_parallel(out_path, header_file, header_end, spans, mine, finish):
+    """Multi-GPU merge, every rank's share: `spans` = all runs in final order, `mine` = the indices this caller copies, finish = this
+    caller also creates the file (it must do so before anybody copies: the callers synchronise around it).  -> destination offsets."""
+    dst, total = stitch_layout(header_end, spans)
+    if finish:
+        stitch_create(out_path, header_file, header_end, total)
+    mine = list(mine)
+    stitch_copy(out_path, [spans[i] for i in mine], [dst[i] for i in mine])
+    return dst
 
 
 def align_info(batch):

@@ -29,10 +29,10 @@ def build_parser():
     p = argparse.ArgumentParser("ccsmeth_amd call_mods", description="call 5mCpG from a HiFi BAM with kinetics (MI355X)")
     p.add_argument("--input", "-i", required=True, help="input BAM (fi/ri/fp/rp/fn/rn tags)")
     p.add_argument("--holes_batch", type=int, default=50,
-                   help="reads per unit of work (reference default 50).  With --io native the default means 256: a hole-batch is cut\n"
-                        "into GPU chunks of >= 12288 sites, its last chunk is ragged and the GPU drains between hole-batches (16000\n"
-                        "reads: 1.89 M sites/s at 64, 2.00-2.01 M at 128-512, 1.85 M at 2048); any other value is taken as given.\n"
-                        "The calls do not depend on it")
+                   help="reads per unit of work (reference default 50).  With --io native the value 50 is run as 256 (logged; a hole-batch\n"
+                        "is cut into GPU launches of >= 12288 sites, its last launch is ragged and the GPU drains between hole-batches:\n"
+                        "16000 reads run at 1.89 M sites/s with 64, 2.00-2.01 M with 128-512, 1.85 M with 2048); --holes_batch_exact keeps\n"
+                        "50; any other value is taken as given.  The calls do not depend on it")
     p.add_argument("--output", "-o", required=True, help="output prefix; writes <output>.modbam.bam")
     p.add_argument("--gzip", action="store_true", default=False, help="(reference: TSV output only) ignored")
     p.add_argument("--keep_pulse", action="store_true", default=False)
@@ -69,8 +69,13 @@ def build_parser():
     p.add_argument("--skip_unmapped", default="yes")
     p.add_argument("--threads", "-p", type=int, default=10, help="BGZF inflate / deflate threads of --io native")
     p.add_argument("--dispatch", default="dynamic", choices=("dynamic", "static"),
-                   help="multi-GPU runs (torch.distributed.run): dynamic = every rank claims the next unclaimed hole-batch (the reference's "
-                        "shared queue); static = hole-batch i goes to rank i mod world")
+                   help="multi-GPU runs (torch.distributed.run): dynamic = every rank claims the next unclaimed chunk of the input (the "
+                        "reference's shared queue); static = chunk i goes to rank i mod world")
+    p.add_argument("--chunk_mb", type=float, default=32.0,
+                   help="multi-GPU runs: compressed MiB of input per unit handed to a rank (a rank finds its chunk's first record itself; "
+                        "nothing is inflated twice)")
+    p.add_argument("--holes_batch_exact", action="store_true", default=False,
+                   help="--io native: run --holes_batch 50 as 50 reads (by default the reference's 50 is run as 256: see --holes_batch)")
     p.add_argument("--threads_call", type=int, default=3, help="(reference: call workers) ignored: one process per GPU")
     p.add_argument("--tseed", type=int, default=1234)
     p.add_argument("--use_compile", default="no")
@@ -82,9 +87,9 @@ def build_parser():
     p.add_argument("--arithmetic", default="auto", choices=["auto", "split3", "hybrid", "split-mx"],
                    help="MFMA arithmetic of the model: auto (default) = the fastest of split-mx (fp16 main product + one block-scaled\n"
                         "fp6/fp4 correction product), hybrid (split-mx for the GRUs' input part, three fp16 passes for their recurrent\n"
-                        "part) and split3 (three fp16 passes everywhere: fp32-class, max abs error < 1e-6) that keeps a probe batch\n"
-                        "through THIS checkpoint within 1.5e-5 of split3.  Trained checkpoints usually end at hybrid: split-mx leaves\n"
-                        "~0.1 %% of their sites beyond 1e-4.  The other values force one")
+                        "part) and split3 (three fp16 passes everywhere: fp32-class, max abs error < 1e-6) whose probe batch through THIS\n"
+                        "checkpoint leaves at most 0.5 %% of the sites beyond 1e-5 and none beyond 5e-5 of split3.  Trained checkpoints\n"
+                        "usually end at hybrid: split-mx leaves ~0.1 %% of their sites beyond 1e-4.  The other values force one")
     p.add_argument("--extract", default="device", choices=["device", "host"],
                    help="where the 21-mer features are built: on the GPU from the raw read arrays (default) or NumPy on the host")
     return p
@@ -248,8 +253,8 @@ def _read_of(rec):
 
 
 def call_mods(args, log=sys.stderr, pipe=None):
-    """`pipe`: an object with CallModsPipeline's run_native_batch / _site_counter / close (the CPU tests of the multi-rank
-    hand-out pass a stand-in; None = the GPU pipeline on the checkpoint of --model_file)."""
+    """`pipe`: an object with CallModsPipeline's run_native_batch / close (the CPU tests of the multi-rank hand-out pass a
+    stand-in; None = the GPU pipeline on the checkpoint of --model_file)."""
     t0 = time.time()
     if pipe is None and not os.path.exists(args.model_file):
         raise ValueError("--model_file is not set right!")            # call_modifications.py:484-485
@@ -293,17 +298,21 @@ def call_mods(args, log=sys.stderr, pipe=None):
     if world > 1 and not (args.io == "native" and args.extract == "device"):
         raise ValueError("multi-GPU call_mods needs --io native --extract device")
     if args.io == "native" and args.extract == "device":
-        # file -> libccsm_bam -> ccsm_forward_reads_host -> libccsm_bam -> file; the next chunk is inflated / parsed and the
+        # file -> libccsm_bam -> ccsm_forward_reads_host -> libccsm_bam -> file; the next hole-batch is inflated / parsed and the
         # previous one deflated / written by two helper threads while the GPU works on the current one.
-        # Multi-GPU (torch.distributed.run, one process per GPU; ccsmeth_amd/sharding.py): rank 0 scans the input once
-        # in a background thread and publishes every hole-batch's place in the file and the running site index of its first site;
-        # every rank claims the next unclaimed batch (the reference's shared queue, call_modifications.py:561-578), seeks to it,
-        # and writes it as a block-aligned run into its own part file; the Philox counter of a batch is its published site index,
-        # so every probability equals the single-GPU run's; rank 0 stitches the runs back into input order.
+        # Multi-GPU (torch.distributed.run, one process per GPU; ccsmeth_amd/sharding.py): the input is cut into chunks
+        # of --chunk_mb compressed MiB; every rank claims the next unclaimed chunk number (the reference's shared queue,
+        # call_modifications.py:561-578, as a counter), locates the chunk's first record itself and inflates only its own chunks;
+        # a chunk's records go into the rank's part file as one block-aligned run; initial states are keyed by (read name, position),
+        # so every probability equals the single-GPU run's; at the end every rank copies its own runs to their place in the output
+        # (in parallel) and the index is built from the writers' run tables - nothing is read back.
         from concurrent.futures import ThreadPoolExecutor
-        from .bamnative import NativeBamReader, NativeBamWriter, stitch_runs
-        if args.holes_batch == 50:                                 # the reference's default: see --help
-            args.holes_batch = 256
+        from .bamnative import NativeBamReader, NativeBamWriter, index_write, stitch_copy, stitch_create, stitch_layout
+        holes_batch = args.holes_batch
+        if holes_batch == 50 and not args.holes_batch_exact:       # the reference's default: see --help
+            holes_batch = 256
+            print("[main]--holes_batch 50 (the reference's default) is run as 256 reads per unit of work; pass --holes_batch_exact to "
+                  "keep 50 (the calls do not depend on it)", file=log)
 
         def filters(b):
             """(skip mask or None, site window or None, sites of the batch that will be called)"""
@@ -318,113 +327,157 @@ def call_mods(args, log=sys.stderr, pipe=None):
             sites = int(np.where((b.length > 0) & (~skip if skip is not None else True), b.n_sites, 0).sum())
             return skip, window, sites
 
-        dist = board = scan = None
+        dist = queue = None
+        chunk_bytes = max(1, int(args.chunk_mb * (1 << 20)))
         if world > 1:
             import torch.distributed as dist
             from . import sharding
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if not dist.is_initialized():
                 dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side bookkeeping only
-            store, connect = sharding.open_board_store(world, rank)
-            board = sharding.BatchBoard(store, world, rank, dispatch=args.dispatch)
-            if rank == 0:       # the scan gets the host cores the other ranks' readers do not need, and its own connection to the board
-                scan_threads = max(args.threads, (os.cpu_count() or 1) // 2)
-                scan = sharding.start_scan_thread(lambda: NativeBamReader(args.input, threads=scan_threads), args.holes_batch,
-                                                  lambda b: filters(b)[2], sharding.BatchBoard(connect(), world, rank, dispatch=args.dispatch))
+            queue = sharding.ChunkQueue(sharding.open_board_store(world, rank), world, rank,
+                                        sharding.n_chunks_of(os.path.getsize(args.input), chunk_bytes), dispatch=args.dispatch)
         part_path = out_path if world == 1 else "%s.part%d" % (out_path, rank)
-        runs = []
-        with NativeBamReader(args.input, threads=args.threads) as rd:
-            header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
-            if not args.no_sort and rd.n_ref == 0:
-                header = _set_coordinate_order(header)             # no reference: every record sorts equal, input order is kept
-            header_inflated = rd.inflated_bytes
-            with NativeBamWriter(part_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
-                    ThreadPoolExecutor(1) as rpool, ThreadPoolExecutor(1) as wpool:
-                header_end = wr.flush()
-                seq_state = {"bi": 0, "site_base": 0}
+        runs, chunk_log = [], []          # [(chunk, file start, file end, IndexRun)], [(chunk, first voffset, end voffset, records)]
+        t_work = time.time()
+        try:
+            with NativeBamReader(args.input, threads=args.threads) as rd:
+                header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))
+                if not args.no_sort and rd.n_ref == 0:
+                    header = _set_coordinate_order(header)             # no reference: every record sorts equal, input order is kept
+                header_inflated = rd.inflated_bytes
+                first_voffset = rd.tell()
+                n_ref = rd.n_ref
+                with NativeBamWriter(part_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
+                        ThreadPoolExecutor(1) as rpool, ThreadPoolExecutor(1) as wpool:
+                    header_end = wr.flush()
+                    wr.track_index(True)
+                    cur = {}
 
-                def fetch():
-                    """next (batch, index, site index of its first site) of this rank, or None"""
-                    if board is None:
-                        b = rd.next_batch(args.holes_batch)
-                        if b is None:
-                            return None
-                        item = (b, seq_state["bi"], seq_state["site_base"])
-                        seq_state["bi"] += 1
-                        seq_state["site_base"] += filters(b)[2]
-                        return item
-                    c = board.claim()
-                    if c is None:
-                        return None
-                    index, vstart, vend, n_reads, site_base = c
-                    rd.seek(vstart, vend)
-                    b = rd.next_batch(n_reads)
-                    if b is None or b.n_reads != n_reads:
-                        raise IOError("hole-batch %d: expected %d records at its published offset" % (index, n_reads))
-                    return b, index, site_base
-                nxt = rpool.submit(fetch)
-                pending = None
-
-                def write(b, first, locs, prob1, tagged, index):
-                    n = wr.write_batch(b, first, locs, prob1, tagged, rm_pulse)
-                    b.close()
-                    if world > 1:
-                        runs.append((index, wr.flush()))
-                    return n
-                while True:
-                    item = nxt.result()
-                    if item is None:
-                        break
-                    b, bi, site_base = item
+                    def fetch():
+                        """("batch", batch, chunk) | ("end", chunk, first voffset, end voffset, records) | None when this rank is done"""
+                        if queue is None:
+                            b = rd.next_batch(holes_batch)
+                            return None if b is None else ("batch", b, 0)
+                        while True:
+                            if not cur:
+                                k = queue.claim()
+                                if k is None:
+                                    return None
+                                v0 = rd.seek_chunk(k * chunk_bytes, (k + 1) * chunk_bytes)
+                                if v0 == 0:
+                                    chunk_log.append((k, 0, 0, 0))
+                                    continue
+                                cur.update(k=k, v0=v0, n=0)
+                            b = rd.next_batch(holes_batch)
+                            if b is None:
+                                item = ("end", cur["k"], cur["v0"], rd.tell(), cur["n"])
+                                cur.clear()
+                                return item
+                            cur["n"] += b.n_reads
+                            return ("batch", b, cur["k"])
                     nxt = rpool.submit(fetch)
-                    skip, window, _ = filters(b)
-                    pipe._site_counter = site_base
-                    first, locs, prob1, tagged, failed = pipe.run_native_batch(b, skip)
-                    if window is not None:
-                        first, locs, prob1, tagged = _filter_sites_by_window(first, locs, prob1, tagged, window)
+                    pending = None
+
+                    def write(b, first, locs, prob1, tagged):
+                        n = wr.write_batch(b, first, locs, prob1, tagged, rm_pulse)
+                        b.close()
+                        return n
+
+                    def end_run(k):
+                        a = runs[-1][2] if runs else header_end
+                        e = wr.flush()
+                        runs.append((k, a, e, wr.take_index()))
+                        return 0
+                    while True:
+                        item = nxt.result()
+                        if item is None:
+                            break
+                        nxt = rpool.submit(fetch)
+                        if item[0] == "end":
+                            _, k, v0, v1, n = item
+                            chunk_log.append((k, v0, v1, n))
+                            if pending is not None:
+                                cnt_mm += pending.result()
+                            pending = wpool.submit(end_run, k)
+                            continue
+                        b = item[1]
+                        skip, window, _ = filters(b)
+                        first, locs, prob1, tagged, failed = pipe.run_native_batch(b, skip)
+                        if window is not None:
+                            first, locs, prob1, tagged = _filter_sites_by_window(first, locs, prob1, tagged, window)
+                        if pending is not None:
+                            cnt_mm += pending.result()
+                        pending = wpool.submit(write, b, first, locs, prob1, tagged)
+                        cnt_w += b.n_reads
+                        cnt_sites += len(locs)
+                        cnt_failed += failed
                     if pending is not None:
                         cnt_mm += pending.result()
-                    pending = wpool.submit(write, b, first, locs, prob1, tagged, bi)
-                    cnt_w += b.n_reads
-                    cnt_sites += len(locs)
-                    cnt_failed += failed
-                if pending is not None:
-                    cnt_mm += pending.result()
-            work_inflated = rd.inflated_bytes - header_inflated
+                    if world == 1:
+                        end_run(0)
+                work_inflated = rd.inflated_bytes - header_inflated
+        except BaseException as e:      # noqa: BLE001 - the other ranks must not wait for this one's share
+            if queue is not None:
+                queue.fail("%s: %s" % (type(e).__name__, e))
+            raise
         pipe.close()
-        stats = dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, output=out_path, inflated_bytes=work_inflated, batches=len(runs))
+        t_work = time.time() - t_work
+        stats = dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, output=out_path, inflated_bytes=work_inflated, chunks=len(runs),
+                     seconds_work=t_work)
+        ordered = [(k, part_path, a, e, ir) for k, a, e, ir in runs]
+        t_stitch = time.time()
         if world > 1:
-            if scan is not None:
-                scan[0].join()
-                if "error" in scan[1]:
-                    raise scan[1]["error"]
-                stats["scan_inflated_bytes"] = scan[1]["inflated_bytes"]
+            queue.check()
             gathered = [None] * world
-            dist.all_gather_object(gathered, dict(rank=rank, header_end=header_end, runs=runs, counts=(cnt_w, cnt_mm, cnt_failed, cnt_sites),
-                                                  inflated=work_inflated))
+            dist.all_gather_object(gathered, dict(rank=rank, header_end=header_end, runs=runs, chunks=chunk_log,
+                                                  counts=(cnt_w, cnt_mm, cnt_failed, cnt_sites), inflated=work_inflated, work=t_work))
             cnt_w, cnt_mm, cnt_failed, cnt_sites = (sum(g["counts"][k] for g in gathered) for k in range(4))
+            n_chain = sharding.verify_chain(first_voffset, [c for g in gathered for c in g["chunks"]])
+            if n_chain != cnt_w:
+                raise RuntimeError("the chunks hold %d records but %d were written" % (n_chain, cnt_w))
             stats.update(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, rank_inflated_bytes=[g["inflated"] for g in gathered],
-                         rank_batches=[len(g["runs"]) for g in gathered])
+                         rank_chunks=[len(g["runs"]) for g in gathered], rank_seconds_work=[g["work"] for g in gathered])
+            ordered = sorted((k, "%s.part%d" % (out_path, g["rank"]), a, e, ir) for g in gathered for k, a, e, ir in g["runs"])
+            spans = [(p, a, e) for _, p, a, e, _ in ordered]
+            dst, total = stitch_layout(header_end, spans)
             if rank == 0:
-                spans = []
-                for g in gathered:
-                    start = g["header_end"]
-                    for index, end in g["runs"]:
-                        spans.append((index, "%s.part%d" % (out_path, g["rank"]), start, end))
-                        start = end
-                spans.sort()
-                stitch_runs(out_path, part_path, header_end, [(p, a, e) for _, p, a, e in spans])
+                stitch_create(out_path, part_path, header_end, total)
+            dist.barrier()
+            mine = [i for i, sp in enumerate(spans) if sp[0] == part_path]
+            stitch_copy(out_path, [spans[i] for i in mine], [dst[i] for i in mine])      # every rank moves its own runs, at the same time
             dist.barrier()
             os.remove(part_path)
+            shifts = [d - a for d, (_, a, _) in zip(dst, spans)]
+        else:
+            shifts = [0] * len(ordered)
+        t_stitch = time.time() - t_stitch
         if rank == 0:
-            _post_sort_index(out_path, args, log)
+            t_idx = time.time()
+            indexed = False
+            if not args.no_sort:
+                # the reference's samtools sort + index (call_modifications.py:592-607): records that are already in coordinate order
+                # (every unaligned HiFi BAM; a sorted aligned one) are indexed from the writers' run tables without reading the file
+                # back; only an unsorted input takes the real sort
+                try:
+                    indexed, _ = index_write(out_path + ".bai", n_ref, [ir for *_, ir in ordered], shifts)
+                except IOError as e:
+                    print("[post_process] WARNING: writing the index from the run tables failed (%s); falling back to a pass over the file" % e, file=log)
+                if indexed:
+                    print("[post_process] bam_sort_index costs %.2f seconds (already in order: indexed from the writers' run tables)" % (time.time() - t_idx),
+                          file=log)
+                else:
+                    _post_sort_index(out_path, args, log)
+            stats.update(seconds_stitch=t_stitch, seconds_index=time.time() - t_idx)
             print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
             print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d GPU(s); ccsmeth_amd %s)" %
                   (time.time() - t0, cnt_failed, world, __version__), file=log)
-            if os.environ.get("CCSM_CALLMODS_REPORT"):      # machine-readable run summary (tools/e2e_multirank_probe.py)
+            if os.environ.get("CCSM_CALLMODS_REPORT"):      # machine-readable run summary (tools/e2e_multirank_probe.py, tools/host_feed_probe.py)
                 import json
                 with open(os.environ["CCSM_CALLMODS_REPORT"], "w") as rf:
                     json.dump(dict({k: v for k, v in stats.items() if k != "output"}, seconds=time.time() - t0, world=world), rf)
+        if world > 1:
+            dist.barrier()
         return stats
     with BamReader(args.input) as rd:
         header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))

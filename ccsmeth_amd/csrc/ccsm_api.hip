@@ -39,7 +39,7 @@ ccsm_status fail(ccsm_status st, const std::string& msg) {
             return fail(CCSM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                       \
     } while (0)
 
-constexpr size_t kReadTableBytes = 8 + 64 + 4 * 5 + 4;   // per read: offset | stats | length, fn, rn, nsites, first_site | spare
+constexpr size_t kReadTableBytes = 8 + 64 + 4 * 5 + 4 + 8;   // per read: offset | stats | length, fn, rn, nsites, first_site | spare | h0 key
 constexpr int kNBGru2 = 3;   // batch tiles (of 32 rows) per workgroup of the GRU kernels
 constexpr int kRowPad = 32 * kNBGru2;           // rows are padded to whole workgroups
 // GRU kernels' dynamic LDS: h fragments + x chunk ring + 4 KiB bias table
@@ -100,6 +100,8 @@ struct ccsm_workspace {
     uint8_t* d_in = nullptr;   // features of both strands
     float* d_h0 = nullptr;     // explicit h0 (2 x 6 x max_sites x 256), allocated on first explicit use
     float* d_out = nullptr;    // logits | probs
+    uint8_t* d_keys = nullptr; // per-site random-stream keys (u64 x max_sites | u32 x max_sites), allocated on first use
+    uint8_t* p_keys = nullptr;
     uint8_t* p_in = nullptr;   // pinned host mirrors
     float* p_h0 = nullptr;
     float* p_out = nullptr;
@@ -412,14 +414,19 @@ ccsm_status upload(T** dst, const void* src, size_t bytes) {
     return CCSM_OK;
 }
 
+struct SiteKeys {             // device arrays (per site of the slice) naming the sites' random streams, or NULL
+    const unsigned long long* key = nullptr;
+    const unsigned int* sub = nullptr;
+};
+
 // Cheap per-slice kernels: initial states and layer-0 input fragments of rows [row_base, row_base + 2 n_sites).
 ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, int row_base, const StrandDev& s1,
                         const StrandDev& s2, int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a,
-                        const float* h0b, uint64_t seed, uint64_t offset, hipStream_t st) {
+                        const float* h0b, uint64_t seed, uint64_t offset, hipStream_t st, SiteKeys sk = SiteKeys()) {
     const size_t total4 = (size_t)2 * kLayers * 2 * n_sites * (kHidden / 4);
     const int grid = (int)std::min<size_t>((total4 + 255) / 256, 4096);
     hipLaunchKernelGGL(prep_h0_kernel, dim3(grid), dim3(256), 0, st, ws->h0buf, h0a, h0b, n_sites, row_base, ws->rows_p, h0_mode,
-                       seed, offset);
+                       seed, offset, sk.key, sk.sub);
     const int total = 2 * n_sites * kSeqLen * 2;
     hipLaunchKernelGGL(pack_x0_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws->x0, s1, s2, m->embed, n_sites, row_base,
                        kmer_is_f32, npass_per_base, m->feat);
@@ -523,11 +530,11 @@ ccsm_status dispatch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st
 // add one slice (device pointers) to the workspace
 ccsm_status add_slice(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const StrandDev& s1, const StrandDev& s2,
                       int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a, const float* h0b, uint64_t seed,
-                      uint64_t offset, float* logits, float* probs, hipStream_t st) {
+                      uint64_t offset, float* logits, float* probs, hipStream_t st, SiteKeys sk = SiteKeys()) {
     if (ws->n_slices >= kMaxSlices) return fail(CCSM_ERR_CAPACITY, "too many slices in one group (max 16)");
     if (ws->rows_used + 2 * n_sites > 2 * ws->max_sites) return fail(CCSM_ERR_CAPACITY, "group exceeds the workspace's max_sites");
     const int row_base = ws->rows_used;
-    ccsm_status rc = launch_prep(m, ws, n_sites, row_base, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, st);
+    ccsm_status rc = launch_prep(m, ws, n_sites, row_base, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, st, sk);
     if (rc != CCSM_OK) return rc;
     const int i = ws->n_slices++;
     ws->slice_row[i] = row_base;
@@ -540,10 +547,10 @@ ccsm_status add_slice(const ccsm_model* m, ccsm_workspace* ws, int n_sites, cons
 
 ccsm_status dispatch_forward(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const StrandDev& s1, const StrandDev& s2,
                              int kmer_is_f32, int npass_per_base, int h0_mode, const float* h0a, const float* h0b,
-                             uint64_t seed, uint64_t offset, float* logits, float* probs, hipStream_t st) {
+                             uint64_t seed, uint64_t offset, float* logits, float* probs, hipStream_t st, SiteKeys sk = SiteKeys()) {
     ws->n_slices = 0;
     ws->rows_used = 0;
-    ccsm_status rc = add_slice(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st);
+    ccsm_status rc = add_slice(m, ws, n_sites, s1, s2, kmer_is_f32, npass_per_base, h0_mode, h0a, h0b, seed, offset, logits, probs, st, sk);
     if (rc != CCSM_OK) return rc;
     return dispatch_run(m, ws, st);
 }
@@ -873,6 +880,8 @@ void ccsm_workspace_destroy(ccsm_workspace* ws) {
     if (ws->rp_bytes) (void)hipHostFree(ws->rp_bytes);
     if (ws->rp_table) (void)hipHostFree(ws->rp_table);
     if (ws->rp_locs) (void)hipHostFree(ws->rp_locs);
+    (void)hipFree(ws->d_keys);
+    if (ws->p_keys) (void)hipHostFree(ws->p_keys);
     if (ws->p_in) (void)hipHostFree(ws->p_in);
     if (ws->p_h0) (void)hipHostFree(ws->p_h0);
     if (ws->p_out) (void)hipHostFree(ws->p_out);
@@ -890,9 +899,11 @@ ccsm_status ccsm_forward_device(const ccsm_model* m, ccsm_workspace* ws, int n_s
     HIP_TRY(hipSetDevice(m->device));
     const StrandDev s1 = strand_dev(b->strand[0]), s2 = strand_dev(b->strand[1]);
     const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
+    SiteKeys sk;
+    if (h0) { sk.key = reinterpret_cast<const unsigned long long*>(h0->site_key); sk.sub = reinterpret_cast<const unsigned int*>(h0->site_sub); }
     return dispatch_forward(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
                             h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
-                            static_cast<hipStream_t>(stream));
+                            static_cast<hipStream_t>(stream), sk);
 }
 
 ccsm_status ccsm_group_add_device(const ccsm_model* m, ccsm_workspace* ws, int n_sites, const ccsm_batch* b, const ccsm_h0* h0,
@@ -905,9 +916,11 @@ ccsm_status ccsm_group_add_device(const ccsm_model* m, ccsm_workspace* ws, int n
     HIP_TRY(hipSetDevice(m->device));
     const StrandDev s1 = strand_dev(b->strand[0]), s2 = strand_dev(b->strand[1]);
     const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
+    SiteKeys sk;
+    if (h0) { sk.key = reinterpret_cast<const unsigned long long*>(h0->site_key); sk.sub = reinterpret_cast<const unsigned int*>(h0->site_sub); }
     return add_slice(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
                      h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
-                     static_cast<hipStream_t>(stream));
+                     static_cast<hipStream_t>(stream), sk);
 }
 
 ccsm_status ccsm_group_run(const ccsm_model* m, ccsm_workspace* ws, void* stream) {
@@ -985,10 +998,24 @@ ccsm_status ccsm_submit_host(const ccsm_model* m, ccsm_workspace* ws, int n_site
         h0a = ws->d_h0;
         h0b = ws->d_h0 + hb / sizeof(float);
     }
+    SiteKeys sk;
+    if (mode == CCSM_H0_DEVICE_RNG && h0 && h0->site_key) {          // 12 bytes per site next to the 680 of the features
+        if (!ws->d_keys) {
+            HIP_TRY(hipMalloc((void**)&ws->d_keys, (size_t)ws->max_sites * 12 + 64));
+            HIP_TRY(hipHostMalloc((void**)&ws->p_keys, (size_t)ws->max_sites * 12 + 64, hipHostMallocDefault));
+        }
+        std::memcpy(ws->p_keys, h0->site_key, n * 8);
+        if (h0->site_sub) std::memcpy(ws->p_keys + (size_t)ws->max_sites * 8, h0->site_sub, n * 4);
+        HIP_TRY(hipMemcpyAsync(ws->d_keys, ws->p_keys, n * 8, hipMemcpyHostToDevice, hs));
+        if (h0->site_sub)
+            HIP_TRY(hipMemcpyAsync(ws->d_keys + (size_t)ws->max_sites * 8, ws->p_keys + (size_t)ws->max_sites * 8, n * 4, hipMemcpyHostToDevice, hs));
+        sk.key = reinterpret_cast<const unsigned long long*>(ws->d_keys);
+        sk.sub = h0->site_sub ? reinterpret_cast<const unsigned int*>(ws->d_keys + (size_t)ws->max_sites * 8) : nullptr;
+    }
     float* d_logits = ws->d_out;
     float* d_probs = ws->d_out + n * 2;
     st = dispatch_forward(m, ws, n_sites, sd[0], sd[1], b->kmer_is_f32, b->npass_per_base, mode, h0a, h0b, h0 ? h0->seed : 0,
-                          h0 ? h0->offset : 0, d_logits, d_probs, hs);
+                          h0 ? h0->offset : 0, d_logits, d_probs, hs, sk);
     if (st != CCSM_OK) return st;
     HIP_TRY(hipMemcpyAsync(ws->p_out, ws->d_out, n * 4 * sizeof(float), hipMemcpyDeviceToHost, hs));
     ws->pending_sites = n_sites;
@@ -1142,11 +1169,27 @@ ccsm_status ccsm_submit_reads_host(const ccsm_model* m, ccsm_workspace* ws, cons
         h0a = ws->d_h0;
         h0b = ws->d_h0 + hb / sizeof(float);
     }
+    // per-read keys of the device-drawn initial states: the extraction writes each site's key next to its location, and the states
+    // are then drawn from (key, location)
+    unsigned long long* d_rkey = nullptr;
+    unsigned long long* d_skey = nullptr;
+    if (mode == CCSM_H0_DEVICE_RNG && rd->h0_key) {
+        if (!ws->d_keys) {
+            HIP_TRY(hipMalloc((void**)&ws->d_keys, (size_t)ws->max_sites * 12 + 64));
+            HIP_TRY(hipHostMalloc((void**)&ws->p_keys, (size_t)ws->max_sites * 12 + 64, hipHostMallocDefault));
+        }
+        // the read keys ride in the per-read table (slot at byte 96 of every entry block)
+        std::memcpy(at(ws->rp_table, 96), rd->h0_key, (size_t)nr * 8);
+        d_rkey = reinterpret_cast<unsigned long long*>(at(ws->r_table, 96));
+        HIP_TRY(hipMemcpyAsync(d_rkey, at(ws->rp_table, 96), (size_t)nr * 8, hipMemcpyHostToDevice, hs));
+        d_skey = reinterpret_cast<unsigned long long*>(ws->d_keys);
+    }
+    hipLaunchKernelGGL(ccsm_extract::extract_pack_kernel, dim3(nr, ccsm_extract::kPackParts), dim3(256), 0, hs, rt, d_arr[0], d_arr[1], d_arr[2], d_arr[3],
+                       d_arr[4], d_stats, d_first, m->embed, ws->x0, ws->r_locs, n_sites, 0, d_rkey, d_skey);
     const size_t total4 = (size_t)2 * kLayers * 2 * n_sites * (kHidden / 4);
     hipLaunchKernelGGL(prep_h0_kernel, dim3((int)std::min<size_t>((total4 + 255) / 256, 4096)), dim3(256), 0, hs, ws->h0buf, h0a,
-                       h0b, n_sites, 0, ws->rows_p, mode, h0 ? h0->seed : 0, h0 ? h0->offset : 0);
-    hipLaunchKernelGGL(ccsm_extract::extract_pack_kernel, dim3(nr, ccsm_extract::kPackParts), dim3(256), 0, hs, rt, d_arr[0], d_arr[1], d_arr[2], d_arr[3],
-                       d_arr[4], d_stats, d_first, m->embed, ws->x0, ws->r_locs, n_sites, 0);
+                       h0b, n_sites, 0, ws->rows_p, mode, h0 ? h0->seed : 0, h0 ? h0->offset : 0, d_skey,
+                       d_skey ? reinterpret_cast<const unsigned int*>(ws->r_locs) : nullptr);
     HIP_TRY(hipGetLastError());
     ws->n_slices = 1;
     ws->rows_used = 2 * n_sites;
@@ -1154,7 +1197,17 @@ ccsm_status ccsm_submit_reads_host(const ccsm_model* m, ccsm_workspace* ws, cons
     ws->slice_n[0] = n_sites;
     ws->slice_logits[0] = ws->d_out;
     ws->slice_probs[0] = ws->d_out + (size_t)n_sites * 2;
-    ccsm_status st = dispatch_run(m, ws, hs);
+    // CCSM_NULL_MODEL=1 (diagnostics: tools/host_feed_probe.py): everything but the BiGRU / attention launches - transfers, extraction,
+    // initial states, result copies - with constant outputs (p0 = p1), to measure what the HOST side of call_mods sustains
+    static const bool null_model = []() { const char* e = std::getenv("CCSM_NULL_MODEL"); return e && e[0] == '1'; }();
+    ccsm_status st = CCSM_OK;
+    if (null_model) {
+        ws->n_slices = 0;
+        ws->rows_used = 0;
+        HIP_TRY(hipMemsetAsync(ws->d_out, 0x3f, (size_t)n_sites * 4 * sizeof(float), hs));
+    } else {
+        st = dispatch_run(m, ws, hs);
+    }
     if (st != CCSM_OK) { ws->r_pending = false; return st; }
     HIP_TRY(hipMemcpyAsync(ws->p_out, ws->d_out, (size_t)n_sites * 4 * sizeof(float), hipMemcpyDeviceToHost, hs));
     HIP_TRY(hipMemcpyAsync(ws->rp_locs, ws->r_locs, (size_t)n_sites * sizeof(int), hipMemcpyDeviceToHost, hs));

@@ -1,9 +1,13 @@
 // libccsm_bam: native BGZF / BAM reader and modbam writer of the call_mods path (include/ccsm_bam.h).
 // Host only.  Follows the SAM/BAM specification v1 (BGZF = gzip members with a 'BC' extra subfield, little-endian records);
 // mirrors ccsmeth_amd/bamio.py + ccsmeth_amd/_bam2modbam.py, which the tests compare it with.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,12 +51,118 @@ void parallel_for(int n, int threads, F f) {   // f(i) for i in [0, n), static i
         pool.emplace_back([=]() { for (int i = t; i < n; i += threads) f(i); });
     for (auto& th : pool) th.join();
 }
+template <typename F>
+void parallel_slots(int n, int threads, F f) {   // f(i, slot) for i in [0, n): items are claimed dynamically, slot = the worker's number
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) {
+        for (int i = 0; i < n; ++i) f(i, 0);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t)
+        pool.emplace_back([&next, n, t, &f]() { for (int i; (i = next.fetch_add(1)) < n;) f(i, t); });
+    for (auto& th : pool) th.join();
+}
+
+// ---- DEFLATE codec: libdeflate when the runtime library is present (what htslib itself prefers: ~2-3x zlib's inflate rate and
+// ~2x its level-6 deflate rate on BAM records), else zlib.  The image carries libdeflate.so.0 without its header, so the six entry
+// points are resolved by name; CCSM_BAM_ZLIB=1 forces zlib.  Both produce / accept standard raw DEFLATE streams: files written
+// with one are read by the other (and by htslib).
+struct LibDeflate {
+    void* (*alloc_dec)() = nullptr;
+    int (*dec)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*free_dec)(void*) = nullptr;
+    void* (*alloc_com)(int) = nullptr;
+    size_t (*com)(void*, const void*, size_t, void*, size_t) = nullptr;
+    void (*free_com)(void*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+    bool ok = false;
+};
+const LibDeflate& libdeflate() {
+    static const LibDeflate ld = []() {
+        LibDeflate d;
+        const char* z = std::getenv("CCSM_BAM_ZLIB");
+        if (z && z[0] == '1') return d;
+        void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return d;
+        d.alloc_dec = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+        d.dec = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(dlsym(h, "libdeflate_deflate_decompress"));
+        d.free_dec = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+        d.alloc_com = reinterpret_cast<void* (*)(int)>(dlsym(h, "libdeflate_alloc_compressor"));
+        d.com = reinterpret_cast<size_t (*)(void*, const void*, size_t, void*, size_t)>(dlsym(h, "libdeflate_deflate_compress"));
+        d.free_com = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_compressor"));
+        d.crc = reinterpret_cast<uint32_t (*)(uint32_t, const void*, size_t)>(dlsym(h, "libdeflate_crc32"));
+        d.ok = d.alloc_dec && d.dec && d.free_dec && d.alloc_com && d.com && d.free_com && d.crc;
+        return d;
+    }();
+    return ld;
+}
+inline uint32_t crc_of(const uint8_t* p, size_t n) {
+    const LibDeflate& ld = libdeflate();
+    return ld.ok ? ld.crc(0, p, n) : (uint32_t)crc32(0L, p, (uInt)n);
+}
+// One worker's inflate / deflate state (allocated lazily, reused over the blocks that worker handles)
+struct Codec {
+    void* dec = nullptr;
+    void* com = nullptr;
+    int com_level = 0;
+    ~Codec() {
+        const LibDeflate& ld = libdeflate();
+        if (dec) ld.free_dec(dec);
+        if (com) ld.free_com(com);
+    }
+    // raw DEFLATE `in` -> exactly `isize` bytes at out, CRC checked
+    bool inflate_block(const uint8_t* in, size_t in_len, uint8_t* out, size_t isize, uint32_t crc) {
+        if (isize == 0) return true;
+        const LibDeflate& ld = libdeflate();
+        if (ld.ok) {
+            if (!dec && !(dec = ld.alloc_dec())) return false;
+            size_t got = 0;
+            if (ld.dec(dec, in, in_len, out, isize, &got) != 0 || got != isize) return false;
+        } else {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            zs.next_in = const_cast<uint8_t*>(in);
+            zs.avail_in = (uInt)in_len;
+            zs.next_out = out;
+            zs.avail_out = (uInt)isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            const size_t tot = zs.total_out;
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || tot != isize) return false;
+        }
+        return crc_of(out, isize) == crc;
+    }
+    // `len` bytes -> raw DEFLATE at out (capacity cap); 0 = failed / did not fit
+    size_t deflate_block(const uint8_t* in, size_t len, uint8_t* out, size_t cap, int level) {
+        const LibDeflate& ld = libdeflate();
+        if (ld.ok) {
+            if (com && com_level != level) { ld.free_com(com); com = nullptr; }
+            if (!com && !(com = ld.alloc_com(level))) return 0;
+            com_level = level;
+            return ld.com(com, in, len, out, cap);
+        }
+        z_stream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+        zs.next_in = const_cast<uint8_t*>(in);
+        zs.avail_in = (uInt)len;
+        zs.next_out = out;
+        zs.avail_out = (uInt)cap;
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        return rc == Z_STREAM_END ? clen : 0;
+    }
+};
 
 struct RawBlock {
     std::vector<uint8_t> cdata;
     uint64_t coffset = 0;          // file offset of the block's first byte
     uint32_t crc = 0, isize = 0;
-    std::vector<uint8_t> data;
     bool ok = true;
 };
 
@@ -114,7 +224,17 @@ struct OwnedBatch {
     std::vector<int32_t> flag, length, n_sites;
     std::vector<uint8_t> seq, fi, ri, fp, rp;
     std::vector<float> fn, rn;
+    std::vector<uint64_t> name_hash;
 };
+
+// 64-bit FNV-1a of a read name (without its NUL): the key of the read's device-drawn initial states (ccsm_reads.h0_key), so that a
+// site's probability depends on the read it sits in and its position there, not on where the read stands in the file or on which
+// GPU it is processed
+inline uint64_t fnv1a64(const uint8_t* p, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
 
 
 struct OwnedCalls {
@@ -318,6 +438,9 @@ struct ccsm_bam_reader {
     uint64_t erased = 0;           // bytes dropped from the front of `stream` so far
     uint64_t next_coffset = 0;
     uint64_t limit_coffset = ~0ull; // blocks starting beyond this file offset are not read (ccsm_bam_seek with an end offset)
+    uint64_t first_voffset = 0;     // virtual offset of the first record (behind the header)
+    uint64_t stop_coffset = ~0ull;  // chunk mode (ccsm_bam_seek_chunk): records starting in a block at or beyond it are not returned
+    std::vector<Codec> codecs;      // one per inflate worker
     uint64_t inflated = 0;         // bytes inflated so far (ccsm_bam_inflated_bytes)
     uint64_t abs_pos() const { return erased + pos; }
     // voffset of absolute inflated position p; at a block boundary: the start of the following block when there is one
@@ -367,7 +490,10 @@ struct ccsm_bam_reader {
         return true;
     }
 
-    // make at least `need` unconsumed bytes available (fewer only at end of file)
+    // make at least `need` unconsumed bytes available (fewer only at end of file / of the seek range).  Blocks are read and inflated
+    // in rounds of up to kBlocksPerRound, one round's blocks in parallel, straight into `stream`.  Inside a seek range
+    // (limit_coffset) a round takes every block that is left of the range; in chunk mode (stop_coffset) reading goes on behind the
+    // chunk only as far as the record in hand needs.
     int fill(size_t need) {
         while (stream.size() - pos < need && !file_eof) {
             if (pos > 0 && pos >= stream.size() / 2) {
@@ -378,38 +504,32 @@ struct ccsm_bam_reader {
             std::vector<RawBlock> blocks;
             blocks.reserve(kBlocksPerRound);
             std::string err;
-            // sequential reading inflates whole rounds of blocks; inside a seek range only what the request needs (+ one block)
-            int round = kBlocksPerRound;
-            if (limit_coffset != ~0ull) round = (int)std::min<size_t>(kBlocksPerRound, (need - (stream.size() - pos)) / 65280 + 2);
-            for (int i = 0; i < round; ++i) {
+            size_t have = stream.size() - pos;
+            for (int i = 0; i < kBlocksPerRound; ++i) {
+                if (next_coffset >= stop_coffset && have >= need) break;
                 RawBlock b;
                 if (!read_block(b, err)) {
                     if (!err.empty()) return fail(err);
                     file_eof = true;
                     break;
                 }
+                have += b.isize;
                 blocks.push_back(std::move(b));
             }
-            parallel_for((int)blocks.size(), threads, [&](int i) {
+            std::vector<size_t> at(blocks.size());
+            size_t total = stream.size();
+            for (size_t i = 0; i < blocks.size(); ++i) { at[i] = total; total += blocks[i].isize; }
+            stream.resize(total);
+            if (codecs.size() < (size_t)threads) codecs.resize((size_t)threads);
+            uint8_t* base = stream.data();
+            parallel_slots((int)blocks.size(), threads, [&](int i, int slot) {
                 RawBlock& b = blocks[(size_t)i];
-                b.data.resize(b.isize);
-                if (b.isize == 0) return;
-                z_stream zs;
-                std::memset(&zs, 0, sizeof(zs));
-                if (inflateInit2(&zs, -15) != Z_OK) { b.ok = false; return; }
-                zs.next_in = b.cdata.data();
-                zs.avail_in = (uInt)b.cdata.size();
-                zs.next_out = b.data.data();
-                zs.avail_out = (uInt)b.data.size();
-                const int rc = inflate(&zs, Z_FINISH);
-                inflateEnd(&zs);
-                if (rc != Z_STREAM_END || zs.total_out != b.isize || (uint32_t)crc32(0L, b.data.data(), (uInt)b.data.size()) != b.crc)
-                    b.ok = false;
+                b.ok = codecs[(size_t)slot].inflate_block(b.cdata.data(), b.cdata.size(), base + at[(size_t)i], b.isize, b.crc);
             });
-            for (auto& b : blocks) {
+            for (size_t i = 0; i < blocks.size(); ++i) {
+                const RawBlock& b = blocks[i];
                 if (!b.ok) return fail("BGZF block failed its CRC / size check");
-                if (b.isize) bpos.push_back({erased + stream.size(), b.coffset, b.isize});
-                stream.insert(stream.end(), b.data.begin(), b.data.end());
+                if (b.isize) bpos.push_back({erased + at[i], b.coffset, b.isize});
                 inflated += b.isize;
             }
         }
@@ -422,6 +542,25 @@ struct ccsm_bam_writer {
     FILE* fh = nullptr;
     int threads = 1, level = 6;
     std::vector<uint8_t> buf;      // uncompressed bytes not yet written
+    std::vector<Codec> codecs;     // one per deflate worker
+    uint64_t file_off = 0;         // bytes written to the file so far
+    // A "run" = the blocks between two ccsm_bam_writer_flush calls: it starts on a fresh BGZF block, and its blocks are cut every
+    // kBlockPayload uncompressed bytes, so a record's virtual offsets follow from its byte offsets in the run once the compressed
+    // sizes of the run's blocks are known (index tracking: ccsm_bam_writer_track_index).
+    bool track = false;
+    uint64_t run_upos = 0;         // uncompressed bytes put since the run began
+    uint64_t run_file_start = 0;
+    std::vector<uint64_t> blk_off; // file offset of every block of the run written so far
+    struct Pending { int32_t tid, pos, end; uint32_t flag; uint64_t ubeg, uend; };
+    std::vector<Pending> pend;     // placed records of the current run
+    // finished runs since the last ccsm_bam_writer_take_index
+    std::vector<ccsm_bam_index_entry> done;
+    int64_t acc_records = 0, acc_unplaced = 0;
+    bool acc_sorted = true, acc_any = false;
+    uint64_t acc_first_k1 = 0, acc_last_k1 = 0;
+    uint32_t acc_first_k2 = 0, acc_last_k2 = 0;
+    int64_t acc_file_start = -1;
+    std::vector<ccsm_bam_index_entry> handed;   // what the last take returned (owned here)
 
     int flush_blocks(bool all) {
         const size_t nfull = buf.size() / kBlockPayload;
@@ -429,31 +568,35 @@ struct ccsm_bam_writer {
         if (nblk == 0) return 0;
         std::vector<std::vector<uint8_t>> out(nblk);
         std::vector<char> ok(nblk, 1);
-        parallel_for((int)nblk, threads, [&](int i) {
+        if (codecs.size() < (size_t)threads) codecs.resize((size_t)threads);
+        parallel_slots((int)nblk, threads, [&](int i, int slot) {
             const size_t beg = (size_t)i * kBlockPayload, len = std::min(kBlockPayload, buf.size() - beg);
             std::vector<uint8_t>& o = out[(size_t)i];
-            o.resize(18 + compressBound((uLong)len) + 8);
-            z_stream zs;
-            std::memset(&zs, 0, sizeof(zs));
-            if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok[(size_t)i] = 0; return; }
-            zs.next_in = buf.data() + beg;
-            zs.avail_in = (uInt)len;
-            zs.next_out = o.data() + 18;
-            zs.avail_out = (uInt)(o.size() - 26);
-            const int rc = deflate(&zs, Z_FINISH);
-            const size_t clen = zs.total_out;
-            deflateEnd(&zs);
-            if (rc != Z_STREAM_END || clen + 26 > 65536) { ok[(size_t)i] = 0; return; }
+            o.resize(18 + 65536 + 8);
+            // a block is at most 64 KiB on disk: 18 header + clen + 8 trailer <= 65536
+            size_t clen = codecs[(size_t)slot].deflate_block(buf.data() + beg, len, o.data() + 18, 65536 - 26, level);
+            if (clen == 0) {       // did not fit: stored blocks always do (0xff00 + 5 bytes per 65535)
+                z_stream zs;
+                std::memset(&zs, 0, sizeof(zs));
+                if (deflateInit2(&zs, 0, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK) {
+                    zs.next_in = buf.data() + beg; zs.avail_in = (uInt)len; zs.next_out = o.data() + 18; zs.avail_out = (uInt)(65536 - 26);
+                    if (deflate(&zs, Z_FINISH) == Z_STREAM_END) clen = zs.total_out;
+                    deflateEnd(&zs);
+                }
+            }
+            if (clen == 0 || clen + 26 > 65536) { ok[(size_t)i] = 0; return; }
             static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
             std::memcpy(o.data(), head, 16);
             wr16(o.data() + 16, (uint32_t)(clen + 25));
-            wr32(o.data() + 18 + clen, (uint32_t)crc32(0L, buf.data() + beg, (uInt)len));
+            wr32(o.data() + 18 + clen, crc_of(buf.data() + beg, len));
             wr32(o.data() + 18 + clen + 4, (uint32_t)len);
             o.resize(18 + clen + 8);
         });
         for (size_t i = 0; i < nblk; ++i) {
             if (!ok[i]) return fail("BGZF deflate failed");
             if (std::fwrite(out[i].data(), 1, out[i].size(), fh) != out[i].size()) return fail("write failed");
+            if (track) blk_off.push_back(file_off);
+            file_off += out[i].size();
         }
         const size_t used = std::min(buf.size(), nblk * kBlockPayload);
         buf.erase(buf.begin(), buf.begin() + (long)used);
@@ -461,9 +604,30 @@ struct ccsm_bam_writer {
     }
     int put(const uint8_t* p, size_t n) {
         buf.insert(buf.end(), p, p + n);
+        run_upos += n;
         if (buf.size() >= (size_t)kBlocksPerRound * kBlockPayload) return flush_blocks(false);
         return 0;
     }
+    // the run ends here (everything is on disk): resolve its records' virtual offsets and start the next run
+    void end_run() {
+        if (track) {
+            const uint64_t run_total = run_upos;
+            auto voff = [&](uint64_t u) -> uint64_t {
+                const uint64_t b = u / kBlockPayload, in = u % kBlockPayload;
+                if (b < blk_off.size()) return (blk_off[(size_t)b] << 16) | in;
+                // u == run_total on a block boundary: the first block of whatever follows the run
+                (void)run_total;
+                return file_off << 16;
+            };
+            for (const Pending& q : pend) done.push_back({q.tid, q.pos, q.end, q.flag, voff(q.ubeg), voff(q.uend)});
+            if (acc_file_start < 0) acc_file_start = (int64_t)run_file_start;
+        }
+        pend.clear();
+        blk_off.clear();
+        run_upos = 0;
+        run_file_start = file_off;
+    }
+    void note_record(const uint8_t* body, uint64_t ubeg, uint64_t uend);
 };
 
 // No exception may cross the C boundary: allocation failures and the like become an error code + ccsm_bam_last_error().
@@ -502,6 +666,8 @@ int ccsm_bam_open(const char* path, int threads, ccsm_bam_reader** out) try {
         r->refs.insert(r->refs.end(), r->stream.begin() + (long)r->pos, r->stream.begin() + (long)(r->pos + 8 + l_name));
         r->pos += 8 + l_name;
     }
+    if (r->fill(1)) return bail(g_err);
+    r->first_voffset = r->voffset(r->abs_pos());
     *out = r;
     return 0;
 } CCSM_BAM_CATCH
@@ -537,6 +703,7 @@ int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) t
     for (int n = 0; n < max_reads; ++n) {
         if (r->fill(4)) { delete ob; return 1; }
         if (r->avail() == 0) break;
+        if (r->stop_coffset != ~0ull && (r->voffset(r->abs_pos()) >> 16) >= r->stop_coffset) break;   // the chunk's last record is behind us
         if (r->avail() < 4) { delete ob; return fail("truncated BAM record"); }
         const uint32_t bs = rd32(r->stream.data() + r->pos);
         if (bs < 32) { delete ob; return fail("corrupt BAM record (block_size < 32)"); }
@@ -580,6 +747,7 @@ int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) t
         const bool usable = l_seq > 0 && tfi && tri && tfp && trp;
         ob->records.insert(ob->records.end(), rec, rec + 4 + bs);
         ob->rec_offset.push_back((int64_t)ob->records.size());
+        ob->name_hash.push_back(fnv1a64(body + 32, l_name > 0 ? (size_t)l_name - 1 : 0));
         ob->flag.push_back((int32_t)flag);
         ob->offset.push_back((int64_t)ob->seq.size());
         ob->fn.push_back(has_fn && has_rn ? fn : 0.f);     // extract_features.py:115-119: a KeyError on either tag zeroes both
@@ -630,14 +798,16 @@ int ccsm_bam_next(ccsm_bam_reader* r, int32_t max_reads, ccsm_bam_batch** out) t
     ob->view.rp = ob->rp.data();
     ob->view.fn = ob->fn.data();
     ob->view.rn = ob->rn.data();
+    ob->view.name_hash = ob->name_hash.data();
     ob->view.total_bases = (int64_t)ob->seq.size();
     ob->view.voffset_end = r->voffset(r->abs_pos());
     *out = &ob->view;
     return 0;
 } CCSM_BAM_CATCH
 
-int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_end) try {
-    if (!r) return fail("reader must be non-NULL");
+namespace {
+// continue reading at a BGZF virtual offset; limit = last block file offset that may be read (~0: none), stop = chunk end (~0: none)
+int reposition(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t limit, uint64_t stop) {
     const uint64_t coff = voffset_start >> 16, uoff = voffset_start & 0xffffu;
     if (std::fseek(r->fh, (long)coff, SEEK_SET) != 0) return fail("seek failed");
     r->erased += r->stream.size();          // absolute positions stay monotonic (the virtual-offset bookkeeping keys on them)
@@ -646,12 +816,159 @@ int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_e
     r->bpos.clear();
     r->next_coffset = coff;
     r->file_eof = false;
-    r->limit_coffset = voffset_end == 0 ? ~0ull : (voffset_end >> 16);
+    r->limit_coffset = limit;
+    r->stop_coffset = stop;
     if (uoff) {
         if (r->fill((size_t)uoff)) return 1;
         if (r->avail() < (size_t)uoff) return fail("seek beyond the end of the BGZF block");
         r->pos += (size_t)uoff;
     }
+    return 0;
+}
+}  // namespace
+
+int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_end) try {
+    if (!r) return fail("reader must be non-NULL");
+    return reposition(r, voffset_start, voffset_end == 0 ? ~0ull : (voffset_end >> 16), ~0ull);
+} CCSM_BAM_CATCH
+
+namespace {
+// Is there a BAM record at p?  `have` bytes are readable there.  -1: no; 0: cannot tell yet (more bytes needed: *need); 1: yes, and it
+// ends exactly where its block_size says (fixed fields in range, NUL-terminated name without inner NULs, CIGAR operations < 9, the
+// auxiliary fields walk to the very end of the record).  A random offset passes with negligible probability, and the caller's
+// hand-over check (a chunk's first record must be where the previous chunk's last one ended) catches what is left.
+int record_at(const uint8_t* p, size_t have, int32_t n_ref, size_t* need) {
+    if (have < 36) { *need = 36; return 0; }
+    const uint32_t bs = rd32(p);
+    if (bs < 32 + 2 || bs > (1u << 29)) return -1;
+    const uint8_t* body = p + 4;
+    const int32_t tid = (int32_t)rd32(body), pos = (int32_t)rd32(body + 4);
+    const uint32_t l_name = body[8], n_cig = rd16(body + 12), l_seq = rd32(body + 16);
+    const int32_t mtid = (int32_t)rd32(body + 20), mpos = (int32_t)rd32(body + 24);
+    if (tid < -1 || tid >= n_ref || mtid < -1 || mtid >= n_ref || pos < -1 || mpos < -1 || l_name < 1 || l_seq > (1u << 29)) return -1;
+    const size_t fixed = 32 + (size_t)l_name + 4 * (size_t)n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
+    if (fixed > bs) return -1;
+    if (have < 36 + (size_t)l_name) { *need = 36 + (size_t)l_name; return 0; }
+    if (body[32 + l_name - 1] != 0 || std::memchr(body + 32, 0, l_name - 1) != nullptr) return -1;
+    for (uint32_t i = 0; i + 1 < l_name; ++i) if (body[32 + i] < 0x21 || body[32 + i] > 0x7e) return -1;
+    if (have < 4 + (size_t)bs) { *need = 4 + (size_t)bs; return 0; }
+    const uint8_t* cig = body + 32 + l_name;
+    for (uint32_t c = 0; c < n_cig; ++c) if ((rd32(cig + 4 * c) & 15) > 8) return -1;
+    bool names_ok = true;
+    const bool walked = walk_tags(body + fixed, body + bs, [&](uint8_t t0, uint8_t t1, uint8_t, uint8_t, int64_t, const uint8_t*, const uint8_t*, size_t) {
+        const bool a0 = (t0 >= 'A' && t0 <= 'Z') || (t0 >= 'a' && t0 <= 'z');
+        const bool a1 = a0 && ((t1 >= 'A' && t1 <= 'Z') || (t1 >= 'a' && t1 <= 'z') || (t1 >= '0' && t1 <= '9'));
+        names_ok = names_ok && a1;
+    });
+    return walked && names_ok ? 1 : -1;
+}
+}  // namespace
+
+int ccsm_bam_seek_chunk(ccsm_bam_reader* r, uint64_t coffset_lo, uint64_t coffset_hi, uint64_t* voffset_first) try {
+    if (!r || !voffset_first) return fail("reader and voffset_first must be non-NULL");
+    if (coffset_hi <= coffset_lo) return fail("empty chunk");
+    *voffset_first = 0;
+    // 1. the first BGZF block at or behind coffset_lo: a gzip member header with the 'BC' subfield whose size leads to another one (or
+    //    to the end of the file), three deep
+    if (std::fseek(r->fh, 0, SEEK_END) != 0) return fail("seek failed");
+    const uint64_t fsize = (uint64_t)std::ftell(r->fh);
+    auto block_at = [&](uint64_t off, uint64_t* next) -> bool {      // header check only
+        uint8_t h[18];
+        if (off + 18 > fsize) return false;
+        if (std::fseek(r->fh, (long)off, SEEK_SET) != 0 || std::fread(h, 1, 18, r->fh) != 18) return false;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return false;
+        const uint32_t xlen = rd16(h + 10);
+        if (xlen < 6) return false;
+        uint32_t bsize = 0;
+        if (xlen == 6) {
+            if (h[12] != 66 || h[13] != 67 || rd16(h + 14) != 2) return false;
+            bsize = rd16(h + 16);
+        } else {                                                      // other extra subfields: walk them
+            std::vector<uint8_t> x(xlen);
+            std::memcpy(x.data(), h + 12, 6);
+            if (std::fread(x.data() + 6, 1, xlen - 6, r->fh) != xlen - 6) return false;
+            bool found = false;
+            for (size_t o = 0; o + 4 <= xlen;) {
+                const uint32_t sl = rd16(x.data() + o + 2);
+                if (x[o] == 66 && x[o + 1] == 67 && sl == 2 && o + 6 <= xlen) { bsize = rd16(x.data() + o + 4); found = true; }
+                o += 4 + sl;
+            }
+            if (!found) return false;
+        }
+        if ((uint64_t)bsize + 1 < (uint64_t)xlen + 20 || off + bsize + 1 > fsize) return false;
+        *next = off + bsize + 1;
+        return true;
+    };
+    auto chain_ok = [&](uint64_t off) -> bool {
+        for (int d = 0; d < 3; ++d) {
+            if (off == fsize) return true;
+            uint64_t nx;
+            if (!block_at(off, &nx)) return false;
+            off = nx;
+        }
+        return true;
+    };
+    uint64_t blk = ~0ull;
+    if (coffset_lo >= fsize) return 0;                                  // behind the file: an empty chunk
+    if (coffset_lo == 0) {                                              // the first chunk begins behind the header, no search
+        if ((r->first_voffset >> 16) >= coffset_hi) return 0;
+        if (reposition(r, r->first_voffset, ~0ull, coffset_hi)) return 1;
+        if (r->fill(1)) return 1;
+        if (r->avail() == 0) return 0;                                  // a file without records
+        *voffset_first = r->voffset(r->abs_pos());
+        return 0;
+    }
+    {
+        // a block is at most 64 KiB, so one lies in any 64 KiB window that is not the tail of the last block
+        std::vector<uint8_t> win((size_t)std::min<uint64_t>(fsize - coffset_lo, 65536 + 4));
+        if (std::fseek(r->fh, (long)coffset_lo, SEEK_SET) != 0 || std::fread(win.data(), 1, win.size(), r->fh) != win.size()) return fail("read failed");
+        for (size_t i = 0; i + 4 <= win.size(); ++i)
+            if (win[i] == 0x1f && win[i + 1] == 0x8b && win[i + 2] == 8 && win[i + 3] == 4 && chain_ok(coffset_lo + i)) { blk = coffset_lo + i; break; }
+    }
+    if (blk == ~0ull || blk >= coffset_hi) return 0;                    // no block starts in [lo, hi)
+    // 2. the first record that starts in a block of [blk, hi): inflate from blk and test every offset
+    if (std::fseek(r->fh, (long)blk, SEEK_SET) != 0) return fail("seek failed");
+    r->erased += r->stream.size();
+    r->stream.clear();
+    r->pos = 0;
+    r->bpos.clear();
+    r->next_coffset = blk;
+    r->file_eof = false;
+    r->limit_coffset = ~0ull;
+    r->stop_coffset = coffset_hi;
+    size_t p = 0, want = 36;
+    for (;;) {
+        if (r->fill(p + want)) return 1;                              // pos stays 0 while we search: fill counts from it
+        const size_t have = r->stream.size() > p ? r->stream.size() - p : 0;
+        if (have < 4) return 0;                                        // ran off the end of the file: no record starts in the chunk
+        if ((r->voffset(r->erased + p) >> 16) >= coffset_hi) return 0;  // the search left the chunk: no record starts in it
+        size_t need = 0;
+        int v = record_at(r->stream.data() + p, have, r->n_ref, &need);
+        if (v == 0) {
+            if (have >= need) v = -1;                                  // cannot happen; be safe
+            else if (r->file_eof) v = -1;                              // would run over the end of the file
+            else { want = need; continue; }
+        }
+        if (v == 1) {                                                  // and the record behind it must be one too (or the file ends)
+            const size_t q = p + 4 + rd32(r->stream.data() + p);
+            size_t nneed = 36;
+            for (;;) {
+                if (r->fill(q + nneed)) return 1;
+                const size_t h2 = r->stream.size() > q ? r->stream.size() - q : 0;
+                if (h2 == 0 && r->file_eof) break;                     // the candidate is the last record of the file
+                size_t n2 = 0;
+                const int v2 = record_at(r->stream.data() + q, h2, r->n_ref, &n2);
+                if (v2 == 0 && !r->file_eof && h2 < n2) { nneed = n2; continue; }
+                if (v2 != 1) v = -1;
+                break;
+            }
+        }
+        if (v == 1) break;
+        ++p;
+        want = 36;
+    }
+    r->pos = p;
+    *voffset_first = r->voffset(r->abs_pos());
     return 0;
 } CCSM_BAM_CATCH
 
@@ -741,7 +1058,9 @@ int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int3
             ++cnt;
         }
         wr32(rec.data(), (uint32_t)(rec.size() - 4));
+        const uint64_t ubeg = w->run_upos;
         if (w->put(rec.data(), rec.size())) return 1;
+        if (w->track) w->note_record(rec.data() + 4, ubeg, w->run_upos);
     }
     if (n_tagged) *n_tagged = cnt;
     return 0;
@@ -751,7 +1070,36 @@ int ccsm_bam_writer_flush(ccsm_bam_writer* w, int64_t* file_offset) try {
     if (!w) return fail("writer must be non-NULL");
     if (w->flush_blocks(true)) return 1;
     if (std::fflush(w->fh) != 0) return fail("write failed");
-    if (file_offset) *file_offset = (int64_t)std::ftell(w->fh);
+    w->end_run();
+    if (file_offset) *file_offset = (int64_t)w->file_off;
+    return 0;
+} CCSM_BAM_CATCH
+
+int ccsm_bam_writer_track_index(ccsm_bam_writer* w, int enable) {
+    if (!w) return fail("writer must be non-NULL");
+    if (w->run_upos != 0) return fail("index tracking can only be switched at a run boundary (right after ccsm_bam_writer_flush)");
+    w->track = enable != 0;
+    return 0;
+}
+
+int ccsm_bam_writer_take_index(ccsm_bam_writer* w, ccsm_bam_index_run* out) try {
+    if (!w || !out) return fail("writer and out must be non-NULL");
+    if (!w->track) return fail("index tracking is off");
+    if (w->run_upos != 0) return fail("ccsm_bam_writer_take_index must follow ccsm_bam_writer_flush");
+    w->handed.swap(w->done);
+    w->done.clear();
+    out->n_records = w->acc_records;
+    out->n_unplaced = w->acc_unplaced;
+    out->sorted = w->acc_sorted ? 1 : 0;
+    out->first_k1 = w->acc_first_k1; out->first_k2 = w->acc_first_k2;
+    out->last_k1 = w->acc_last_k1; out->last_k2 = w->acc_last_k2;
+    out->n_entries = (int64_t)w->handed.size();
+    out->entries = w->handed.data();
+    out->file_start = w->acc_file_start < 0 ? (int64_t)w->file_off : w->acc_file_start;
+    out->file_end = (int64_t)w->file_off;
+    w->acc_records = w->acc_unplaced = 0;
+    w->acc_sorted = true; w->acc_any = false;
+    w->acc_file_start = -1;
     return 0;
 } CCSM_BAM_CATCH
 
@@ -830,22 +1178,133 @@ struct RefIndex {
     uint64_t off_beg = ~0ull, off_end = 0, n_mapped = 0, n_unmapped = 0;
 };
 
-}  // namespace
-
-int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads, int* sorted, int64_t* n_records) try {
-    if (!bam_path || !bai_path) return fail("paths must be non-NULL");
-    ccsm_bam_reader* r = nullptr;
-    if (ccsm_bam_open(bam_path, threads, &r)) return 1;
-    std::vector<RefIndex> refs((size_t)std::max(0, r->n_ref));
+// BAI index (SAM spec 5.2) fed record by record in file order: binning index, 16 kb linear index, htslib's metadata pseudo-bin
+// 37450, n_no_coor; plus the check that the records are in samtools' coordinate order.
+struct BaiBuilder {
+    std::vector<RefIndex> refs;
     uint64_t n_no_coor = 0, prev1 = 0;
     uint32_t prev2 = 0;
     bool is_sorted = true, first = true;
     int64_t count = 0;
     int save_bin = -1, save_tid = -2;
     uint64_t save_off = 0, last_off = 0;
-    auto flush_bin = [&]() {
+    explicit BaiBuilder(int32_t n_ref) : refs((size_t)std::max(0, n_ref)) {}
+    void flush_bin() {
         if (save_bin >= 0 && save_tid >= 0 && save_tid < (int)refs.size()) refs[(size_t)save_tid].bins[(uint32_t)save_bin].emplace_back(save_off, last_off);
-    };
+    }
+    void order(uint64_t k1, uint32_t k2) {
+        if (!first && (k1 < prev1 || (k1 == prev1 && k2 < prev2))) is_sorted = false;
+        first = false; prev1 = k1; prev2 = k2;
+    }
+    // [b, e) = the record's span on the reference as index_span() gives it; returns 1 (with the error set) on a record a BAI cannot hold
+    int add(int32_t tid, int64_t b, int64_t e, bool unmapped, uint64_t beg_off, uint64_t end_off) {
+        ++count;
+        if (tid >= (int32_t)refs.size()) return fail("record refers to a reference id beyond the header");
+        if (tid < 0) {
+            ++n_no_coor;
+            if (save_tid >= 0) { last_off = beg_off; flush_bin(); save_bin = -1; save_tid = -1; }
+            last_off = end_off;
+            return 0;
+        }
+        RefIndex& ri = refs[(size_t)tid];
+        if (b >= (1LL << 29)) return fail("record position beyond the range of a BAI index (2^29)");
+        if (e > (1LL << 29)) e = 1LL << 29;
+        const int bin = reg2bin(b, e);
+        if (bin != save_bin || tid != save_tid) {
+            last_off = beg_off;
+            flush_bin();
+            save_bin = bin; save_tid = tid; save_off = beg_off;
+        }
+        if (!unmapped) {
+            const size_t w0 = (size_t)(b >> 14), w1 = (size_t)((e - 1) >> 14);
+            if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, ~0ull);
+            for (size_t w = w0; w <= w1; ++w) if (ri.linear[w] == ~0ull) ri.linear[w] = beg_off;
+            ++ri.n_mapped;
+        } else {
+            ++ri.n_unmapped;
+        }
+        if (ri.off_beg == ~0ull) ri.off_beg = beg_off;
+        ri.off_end = end_off;
+        last_off = end_off;
+        return 0;
+    }
+    // unplaced records that are not fed one by one (the writer's run tables only count them)
+    void add_unplaced(int64_t n) {
+        if (n <= 0) return;
+        if (save_tid >= 0) { flush_bin(); save_bin = -1; save_tid = -1; }
+        n_no_coor += (uint64_t)n;
+        count += n;
+    }
+    int write(const char* bai_path) {
+        flush_bin();
+        save_bin = -1;
+        FILE* f = std::fopen(bai_path, "wb");
+        if (!f) return fail(std::string("cannot write ") + bai_path);
+        std::vector<uint8_t> out;
+        auto p32 = [&](uint32_t v) { uint8_t b[4]; wr32(b, v); out.insert(out.end(), b, b + 4); };
+        auto p64 = [&](uint64_t v) { p32((uint32_t)v); p32((uint32_t)(v >> 32)); };
+        out.insert(out.end(), {'B', 'A', 'I', 1});
+        p32((uint32_t)refs.size());
+        for (auto& ri : refs) {
+            const bool any = ri.off_beg != ~0ull;
+            p32((uint32_t)(ri.bins.size() + (any ? 1 : 0)));
+            for (auto& kv : ri.bins) {
+                p32(kv.first);
+                p32((uint32_t)kv.second.size());
+                for (auto& ch : kv.second) { p64(ch.first); p64(ch.second); }
+            }
+            if (any) {                                   // htslib's metadata pseudo-bin
+                p32(37450); p32(2);
+                p64(ri.off_beg); p64(ri.off_end); p64(ri.n_mapped); p64(ri.n_unmapped);
+            }
+            for (size_t w = ri.linear.size(); w-- > 0;)  // empty windows take the next window's offset
+                if (ri.linear[w] == ~0ull) ri.linear[w] = (w + 1 < ri.linear.size()) ? ri.linear[w + 1] : 0;
+            p32((uint32_t)ri.linear.size());
+            for (uint64_t v : ri.linear) p64(v);
+        }
+        p64(n_no_coor);
+        const bool okw = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+        if (std::fclose(f) != 0 || !okw) return fail("write failed");
+        return 0;
+    }
+};
+
+// [b, e) a record covers on its reference for the index: pos .. pos + reference length of the CIGAR (one base when unmapped / no CIGAR)
+inline void index_span(const uint8_t* body, int64_t& b, int64_t& e) {
+    const int32_t pos = (int32_t)rd32(body + 4);
+    const uint32_t l_name = body[8], n_cig = rd16(body + 12), flag = rd16(body + 14);
+    int64_t reflen = 0;
+    const uint8_t* cig = body + 32 + l_name;
+    for (uint32_t c = 0; c < n_cig; ++c) {
+        const uint32_t v = rd32(cig + 4 * c), op = v & 15;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;
+    }
+    b = pos < 0 ? 0 : pos;
+    e = (flag & 4) || reflen == 0 ? b + 1 : b + reflen;
+}
+
+}  // namespace
+
+void ccsm_bam_writer::note_record(const uint8_t* body, uint64_t ubeg, uint64_t uend) {
+    uint64_t k1; uint32_t k2;
+    sort_key(body, k1, k2);
+    if (!acc_any) { acc_first_k1 = k1; acc_first_k2 = k2; }
+    else if (k1 < acc_last_k1 || (k1 == acc_last_k1 && k2 < acc_last_k2)) acc_sorted = false;
+    acc_any = true; acc_last_k1 = k1; acc_last_k2 = k2;
+    ++acc_records;
+    const int32_t tid = (int32_t)rd32(body);
+    if (tid < 0) { ++acc_unplaced; return; }
+    int64_t b, e;
+    index_span(body, b, e);
+    pend.push_back({tid, (int32_t)std::min<int64_t>(b, INT32_MAX), (int32_t)std::min<int64_t>(e, INT32_MAX), rd16(body + 14), ubeg, uend});
+}
+
+
+int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads, int* sorted, int64_t* n_records) try {
+    if (!bam_path || !bai_path) return fail("paths must be non-NULL");
+    ccsm_bam_reader* r = nullptr;
+    if (ccsm_bam_open(bam_path, threads, &r)) return 1;
+    BaiBuilder bb(r->n_ref);
     int rc = 0;
     for (;;) {
         if (r->fill(4)) { rc = 1; break; }
@@ -857,88 +1316,57 @@ int ccsm_bam_index_build(const char* bam_path, const char* bai_path, int threads
         if (r->avail() < 4 + (size_t)bs) { rc = fail("truncated BAM record"); break; }
         const uint64_t beg_off = r->voffset(r->abs_pos());
         const uint8_t* body = r->stream.data() + r->pos + 4;
-        const int32_t tid = (int32_t)rd32(body), pos = (int32_t)rd32(body + 4);
+        const int32_t tid = (int32_t)rd32(body);
         const uint32_t l_name = body[8], n_cig = rd16(body + 12), flag = rd16(body + 14);
         if (32 + (size_t)l_name + 4 * (size_t)n_cig > bs) { rc = fail("corrupt BAM record (field lengths exceed block_size)"); break; }
         uint64_t k1; uint32_t k2;
         sort_key(body, k1, k2);
-        if (!first && (k1 < prev1 || (k1 == prev1 && k2 < prev2))) is_sorted = false;
-        first = false; prev1 = k1; prev2 = k2;
-        int64_t reflen = 0;
-        const uint8_t* cig = body + 32 + l_name;
-        for (uint32_t c = 0; c < n_cig; ++c) {
-            const uint32_t v = rd32(cig + 4 * c), op = v & 15;
-            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;
-        }
+        bb.order(k1, k2);
+        int64_t b, e;
+        index_span(body, b, e);
         r->pos += 4 + bs;
         const uint64_t end_off = r->voffset(r->abs_pos());
-        ++count;
-        if (tid >= r->n_ref) { rc = fail("record refers to a reference id beyond the header"); break; }
-        if (tid < 0) { ++n_no_coor; }
-        if (tid >= 0) {
-            RefIndex& ri = refs[(size_t)tid];
-            const int64_t b = pos < 0 ? 0 : pos;
-            int64_t e = (flag & 4) || reflen == 0 ? b + 1 : b + reflen;
-            if (b >= (1LL << 29)) { rc = fail("record position beyond the range of a BAI index (2^29)"); break; }
-            if (e > (1LL << 29)) e = 1LL << 29;
-            const int bin = reg2bin(b, e);
-            if (bin != save_bin || tid != save_tid) {
-                last_off = beg_off;
-                flush_bin();
-                save_bin = bin; save_tid = tid; save_off = beg_off;
-            }
-            if (!(flag & 4)) {
-                const size_t w0 = (size_t)(b >> 14), w1 = (size_t)((e - 1) >> 14);
-                if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, ~0ull);
-                for (size_t w = w0; w <= w1; ++w) if (ri.linear[w] == ~0ull) ri.linear[w] = beg_off;
-                ++ri.n_mapped;
-            } else {
-                ++ri.n_unmapped;
-            }
-            if (ri.off_beg == ~0ull) ri.off_beg = beg_off;
-            ri.off_end = end_off;
-        } else if (save_tid >= 0) {
-            last_off = beg_off;
-            flush_bin();
-            save_bin = -1; save_tid = -1;
-        }
-        last_off = end_off;
+        if ((rc = bb.add(tid, b, e, (flag & 4) != 0, beg_off, end_off)) != 0) break;
     }
-    if (rc == 0) flush_bin();
     ccsm_bam_close(r);
     if (rc) return rc;
-    if (sorted) *sorted = is_sorted ? 1 : 0;
-    if (n_records) *n_records = count;
-    if (!is_sorted) return 0;                       // an index over unsorted records is meaningless: none is written
-    FILE* f = std::fopen(bai_path, "wb");
-    if (!f) return fail(std::string("cannot write ") + bai_path);
-    std::vector<uint8_t> out;
-    auto p32 = [&](uint32_t v) { uint8_t b[4]; wr32(b, v); out.insert(out.end(), b, b + 4); };
-    auto p64 = [&](uint64_t v) { p32((uint32_t)v); p32((uint32_t)(v >> 32)); };
-    out.insert(out.end(), {'B', 'A', 'I', 1});
-    p32((uint32_t)refs.size());
-    for (auto& ri : refs) {
-        const bool any = ri.off_beg != ~0ull;
-        p32((uint32_t)(ri.bins.size() + (any ? 1 : 0)));
-        for (auto& kv : ri.bins) {
-            p32(kv.first);
-            p32((uint32_t)kv.second.size());
-            for (auto& ch : kv.second) { p64(ch.first); p64(ch.second); }
-        }
-        if (any) {                                   // htslib's metadata pseudo-bin
-            p32(37450); p32(2);
-            p64(ri.off_beg); p64(ri.off_end); p64(ri.n_mapped); p64(ri.n_unmapped);
-        }
-        for (size_t w = ri.linear.size(); w-- > 0;)  // empty windows take the next window's offset
-            if (ri.linear[w] == ~0ull) ri.linear[w] = (w + 1 < ri.linear.size()) ? ri.linear[w + 1] : 0;
-        p32((uint32_t)ri.linear.size());
-        for (uint64_t v : ri.linear) p64(v);
-    }
-    p64(n_no_coor);
-    const bool okw = std::fwrite(out.data(), 1, out.size(), f) == out.size();
-    if (std::fclose(f) != 0 || !okw) return fail("write failed");
-    return 0;
+    if (sorted) *sorted = bb.is_sorted ? 1 : 0;
+    if (n_records) *n_records = bb.count;
+    if (!bb.is_sorted) return 0;                       // an index over unsorted records is meaningless: none is written
+    return bb.write(bai_path);
 } CCSM_BAM_CATCH
+
+int ccsm_bam_index_write(const char* bai_path, int32_t n_ref, int32_t n_runs, const ccsm_bam_index_run* runs, const int64_t* shift,
+                         int* sorted, int64_t* n_records) try {
+    if (!bai_path || n_runs < 0 || (n_runs > 0 && !runs)) return fail("bad arguments");
+    BaiBuilder bb(n_ref);
+    for (int32_t i = 0; i < n_runs; ++i) {
+        const ccsm_bam_index_run& r = runs[i];
+        if (r.n_records == 0) continue;
+        if (!r.sorted) bb.is_sorted = false;
+        bb.order(r.first_k1, r.first_k2);
+        bb.order(r.last_k1, r.last_k2);
+        if (!bb.is_sorted) break;
+        const uint64_t sh = (uint64_t)(shift ? shift[i] : 0) << 16;      // two's complement: a negative shift subtracts
+        if (r.n_entries > 0 && !r.entries) return fail("run without its entries");
+        for (int64_t k = 0; k < r.n_entries; ++k) {
+            const ccsm_bam_index_entry& q = r.entries[k];
+            if (bb.add(q.tid, q.pos, q.end, (q.flag & 4) != 0, q.vbeg + sh, q.vend + sh)) return 1;
+        }
+        // in a sorted file a run's unplaced records follow its placed ones
+        bb.add_unplaced(r.n_unplaced);
+    }
+    if (sorted) *sorted = bb.is_sorted ? 1 : 0;
+    if (n_records) {
+        int64_t n = 0;
+        for (int32_t i = 0; i < n_runs; ++i) n += runs[i].n_records;
+        *n_records = n;
+    }
+    if (!bb.is_sorted) return 0;
+    return bb.write(bai_path);
+} CCSM_BAM_CATCH
+
+
 
 // Coordinate sort (samtools sort order: reference id with unplaced reads last, position, reverse-strand flag; stable).  Records are
 // collected up to max_bytes (0 = no limit); when the input is larger, each full collection is sorted and spilled as a run

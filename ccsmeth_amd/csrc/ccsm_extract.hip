@@ -121,7 +121,9 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(ReadTable rt, const u
                                                            const uint8_t* __restrict__ fp, const uint8_t* __restrict__ rp,
                                                            const double* __restrict__ stats, const int* __restrict__ first_site /* n_reads + 1 */,
                                                            const float* __restrict__ embed, uint4* __restrict__ x0,
-                                                           int* __restrict__ locs, int n_sites_total, int row_base) {
+                                                           int* __restrict__ locs, int n_sites_total, int row_base,
+                                                           const unsigned long long* __restrict__ read_key /* n_reads or NULL */,
+                                                           unsigned long long* __restrict__ site_key /* per site, when read_key */) {
     // grid = (reads, kPackParts): every part redoes the (cheap) ordered scan of the read's CG sites and writes the rows of
     // its own share of them, so that a chunk of a few long reads still spreads over the chip
     __shared__ int s_wtot[4];
@@ -149,7 +151,10 @@ __global__ __launch_bounds__(256) void extract_pack_kernel(ReadTable rt, const u
             tot += c;
         }
         const int idx = base + woff + __popcll(mask & ((1ull << lane) - 1ull));
-        if (hit && idx < cap) locs[first + idx] = i;     // every part writes the same values
+        if (hit && idx < cap) {                          // every part writes the same values
+            locs[first + idx] = i;
+            if (read_key) site_key[first + idx] = read_key[r];
+        }
         base += tot;
         __syncthreads();
     }

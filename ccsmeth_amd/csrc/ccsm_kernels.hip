@@ -124,8 +124,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 //
 // h0buf[ld][row][256] fp32, ld = 2*layer + dir, row stride = rows_cap (the workspace's padded row capacity).
 // mode 0: explicit (src1/src2 = (6, n_sites, 256) per strand, reference init_hidden layout); 1: zeros; 2: Philox N(0,1).
+// Philox counter of a drawn value: (key, sub | strand*6+ld, u4) with key = offset + site index and sub = 0 by default; with
+// site_key (and optionally site_sub) the caller names every site's stream itself - call_mods uses (hash of the read name, position
+// of the C in the read), so that a site's initial states do not depend on where its read stands in the file, on the batching or
+// on which GPU processes it.
 __global__ void prep_h0_kernel(float* __restrict__ h0buf, const float* __restrict__ src1, const float* __restrict__ src2,
-                               int n_sites, int row_base, int rows_cap, int mode, uint64_t seed, uint64_t offset) {
+                               int n_sites, int row_base, int rows_cap, int mode, uint64_t seed, uint64_t offset,
+                               const unsigned long long* __restrict__ site_key, const unsigned int* __restrict__ site_sub) {
     const size_t total4 = (size_t)2 * kLayers * 2 * n_sites * (kHidden / 4);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
         const int u4 = (int)(i % (kHidden / 4));
@@ -140,10 +145,11 @@ __global__ void prep_h0_kernel(float* __restrict__ h0buf, const float* __restric
                 const float* src = strand ? src2 : src1;
                 v = *reinterpret_cast<const float4*>(src + ((size_t)ld * n_sites + site) * kHidden + u4 * 4);
             } else {
-                // counter = (offset + site, strand*6+ld, u4) -> 4 uniforms -> 4 normals (2 Box-Muller pairs)
-                const uint64_t gs = offset + (uint64_t)site;
+                // counter = (key, sub << 4 | strand*6+ld, u4) -> 4 uniforms -> 4 normals (2 Box-Muller pairs)
+                const uint64_t gs = site_key ? (uint64_t)site_key[site] : offset + (uint64_t)site;
+                const uint32_t sub = site_key && site_sub ? site_sub[site] << 4 : 0u;
                 uint32_t r[4];
-                philox4x32_10((uint32_t)gs, (uint32_t)(gs >> 32), (uint32_t)(strand * 6 + ld), (uint32_t)u4,
+                philox4x32_10((uint32_t)gs, (uint32_t)(gs >> 32), sub | (uint32_t)(strand * 6 + ld), (uint32_t)u4,
                               (uint32_t)seed, (uint32_t)(seed >> 32), r);
                 const float k2pi = 6.283185307179586f, inv = 2.3283064365386963e-10f;  // 2^-32
                 const float u0 = ((float)r[0] + 1.0f) * inv, u1 = (float)r[1] * inv;

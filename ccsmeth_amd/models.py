@@ -166,10 +166,11 @@ class Workspace:
                                                      logits.ctypes.data, probs.ctypes.data, stream))
         return logits, probs
 
-    def forward_reads(self, reads, h0=None, seed=0, offset=0, stream=None):
+    def forward_reads(self, reads, h0=None, seed=0, offset=0, stream=None, read_keys=None):
         """Read-level call (ccsm_forward_reads_host): feature extraction and the model on the GPU.
 
-        reads: list of (seq str|bytes, fi, ri, fp, rp uint8 arrays of len(seq), fn, rn).  Returns (first_site int32
+        reads: list of (seq str|bytes, fi, ri, fp, rp uint8 arrays of len(seq), fn, rn).  read_keys (uint64 per read): device-drawn
+        initial states keyed by (read key, position of the C) instead of offset + running site index.  Returns (first_site int32
         (n_reads+1), locs int32 (n_sites), logits, probs float32 (n_sites, 2))."""
         nr = len(reads)
         lens = np.array([len(r[0]) for r in reads], np.int32)
@@ -196,6 +197,11 @@ class Workspace:
         rd.offset, rd.length = offs.ctypes.data, lens.ctypes.data
         rd.seq, rd.fi, rd.ri, rd.fp, rd.rp = (a.ctypes.data for a in cat)
         rd.fn, rd.rn = fn.ctypes.data, rn.ctypes.data
+        if read_keys is not None:
+            read_keys = np.ascontiguousarray(read_keys, np.uint64)
+            if len(read_keys) != nr:
+                raise ValueError("read_keys must have one entry per read")
+            rd.h0_key = read_keys.ctypes.data
         h = _lib.H0()
         keep = []
         if h0 is None:
@@ -262,9 +268,10 @@ class Workspace:
         return first, locs[:n], logits[:n], probs[:n]
 
     def submit_reads_arrays(self, offset, length, seq, fi, ri, fp, rp, fn, rn, site_counts=None, seed=0, offset_counter=0,
-                            h0=None, stream=None):
+                            h0=None, stream=None, read_keys=None):
         """ccsm_submit_reads_host: enqueue one chunk of reads (arrays as forward_reads_arrays); with site_counts (int32 per
-        read, e.g. bamnative.Batch.n_sites) the call does not wait for the GPU.  Collect with wait_reads()."""
+        read, e.g. bamnative.Batch.n_sites) the call does not wait for the GPU.  read_keys (uint64 per read, e.g.
+        bamnative.Batch.name_hash): initial states keyed by (read key, position of the C).  Collect with wait_reads()."""
         offset = np.ascontiguousarray(offset, np.int64)
         length = np.ascontiguousarray(length, np.int32)
         fn, rn = np.ascontiguousarray(fn, np.float32), np.ascontiguousarray(rn, np.float32)
@@ -284,6 +291,11 @@ class Workspace:
         rd.offset, rd.length = offset.ctypes.data, length.ctypes.data
         rd.seq, rd.fi, rd.ri, rd.fp, rd.rp = (a.ctypes.data for a in arrs)
         rd.fn, rd.rn = fn.ctypes.data, rn.ctypes.data
+        if read_keys is not None:
+            read_keys = np.ascontiguousarray(read_keys, np.uint64)
+            if len(read_keys) != nr:
+                raise ValueError("read_keys must have one entry per read")
+            rd.h0_key = read_keys.ctypes.data
         h = _lib.H0()
         if h0 is None:
             h.mode = _lib.H0_DEVICE_RNG

@@ -17,6 +17,16 @@ from .call_modifications import prob1_norm_round6
 from .extract_features import count_kept_sites, extract_read_arrays
 
 Read = namedtuple("Read", "name seq fi ri fp rp fn rn is_reverse")
+
+
+def read_key(name):
+    """64-bit FNV-1a of the read name: the key of a read's device-drawn initial states (ccsm_reads.h0_key; the native reader
+    hands the same value over as ccsm_bam_batch.name_hash).  A site draws from (this key, position of its C in the read), so its
+    probability does not depend on where the read stands in the file, on the batching or on which GPU handles it."""
+    h = 0xcbf29ce484222325
+    for c in (name.encode("ascii", "replace") if isinstance(name, str) else bytes(name)):
+        h = ((h ^ c) * 0x100000001b3) & 0xffffffffffffffff
+    return h
 ReadCalls = namedtuple("ReadCalls", "name n_sites locs probs mm ml mm_flag")
 
 
@@ -59,8 +69,8 @@ class CallModsPipeline:
     # ---- device-side extraction -----------------------------------------------------------------------------------
     def _run_device(self, reads):
         """Chunks of whole reads holding <= batch_size sites (one larger read alone if it exceeds that) go through
-        ccsm_forward_reads_host.  The Philox h0 counter is the running site index, as in the host path, so both paths give
-        the same probabilities for the same seed."""
+        ccsm_forward_reads_host.  The Philox counter of a site's initial states is (hash of the read name, position of the C), as in
+        the host path and the native-BAM path, so all three give the same probabilities for the same seed."""
         out = [None] * len(reads)
         failed = 0
         cnts = []
@@ -78,9 +88,8 @@ class CallModsPipeline:
                     self._rws.close()
                 self._rws = self.dm.workspace(max(csites, self.batch_size))
             rd = [(reads[i].seq, reads[i].fi, reads[i].ri, reads[i].fp, reads[i].rp, reads[i].fn, reads[i].rn) for i in chunk]
-            first, locs, _, probs = self._rws.forward_reads(rd, seed=self.seed, offset=self._site_counter,
-                                                           stream=self._slots[0].stream)
-            self._site_counter += len(locs)
+            first, locs, _, probs = self._rws.forward_reads(rd, seed=self.seed, stream=self._slots[0].stream,
+                                                           read_keys=np.array([read_key(reads[i].name) for i in chunk], np.uint64))
             p1 = prob1_norm_round6(probs)
             for j, i in enumerate(chunk):
                 a, b = int(first[j]), int(first[j + 1])
@@ -112,8 +121,11 @@ class CallModsPipeline:
             b.strand[s].kmer, b.strand[s].ipd, b.strand[s].pw, b.strand[s].npass = (a.ctypes.data for a in arrs)
         b.kmer_is_f32, b.npass_per_base = 0, 0
         h = _lib.H0()
-        h.mode, h.seed, h.offset = _lib.H0_DEVICE_RNG, self.seed, self._site_counter
-        self._site_counter += n
+        h.mode, h.seed = _lib.H0_DEVICE_RNG, self.seed
+        skey = np.ascontiguousarray(feats["site_key"], np.uint64)
+        ssub = np.ascontiguousarray(feats["site_sub"], np.uint32)
+        keep += [skey, ssub]
+        h.site_key, h.site_sub = skey.ctypes.data, ssub.ctypes.data
         _lib.check(lib.ccsm_submit_host(self.dm.handle, slot.ws.handle, n, C.byref(b), C.byref(h), slot.stream))
         slot.pending = (n, meta)
 
@@ -176,8 +188,7 @@ class CallModsPipeline:
                 self._rwss[k] = self.dm.workspace(max(csites, self.batch_size))
             self._rwss[k].submit_reads_arrays(batch.offset[sel], batch.length[sel], batch.seq, batch.fi, batch.ri, batch.fp, batch.rp,
                                               batch.fn[sel], batch.rn[sel], site_counts=cnt[sel], seed=self.seed,
-                                              offset_counter=self._site_counter, stream=self._slots[k].stream)
-            self._site_counter += csites
+                                              stream=self._slots[k].stream, read_keys=batch.name_hash[sel])
             inflight.append((k, sel))
             start += take
             turn += 1
@@ -195,7 +206,7 @@ class CallModsPipeline:
             return self._run_device(reads)
         acc = [[] for _ in reads]
         failed = 0
-        keys = ("kmer1", "ipd1", "pw1", "npass1", "kmer2", "ipd2", "pw2", "npass2")
+        keys = ("kmer1", "ipd1", "pw1", "npass1", "kmer2", "ipd2", "pw2", "npass2", "site_key", "site_sub")
         cur = {k: [] for k in keys}
         meta, nsites, turn = [], 0, 0
 
@@ -225,6 +236,8 @@ class CallModsPipeline:
                 cur["npass1"].append(np.full(take, read.fn, np.float32))
                 cur["kmer2"].append(arr["rkmer"][sl]); cur["ipd2"].append(arr["ripd"][sl]); cur["pw2"].append(arr["rpw"][sl])
                 cur["npass2"].append(np.full(take, read.rn, np.float32))
+                cur["site_key"].append(np.full(take, read_key(read.name), np.uint64))
+                cur["site_sub"].append(np.asarray(arr["loc"][sl], np.uint32))
                 meta.append((ridx, arr["loc"][sl]))
                 nsites += take
                 start += take

@@ -1,22 +1,19 @@
 """Read sharding across the GPUs of one node: independent units, no exchange on the data path.
 
 The reference hands hole-batches (50 reads) to its call-workers through ONE shared queue, worker i on GPU i mod n
-(call_modifications.py:465-471, 561-578), filled by one reader process (extract_features.py:129-177).  Here, with one
-process per GPU:
-  * ONE rank scans the input once (a background thread with its own reader) and publishes, per hole-batch, where it lies in the
-    file (BGZF virtual offsets of its first record and of the byte behind its last), how many records it holds and the running
-    site index of its first site (the Philox counter of the initial states: every probability is independent of who computes
-    the batch) on a key-value board (torch.distributed.TCPStore);
-  * every rank claims the next unclaimed batch index (an atomic counter on the board: the shared queue), SEEKS its own reader
-    to the batch and inflates only that range (libccsm_bam: ccsm_bam_seek), so the input is inflated twice in total — once by the
-    scan, once by whoever processes a batch — instead of once per rank;
-  * `dispatch="static"` hands batch i to rank i mod world instead (deterministic shares, used by the tests).
-The only other communication is the end-of-run gather of the output runs and counters (gloo)."""
-import struct
-import threading
-
-_DESC = struct.Struct("<QQIQ")      # voffset_start, voffset_end, n_reads, site_base
-_END = b"END"
+(call_modifications.py:465-471, 561-578), filled by one reader process that inflates the whole input
+(extract_features.py:129-177).  Here, with one process per GPU, the queue is a counter and nobody reads the file for anybody else:
+  * the input is cut into chunks of `chunk_bytes` COMPRESSED bytes; chunk k = the records that start in a BGZF block whose file
+    offset lies in [k * chunk_bytes, (k + 1) * chunk_bytes);
+  * every rank claims the next unclaimed chunk number (an atomic counter on a torch.distributed.TCPStore: the shared queue;
+    `dispatch="static"`: chunk k goes to rank k mod world, deterministic shares for the tests), finds the chunk's first record
+    itself (libccsm_bam: ccsm_bam_seek_chunk) and inflates only its own chunk: the input is inflated exactly once in total;
+  * a site's device-drawn initial states are keyed by (hash of the read name, position of the C in the read), so every
+    probability is independent of who computes the read, of the chunking and of the batching;
+  * record-start detection inside a BGZF stream is a heuristic, so the ranks' reports are chained at the end: where chunk k's last
+    record ended must be where the next non-empty chunk was found to begin (verify_chain) - any miss is an error, never a silently
+    dropped or duplicated read.
+The only other communication is the end-of-run gather of the output runs, index tables and counters (gloo)."""
 
 
 def shard_indices(n_units, rank, world_size):
@@ -26,87 +23,69 @@ def shard_indices(n_units, rank, world_size):
     return range(rank, n_units, world_size)
 
 
-class BatchBoard:
-    """Descriptors of consecutive hole-batches on a torch.distributed store + the claim counter."""
+def n_chunks_of(file_size, chunk_bytes):
+    if chunk_bytes <= 0:
+        raise ValueError("chunk size must be positive")
+    return max(1, -(-int(file_size) // int(chunk_bytes)))
 
-    def __init__(self, store, world, rank, dispatch="dynamic", prefix="ccsm"):
+
+class ChunkQueue:
+    """The shared work queue: chunk numbers 0 .. n_chunks - 1, each handed out once."""
+
+    def __init__(self, store, world, rank, n_chunks, dispatch="dynamic", prefix="ccsm"):
         if dispatch not in ("dynamic", "static"):
             raise ValueError("dispatch must be 'dynamic' or 'static'")
-        self.store, self.world, self.rank, self.dispatch, self.prefix = store, int(world), int(rank), dispatch, prefix
-        self._next_static = self.rank
+        self.store, self.world, self.rank, self.n_chunks, self.dispatch, self.prefix = store, int(world), int(rank), int(n_chunks), dispatch, prefix
+        self._static = iter(shard_indices(self.n_chunks, self.rank, self.world))
         self.claimed = []
 
-    def _key(self, i):
-        return "%s/b%d" % (self.prefix, i)
-
-    # ---- scanning rank
-    def publish(self, i, voffset_start, voffset_end, n_reads, site_base):
-        self.store.set(self._key(i), _DESC.pack(voffset_start, voffset_end, n_reads, site_base))
-
-    def finish(self, n_batches):
-        """No more batches: every rank reads at most one index behind the end."""
-        for k in range(self.world + 1):
-            self.store.set(self._key(n_batches + k), _END)
-
-    # ---- every rank
     def claim(self):
-        """(index, voffset_start, voffset_end, n_reads, site_base) of the next batch of this rank, or None when the input is done.
-        Blocks until the scan has published the claimed index."""
+        """Next chunk number of this rank, or None when the input is handed out.  Raises when another rank has reported a failure
+        (so that nobody keeps working towards a gather that will never complete)."""
+        self.check()
         if self.dispatch == "dynamic":
-            i = int(self.store.add("%s/next" % self.prefix, 1)) - 1
+            k = int(self.store.add("%s/next" % self.prefix, 1)) - 1
         else:
-            i = self._next_static
-            self._next_static += self.world
-        raw = self.store.get(self._key(i))
-        if raw == _END:
+            k = next(self._static, self.n_chunks)
+        if k >= self.n_chunks:
             return None
-        self.claimed.append(i)
-        return (i,) + _DESC.unpack(raw)
+        self.claimed.append(k)
+        return k
 
-
-def scan_hole_batches(reader, holes_batch, sites_of_batch, board, on_error=None):
-    """The scanning rank's pass over the whole input: publish every hole-batch, then the end marks.  `sites_of_batch(batch)` =
-    CpG sites of the batch that will be called (after the read filters).  Returns (batches, sites)."""
-    i, site_base = 0, 0
-    try:
-        while True:
-            b = reader.next_batch(holes_batch)
-            if b is None:
-                break
-            board.publish(i, b.voffset_start, b.voffset_end, b.n_reads, site_base)
-            site_base += int(sites_of_batch(b))
-            b.close()
-            i += 1
-    except BaseException as e:      # noqa: BLE001 - the claimers must not wait forever
-        if on_error is not None:
-            on_error(e)
-        raise
-    finally:
-        board.finish(i)
-    return i, site_base
-
-
-def start_scan_thread(make_reader, holes_batch, sites_of_batch, board):
-    """Run scan_hole_batches in a daemon thread with its own reader; returns (thread, result dict: batches, sites, inflated_bytes, error)."""
-    res = {}
-
-    def run():
+    def fail(self, message):
+        """Tell the other ranks that this one is giving up."""
         try:
-            with make_reader() as rd:
-                res["batches"], res["sites"] = scan_hole_batches(rd, holes_batch, sites_of_batch, board)
-                res["inflated_bytes"] = rd.inflated_bytes
-        except BaseException as e:      # noqa: BLE001
-            res["error"] = e
-    th = threading.Thread(target=run, name="ccsm-scan", daemon=True)
-    th.start()
-    return th, res
+            self.store.set("%s/error" % self.prefix, ("rank %d: %s" % (self.rank, message)).encode("utf-8", "replace"))
+        except Exception:   # noqa: BLE001 - the store may be what failed
+            pass
+
+    def check(self):
+        if self.store.check(["%s/error" % self.prefix]):
+            raise RuntimeError("call_mods aborted: " + self.store.get("%s/error" % self.prefix).decode("utf-8", "replace"))
+
+
+def verify_chain(first_voffset, chunks):
+    """chunks: [(k, voffset of the chunk's first record, voffset behind its last record, n_records)] of every rank, empty chunks with
+    n_records == 0.  The first non-empty chunk must begin at the file's first record and every later one where its predecessor ended;
+    returns the total number of records."""
+    prev_end, total, seen = int(first_voffset), 0, set()
+    for k, v0, v1, n in sorted(chunks):
+        if k in seen:
+            raise RuntimeError("chunk %d was processed twice" % k)
+        seen.add(k)
+        if n == 0:
+            continue
+        if int(v0) != prev_end:
+            raise RuntimeError("chunk %d begins at virtual offset %#x but the records before it end at %#x: record-start detection "
+                               "failed on this input (re-run with one GPU, or report the file)" % (k, int(v0), prev_end))
+        prev_end = int(v1)
+        total += int(n)
+    return total
 
 
 def open_board_store(world, rank, port=None, host=None, timeout_s=1800):
-    """The board's store: a TCPStore on MASTER_ADDR hosted by rank 0, on CCSM_BOARD_PORT or, by default, a free port that rank 0
-    picks and broadcasts through the (already initialised) process group.  Returns (store, connect): `connect()` opens one more
-    client connection — a store client serialises its calls, so the scanning thread must not share the connection on which the
-    same process's claimer blocks in get() (observed: the scan's set() waits behind that get() forever)."""
+    """The queue's store: a TCPStore on MASTER_ADDR hosted by rank 0, on CCSM_BOARD_PORT or, by default, a free port that rank 0
+    picks and broadcasts through the (already initialised) process group."""
     import datetime
     import os
     import socket
@@ -123,8 +102,4 @@ def open_board_store(world, rank, port=None, host=None, timeout_s=1800):
         dist.broadcast_object_list(box, src=0)
         port = box[0]
     tmo = datetime.timedelta(seconds=timeout_s)
-    store = dist.TCPStore(host, int(port), int(world), is_master=(rank == 0), timeout=tmo, wait_for_workers=True)
-
-    def connect():
-        return dist.TCPStore(host, int(port), None, is_master=False, timeout=tmo, wait_for_workers=False)
-    return store, connect
+    return dist.TCPStore(host, int(port), int(world), is_master=(rank == 0), timeout=tmo, wait_for_workers=True)

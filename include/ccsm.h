@@ -99,13 +99,19 @@ typedef struct {
 /* Initial hidden state.  The reference draws torch.randn(6, N, 256) twice per forward, strand 1 first
  * (models.py:77-87, 125-130), unseeded in its worker processes, so its outputs are only reproducible when h0 is
  * pinned: EXPLICIT takes both tensors (index 2l = layer-l forward, 2l+1 = backward), DEVICE_RNG draws N(0,1) on
- * the GPU (Philox4x32-10 keyed by seed, counter = offset + site index), ZERO is for tests. */
+ * the GPU (Philox4x32-10 keyed by seed, counter = offset + site index, or per-site keys: below), ZERO is for tests. */
 typedef enum { CCSM_H0_EXPLICIT = 0, CCSM_H0_ZERO = 1, CCSM_H0_DEVICE_RNG = 2 } ccsm_h0_mode;
 typedef struct {
     int32_t mode;
     const float* h0[2]; /* EXPLICIT: (6, N, 256) fp32 for strand 1 and strand 2 */
     uint64_t seed;
     uint64_t offset;
+    /* DEVICE_RNG, optional (NULL: the counter is offset + site index): the caller names each site's random stream itself, counter =
+     * (site_key[i], site_sub[i]) with site_sub < 2^28 (NULL = 0).  call_mods passes (64-bit hash of the read name, position of the C in
+     * the read): a site's initial states - and with them its probability - then do not depend on the read's place in the file, on
+     * how sites are batched or on which GPU handles the read.  Host arrays for the *_host entry points, device arrays for *_device. */
+    const uint64_t* site_key;
+    const uint32_t* site_sub;
 } ccsm_h0;
 
 typedef struct ccsm_model ccsm_model;
@@ -171,6 +177,9 @@ typedef struct ccsm_reads {
     const uint8_t* rp;
     const float* fn;         /* (n_reads) */
     const float* rn;         /* (n_reads) */
+    const uint64_t* h0_key;  /* (n_reads) or NULL.  DEVICE_RNG with keys: site k of read r draws its initial states from the counter
+                                (h0_key[r], locs[k]) instead of (offset + running site index): see ccsm_h0.site_key.
+                                ccsm_bam_batch.name_hash is such a key */
 } ccsm_reads;
 /* Outputs (host): first_site (n_reads + 1) prefix of kept CG sites per read; locs (capacity max_sites) position of
  * each site's C in its read, in read order then ascending; logits / probs (capacity max_sites x 2); *n_sites.

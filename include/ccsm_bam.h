@@ -41,6 +41,7 @@ typedef struct ccsm_bam_batch {
     const uint8_t* rp;
     const float* fn;            /* (n_reads) */
     const float* rn;
+    const uint64_t* name_hash;  /* (n_reads) 64-bit FNV-1a of the read name: the read's key for device-drawn initial states (ccsm_reads.h0_key) */
     int64_t total_bases;        /* bytes used in seq / fi / ri / fp / rp */
     uint64_t voffset_start;     /* BGZF virtual file offset (block file offset << 16 | offset in the block) of the first record */
     uint64_t voffset_end;       /* ... and of the byte behind the last one */
@@ -64,6 +65,16 @@ void ccsm_bam_close(ccsm_bam_reader* r);
  * one block per range.  ccsm_bam_tell = virtual offset of the next record; ccsm_bam_inflated_bytes = bytes inflated so far. */
 int ccsm_bam_seek(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t voffset_end);
 int ccsm_bam_tell(ccsm_bam_reader* r, uint64_t* voffset);
+/* Chunked reading without a scan (multi-GPU call_mods: every rank claims the next chunk number from a shared counter; nothing of the
+ * file is inflated twice).  A chunk = the records that START in a BGZF block whose file offset lies in [coffset_lo, coffset_hi); the
+ * last of them may end in a later chunk's blocks, which are then read as far as that record needs.  ccsm_bam_seek_chunk finds the
+ * first BGZF block at or behind coffset_lo (gzip member header with the BC subfield, chained three deep), inflates from there and
+ * locates the first record start by validating candidates (fixed fields in range for this header's reference count, NUL-terminated
+ * printable name, CIGAR operations, auxiliary fields that walk to the exact end of the record, and a second valid record behind it);
+ * subsequent ccsm_bam_next calls return the chunk's records and then NULL.  *voffset_first = virtual offset of that first record,
+ * 0 when no record starts in the chunk.  The detection is a heuristic; what makes it safe is the caller's hand-over check: the
+ * ccsm_bam_tell after a chunk's last batch must equal the next non-empty chunk's *voffset_first (call_mods raises otherwise). */
+int ccsm_bam_seek_chunk(ccsm_bam_reader* r, uint64_t coffset_lo, uint64_t coffset_hi, uint64_t* voffset_first);
 int64_t ccsm_bam_inflated_bytes(const ccsm_bam_reader* r);
 
 /* level = zlib level of the BGZF blocks (1..9), threads = deflate workers. */
@@ -82,6 +93,36 @@ int ccsm_bam_write_batch(ccsm_bam_writer* w, const ccsm_bam_batch* b, const int3
  * (the multi-GPU call_mods stitches the per-rank files back into input order out of such runs). */
 int ccsm_bam_writer_flush(ccsm_bam_writer* w, int64_t* file_offset);
 int ccsm_bam_writer_close(ccsm_bam_writer* w);
+
+/* ---- the index from the writer's own bookkeeping: no second pass over the output -------------------------------------------------
+ * The reference indexes its modbam by re-reading it (pysam.index, call_modifications.py:602-606).  The writer knows where every record
+ * lands: with tracking on it keeps, per placed record (reference id >= 0), the reference span and the virtual offsets of its first
+ * byte and of the byte behind it, and per run (the blocks between two ccsm_bam_writer_flush calls) the record counts, whether the run
+ * is in samtools' coordinate order, and the sort keys of its first and last record.  ccsm_bam_index_write turns a list of such run
+ * tables - given in FINAL file order, each with the distance its blocks were moved by when the per-GPU part files were stitched -
+ * into the .bai, or reports that the records are not in coordinate order (then no index is written and the caller sorts). */
+typedef struct ccsm_bam_index_entry {
+    int32_t tid, pos, end;     /* reference id, [pos, end) on the reference (one base for an unmapped record placed with its mate) */
+    uint32_t flag;             /* BAM FLAG */
+    uint64_t vbeg, vend;       /* virtual file offsets in the file the writer wrote */
+} ccsm_bam_index_entry;
+typedef struct ccsm_bam_index_run {
+    int64_t n_records, n_unplaced;          /* records of the run(s); those without a reference id */
+    int32_t sorted;                         /* 1: in coordinate order within */
+    uint64_t first_k1; uint32_t first_k2;   /* sort key (reference id with unplaced last, position + 1 | reverse strand) of the first ... */
+    uint64_t last_k1; uint32_t last_k2;     /* ... and the last record */
+    int64_t n_entries;
+    const ccsm_bam_index_entry* entries;    /* placed records in file order; owned by the writer until its next take / close */
+    int64_t file_start, file_end;           /* byte span of the run(s) in the writer's file */
+} ccsm_bam_index_run;
+/* Switch tracking on / off; only at a run boundary (right after open + flush, or after any flush). */
+int ccsm_bam_writer_track_index(ccsm_bam_writer* w, int enable);
+/* The table of everything written since the previous take (one or more whole runs); must directly follow a flush. */
+int ccsm_bam_writer_take_index(ccsm_bam_writer* w, ccsm_bam_index_run* out);
+/* shift[i] (may be NULL = zeros) = final file offset of run i's first byte minus runs[i].file_start.  *sorted = 0: not in coordinate
+ * order, nothing written. */
+int ccsm_bam_index_write(const char* bai_path, int32_t n_ref, int32_t n_runs, const ccsm_bam_index_run* runs, const int64_t* shift,
+                         int* sorted, int64_t* n_records);
 
 /* ---- per-read modification calls of an aligned modbam projected on the reference: the feed of `ccsmeth call_freqb` -------
  * Replaces the per-read part of _readmods_to_bed_of_one_region (call_mods_freq_bam.py:486-537): record filters (:489-500),

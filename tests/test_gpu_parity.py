@@ -754,9 +754,10 @@ def test_read_level_extraction_long_reads(model7):
 
 
 def test_call_mods_two_ranks_equal_single_process(tmp_path):
-    """Multi-GPU call_mods (one process per GPU, reads sharded by hole-batch, no data-path collective): two ranks — here both on
+    """Multi-GPU call_mods (one process per GPU, the input handed out in chunks, no data-path collective): two ranks — here both on
     cuda:0, bookkeeping over gloo — must produce, after stitching, exactly the records of the single-process run, in input
-    order, with the same probabilities (the Philox counter of a site is its global index, whichever rank computes it)."""
+    order, with the same probabilities (the Philox counter of a site is (hash of its read's name, its position), whichever rank
+    computes it), and the same index."""
     import subprocess
     import sys
     import torch
@@ -781,7 +782,7 @@ def test_call_mods_two_ranks_equal_single_process(tmp_path):
     base = [sys.executable, "-m", "ccsmeth_amd", "call_mods", "-i", inp, "-m", ckpt, "--batch_size", "300", "--holes_batch", "3"]
     env = dict(os.environ, PYTHONPATH=ROOT)
     subprocess.run(base + ["-o", str(tmp_path / "single")], check=True, env=env, cwd=ROOT, timeout=600)
-    procs = [subprocess.Popen(base + ["-o", str(tmp_path / "multi")], cwd=ROOT,
+    procs = [subprocess.Popen(base + ["-o", str(tmp_path / "multi"), "--chunk_mb", "0.02"], cwd=ROOT,
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
              for r in range(2)]
     for p in procs:
@@ -797,6 +798,69 @@ def test_call_mods_two_ranks_equal_single_process(tmp_path):
     assert len(r1) == 23 and r1 == r2
     assert h1.split("@PG")[0] == h2.split("@PG")[0]
     assert sum(1 for r in r1 if any(t == "ML" for t, _, _ in r[3])) >= 20
+    assert open(str(tmp_path / "single.modbam.bam.bai"), "rb").read() == open(str(tmp_path / "multi.modbam.bam.bai"), "rb").read()
+
+
+def test_keyed_initial_states_do_not_depend_on_order_or_batching(model7):
+    """ccsm_reads.h0_key / ccsm_h0.site_key: with per-read keys a site's device-drawn initial states are a function of (key, position
+    of the C), so the same reads in another order, split over several calls, or handed over as extracted features (host entry point
+    with per-site keys) give bit-identical probabilities; without keys the counter is offset + running site index, as before."""
+    import ctypes as C
+    from ccsmeth_amd import _lib
+    from ccsmeth_amd import extract_features as ef
+    from ccsmeth_amd.pipeline import read_key
+    _, dm = model7
+    rng = np.random.default_rng(31)
+    reads, names = [], []
+    for i in range(9):
+        L = int(rng.integers(300, 2500))
+        seq = rng.choice(list("ACGT"), size=L)
+        for j in range(12, L - 12, 23):
+            seq[j], seq[j + 1] = "C", "G"
+        kin = lambda: rng.integers(0, 256, L).astype(np.uint8)  # noqa: E731
+        reads.append(("".join(seq), kin(), kin(), kin(), kin(), float(rng.integers(3, 30)), float(rng.integers(3, 30))))
+        names.append("m84/%d/ccs" % (1000 + i))
+    keys = np.array([read_key(n) for n in names], np.uint64)
+    ws = dm.workspace(4096)
+    first, locs, _, probs = ws.forward_reads(reads, seed=77, read_keys=keys)
+    per_read = [probs[first[i]:first[i + 1]] for i in range(9)]
+    # another order, in two calls
+    order = rng.permutation(9)
+    for part in (order[:4], order[4:]):
+        f2, l2, _, p2 = ws.forward_reads([reads[i] for i in part], seed=77, read_keys=keys[part])
+        for j, i in enumerate(part):
+            assert np.array_equal(p2[f2[j]:f2[j + 1]], per_read[i])
+            assert np.array_equal(l2[f2[j]:f2[j + 1]], locs[first[i]:first[i + 1]])
+    # the same sites as extracted features through ccsm_forward_host with per-site keys (features are byte-identical: the
+    # device extraction is pinned to the host mirror by test_read_level_extraction_vs_reference_golden)
+    arrs = [ef.extract_read_arrays(r[0], r[1], r[2], r[3], r[4]) for r in reads]
+    cat = lambda k: np.concatenate([a[k] for a in arrs])  # noqa: E731
+    n = len(locs)
+    feats = dict(kmer1=cat("fkmer"), ipd1=cat("fipd").astype(np.float32), pw1=cat("fpw").astype(np.float32),
+                 kmer2=cat("rkmer"), ipd2=cat("ripd").astype(np.float32), pw2=cat("rpw").astype(np.float32),
+                 npass1=np.concatenate([np.full(len(a["loc"]), r[5], np.float32) for a, r in zip(arrs, reads)]),
+                 npass2=np.concatenate([np.full(len(a["loc"]), r[6], np.float32) for a, r in zip(arrs, reads)]))
+    b = _lib.Batch()
+    keep = []
+    for s_, sfx in enumerate(("1", "2")):
+        a4 = [np.ascontiguousarray(feats["kmer" + sfx], np.uint8), np.ascontiguousarray(feats["ipd" + sfx]), np.ascontiguousarray(feats["pw" + sfx]),
+              np.ascontiguousarray(feats["npass" + sfx])]
+        keep += a4
+        b.strand[s_].kmer, b.strand[s_].ipd, b.strand[s_].pw, b.strand[s_].npass = (x.ctypes.data for x in a4)
+    h = _lib.H0()
+    skey = np.ascontiguousarray(np.repeat(keys, np.diff(first)), np.uint64)
+    ssub = np.ascontiguousarray(cat("loc"), np.uint32)
+    h.mode, h.seed, h.site_key, h.site_sub = _lib.H0_DEVICE_RNG, 77, skey.ctypes.data, ssub.ctypes.data
+    lg, pr = np.empty((n, 2), np.float32), np.empty((n, 2), np.float32)
+    _lib.check(dm._lib.ccsm_forward_host(dm.handle, ws.handle, n, C.byref(b), C.byref(h), lg.ctypes.data, pr.ctypes.data, None))
+    assert np.array_equal(pr, probs)
+    # other keys, other states; no keys: the running-index counter
+    f3, _, _, p3 = ws.forward_reads(reads, seed=77, read_keys=keys + np.uint64(1))
+    assert np.abs(p3 - probs).max() > 1e-4
+    _, _, _, p4 = ws.forward_reads(reads, seed=77, offset=5)
+    _, _, _, p5 = ws.forward_reads(reads, seed=77, offset=5)
+    assert np.array_equal(p4, p5) and np.abs(p4 - probs).max() > 1e-4
+    ws.close()
 
 
 def test_read_level_submit_wait_pipelined(model7):

@@ -1,7 +1,8 @@
-"""N > 1 path of `call_mods` on CPU (gloo, no GPU): the hole-batch board of ccsmeth_amd/sharding.py — one scanning rank, every
-rank seeking to the batches it claims — with the model replaced by a stand-in whose "probabilities" are a function of the running
-site index only (what the Philox counter of the real initial states is): the stitched 8-rank output must be identical to the
-single-process output, and no rank may inflate more than its share of the file."""
+"""N > 1 path of `call_mods` on CPU (gloo, no GPU): the chunk queue of ccsmeth_amd/sharding.py — every rank claims chunk numbers,
+finds its chunks' first records itself and inflates only its own chunks — with the model replaced by a stand-in whose
+"probabilities" are a function of (read-name hash, position of the C) only (what the Philox counter of the real initial states is):
+the stitched 8-rank output must be identical to the single-process output, the index must equal the one made by re-reading the file,
+and the ranks together must inflate the file once."""
 import gzip
 import os
 import socket
@@ -18,10 +19,7 @@ ARGV = ["ccsmeth_amd", "call_mods", "--test"]      # the @PG line quotes sys.arg
 
 
 class StubPipe:
-    """CallModsPipeline's native-batch interface without a GPU: site locations from the sequence, prob = f(running site index)."""
-
-    def __init__(self):
-        self._site_counter = 0
+    """CallModsPipeline's native-batch interface without a GPU: site locations from the sequence, prob = f(read key, location)."""
 
     def run_native_batch(self, batch, skip=None):
         nr = batch.n_reads
@@ -39,9 +37,10 @@ class StubPipe:
             lc = lc[(lc >= 10) & (lc < n - 10) & (rl >= 10) & (rl < n - 10)]
             assert len(lc) == cnt[r]
             locs[first[r]:first[r + 1]] = lc
-        idx = (self._site_counter + np.arange(len(locs), dtype=np.uint64)) * np.uint64(2654435761) % np.uint64(2 ** 32)
+        key = np.repeat(batch.name_hash.astype(np.uint64), cnt)
+        with np.errstate(over="ignore"):
+            idx = ((key ^ (key >> np.uint64(29))) + locs.astype(np.uint64)) * np.uint64(2654435761) % np.uint64(2 ** 32)
         prob1 = np.round(idx.astype(np.float64) / 2 ** 32, 6).astype(np.float32)
-        self._site_counter += len(locs)
         return first, locs, prob1, (cnt > 0).astype(np.uint8), 0
 
     def close(self):
@@ -50,8 +49,8 @@ class StubPipe:
 
 def _args(inp, out, dispatch="dynamic"):
     from ccsmeth_amd.call_mods import build_parser
-    return build_parser().parse_args(["-i", inp, "-m", "unused.ckpt", "-o", out, "--holes_batch", "10", "--threads", "2", "--no_sort",
-                                      "--dispatch", dispatch])
+    return build_parser().parse_args(["-i", inp, "-m", "unused.ckpt", "-o", out, "--holes_batch", "10", "--threads", "2",
+                                      "--dispatch", dispatch, "--chunk_mb", "0.08"])
 
 
 def _free_port():
@@ -65,7 +64,7 @@ def _free_port():
 def _worker(rank, world, ports, inp, out, dispatch, q):
     from ccsmeth_amd.call_mods import call_mods
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[0]),
-                      **({"CCSM_BOARD_PORT": str(ports[1])} if dispatch == "static" else {}))
+                      **({"CCSM_BOARD_PORT": str(ports[1])} if dispatch == "static" else {}))     # both ways of choosing the store's port
     sys.argv = list(ARGV)
     res = call_mods(_args(inp, out, dispatch), log=open(os.devnull, "w"), pipe=StubPipe())
     q.put((rank, res))
@@ -110,23 +109,27 @@ def test_eight_ranks_equal_single_process(bam, dispatch, monkeypatch):
     r0 = res[0]
     assert (r0["reads"], r0["tagged"], r0["failed"]) == (one["reads"], one["tagged"], one["failed"])
     assert _payload(r0["output"]) == _payload(one["output"])              # every record, tag and probability byte
-    n_batches = -(-203 // 10)
-    assert sum(r0["rank_batches"]) == n_batches
+    # the index came from the writers' run tables in both runs: equal to each other and to a fresh pass over the stitched file
+    from ccsmeth_amd import bamnative
+    assert open(r0["output"] + ".bai", "rb").read() == open(one["output"] + ".bai", "rb").read()
+    ok, n = bamnative.index_build(r0["output"], r0["output"] + ".check.bai", threads=2)
+    assert ok and n == 203 and open(r0["output"] + ".check.bai", "rb").read() == open(r0["output"] + ".bai", "rb").read()
+    chunk = int(0.08 * (1 << 20))
+    n_chunks = -(-os.path.getsize(inp) // chunk)
+    assert n_chunks > 30 and 0 < sum(r0["rank_chunks"]) <= n_chunks
     total = len(_payload(inp))                                             # inflated size of the input
-    block = 65536                                                          # a range starts and ends inside BGZF blocks: <= one extra block each side
+    slack = 2 * 65536 + 2 * 6000 * 6                                       # per chunk: a block either side + the record that overhangs
     shares = r0["rank_inflated_bytes"]
-    assert sum(shares) <= total + n_batches * 2 * block                    # the workers together inflate the file once
-    assert r0["scan_inflated_bytes"] <= total + block                      # the scan: one pass
+    assert total * 0.99 <= sum(shares) <= total + n_chunks * slack        # the ranks together inflate the file once; nobody scans
     if dispatch == "static":
-        mine = [len(shard_indices(n_batches, r, world)) for r in range(world)]
-        assert r0["rank_batches"] == mine
-        for r in range(world):                                             # a rank's share of the file (3 of 21 batches ~ 1/8) + epsilon
-            assert shares[r] <= total * mine[r] / n_batches * 1.1 + mine[r] * 2 * block
+        mine = [len(shard_indices(n_chunks, r, world)) for r in range(world)]
+        for r in range(world):                                             # a rank's share of the file + epsilon
+            assert shares[r] <= total * mine[r] / n_chunks * 1.25 + mine[r] * slack
 
 
 def test_two_ranks_many_small_batches_per_block(tmp_path, monkeypatch):
-    """Hole-batches much smaller than a BGZF block (several per block, claimed faster than the scan publishes them): the claimers block
-    on the board while the scan is still publishing — on its own connection, or nobody moves."""
+    """Reads much smaller than a BGZF block and chunks of a few hundred bytes: most chunks hold no record start, the rest a handful of
+    records that end in later chunks' blocks."""
     from ccsmeth_amd import bamio
     from ccsmeth_amd.call_mods import build_parser, call_mods
     rng = np.random.default_rng(77)
@@ -143,7 +146,8 @@ def test_two_ranks_many_small_batches_per_block(tmp_path, monkeypatch):
     monkeypatch.setattr(sys, "argv", list(ARGV))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
-    mk = lambda out: build_parser().parse_args(["-i", inp, "-m", "x", "-o", out, "--holes_batch", "3", "--threads", "2", "--no_sort"])  # noqa: E731
+    mk = lambda out: build_parser().parse_args(["-i", inp, "-m", "x", "-o", out, "--holes_batch", "3", "--threads", "2", "--no_sort",  # noqa: E731
+                                                "--chunk_mb", "0.0005"])
     one = call_mods(mk(str(tmp_path / "one")), log=open(os.devnull, "w"), pipe=StubPipe())
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -156,14 +160,14 @@ def test_two_ranks_many_small_batches_per_block(tmp_path, monkeypatch):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert _payload(res[0]["output"]) == _payload(one["output"])
-    assert sum(res[0]["rank_batches"]) == 8 and res[0]["sites"] == one["sites"]
+    assert sum(res[0]["rank_chunks"]) >= 2 and res[0]["sites"] == one["sites"] and res[0]["reads"] == 23
 
 
 def _worker_small(rank, world, ports, inp, out, q):
     from ccsmeth_amd.call_mods import build_parser, call_mods
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[0]))
     sys.argv = list(ARGV)
-    a = build_parser().parse_args(["-i", inp, "-m", "x", "-o", out, "--holes_batch", "3", "--threads", "2", "--no_sort"])
+    a = build_parser().parse_args(["-i", inp, "-m", "x", "-o", out, "--holes_batch", "3", "--threads", "2", "--no_sort", "--chunk_mb", "0.0005"])
     q.put((rank, call_mods(a, log=open(os.devnull, "w"), pipe=StubPipe())))
 
 
