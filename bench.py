@@ -243,6 +243,54 @@ def extras(weights, dm, dev, pool, grp):
                     "roofline_frac": ach / PEAK_F16_MFMA, "launch_ms": float(np.mean(kt[1:3])), "mfma_passes_per_flop": ARITH[prec][2]}
         return run
 
+    def trained():
+        # What a user's checkpoint gets: one deterministic checkpoint trained HERE (seed 41, 960 steps of libccsm_train at batch 512 on
+        # a learnable synthetic labelling, ~6 s), served in whatever arithmetic ccsm_create's probe selects for it; its rate on the
+        # benchmark's workload, and its probabilities against the C oracle on 8192 fresh sites (h0 pinned).
+        from ccsmeth_amd.models import DeviceModel
+        from ccsmeth_amd.train import Trainer
+        from ccsmeth_amd.utils import synth
+        from oracle import c_oracle
+        n, steps_t, wseed = 512, 960, 41
+        tpool = synth.synth_sites(n * 8, 42)
+        lab = lambda q: (q["ipd1"][:, 10] + q["ipd2"][:, 10] > 0).astype(np.int64)  # noqa: E731
+        t0 = time.perf_counter()
+        tr = Trainer(synth.synth_weights(wseed), device=dev.index, max_sites=n)
+        loss = float("nan")
+        for k in range(steps_t):
+            i = (k % 8) * n
+            q = {key: v[i:i + n] for key, v in tpool.items()}
+            loss, _ = tr.forward_backward(q, lab(q), h0=None, dropout_rate=0.5, seed=wseed, step=k)
+            tr.step(1e-3)
+        wt = tr.state_dict()
+        tr.close()
+        t_train = time.perf_counter() - t0
+        dmt = DeviceModel(wt, device=dev.index, precision=0)
+        r = Runner(dmt, pool, dev, grp, 0)
+        steps = 4 * grp
+        dt, _, _, _ = timed(r, steps, grp, fence)
+        kt, _ = r.kernel_times()
+        r.close()
+        m = 8192
+        sv = synth.synth_sites(m, 143)
+        h1, h2 = synth.synth_h0(m, 144)
+        ws = dmt.workspace(m)
+        _, gpu = ws.forward_host(sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"], h0=(h1, h2))
+        ws.close()
+        _, ref = c_oracle.forward(wt, sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"], h1, h2,
+                                  threads=c_oracle.usable_threads())
+        d = np.abs(gpu - ref)[:, 1]
+        res = {"value": steps * BATCH / dt, "unit": "sites/s", "arithmetic_selected": {3: "split3", 4: "split-mx", 5: "hybrid"}.get(dmt.precision, dmt.precision),
+               "probe": {"split_mx_max": dmt.probe_error, "split_mx_tail_gt_1e-5": dmt.probe_tail, "hybrid_max": dmt.probe_error_hybrid,
+                         "hybrid_tail_gt_1e-5": dmt.probe_tail_hybrid},
+               "launch_ms": float(np.mean(kt[1:3])), "roofline_frac": 2.0 * MAC_GRU12 * BATCH * grp / (float(np.mean(kt[1:3])) * 1e-3) / PEAK_F16_MFMA,
+               "max_abs_dprob_vs_oracle": float(d.max()), "sites_checked": m, "sites_beyond_1e-5": int((d > 1e-5).sum()), "sites_beyond_5e-5": int((d > 5e-5).sum()),
+               "frac_called_methylated": float((ref[:, 1] > 0.5).mean()), "train": {"steps": steps_t, "batch": n, "seed": wseed, "last_loss": float(loss), "seconds": t_train},
+               "what": "a checkpoint trained in this process by libccsm_train, served through ccsm_create(precision 0): the arithmetic the probe selects, "
+                       "its rate on the benchmark's workload, max |dprob| against oracle/attbigru2s_oracle.c over 8192 sites (explicit h0)"}
+        dmt.close()
+        return res
+
     def pcie():
         # features in host memory every step, logits/probs back to host memory: ccsm_submit_host / ccsm_wait_host on two workspaces
         import ctypes as C
@@ -346,6 +394,7 @@ def extras(weights, dm, dev, pool, grp):
     for prec, name in ((5, "hybrid"), (3, "split3"), (4, "split-mx")):     # the arithmetics the probe did not select for these weights
         if prec != dm.precision:
             leg(name, other_arithmetic(prec))
+    leg("trained", trained)
     leg("torch_cpu_path", torch_cpu)
     leg("pcie_inclusive", pcie)
     leg("call_mods_end_to_end", call_mods_e2e)

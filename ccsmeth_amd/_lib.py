@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("CCSM_LIB_PATH") or os.path.join(_HERE, "lib", "libccs
 SEQ_LEN, HIDDEN, LAYERS, CLASSES = 21, 256, 3, 2
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = range(6)
 H0_EXPLICIT, H0_ZERO, H0_DEVICE_RNG = 0, 1, 2
-PRECISION_SPLIT3, PRECISION_SPLIT2, PRECISION_FP16 = 3, 2, 1
+PRECISION_SPLIT3, PRECISION_SPLIT_MX, PRECISION_HYBRID = 3, 4, 5      # ccsm_precision (include/ccsm.h); 0 = chosen by ccsm_create's probe
 
 _FP = C.POINTER(C.c_float)
 

@@ -262,6 +262,9 @@ def call_mods(args, log=sys.stderr, pipe=None):
         raise ValueError("--input_file does not exist!")              # :486-488
     _check_scope(args)
     from collections import OrderedDict
+    if pipe is None and os.environ.get("CCSM_NULL_MODEL") == "2":      # diagnostics: the host side alone (tools/host_feed_probe.py)
+        from .pipeline import HostNullPipe
+        pipe = HostNullPipe()
     if pipe is None:
         from .models import ModelAttRNN
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:

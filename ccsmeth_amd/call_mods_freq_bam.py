@@ -417,14 +417,15 @@ def call_mods_frequency_from_bamfile(args, log=sys.stderr, model=None):
     paths = [args.output + ".{}.{}.{}".format(args.call_mode, w, fext) for w in ("all", "hp1", "hp2")]
     spool_dir = tempfile.mkdtemp(prefix="ccsm_freqb_", dir=out_dir)
     spooled = {}
+    current = None                       # reference id of the run of records being collected
 
     def finish(t, names):
         nonlocal n_sites
         done.add(t)
         parts = rows_of.pop(t, None)
-        name = names[t]
-        if parts is None or name not in regions_of:
+        if parts is None or not (0 <= t < len(names)) or names[t] not in regions_of:
             return
+        name = names[t]
         rows = tuple(np.concatenate([p[k] for p in parts]) for k in range(4))
         beds = _bed_of_contig(name, dnacontigs[name], regions_of[name], rows, motifs_filter, args, tables, model)
         n_sites += len(beds[0])
@@ -433,7 +434,7 @@ def call_mods_frequency_from_bamfile(args, log=sys.stderr, model=None):
             with open(fp, "w") as wf:
                 for item in bed:
                     _write_one_line(item, wf, args.bed)
-        spooled[name] = files
+        spooled[t] = files
 
     try:
         with bamnative.NativeBamReader(args.input_bam, threads=max(1, args.threads)) as rd:
@@ -455,23 +456,28 @@ def call_mods_frequency_from_bamfile(args, log=sys.stderr, model=None):
                 n_rec += seen
                 n_used += used
                 if len(tid):
-                    uniq = np.unique(tid).tolist()
-                    for t in uniq:
+                    # the rows come in record order: runs of equal reference id.  A contig whose run has ended must not come back
+                    # (its bed lines are already written): checked row by row, so the verdict does not depend on where the batches
+                    # of 4096 records happen to be cut
+                    cut = np.flatnonzero(np.diff(tid)) + 1
+                    starts = np.concatenate(([0], cut))
+                    ends = np.concatenate((cut, [len(tid)]))
+                    for a, e in zip(starts.tolist(), ends.tolist()):
+                        t = int(tid[a])
+                        if current is not None and t != current:
+                            finish(current, names)
                         if t in done:
-                            raise ValueError("--input_bam is not coordinate-sorted (records of %s after a later contig): sort and index it first, "
-                                             "as the reference's region fetches require" % names[t])
+                            raise ValueError("--input_bam is not coordinate-sorted (records of %s after those of a later contig): sort and index "
+                                             "it first (samtools sort / call_mods without --no_sort), as the reference's region fetches require"
+                                             % (names[t] if 0 <= t < len(names) else t))
+                        current = t
                         if 0 <= t < len(names) and names[t] in regions_of:
-                            m = tid == t
-                            rows_of.setdefault(t, []).append((pos[m], strand[m], ml[m], hap[m]))
-                    last = int(tid[-1])
-                    for t in [t for t in list(rows_of) if t < last] + [t for t in uniq if t < last and t not in rows_of]:
-                        if t not in done:
-                            finish(t, names)
+                            rows_of.setdefault(t, []).append((pos[a:e], strand[a:e], ml[a:e], hap[a:e]))
             for t in sorted(rows_of):
                 finish(t, names)
         files = [open(p, "w") for p in paths]
-        for name in sorted(spooled):
-            for wf, fp in zip(files, spooled[name]):
+        for _, t in sorted((names[t], t) for t in spooled):      # by contig name, as before; duplicate @SQ names keep both contigs
+            for wf, fp in zip(files, spooled[t]):
                 with open(fp, "r") as rf:
                     shutil.copyfileobj(rf, wf)
         for wf in files:
@@ -601,7 +607,9 @@ def build_freqb_parser():
     import argparse
     p = argparse.ArgumentParser(prog="ccsmeth_amd call_freqb", description="call modification frequencies from an aligned modbam")
     p.add_argument('--threads', type=int, default=5)
-    p.add_argument('--input_bam', type=str, required=True)
+    p.add_argument('--input_bam', type=str, required=True,
+                   help='aligned modbam with MM/ML tags, coordinate-sorted (every contig\'s records together: the file is streamed once, contig by '
+                        'contig; an unsorted file is rejected)')
     p.add_argument('--ref', type=str, required=True)
     p.add_argument('--contigs', type=str, default=None)
     p.add_argument('--chunk_len', type=int, default=500000)

@@ -404,6 +404,7 @@ struct ccsm_trainer {
     int seq_mode = -1;                 // recurrent part: 1 = one fused launch per layer and direction (ccsm_train_seq.hip), 0 = one rocBLAS
                                        // product + gate kernel per timestep, -1 = by batch size (fused from 768 rows up: measured 4.13 vs
                                        // 3.92 ms per step at 256 sites, 5.73 vs 6.40 at 512, 13.6 vs 18.4 at 2048); CCSM_TRAIN_STEPWISE=0|1 forces
+    long fused_fallbacks = 0;          // backward passes repeated stepwise because the fused kernel flagged saturation
     bool stepwise_for(int M) const { return seq_mode == 0 || (seq_mode < 0 && M < 768); }
 };
 
@@ -548,7 +549,7 @@ ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, bool have_la
     att_score_kernel<<<blocks((int64_t)T * M, 4), 256, 0, st>>>(t->KS, t->q, P + kOff.va, t->e, M);
     att_softmax_kernel<<<blocks(M), 256, 0, st>>>(t->e, t->a, M);
     att_context_kernel<<<blocks((int64_t)M * H2), 256, 0, st>>>(t->a, O2, t->c, M);
-    HIPCHK(hipMemsetAsync(t->loss, 0, sizeof(float), st));
+    HIPCHK(hipMemsetAsync(t->loss, 0, 2 * sizeof(float), st));      // [loss sum | saturation flag of the fused backward kernels]
     fc_loss_kernel<<<blocks(N, 4), 256, 0, st>>>(t->c, P + kOff.fcw, P + kOff.fcb, have_labels ? t->labels : nullptr, t->ctl,
                                                  drop ? rate : 0.f, t->feat, t->logits, train ? t->dlogits : nullptr, t->loss, N);
     HIPCHK(hipGetLastError());
@@ -567,7 +568,8 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
     if (!t->stepwise_for(M)) {     // all 21 steps in one launch (ccsm_train_seq.hip)
         gru_seq_bwd_kernel<<<(M + 31) / 32, 512, kSbLds, st>>>(dO + d * H, t->out[l] + d * H, t->h0 + (size_t)(2 * l + d) * M * H,
                                                                t->whh_t_frag + (size_t)(2 * l + d) * kSqFragPerDir, t->sav[l][d][0], t->sav[l][d][1],
-                                                               t->sav[l][d][2], t->sav[l][d][3], dgi, dgh, Gd + kOff.b_ih[l][d], Gd + kOff.b_hh[l][d], M, d);
+                                                               t->sav[l][d][2], t->sav[l][d][3], dgi, dgh, Gd + kOff.b_ih[l][d], Gd + kOff.b_hh[l][d], M, d,
+                                                               reinterpret_cast<int*>(t->loss + 1));
         HIPCHK(hipGetLastError());
     } else {
         HIPCHK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)M * H, st));
@@ -721,7 +723,7 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
     }
     TRY(dalloc(&t->hn, M * H2)); TRY(dalloc(&t->q, M * H)); TRY(dalloc(&t->KS, T * M * H)); TRY(dalloc(&t->e, T * M)); TRY(dalloc(&t->a, T * M));
     TRY(dalloc(&t->c, M * H2)); TRY(dalloc(&t->feat, (size_t)max_sites * 2 * H2)); TRY(dalloc(&t->logits, (size_t)max_sites * NC));
-    TRY(dalloc(&t->dlogits, (size_t)max_sites * NC)); TRY(dalloc(&t->loss, 1)); TRY(dalloc(&t->ctl, 1));
+    TRY(dalloc(&t->dlogits, (size_t)max_sites * NC)); TRY(dalloc(&t->loss, 2)); TRY(dalloc(&t->ctl, 1));
     { const char* e = std::getenv("CCSM_TRAIN_SP20"); if (e) t->sp20 = std::atoi(e); e = std::getenv("CCSM_TRAIN_SP21"); if (e) t->sp21 = std::atoi(e);
       if (t->sp20 < 0 || (t->sp20 && (T - 1) % t->sp20)) t->sp20 = 0;
       if (t->sp21 < 0 || (t->sp21 && T % t->sp21)) t->sp21 = 0; }
@@ -838,9 +840,24 @@ static ccsm_status run(ccsm_trainer* t, int n_sites, const ccsm_batch* batch, co
         HIPCHK(hipGraphLaunch(g->exec, t->stream));
     }
     float lsum = 0.f;
-    HIPCHK(hipMemcpyAsync(&lsum, t->loss, sizeof(float), hipMemcpyDeviceToHost, t->stream));
+    float lbuf[2] = {0.f, 0.f};
+    HIPCHK(hipMemcpyAsync(lbuf, t->loss, 2 * sizeof(float), hipMemcpyDeviceToHost, t->stream));
     if (logits) HIPCHK(hipMemcpyAsync(logits, t->logits, sizeof(float) * (size_t)n_sites * NC, hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
+    lsum = lbuf[0];
+    int sat = 0;
+    std::memcpy(&sat, &lbuf[1], sizeof(int));
+    if (train && sat && !t->stepwise_for(2 * n_sites)) {
+        // a gate gradient left the range of the fused kernels' scaled fp16 operands (|.| > 14.6: e.g. a sum-reduced loss or a very
+        // large pos_weight): this step's backward pass is repeated step by step in fp32; the saved activations are the same
+        const int keep = t->seq_mode;
+        t->seq_mode = 0;
+        s = backward(t, n_sites, rate);
+        t->seq_mode = keep;
+        if (s != CCSM_OK) return s;
+        HIPCHK(hipStreamSynchronize(t->stream));
+        t->fused_fallbacks += 1;
+    }
     if (loss) *loss = labels ? (float)(lsum / wsum) : 0.f;
     return CCSM_OK;
 }
@@ -894,6 +911,8 @@ ccsm_status ccsm_train_set_params(ccsm_trainer* t, const float* host_flat) {
     HIPCHK(hipMemcpy(t->params, host_flat, sizeof(float) * kOff.total, hipMemcpyHostToDevice));
     return CCSM_OK;
 }
+long ccsm_train_fused_fallbacks(const ccsm_trainer* t) { return t ? t->fused_fallbacks : 0; }
+
 ccsm_status ccsm_train_get_grads(ccsm_trainer* t, float* host_flat) {
     if (!t || !host_flat) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");
     HIPCHK(hipSetDevice(t->device));

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
                                                             const float* __restrict__ R, const float* __restrict__ Z,
                                                             const float* __restrict__ Nn, const float* __restrict__ HP,
                                                             float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ db_ih,
-                                                            float* __restrict__ db_hh, int M, int reverse) {
+                                                            float* __restrict__ db_hh, int M, int reverse, int* __restrict__ saturated) {
     extern __shared__ __attribute__((aligned(16))) _Float16 sb_lds[];
     _Float16* t_hi = sb_lds;
     _Float16* t_lo = sb_lds + 32 * kSbRowHalfs;
@@ -280,11 +280,15 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
                 }
                 const int row = 4 * hh + c;
                 // gradients are small (a mean over the batch): scaled by 2^12 into fp16's normal range before the split (a value of 1e-7
-                // would otherwise be a subnormal hi with no lo), saturated instead of overflowing; the product is scaled back
+                // would otherwise be a subnormal hi with no lo), saturated instead of overflowing (and flagged); the product is scaled back
                 const float v3[3] = {dr, dz, dnr};
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
-                    const float v = fminf(fmaxf(v3[g] * kSbScale, -60000.f), 60000.f);
+                    const float vs = v3[g] * kSbScale;
+                    const float v = fminf(fmaxf(vs, -60000.f), 60000.f);
+                    // |gate gradient| > 14.6: the recurrent product would silently lose it.  The host repeats the backward pass step by
+                    // step in fp32 (rocBLAS) when this flag is up (NaNs raise it too)
+                    if (!(fabsf(vs) <= 60000.f) && c < rows_left) *saturated = 1;
                     const _Float16 x = (_Float16)v;
                     t_hi[row * kSbRowHalfs + g * H + u] = x;
                     t_lo[row * kSbRowHalfs + g * H + u] = (_Float16)(v - (float)x);

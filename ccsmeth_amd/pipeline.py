@@ -255,6 +255,34 @@ class CallModsPipeline:
         return out, failed
 
 
+class HostNullPipe:
+    """CCSM_NULL_MODEL=2 (diagnostics, tools/host_feed_probe.py): CallModsPipeline's native-batch interface without any GPU work - the
+    kept CG sites from a host scan of the forward sequences, every probability 0.5.  What is left of call_mods is exactly its host
+    side (BGZF inflate, record parse, MM/ML encoding, BGZF deflate, hand-out, stitching, index), with no GPU shared between the
+    ranks of a probe that runs them all on one device."""
+
+    def run_native_batch(self, batch, skip=None):
+        nr = batch.n_reads
+        cnt = np.where(batch.length > 0, batch.n_sites, 0).astype(np.int64)
+        if skip is not None:
+            cnt[np.asarray(skip, bool)] = 0
+        first = np.zeros(nr + 1, np.int32)
+        np.cumsum(cnt, out=first[1:])
+        seq = batch.seq
+        hit = np.flatnonzero((seq[:-1] == 67) & (seq[1:] == 71)) if len(seq) > 1 else np.empty(0, np.int64)
+        rid = np.searchsorted(batch.offset, hit, side="right") - 1          # reads are laid out back to back
+        loc = hit - batch.offset[rid]
+        n = batch.length[rid].astype(np.int64)
+        keep = (cnt[rid] > 0) & (loc + 1 < n) & (loc >= 10) & (loc < n - 10) & (n - 2 - loc >= 10) & (n - 2 - loc < n - 10)
+        locs = loc[keep].astype(np.int32)
+        if len(locs) != int(first[-1]):
+            raise RuntimeError("host scan and reader site counts disagree")
+        return first, locs, np.full(len(locs), 0.5, np.float32), (cnt > 0).astype(np.uint8), int(nr - np.count_nonzero(cnt > 0))
+
+    def close(self):
+        pass
+
+
 def _tags_for_read(read, locs, probs):
     """call_modifications.py:230-263: sort by loc, MM over the forward sequence, ML = floor(p*256); a failed assertion
     leaves the read untagged (mm_flag 0)."""

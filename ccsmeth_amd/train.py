@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCSM_TRAIN_LIB_PATH") or os.path.join(_HERE, "lib", "libccsm_train.so")   # the variable: A/B builds (tools/)
 EXPORTS = ("ccsm_train_last_error", "ccsm_train_num_params", "ccsm_train_param_offsets", "ccsm_train_create", "ccsm_train_destroy",
            "ccsm_train_forward_backward", "ccsm_train_eval", "ccsm_train_step", "ccsm_train_grad_ptr", "ccsm_train_get_params",
-           "ccsm_train_set_params", "ccsm_train_get_grads")
+           "ccsm_train_set_params", "ccsm_train_get_grads", "ccsm_train_fused_fallbacks")
 
 PARAM_NAMES = ["embed.weight"] + [f"rnn.{k}_l{l}{sfx}" for l in range(3) for sfx in ("", "_reverse")
                                   for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] + \
@@ -61,6 +61,8 @@ def load():
     lib.ccsm_train_get_params.argtypes = [vp, vp]
     lib.ccsm_train_set_params.argtypes = [vp, vp]
     lib.ccsm_train_get_grads.argtypes = [vp, vp]
+    lib.ccsm_train_fused_fallbacks.argtypes = [vp]
+    lib.ccsm_train_fused_fallbacks.restype = C.c_long
     _tl = lib
     return lib
 
@@ -206,6 +208,11 @@ class Trainer:
         flat = np.empty(self.num_params, np.float32)
         _check(self._lib.ccsm_train_get_params(self.handle, flat.ctypes.data))
         return self._split(flat)
+
+    @property
+    def fused_fallbacks(self):
+        """backward passes repeated step by step because a gate gradient left the fused kernels' range (include/ccsm_train.h)"""
+        return int(self._lib.ccsm_train_fused_fallbacks(self.handle))
 
     def grads(self):
         flat = np.empty(self.num_params, np.float32)

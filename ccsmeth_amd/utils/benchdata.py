@@ -25,6 +25,31 @@ def write_synthetic_hifi_bam(path, n_reads, read_len, cpg=0.012, seed=3):
     return time.time() - t0, os.path.getsize(path)
 
 
+def replicate_bam(src, dst, times, threads=8):
+    """A `times` x larger copy of an unaligned BAM for throughput runs: the records are rewritten once behind a block-aligned
+    header (native reader -> native writer, nothing changed), then that run of BGZF blocks is appended `times` times (read names
+    repeat).  Returns the size of dst."""
+    from .. import bamnative as bn
+    tmp = dst + ".once"
+    with bn.NativeBamReader(src, threads=threads) as rd, bn.NativeBamWriter(tmp, rd.header_text, rd.raw_refs, rd.n_ref, threads=threads, level=1) as w:
+        header_end = w.flush()
+        while True:
+            b = rd.next_batch(512)
+            if b is None:
+                break
+            w.write_batch(b, rm_pulse=False)
+            b.close()
+        end = w.flush()
+    with open(tmp, "rb") as fh, open(dst, "wb") as out:
+        out.write(fh.read(header_end))
+        body = fh.read(end - header_end)
+        for _ in range(times):
+            out.write(body)
+        out.write(bn.BGZF_EOF)
+    os.remove(tmp)
+    return os.path.getsize(dst)
+
+
 def call_mods_end_to_end(n_reads=4000, read_len=15000):
     """`call_mods --io native` on a synthetic BAM (BGZF inflate, parse, feature extraction + model on the GPU, MM/ML, BGZF deflate);
     second of two runs (the first pays page-ins and library loads)."""

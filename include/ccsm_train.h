@@ -55,6 +55,11 @@ ccsm_status ccsm_train_eval(ccsm_trainer* t, int n_sites, const ccsm_batch* batc
  * max_norm <= 0 skips the clipping.  *grad_norm = the total norm before clipping. */
 ccsm_status ccsm_train_step(ccsm_trainer* t, float lr, float beta1, float beta2, float eps, float max_norm, float* grad_norm);
 
+/* The fused recurrent backward kernels (batches of >= 384 sites) carry the gate gradients as scaled fp16 pairs, exact up to
+ * |gradient| = 14.6; a step in which one exceeds that (a sum-reduced loss, an extreme pos_weight) is detected on the device and its
+ * backward pass is repeated step by step in fp32 before ccsm_train_forward_backward returns.  How often that has happened: */
+long ccsm_train_fused_fallbacks(const ccsm_trainer* t);
+
 /* Flat buffers: device pointer of the gradients (for the caller's all-reduce), and host copies in / out. */
 ccsm_status ccsm_train_grad_ptr(ccsm_trainer* t, float** d_grads);
 ccsm_status ccsm_train_get_params(ccsm_trainer* t, float* host_flat);

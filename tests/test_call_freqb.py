@@ -194,6 +194,21 @@ def test_errors(tmp_path):
     a = _args("count_default", str(tmp_path / "o"), contigs="nope")
     with pytest.raises(ValueError, match="not in --ref"):
         fb.call_mods_frequency_from_bamfile(a)
+    # a modbam whose contigs come back after a later one (e.g. call_mods --no_sort output of shuffled reads) is rejected whatever the
+    # record batching: here the whole file is one batch, and the out-of-place record sits in the middle of it
+    with bamio.BamReader(BAM) as rd:
+        hdr, refs, recs = rd.header_text, rd.references, list(rd)
+    tids = sorted({r.ref_id for r in recs if r.ref_id >= 0})
+    if len(tids) >= 2:
+        first = [r for r in recs if r.ref_id == tids[0]]
+        second = [r for r in recs if r.ref_id == tids[1]]
+        shuffled = str(tmp_path / "shuffled.bam")
+        with bamio.BamWriter(shuffled, hdr, refs) as w:
+            for r in first[:-1] + second[:3] + first[-1:] + second[3:]:
+                w.write(r)
+        a = _args("count_default", str(tmp_path / "o"), input_bam=shuffled)
+        with pytest.raises(ValueError, match="not coordinate-sorted"):
+            fb.call_mods_frequency_from_bamfile(a, log=open(os.devnull, "w"))
 
 
 # ---- the per-record projection against a pure-Python restatement (covers what the goldens' generator cannot: several

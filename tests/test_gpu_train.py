@@ -148,6 +148,79 @@ def test_dropout_and_device_rng_h0_train_and_reduce_loss():
     assert 0.05 < float((ref[:, 1] > 0.5).mean()) < 0.95                # a model that actually discriminates
 
 
+@pytest.mark.parametrize("wseed,steps", [(41, 960), (5, 320)])
+def test_trained_checkpoint_tail_over_8192_sites(wseed, steps):
+    """The tail statistics that decide what a TRAINED checkpoint is served with, in the suite instead of a diagnostic log:
+    a checkpoint trained here goes through ccsm_create's probe, and whatever arithmetic the probe selects must keep all of 8192 fresh
+    sites within the north-star bar (1e-4) of the C oracle - and within the selection rule's own bound (none beyond 5e-5, at most
+    1 % beyond 1e-5: twice the probe's 0.5 % to allow for the other sample).  split-mx forced on the same checkpoint is reported
+    beside it: it is the arithmetic the probe exists to reject (its tail is what `bench.py` extras.trained.probe shows)."""
+    from ccsmeth_amd.models import DeviceModel
+    from ccsmeth_amd.train import Trainer
+    from oracle import c_oracle
+    n = 512
+    pool = synth.synth_sites(n * 8, 42)
+    lab = lambda q: (q["ipd1"][:, 10] + q["ipd2"][:, 10] > 0).astype(np.int64)  # noqa: E731
+    tr = Trainer(synth.synth_weights(wseed), device=0, max_sites=n)
+    for k in range(steps):
+        i = (k % 8) * n
+        q = {key: v[i:i + n] for key, v in pool.items()}
+        tr.forward_backward(q, lab(q), h0=None, dropout_rate=0.5, seed=wseed, step=k)
+        tr.step(1e-3)
+    wt = tr.state_dict()
+    tr.close()
+    m = 8192
+    sv = synth.synth_sites(m, 143)
+    h1, h2 = synth.synth_h0(m, 144)
+    args = (sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"])
+    _, ref = c_oracle.forward(wt, *args, h1, h2, threads=c_oracle.usable_threads())
+    assert 0.05 < float((ref[:, 1] > 0.5).mean()) < 0.95                # a model that discriminates
+    res = {}
+    for prec in (0, 4):
+        dm = DeviceModel(wt, device=0, precision=prec)
+        ws = dm.workspace(m)
+        _, probs = ws.forward_host(*args, h0=(h1, h2))
+        ws.close()
+        d = np.abs(probs - ref)[:, 1]
+        res[prec] = (dm.precision, float(d.max()), int((d > 1e-5).sum()), int((d > 5e-5).sum()))
+        dm.close()
+    print("trained checkpoint (seed %d, %d steps): selected %d max %.2e (>1e-5: %d, >5e-5: %d) | split-mx forced max %.2e (>1e-5: %d, >5e-5: %d)"
+          % ((wseed, steps) + res[0] + res[4][1:]))
+    sel, mx, n1, n5 = res[0]
+    assert mx < 1e-4 and n5 == 0 and n1 <= m // 100, res
+    if sel == 3:
+        assert mx < 2e-6
+
+
+def test_large_gate_gradients_fall_back_to_the_stepwise_backward(monkeypatch):
+    """The fused backward kernel's scaled-fp16 operand saturates above |gate gradient| = 14.6 (a pos_weight of 1e6 gets there with a
+    mean loss): the step is flagged on the device and its backward pass repeated step by step, so the gradients equal those of a
+    trainer that runs stepwise throughout; ordinary gradients never take the detour."""
+    from ccsmeth_amd.train import Trainer
+    n = 512                                              # 1024 strand rows: the fused path
+    sites = synth.synth_sites(n, 61)
+    labels = (np.arange(n) % 97 == 0).astype(np.int64)   # a few positives carry the whole weighted loss
+    h1, h2 = synth.synth_h0(n, 62)
+    w = synth.synth_weights(9)
+    out = {}
+    for mode in ("fused", "stepwise"):
+        if mode == "stepwise":
+            monkeypatch.setenv("CCSM_TRAIN_STEPWISE", "1")
+        tr = Trainer(w, device=0, max_sites=n)
+        l_small, _ = tr.forward_backward(sites, labels, h0=(h1, h2), pos_weight=2.0)
+        g_small = tr.grads()
+        fb0 = tr.fused_fallbacks
+        l_big, _ = tr.forward_backward(sites, labels, h0=(h1, h2), pos_weight=1e6)
+        out[mode] = (g_small, tr.grads(), fb0, tr.fused_fallbacks, l_small, l_big)
+        tr.close()
+    assert out["fused"][2] == 0 and out["stepwise"][3] == 0
+    if out["fused"][3] == 0:
+        pytest.skip("pos_weight 1e6 did not saturate the fused kernel on this initialisation")
+    for k in out["fused"][1]:
+        a, b = out["fused"][1][k], out["stepwise"][1][k]
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-6 * np.abs(b).max()), k
+
+
 def test_device_drawn_initial_states_advance_by_sites():
     """The h0 generator's counter is the running SITE index (trainm: step * batch_size): site j of a batch drawn at offset o + 1
     gets the window site j + 1 gets at offset o, and two consecutive steps of N sites share no window at all (the defect this

@@ -1,13 +1,15 @@
 """What does the HOST side of multi-GPU `call_mods` sustain?  ("the host feature path, not xGMI, is the
 scaling limiter".)
 
-Runs `python -m ccsmeth_amd call_mods` on a synthetic HiFi BAM with 1 / 2 / 4 / 8 ranks, every rank on the ONE GPU of this box, with
-CCSM_NULL_MODEL=1: BGZF inflate, record parse, transfers, on-device feature extraction and initial states, result copies, MM/ML,
-BGZF deflate, stitching and indexing all run; only the BiGRU / attention launches are left out (their outputs are constants).  The
-rate that comes out is the ceiling the host pipeline puts on an N-GPU node with this many host cores; the same runs with the real model
-on one rank give the 1-GPU end-to-end rate beside it.
-    python tools/host_feed_probe.py            env: NREADS (16000), READ_LEN (15000), WORLDS ("1,2,4,8"), CORES (cgroup quota or cpu count),
-                                                    REAL ("1": also the real model at world 1), KEEP_INPUT=path (reuse / keep the BAM)"""
+Runs `python -m ccsmeth_amd call_mods` on a synthetic HiFi BAM with 1 / 2 / 4 / 8 ranks on this one-GPU box with the model left out:
+  CCSM_NULL_MODEL=2 ("host"): no GPU work at all - BGZF inflate, record parse, site scan, MM/ML, BGZF deflate, hand-out, stitching and
+                    indexing; the ceiling the host pipeline alone puts on an N-GPU node with this many host cores;
+  CCSM_NULL_MODEL=1 ("gpu-shared"): transfers, on-device feature extraction and initial states, result copies as well, only the
+                    BiGRU / attention launches left out - all ranks share the ONE GPU here, so its time slicing between N processes is
+                    in the figure (it would not be on N GPUs).
+The same run with the real model on one rank gives the 1-GPU end-to-end rate beside them.
+    python tools/host_feed_probe.py            env: NREADS (16000 generated), TIMES (6: the records are appended that often), READ_LEN (15000),
+                                                    WORLDS ("1,2,4,8"), CORES (cgroup quota or cpu count), MODES ("2,1"), REAL ("1")"""
 import json
 import os
 import resource
@@ -37,9 +39,15 @@ nreads, read_len = int(os.environ.get("NREADS", "16000")), int(os.environ.get("R
 inp = os.environ.get("KEEP_INPUT") or os.path.join(tmp, "hf_in.bam")
 ckpt = os.path.join(tmp, "hf.ckpt")
 cores = int(os.environ.get("CORES", "0")) or host_cores()
+times = int(os.environ.get("TIMES", "6"))
 if not os.path.exists(inp):
-    secs, size = benchdata.write_synthetic_hifi_bam(inp, nreads, read_len)
-    print("# input: %d reads x %d bases, %.2f GiB compressed, generated in %.0f s" % (nreads, read_len, size / 2 ** 30, secs))
+    base = inp + ".base"
+    secs, size = benchdata.write_synthetic_hifi_bam(base, nreads, read_len)
+    t0 = time.time()
+    size = benchdata.replicate_bam(base, inp, times, threads=min(cores, 16))
+    os.remove(base)
+    print("# input: %d reads x %d bases generated in %.0f s, their records %d times over = %d reads, %.2f GiB compressed (+%.0f s)"
+          % (nreads, read_len, secs, times, nreads * times, size / 2 ** 30, time.time() - t0))
 else:
     print("# input: %s, %.2f GiB compressed (reused)" % (inp, os.path.getsize(inp) / 2 ** 30))
 torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
@@ -60,7 +68,7 @@ def run(world, null_model, threads, extra=()):
     t0 = time.time()
     procs = []
     for r in range(world):
-        env = dict(os.environ, PYTHONPATH=ROOT, CCSM_CALLMODS_REPORT=rep, CCSM_NULL_MODEL="1" if null_model else "0")
+        env = dict(os.environ, PYTHONPATH=ROOT, CCSM_CALLMODS_REPORT=rep, CCSM_NULL_MODEL=str(null_model))
         if world > 1:
             env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
@@ -76,7 +84,7 @@ def run(world, null_model, threads, extra=()):
     work = max(d.get("rank_seconds_work", [d["seconds_work"]]))
     print("world %d %-10s threads/rank %2d | %8d sites | work %6.2f s = %6.2f M sites/s | stitch %5.2f s index %5.2f s (%.1f %% of the run) | "
           "whole run %6.2f s = %6.2f M sites/s | process wall %5.1f s, %6.1f CPU-s = %.2f CPU-s per M sites, %4.1f cores busy"
-          % (world, "null-model" if null_model else "real-model", threads, d["sites"], work, d["sites"] / work / 1e6, d["seconds_stitch"], d["seconds_index"],
+          % (world, {0: "real-model", 1: "gpu-shared", 2: "host"}[null_model], threads, d["sites"], work, d["sites"] / work / 1e6, d["seconds_stitch"], d["seconds_index"],
              100.0 * (d["seconds_stitch"] + d["seconds_index"]) / d["seconds"], d["seconds"], d["sites"] / d["seconds"] / 1e6, wall, cpu, cpu / (d["sites"] / 1e6),
              cpu / wall), flush=True)
     for f in (out + ".modbam.bam", out + ".modbam.bam.bai"):
@@ -86,10 +94,11 @@ def run(world, null_model, threads, extra=()):
 
 
 worlds = [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]
-run(1, True, min(cores, 16))                      # warm the page cache and the libraries
+run(1, 2, min(cores, 16))                         # warm the page cache and the libraries
 if os.environ.get("REAL", "1") == "1":
-    run(1, False, min(cores, 16))
-for w in worlds:
-    run(w, True, max(2, cores // w))
+    run(1, 0, min(cores, 16))
+for mode in [int(m) for m in os.environ.get("MODES", "2,1").split(",")]:
+    for w in worlds:
+        run(w, mode, max(2, cores // w))
 if not os.environ.get("KEEP_INPUT"):
     os.remove(inp)
