@@ -6,158 +6,267 @@
 //   call_mods_freq_bam.py:265-305     _cal_modfreq_in_aggregate_mode: zero-padded windows, pad positions first-1000 /
 //                                     last+1000, batches of 1024, h0 = torch.randn(2, B, 32) from the stream seeded per
 //                                     region (call_mods_freq_bam.py:313)
-// 275 KFLOP and 88 B per site: far below MFMA tile sizes (K = 21 / 32 / 64), so this is an fp32 VALU kernel:
-// one wavefront per site, lane = direction * 32 + hidden unit, GRU weights resident in VGPRs (168 per lane) across the
-// sites a wave walks, windows built on the fly from the (M,20) histogram table (never materialising the reference's
-// (M,11,21) tensor), hidden state and the 11x64 layer output in LDS, wave-level reductions for the attention scores.
+//
+// Round 3: the products run on the matrix cores.  H = 32 is exactly one 32x32 MFMA tile, so a wave takes a TILE of 32 consecutive
+// sites as the MFMA's column dimension and computes, per timestep and direction, G^T[unit][site] = W[unit][k] X^T[k][site] for the
+// three gates (the transposed form of the attbigru2s kernels: an accumulator lane holds 16 hidden units of ONE site, and turning the
+// new state into the next step's B operand is two half-wave exchanges).  Arithmetic: fp32 operands as fp16 hi + lo pairs, three
+// v_mfma_f32_32x32x16_f16 passes (hi*hi + lo*hi + hi*lo), fp32 accumulation - fp32-class, like CCSM_PRECISION_SPLIT3.
+//   * the 20 histogram columns + a constant-1 column (whose weights are the biases) are K = 32 of the input part; the position
+//     feature (a distance in bases: unbounded, no fp16 operand) is a rank-1 fp32 update on the vector ALU;
+//   * a tile's 42 window rows are split into hi / lo halfs ONCE into wave-private LDS; timestep t of site n reads row n + t;
+//   * the layer output is never stored: the attention keys K_t = Ua out_t are accumulated into 11 register tiles as the steps
+//     produce out_t (both directions add into the same tile), and fc1 being linear, fc1 . context = sum_t a_t (fc1 . out_t) needs one
+//     scalar per (site, t).  The query needs both final states, so the scores are taken after the second direction;
+//   * weights live in LDS as MFMA A fragments (48 + 16 KiB per workgroup), packed on the host.
+// One wave per SIMD (the 11 key tiles + query + 4 gate accumulators are ~250 accumulator registers), four waves per workgroup.
+// 275 KFLOP and 88 B per site.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace ccsm_aggr {
 
-constexpr int L = 11, H = 32, NB = 20, F = 21, WAVES = 4;
+constexpr int L = 11, H = 32, NB = 20, F = 21, WAVES = 4, TILE = 32;
+constexpr int kXRows = TILE + L - 1;      // window rows of a tile: sites base-5 .. base+36
+constexpr int kXStride = 40;              // halfs per staged row: 32 + 8 of padding = 80 B, conflict-free 16-byte reads at one row per lane
+constexpr int kWFrags = 2 * 2 * 3 * 2 * 2;   // [dir][ih|hh][gate][k-block][hi|lo]
+constexpr int kAttFrags = 2 * 2 * 2 * 2;     // [ua|wa][fwd|bwd half][k-block][hi|lo]
+constexpr int kVecFloats = 2 * 128 + 32 + 64 + 1;   // [dir][wpos r|z|n, b_hn] | va | fcw | fcb
+constexpr size_t kLdsBytes = (size_t)(kWFrags + kAttFrags) * 1024 + ((kVecFloats * 4 + 15) / 16) * 16 + (size_t)WAVES * 2 * kXRows * kXStride * 2 +
+                             (size_t)WAVES * (kXRows + 2) * 8 + (size_t)WAVES * L * 64 * 4;
 
-__device__ __forceinline__ float sigmoid_a(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanh_a(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half2a __attribute__((ext_vector_type(2)));
 
-struct Weights {
-    const float* w_ih;   // [2][96][21]
-    const float* w_hh;   // [2][96][32]
-    const float* b_ih;   // [2][96]
-    const float* b_hh;   // [2][96]
-    const float* wa_t;   // [64][32]  Wa transposed: wa_t[k][a] = Wa[a][k]
-    const float* ua_t;   // [64][32]
-    const float* va;     // [32]
-    const float* fcw;    // [64]
-    const float* fcb;    // [1]
+struct Frags {
+    const uint4* w;      // kWFrags fragments of 64 x 16 B
+    const uint4* att;    // kAttFrags fragments
+    const float* vec;    // kVecFloats
 };
+
+__device__ __forceinline__ f32x16 split3(uint4 a_hi, uint4 a_lo, uint4 b_hi, uint4 b_lo, f32x16 c) {
+    c = ccsm::mfma16(a_hi, b_hi, c);
+    c = ccsm::mfma16(a_lo, b_hi, c);
+    return ccsm::mfma16(a_hi, b_lo, c);
+}
+
+// The 16 accumulator values of lane (n, hh) are units 8 (r >> 2) + 4 hh + (r & 3) of site n.  B fragments [k-block][hi|lo] of the same
+// 32 x 32 tile: lane (n, q) holds units 16 kb + 8 q + 0..7 of site n.
+__device__ __forceinline__ void pack_state(const f32x16& v, uint4 (&hi)[2], uint4 (&lo)[2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        uint32_t hp[4], lp[4];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const float a = v[8 * kb + j], b = v[8 * kb + j + 1];
+            const half2a h = {(_Float16)a, (_Float16)b};
+            const half2a l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+            hp[j >> 1] = __builtin_bit_cast(uint32_t, h);
+            lp[j >> 1] = __builtin_bit_cast(uint32_t, l);
+        }
+        ccsm::swap32(hp[0], hp[2]); ccsm::swap32(hp[1], hp[3]);
+        ccsm::swap32(lp[0], lp[2]); ccsm::swap32(lp[1], lp[3]);
+        hi[kb] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+        lo[kb] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+    }
+}
+
+struct TileState {
+    f32x16 K[L];         // attention keys, both directions accumulate
+    f32x16 q;            // Wa [h_fwd_final | h_bwd_final]
+};
+
+// One timestep of one direction for a tile.  S = step number (compile time: the key tile it adds to is a register choice).
+template <int S>
+__device__ __forceinline__ void gru_step(int dir, f32x16& h, uint4 (&ohi)[2], uint4 (&olo)[2], TileState& ts, const uint4* __restrict__ s_w,
+                                         const uint4* __restrict__ s_att, const float* __restrict__ s_vec, const _Float16* __restrict__ xhi,
+                                         const _Float16* __restrict__ xlo, const long long* __restrict__ s_pos, float* __restrict__ s_sp, long long pc,
+                                         int only_close, int lane) {
+    const int n = lane & 31, hh = lane >> 5;
+    const int t = dir ? L - 1 - S : S;
+    // position feature of site n's window element t (s_pos[j] = position of window row j - 1, pads included)
+    float pf;
+    {
+        const long long pn = s_pos[n + t + 1];
+        if (only_close) pf = pn - s_pos[n + t] == 2 ? 1.f : 0.f;
+        else { const long long d = pn - pc; pf = (float)(d < 0 ? -d : d); }
+    }
+    const float* vd = s_vec + dir * 128;
+    asm volatile("" ::: "memory");
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4 wr = *reinterpret_cast<const float4*>(vd + 8 * a + 4 * hh);
+        const float4 wz = *reinterpret_cast<const float4*>(vd + 32 + 8 * a + 4 * hh);
+        const float4 wn = *reinterpret_cast<const float4*>(vd + 64 + 8 * a + 4 * hh);
+        const float4 bh = *reinterpret_cast<const float4*>(vd + 96 + 8 * a + 4 * hh);
+        acc[0][4 * a] = wr.x * pf; acc[0][4 * a + 1] = wr.y * pf; acc[0][4 * a + 2] = wr.z * pf; acc[0][4 * a + 3] = wr.w * pf;
+        acc[1][4 * a] = wz.x * pf; acc[1][4 * a + 1] = wz.y * pf; acc[1][4 * a + 2] = wz.z * pf; acc[1][4 * a + 3] = wz.w * pf;
+        acc[2][4 * a] = wn.x * pf; acc[2][4 * a + 1] = wn.y * pf; acc[2][4 * a + 2] = wn.z * pf; acc[2][4 * a + 3] = wn.w * pf;
+        acc[3][4 * a] = bh.x; acc[3][4 * a + 1] = bh.y; acc[3][4 * a + 2] = bh.z; acc[3][4 * a + 3] = bh.w;
+    }
+    const uint4* W = s_w + (size_t)dir * (kWFrags / 2) * 64 + lane;
+    auto wf = [&](int which, int g, int kb, int hl) { return W[((((which * 3 + g) * 2 + kb) * 2) + hl) * 64]; };
+    // three gate tiles per k-block, issued pass-major so that consecutive MFMAs write different accumulators
+    auto gates3 = [&](int which, int kb, uint4 bh, uint4 bl, f32x16& c0, f32x16& c1, f32x16& c2) {
+        asm volatile("" ::: "memory");      // keep the fragment reads of a k-block next to its products (hoisted, they spill)
+        const uint4 a0h = wf(which, 0, kb, 0), a1h = wf(which, 1, kb, 0), a2h = wf(which, 2, kb, 0);
+        const uint4 a0l = wf(which, 0, kb, 1), a1l = wf(which, 1, kb, 1), a2l = wf(which, 2, kb, 1);
+        c0 = ccsm::mfma16(a0h, bh, c0); c1 = ccsm::mfma16(a1h, bh, c1); c2 = ccsm::mfma16(a2h, bh, c2);
+        c0 = ccsm::mfma16(a0l, bh, c0); c1 = ccsm::mfma16(a1l, bh, c1); c2 = ccsm::mfma16(a2l, bh, c2);
+        c0 = ccsm::mfma16(a0h, bl, c0); c1 = ccsm::mfma16(a1h, bl, c1); c2 = ccsm::mfma16(a2h, bl, c2);
+    };
+    // input part: r, z, n_x  (K = 32: 20 histogram columns, the constant 1 that carries the biases, zeros)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const uint4 bh = *reinterpret_cast<const uint4*>(xhi + (n + t) * kXStride + 16 * kb + 8 * hh);
+        const uint4 bl = *reinterpret_cast<const uint4*>(xlo + (n + t) * kXStride + 16 * kb + 8 * hh);
+        gates3(0, kb, bh, bl, acc[0], acc[1], acc[2]);
+    }
+    // recurrent part: r, z, n_h  (the state's fragments were packed by the previous step, or from h0)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) gates3(1, kb, ohi[kb], olo[kb], acc[0], acc[1], acc[3]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float rr = ccsm::sigmoid_f(acc[0][r]);
+        const float zz = ccsm::sigmoid_f(acc[1][r]);
+        const float nn = ccsm::tanh_f(acc[2][r] + rr * acc[3][r]);
+        h[r] = (h[r] - nn) * zz + nn;
+    }
+    pack_state(h, ohi, olo);
+    asm volatile("" ::: "memory");
+    // out_t's share of the attention keys and of fc1 . out_t
+    const uint4* A = s_att + (size_t)(dir * 4) * 64 + lane;       // ua, this direction's half of the 64 input columns
+    float fp = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4 fw = *reinterpret_cast<const float4*>(s_vec + 288 + 32 * dir + 8 * a + 4 * hh);
+        fp = fmaf(fw.x, h[4 * a], fp); fp = fmaf(fw.y, h[4 * a + 1], fp); fp = fmaf(fw.z, h[4 * a + 2], fp); fp = fmaf(fw.w, h[4 * a + 3], fp);
+    }
+    s_sp[t * 64 + lane] += fp;          // wave-private LDS, indexed by the timestep (a register array indexed through `dir` went to scratch)
+    if (dir == 0) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) ts.K[S] = split3(A[(kb * 2) * 64], A[(kb * 2 + 1) * 64], ohi[kb], olo[kb], ts.K[S]);
+    } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) ts.K[L - 1 - S] = split3(A[(kb * 2) * 64], A[(kb * 2 + 1) * 64], ohi[kb], olo[kb], ts.K[L - 1 - S]);
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void gru_steps(int dir, f32x16& h, uint4 (&ohi)[2], uint4 (&olo)[2], TileState& ts, const uint4* s_w, const uint4* s_att,
+                                          const float* s_vec, const _Float16* xhi, const _Float16* xlo, const long long* s_pos, float* s_sp,
+                                          long long pc, int only_close, int lane) {
+    if constexpr (S < L) {
+        gru_step<S>(dir, h, ohi, olo, ts, s_w, s_att, s_vec, xhi, xlo, s_pos, s_sp, pc, only_close, lane);
+        gru_steps<S + 1>(dir, h, ohi, olo, ts, s_w, s_att, s_vec, xhi, xlo, s_pos, s_sp, pc, only_close, lane);
+    }
+}
 
 // pos: (M) int64 sorted reference positions; hist: (M,20) fp32 normalised histograms; normals: the seeded randn stream;
 // stream_pos: index of the first value this call consumes; out: (M) fp32 raw fc1 output.  only_close (--only_close,
 // call_mods_freq_bam.py:285-290): the position feature is 1 where the window's site lies exactly 2 bases after its predecessor
 // (the padded sequence first-1000, ..., positions, ..., last+1000), else 0, instead of the distance to the centre site.
-__global__ __launch_bounds__(256, 2) void aggr_kernel(Weights w, const long long* __restrict__ pos, const float* __restrict__ hist,
-                                                       const float* __restrict__ normals, long long stream_pos, int m,
-                                                       float* __restrict__ out, int only_close) {
-    __shared__ float s_wa[64 * H], s_ua[64 * H];
-    __shared__ float s_h[WAVES][2 * H];         // current hidden state, [dir*32 + unit]
-    __shared__ float s_o[WAVES][L][2 * H];      // layer output
-    __shared__ float s_e[WAVES][16];
+__global__ __launch_bounds__(256) void aggr_kernel(Frags fr, const long long* __restrict__ pos, const float* __restrict__ hist,
+                                                    const float* __restrict__ normals, long long stream_pos, int m,
+                                                    float* __restrict__ out, int only_close) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* s_w = reinterpret_cast<uint4*>(smem);
+    uint4* s_att = s_w + kWFrags * 64;
+    float* s_vec = reinterpret_cast<float*>(s_att + kAttFrags * 64);
+    _Float16* s_x = reinterpret_cast<_Float16*>(smem + (size_t)(kWFrags + kAttFrags) * 1024 + ((kVecFloats * 4 + 15) / 16) * 16);
+    long long* s_posall = reinterpret_cast<long long*>(s_x + (size_t)WAVES * 2 * kXRows * kXStride);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dir = lane >> 5, unit = lane & 31;
-    for (int i = threadIdx.x; i < 64 * H; i += blockDim.x) { s_wa[i] = w.wa_t[i]; s_ua[i] = w.ua_t[i]; }
-    __syncthreads();
-
-    // this lane's rows of the GRU weights (gate g: row g*32 + unit)
-    float wih[3][F], whh[3][H], bi[3], bh[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        const int row = g * H + unit;
-#pragma unroll
-        for (int k = 0; k < F; ++k) wih[g][k] = w.w_ih[(dir * 96 + row) * F + k];
-#pragma unroll
-        for (int k = 0; k < H; ++k) whh[g][k] = w.w_hh[(dir * 96 + row) * H + k];
-        bi[g] = w.b_ih[dir * 96 + row];
-        bh[g] = w.b_hh[dir * 96 + row];
+    const int n = lane & 31, hh = lane >> 5;
+    for (int i = threadIdx.x; i < kWFrags * 64; i += blockDim.x) s_w[i] = fr.w[i];
+    for (int i = threadIdx.x; i < kAttFrags * 64; i += blockDim.x) s_att[i] = fr.att[i];
+    for (int i = threadIdx.x; i < kVecFloats; i += blockDim.x) s_vec[i] = fr.vec[i];
+    _Float16* xhi = s_x + (size_t)wave * 2 * kXRows * kXStride;
+    _Float16* xlo = xhi + kXRows * kXStride;
+    long long* s_pos = s_posall + wave * (kXRows + 2);
+    float* s_sp = reinterpret_cast<float*>(s_posall + WAVES * (kXRows + 2)) + wave * L * 64;     // [t][lane]: this lane's part of fc1 . out_t
+    // columns 20 .. 31 of every staged row never change: the constant 1 (hi) and zeros
+    for (int i = lane; i < kXRows * 12; i += 64) {
+        const int row = i / 12, k = NB + i % 12;
+        xhi[row * kXStride + k] = k == NB ? (_Float16)1.0f : (_Float16)0.0f;
+        xlo[row * kXStride + k] = (_Float16)0.0f;
     }
-    const float va = w.va[unit];
-    const float fcw = w.fcw[lane];
-    const float fcb = w.fcb[0];
+    __syncthreads();
     const long long pos_lo = pos[0] - 1000, pos_hi = pos[m - 1] + 1000;
+    const float fcb = s_vec[352];
 
-    const int gwave = blockIdx.x * WAVES + wave;
-    const int nwaves = gridDim.x * WAVES;
-    for (int site = gwave; site < m; site += nwaves) {
+    const int n_tiles = (m + TILE - 1) / TILE;
+    for (int tile = blockIdx.x * WAVES + wave; tile < n_tiles; tile += gridDim.x * WAVES) {
+        const int base = tile * TILE;
+        // ---- the tile's window rows: histograms as hi / lo halfs, positions (one row more in front for --only_close)
+        for (int i = lane; i < kXRows * 5; i += 64) {
+            const int row = i / 5, c4 = i % 5, nb = base - L / 2 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nb >= 0 && nb < m) v = reinterpret_cast<const float4*>(hist + (size_t)nb * NB)[c4];
+            const half2a h0 = {(_Float16)v.x, (_Float16)v.y}, h1 = {(_Float16)v.z, (_Float16)v.w};
+            const half2a l0 = {(_Float16)(v.x - (float)h0[0]), (_Float16)(v.y - (float)h0[1])};
+            const half2a l1 = {(_Float16)(v.z - (float)h1[0]), (_Float16)(v.w - (float)h1[1])};
+            *reinterpret_cast<uint2*>(xhi + row * kXStride + 4 * c4) = make_uint2(__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1));
+            *reinterpret_cast<uint2*>(xlo + row * kXStride + 4 * c4) = make_uint2(__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1));
+        }
+        if (lane < kXRows + 1) {
+            const int nb = base - L / 2 - 1 + lane;
+            s_pos[lane] = (nb >= 0 && nb < m) ? pos[nb] : (nb < 0 ? pos_lo : pos_hi);
+        }
+        // wave-private LDS: a wave's own writes are visible to its later reads in program order (no barrier)
+        const int site = base + n;
+        const int sc = site < m ? site : m - 1;
+        const long long pc = pos[sc];
         // h0 = randn(2, B, 32)[dir][site - batch0][unit] with B = size of this site's reference batch of 1024
-        const int batch0 = (site >> 10) << 10;
+        const int batch0 = (sc >> 10) << 10;
         const int bsz = min(1024, m - batch0);
-        float h = normals[stream_pos + (long long)batch0 * 64 + ((long long)dir * bsz + (site - batch0)) * H + unit];
-        const long long pc = pos[site];
-        for (int s = 0; s < L; ++s) {
-            const int t = dir ? L - 1 - s : s;
-            const int nb = site + t - L / 2;
-            const bool in = nb >= 0 && nb < m;
-            float x[F];
-            if (in) {
-                const float4* hp = reinterpret_cast<const float4*>(hist + (size_t)nb * NB);
+        TileState ts;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    const float4 v = hp[q];
-                    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-                }
-            } else {
+        for (int t = 0; t < L; ++t) {
+            s_sp[t * 64 + lane] = 0.f;
 #pragma unroll
-                for (int k = 0; k < NB; ++k) x[k] = 0.f;
-            }
-            const long long pn = in ? pos[nb] : (nb < 0 ? pos_lo : pos_hi);
-            if (only_close) {
-                const int pb = nb - 1;
-                const long long pp = (pb >= 0 && pb < m) ? pos[pb] : (pb < 0 ? pos_lo : pos_hi);
-                x[NB] = pn - pp == 2 ? 1.f : 0.f;
-            } else {
-                const long long d = pn - pc;
-                x[NB] = (float)(d < 0 ? -d : d);
-            }
-            s_h[wave][lane] = h;                       // wave-private LDS: in-order within the wave, no barrier needed
-            float gi[3], gh[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                float a = bi[g];
-#pragma unroll
-                for (int k = 0; k < F; ++k) a = fmaf(wih[g][k], x[k], a);
-                gi[g] = a;
-                gh[g] = bh[g];
-            }
-            const float4* hv = reinterpret_cast<const float4*>(&s_h[wave][dir * H]);
-#pragma unroll
-            for (int q = 0; q < H / 4; ++q) {
-                const float4 v = hv[q];
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    gh[g] = fmaf(whh[g][4 * q], v.x, gh[g]);
-                    gh[g] = fmaf(whh[g][4 * q + 1], v.y, gh[g]);
-                    gh[g] = fmaf(whh[g][4 * q + 2], v.z, gh[g]);
-                    gh[g] = fmaf(whh[g][4 * q + 3], v.w, gh[g]);
-                }
-            }
-            const float r = sigmoid_a(gi[0] + gh[0]);
-            const float z = sigmoid_a(gi[1] + gh[1]);
-            const float n = tanh_a(gi[2] + r * gh[2]);
-            h = (h - n) * z + n;
-            s_o[wave][t][lane] = h;
+            for (int r = 0; r < 16; ++r) ts.K[t][r] = 0.f;
         }
-        s_h[wave][lane] = h;                            // final states = attention query [fwd | bwd]
-        // q[a] = sum_k Wa[a][k] hn[k]: this half sums k in [32*dir, 32*dir+32), then the halves are added
-        float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < H; ++k) q = fmaf(s_wa[(dir * H + k) * H + unit], s_h[wave][dir * H + k], q);
-        q += __shfl_xor(q, 32);
-        // e[t] = sum_a va[a] tanh(q[a] + Ua[a] . out[t]); half 0 takes t = 0..5, half 1 takes t = 6..10
-        const int t0 = dir ? 6 : 0, nt = dir ? 5 : 6;
-        for (int tt = 0; tt < nt; ++tt) {
-            const int t = t0 + tt;
-            float kq = q;
-#pragma unroll 8
-            for (int k = 0; k < 2 * H; ++k) kq = fmaf(s_ua[k * H + unit], s_o[wave][t][k], kq);
-            float e = va * tanh_a(kq);
+        for (int r = 0; r < 16; ++r) ts.q[r] = 0.f;
+#pragma unroll 1
+        for (int dir = 0; dir < 2; ++dir) {
+            f32x16 h;
+            const float* hp = normals + stream_pos + (long long)batch0 * 64 + ((long long)dir * bsz + (sc - batch0)) * H;
 #pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) e += __shfl_xor(e, o);     // reduce over the 32 units of this half
-            if (unit == 0) s_e[wave][t] = e;
+            for (int r = 0; r < 16; ++r) h[r] = hp[8 * (r >> 2) + 4 * hh + (r & 3)];
+            uint4 ohi[2], olo[2];
+            pack_state(h, ohi, olo);
+            gru_steps<0>(dir, h, ohi, olo, ts, s_w, s_att, s_vec, xhi, xlo, s_pos, s_sp, pc, only_close, lane);
+            // final state of this direction = its half of the attention query's input (models.py:686-688)
+            const uint4* A = s_att + (size_t)((2 + dir) * 4) * 64 + lane;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) ts.q = split3(A[(kb * 2) * 64], A[(kb * 2 + 1) * 64], ohi[kb], olo[kb], ts.q);
         }
-        float ev[L], mx = -3.0e38f;
+        // ---- e_t = va . tanh(q + K_t), softmax over t, y = sum_t a_t (fc1 . out_t) + b
+        float va[16];
 #pragma unroll
-        for (int t = 0; t < L; ++t) { ev[t] = s_e[wave][t]; mx = fmaxf(mx, ev[t]); }
-        float den = 0.f;
+        for (int a = 0; a < 4; ++a) {
+            const float4 v = *reinterpret_cast<const float4*>(s_vec + 256 + 8 * a + 4 * hh);
+            va[4 * a] = v.x; va[4 * a + 1] = v.y; va[4 * a + 2] = v.z; va[4 * a + 3] = v.w;
+        }
+        float e[L], mx = -3.0e38f;
 #pragma unroll
-        for (int t = 0; t < L; ++t) { ev[t] = __expf(ev[t] - mx); den += ev[t]; }
-        float c = 0.f;
+        for (int t = 0; t < L; ++t) {
+            float s = 0.f;
 #pragma unroll
-        for (int t = 0; t < L; ++t) c = fmaf(ev[t] / den, s_o[wave][t][lane], c);
-        float y = fcw * c;
+            for (int r = 0; r < 16; ++r) s = fmaf(va[r], ccsm::tanh_f(ts.q[r] + ts.K[t][r]), s);
+            s += __shfl_xor(s, 32);
+            e[t] = s;
+            mx = fmaxf(mx, s);
+        }
+        float den = 0.f, y = 0.f;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) y += __shfl_xor(y, o);
-        if (lane == 0) out[site] = y + fcb;
+        for (int t = 0; t < L; ++t) { e[t] = __expf(e[t] - mx); den += e[t]; }
+#pragma unroll
+        for (int t = 0; t < L; ++t) y = fmaf(e[t] / den, s_sp[t * 64 + lane] + s_sp[t * 64 + (lane ^ 32)], y);
+        if (hh == 0 && site < m) out[site] = y + fcb;
     }
 }
 

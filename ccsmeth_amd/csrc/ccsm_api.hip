@@ -1462,8 +1462,8 @@ ccsm_status ccsm_selftest_mfma(int device, float* max_abs_err) {
 // =========================================================================================================
 struct ccsm_aggr_model {
     int device = 0;
-    float *w_ih = nullptr, *w_hh = nullptr, *b_ih = nullptr, *b_hh = nullptr, *wa_t = nullptr, *ua_t = nullptr, *va = nullptr,
-          *fcw = nullptr, *fcb = nullptr;
+    uint4 *frag_w = nullptr, *frag_att = nullptr;      // MFMA A fragments (ccsm_aggr.hip: Frags)
+    float* vec = nullptr;
     float* normals = nullptr;      // seeded torch.randn stream replica
     int64_t n_normals = 0;
     bool only_close = false;       // --only_close: adjacency indicator instead of the distance feature
@@ -1509,19 +1509,54 @@ ccsm_status ccsm_aggr_create(const ccsm_aggr_weights* w, int device, uint64_t se
     if (!m) return fail(CCSM_ERR_NOMEM, "out of host memory");
     m->device = device;
     using namespace ccsm_aggr;
-    std::vector<float> buf;
     ccsm_status st = CCSM_OK;
-    buf.resize(2 * 96 * F);
-    for (int d = 0; d < 2; ++d) std::memcpy(&buf[d * 96 * F], w->weight_ih[d], sizeof(float) * 96 * F);
-    st = upload(&m->w_ih, buf.data(), buf.size() * 4);
-    if (st == CCSM_OK) { buf.resize(2 * 96 * H); for (int d = 0; d < 2; ++d) std::memcpy(&buf[d * 96 * H], w->weight_hh[d], sizeof(float) * 96 * H); st = upload(&m->w_hh, buf.data(), buf.size() * 4); }
-    if (st == CCSM_OK) { buf.resize(2 * 96); for (int d = 0; d < 2; ++d) std::memcpy(&buf[d * 96], w->bias_ih[d], sizeof(float) * 96); st = upload(&m->b_ih, buf.data(), buf.size() * 4); }
-    if (st == CCSM_OK) { buf.resize(2 * 96); for (int d = 0; d < 2; ++d) std::memcpy(&buf[d * 96], w->bias_hh[d], sizeof(float) * 96); st = upload(&m->b_hh, buf.data(), buf.size() * 4); }
-    if (st == CCSM_OK) { buf.resize(64 * H); for (int k = 0; k < 64; ++k) for (int a = 0; a < H; ++a) buf[k * H + a] = w->att_wa[a * 64 + k]; st = upload(&m->wa_t, buf.data(), buf.size() * 4); }
-    if (st == CCSM_OK) { buf.resize(64 * H); for (int k = 0; k < 64; ++k) for (int a = 0; a < H; ++a) buf[k * H + a] = w->att_ua[a * 64 + k]; st = upload(&m->ua_t, buf.data(), buf.size() * 4); }
-    if (st == CCSM_OK) st = upload(&m->va, w->att_va, sizeof(float) * H);
-    if (st == CCSM_OK) st = upload(&m->fcw, w->fc1_weight, sizeof(float) * 64);
-    if (st == CCSM_OK) st = upload(&m->fcb, w->fc1_bias, sizeof(float));
+    {
+        // A fragment of a 32 x 16 block of a row-major matrix: lane i + 32 q holds M[i][8 q + 0..7] as eight halfs; every value as
+        // fp16 hi + lo, one fragment each
+        std::vector<_Float16> fw((size_t)kWFrags * 512), fa((size_t)kAttFrags * 512);
+        auto put = [](std::vector<_Float16>& dst, int frag_hi, const std::function<float(int, int)>& at) {
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const HalfPair p = split_host(at(lane & 31, 8 * (lane >> 5) + j));
+                    dst[(size_t)frag_hi * 512 + lane * 8 + j] = p.hi;
+                    dst[(size_t)(frag_hi + 1) * 512 + lane * 8 + j] = p.lo;
+                }
+        };
+        for (int d = 0; d < 2; ++d)
+            for (int g = 0; g < 3; ++g)
+                for (int kb = 0; kb < 2; ++kb) {
+                    // input part: columns 0..19 = histogram weights, column 20 = the bias the constant-1 input column carries
+                    // (b_ih + b_hh for r and z; b_in alone for n, whose b_hn sits inside r * (...))
+                    put(fw, ((((d * 2 + 0) * 3 + g) * 2 + kb) * 2), [&](int i, int k8) {
+                        const int row = g * H + i, k = 16 * kb + k8;
+                        if (k < NB) return w->weight_ih[d][row * F + k];
+                        if (k == NB) return w->bias_ih[d][row] + (g < 2 ? w->bias_hh[d][row] : 0.0f);
+                        return 0.0f;
+                    });
+                    put(fw, ((((d * 2 + 1) * 3 + g) * 2 + kb) * 2), [&](int i, int k8) { return w->weight_hh[d][(g * H + i) * H + 16 * kb + k8]; });
+                }
+        for (int which = 0; which < 2; ++which)
+            for (int half = 0; half < 2; ++half)
+                for (int kb = 0; kb < 2; ++kb)
+                    put(fa, (((which * 2 + half) * 2 + kb) * 2), [&](int i, int k8) {
+                        return (which == 0 ? w->att_ua : w->att_wa)[i * 64 + 32 * half + 16 * kb + k8];
+                    });
+        std::vector<float> vec(kVecFloats, 0.f);
+        for (int d = 0; d < 2; ++d) {
+            for (int g = 0; g < 3; ++g)
+                for (int i = 0; i < H; ++i) vec[d * 128 + g * 32 + i] = w->weight_ih[d][(g * H + i) * F + NB];   // the position feature's column
+            for (int i = 0; i < H; ++i) vec[d * 128 + 96 + i] = w->bias_hh[d][2 * H + i];
+        }
+        std::memcpy(&vec[256], w->att_va, sizeof(float) * H);
+        std::memcpy(&vec[288], w->fc1_weight, sizeof(float) * 64);
+        vec[352] = w->fc1_bias[0];
+        st = upload(&m->frag_w, fw.data(), fw.size() * sizeof(_Float16));
+        if (st == CCSM_OK) st = upload(&m->frag_att, fa.data(), fa.size() * sizeof(_Float16));
+        if (st == CCSM_OK) st = upload(&m->vec, vec.data(), vec.size() * sizeof(float));
+        if (st == CCSM_OK && hipFuncSetAttribute(reinterpret_cast<const void*>(&ccsm_aggr::aggr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)kLdsBytes) != hipSuccess)
+            st = fail(CCSM_ERR_HIP, "hipFuncSetAttribute(aggr_kernel)");
+    }
     if (st == CCSM_OK) {
         // the reference seeds, THEN constructs AggrAttRNN (call_mods_freq_bam.py:313-322): its parameter initialisation
         // consumes one 32-bit draw per parameter (14 753) before the first h0 is drawn
@@ -1539,8 +1574,7 @@ ccsm_status ccsm_aggr_create(const ccsm_aggr_weights* w, int device, uint64_t se
 void ccsm_aggr_destroy(ccsm_aggr_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
-    (void)hipFree(m->w_ih); (void)hipFree(m->w_hh); (void)hipFree(m->b_ih); (void)hipFree(m->b_hh);
-    (void)hipFree(m->wa_t); (void)hipFree(m->ua_t); (void)hipFree(m->va); (void)hipFree(m->fcw); (void)hipFree(m->fcb);
+    (void)hipFree(m->frag_w); (void)hipFree(m->frag_att); (void)hipFree(m->vec);
     (void)hipFree(m->normals); (void)hipFree(m->d_pos); (void)hipFree(m->d_hist); (void)hipFree(m->d_out);
     delete m;
 }
@@ -1558,10 +1592,11 @@ ccsm_status ccsm_aggr_forward_device(ccsm_aggr_model* m, int64_t n_sites, const 
     if (stream_pos < 0 || stream_pos + n_sites * 64 > m->n_normals)
         return fail(CCSM_ERR_CAPACITY, "random stream exhausted: create the model with a larger stream_sites");
     HIP_TRY(hipSetDevice(m->device));
-    ccsm_aggr::Weights w{m->w_ih, m->w_hh, m->b_ih, m->b_hh, m->wa_t, m->ua_t, m->va, m->fcw, m->fcb};
-    const int waves = (int)std::min<int64_t>(n_sites, 256 * 8 * 2);
-    const int grid = (waves + ccsm_aggr::WAVES - 1) / ccsm_aggr::WAVES;
-    hipLaunchKernelGGL(ccsm_aggr::aggr_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+    ccsm_aggr::Frags fr{m->frag_w, m->frag_att, m->vec};
+    // one wave per tile of 32 sites, four waves (one per SIMD) per workgroup; at most four workgroups per CU's worth of tiles queued
+    const int64_t tiles = (n_sites + ccsm_aggr::TILE - 1) / ccsm_aggr::TILE;
+    const int grid = (int)std::min<int64_t>((tiles + ccsm_aggr::WAVES - 1) / ccsm_aggr::WAVES, 256 * 4);
+    hipLaunchKernelGGL(ccsm_aggr::aggr_kernel, dim3(grid), dim3(256), ccsm_aggr::kLdsBytes, static_cast<hipStream_t>(stream), fr,
                        reinterpret_cast<const long long*>(refposes), histos, m->normals, (long long)stream_pos, (int)n_sites, out,
                        m->only_close ? 1 : 0);
     HIP_TRY(hipGetLastError());

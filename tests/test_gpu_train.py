@@ -193,15 +193,18 @@ def test_trained_checkpoint_tail_over_8192_sites(wseed, steps):
 
 
 def test_large_gate_gradients_fall_back_to_the_stepwise_backward(monkeypatch):
-    """The fused backward kernel's scaled-fp16 operand saturates above |gate gradient| = 14.6 (a pos_weight of 1e6 gets there with a
-    mean loss): the step is flagged on the device and its backward pass repeated step by step, so the gradients equal those of a
-    trainer that runs stepwise throughout; ordinary gradients never take the detour."""
+    """The fused backward kernel's scaled-fp16 operand saturates above |gate gradient| = 14.6.  The loss is a weighted MEAN, so ordinary
+    models stay orders of magnitude below that; an fc1 layer blown up by 3e6 gets there.  The step is then flagged on the device and
+    its backward pass repeated step by step, so the gradients equal those of a trainer that runs stepwise throughout; ordinary
+    gradients never take the detour."""
     from ccsmeth_amd.train import Trainer
     n = 512                                              # 1024 strand rows: the fused path
     sites = synth.synth_sites(n, 61)
     labels = (np.arange(n) % 97 == 0).astype(np.int64)   # a few positives carry the whole weighted loss
     h1, h2 = synth.synth_h0(n, 62)
     w = synth.synth_weights(9)
+    big = dict(w)
+    big["fc1.weight"] = (w["fc1.weight"] * 3e6).astype(np.float32)
     out = {}
     for mode in ("fused", "stepwise"):
         if mode == "stepwise":
@@ -210,12 +213,14 @@ def test_large_gate_gradients_fall_back_to_the_stepwise_backward(monkeypatch):
         l_small, _ = tr.forward_backward(sites, labels, h0=(h1, h2), pos_weight=2.0)
         g_small = tr.grads()
         fb0 = tr.fused_fallbacks
-        l_big, _ = tr.forward_backward(sites, labels, h0=(h1, h2), pos_weight=1e6)
+        tr.close()
+        tr = Trainer(big, device=0, max_sites=n)
+        l_big, _ = tr.forward_backward(sites, labels, h0=(h1, h2), pos_weight=2.0)
         out[mode] = (g_small, tr.grads(), fb0, tr.fused_fallbacks, l_small, l_big)
         tr.close()
     assert out["fused"][2] == 0 and out["stepwise"][3] == 0
     if out["fused"][3] == 0:
-        pytest.skip("pos_weight 1e6 did not saturate the fused kernel on this initialisation")
+        pytest.skip("fc1 x 3e6 did not saturate the fused kernel on this initialisation")
     for k in out["fused"][1]:
         a, b = out["fused"][1][k], out["stepwise"][1][k]
         assert np.allclose(a, b, rtol=1e-4, atol=1e-6 * np.abs(b).max()), k
