@@ -405,7 +405,9 @@ struct ccsm_trainer {
                                        // product + gate kernel per timestep, -1 = by batch size (fused from 768 rows up: measured 4.13 vs
                                        // 3.92 ms per step at 256 sites, 5.73 vs 6.40 at 512, 13.6 vs 18.4 at 2048); CCSM_TRAIN_STEPWISE=0|1 forces
     long fused_fallbacks = 0;          // backward passes repeated stepwise because the fused kernel flagged saturation
+    bool stepwise_bwd = false;         // CCSM_TRAIN_STEPWISE=bwd (tests): fused forward, stepwise backward - what a saturation fallback runs
     bool stepwise_for(int M) const { return seq_mode == 0 || (seq_mode < 0 && M < 768); }
+    bool stepwise_bwd_for(int M) const { return stepwise_bwd || stepwise_for(M); }
 };
 
 namespace {
@@ -565,7 +567,7 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
     // timesteps per batched weight-gradient product: measured best 2 / 3 up to 1024 sites per step (6.98 vs 8.30 ms at 512), 4 / 3 above
     const int sp20 = t->sp20 ? t->sp20 : (M <= 2048 ? 2 : 4), sp21 = t->sp21 ? t->sp21 : 3;
     float* cpart = t->cpart[d];
-    if (!t->stepwise_for(M)) {     // all 21 steps in one launch (ccsm_train_seq.hip)
+    if (!t->stepwise_bwd_for(M)) {     // all 21 steps in one launch (ccsm_train_seq.hip)
         gru_seq_bwd_kernel<<<(M + 31) / 32, 512, kSbLds, st>>>(dO + d * H, t->out[l] + d * H, t->h0 + (size_t)(2 * l + d) * M * H,
                                                                t->whh_t_frag + (size_t)(2 * l + d) * kSqFragPerDir, t->sav[l][d][0], t->sav[l][d][1],
                                                                t->sav[l][d][2], t->sav[l][d][3], dgi, dgh, Gd + kOff.b_ih[l][d], Gd + kOff.b_hh[l][d], M, d,
@@ -603,7 +605,7 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
         BLASCHK(atb_split(blas, st, G, H, M * sp20, (T - 1) / sp20, dgh, G, t->out[l] + (size_t)M * H2 + H, H2, part, 1, dWhh));
     }
     BLASCHK(atb_split(blas, st, G, in, M * sp21, T / sp21, dgi, G, X, in, part, 0, Gd + kOff.w_ih[l][d]));
-    if (t->stepwise_for(M)) {      // (the fused backward kernel has accumulated the bias gradients already)
+    if (t->stepwise_bwd_for(M)) {      // (the fused backward kernel has accumulated the bias gradients already)
         colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgi, Gd + kOff.b_ih[l][d], T * M, G);
         colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgh, Gd + kOff.b_hh[l][d], T * M, G);
     }
@@ -728,7 +730,7 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
       if (t->sp20 < 0 || (t->sp20 && (T - 1) % t->sp20)) t->sp20 = 0;
       if (t->sp21 < 0 || (t->sp21 && T % t->sp21)) t->sp21 = 0; }
     { const char* e = std::getenv("CCSM_TRAIN_GRAPH"); t->use_graph = e && e[0] == '1'; }   // opt-in: measured +1.5 % (the step is not launch-bound)
-    { const char* e = std::getenv("CCSM_TRAIN_STEPWISE"); if (e && (e[0] == '0' || e[0] == '1')) t->seq_mode = e[0] == '1' ? 0 : 1; }
+    { const char* e = std::getenv("CCSM_TRAIN_STEPWISE"); if (e && (e[0] == '0' || e[0] == '1')) t->seq_mode = e[0] == '1' ? 0 : 1; if (e && e[0] == 'b') t->stepwise_bwd = true; }
     TRY(dalloc(&t->whh_frag, (size_t)2 * L * kSqFragPerDir));
     TRY(dalloc(&t->whh_t_frag, (size_t)2 * L * kSqFragPerDir));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gru_seq_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSbLds));
@@ -847,13 +849,15 @@ static ccsm_status run(ccsm_trainer* t, int n_sites, const ccsm_batch* batch, co
     lsum = lbuf[0];
     int sat = 0;
     std::memcpy(&sat, &lbuf[1], sizeof(int));
-    if (train && sat && !t->stepwise_for(2 * n_sites)) {
-        // a gate gradient left the range of the fused kernels' scaled fp16 operands (|.| > 14.6: e.g. a sum-reduced loss or a very
-        // large pos_weight): this step's backward pass is repeated step by step in fp32; the saved activations are the same
-        const int keep = t->seq_mode;
-        t->seq_mode = 0;
-        s = backward(t, n_sites, rate);
-        t->seq_mode = keep;
+    if (train && sat && !t->stepwise_bwd_for(2 * n_sites)) {
+        // a gate gradient left the range of the fused kernels' scaled fp16 operands (|.| > 14.6: e.g. a sum-reduced loss or a blown-up
+        // fc1 layer): this step is repeated with the backward pass step by step in fp32.  The forward pass runs again first - the
+        // backward pass overwrites the attention scores and keys it reads (e, KS) - with the same inputs, masks and initial states
+        const bool keep = t->stepwise_bwd;
+        t->stepwise_bwd = true;
+        s = forward(t, n_sites, true, rate, labels != nullptr);
+        if (s == CCSM_OK) s = backward(t, n_sites, rate);
+        t->stepwise_bwd = keep;
         if (s != CCSM_OK) return s;
         HIPCHK(hipStreamSynchronize(t->stream));
         t->fused_fallbacks += 1;

@@ -195,8 +195,10 @@ def test_trained_checkpoint_tail_over_8192_sites(wseed, steps):
 def test_large_gate_gradients_fall_back_to_the_stepwise_backward(monkeypatch):
     """The fused backward kernel's scaled-fp16 operand saturates above |gate gradient| = 14.6.  The loss is a weighted MEAN, so ordinary
     models stay orders of magnitude below that; an fc1 layer blown up by 3e6 gets there.  The step is then flagged on the device and
-    its backward pass repeated step by step, so the gradients equal those of a trainer that runs stepwise throughout; ordinary
-    gradients never take the detour."""
+    its backward pass repeated step by step on the same saved activations, so the gradients equal those of a trainer whose backward
+    pass is stepwise from the start (CCSM_TRAIN_STEPWISE=bwd: same fused forward, hence the same loss gradient - a trainer that is
+    stepwise throughout computes a forward that differs in the last bits, which this ill-conditioned model turns into other
+    misclassified sites); ordinary gradients never take the detour."""
     from ccsmeth_amd.train import Trainer
     n = 512                                              # 1024 strand rows: the fused path
     sites = synth.synth_sites(n, 61)
@@ -208,7 +210,7 @@ def test_large_gate_gradients_fall_back_to_the_stepwise_backward(monkeypatch):
     out = {}
     for mode in ("fused", "stepwise"):
         if mode == "stepwise":
-            monkeypatch.setenv("CCSM_TRAIN_STEPWISE", "1")
+            monkeypatch.setenv("CCSM_TRAIN_STEPWISE", "bwd")
         tr = Trainer(w, device=0, max_sites=n)
         l_small, _ = tr.forward_backward(sites, labels, h0=(h1, h2), pos_weight=2.0)
         g_small = tr.grads()
