@@ -45,6 +45,7 @@ constexpr int kRowPad = 32 * kNBGru2;           // rows are padded to whole work
 // GRU kernels' dynamic LDS: h fragments + x chunk ring + 4 KiB bias table
 constexpr int gru2_lds(int kx) { return (kKBH * kNBGru2 * 2 + 2 * (kx >= 4 ? 4 : kx) * kNBGru2 * 2) * 1024 + kWaves * 4 * 32 * 4; }
 // attention kernel dynamic LDS: 2 staging buffers x 28 KiB + e partials + fc partials + fc1.weight
+constexpr int kAttF8Lds = 2 * 28 * 1024 + kWaves * 7 * 32 * 4 + kSeqLen * 32 * 4 + kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4;   // attn_fc_f8_kernel: staging, one group's score partials, scores, fc partials, fc1.weight, va = 79.9 KiB
 constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kWaves * kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4;   // staging, e / fc partials, fc1.weight, va
 
 inline int rows_padded(int n_sites) { return ((2 * n_sites + kRowPad - 1) / kRowPad) * kRowPad; }
@@ -494,7 +495,7 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         tab.n_sites[i] = i < ws->n_slices ? ws->slice_n[i] : 0;
     }
     if constexpr (F8)
-        hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fcw,
+        hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttF8Lds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fcw,
                            ws->part, tab, m->att_scale[0], m->att_scale[1]);
     else
         hipLaunchKernelGGL(attn_fc_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
@@ -770,7 +771,7 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, true>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true, true>), kMx12Lds);
 #endif
-            set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttLds);
+            set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttF8Lds);
         }
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }

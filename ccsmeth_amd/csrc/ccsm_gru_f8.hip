@@ -125,10 +125,14 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     constexpr int NCHUNK = kKB12 / CK;
     constexpr int CHUNK_FRAGS = CK * TG * 2;   // 28 fragments of 1 KiB
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // 79.9 KiB in all (kAttF8Lds; round 2 kept per-wave score partials of all 21 timesteps and a per-wave fc1 array that was never
+    // indexed by wave: 129 KiB).  Occupancy is set by the registers (seven accumulator tiles: 250 VGPRs, two waves per SIMD, one
+    // workgroup per CU), not by this
     char* s_stage = smem;                                                     // [2][CK][TG][hi|corr] fragments
-    float* s_epart = reinterpret_cast<float*>(smem + 2 * CHUNK_FRAGS * 1024);  // [wave][t][32]
-    float* s_pfc = s_epart + kWaves * kSeqLen * 32;                            // [wave][t][32][2]
-    float* s_fcw = s_pfc + kWaves * kSeqLen * 32 * 2;                          // [2][1024]
+    float* s_epart = reinterpret_cast<float*>(smem + 2 * CHUNK_FRAGS * 1024);  // [wave][tt][32]: this timestep group's score partials
+    float* s_e = s_epart + kWaves * TG * 32;                                   // [t][32]: scores, summed over the waves in a fixed order
+    float* s_pfc = s_e + kSeqLen * 32;                                         // [t][32][2]
+    float* s_fcw = s_pfc + kSeqLen * 32 * 2;                                   // [2][1024]
     float* s_va = s_fcw + kClasses * 4 * kHidden;                              // [256]: in LDS, the 16 registers go to the operand pipeline
 
     const int lane = threadIdx.x & 63;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) e += s_va[(wave * 2 + hh) * 16 + r] * tanh_f(kacc[tt][r]);
             e += __shfl_xor(e, 32);
-            if (hh == 0) s_epart[(wave * kSeqLen + t0 + tt) * 32 + n] = e;
+            if (hh == 0) s_epart[(wave * TG + tt) * 32 + n] = e;
         }
         if (wave < TG) {
             pf0 += __shfl_xor(pf0, 32);
@@ -292,7 +296,15 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             }
         }
         __syncthreads();   // all waves are done with both staging buffers before the next group restages buffer 0
+        if (threadIdx.x < TG * 32) {       // the group's scores: the eight waves' partials in a fixed order (deterministic)
+            const int tt = threadIdx.x >> 5, rl = threadIdx.x & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) v += s_epart[(w * TG + tt) * 32 + rl];
+            s_e[(t0 + tt) * 32 + rl] = v;
+        }                                  // (s_epart is next written at the end of the next group, a chunk loop of barriers away)
     }
+    __syncthreads();
 
     // ---- softmax over t and the strand-half of the logits (fixed summation order: deterministic)
     if (threadIdx.x < 32) {
@@ -302,9 +314,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
         float m = -3.0e38f;
 #pragma unroll
         for (int t = 0; t < kSeqLen; ++t) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) v += s_epart[(w * kSeqLen + t) * 32 + rl];
+            const float v = s_e[t * 32 + rl];
             e[t] = v;
             m = fmaxf(m, v);
         }
