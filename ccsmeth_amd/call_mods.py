@@ -281,13 +281,15 @@ def call_mods(args, log=sys.stderr, pipe=None):
         model.cuda(args.device).eval()
         if int(os.environ.get("RANK", "0")) == 0:
             dm = model._dev
-            probe = "" if dm.probe_error < 0 else " (probe batch, max abs dprob against split3: split-mx %.1e%s)" % (
-                dm.probe_error, "" if dm.probe_error_hybrid < 0 else ", hybrid %.1e" % dm.probe_error_hybrid)
+            probe = "" if dm.probe_error < 0 else (" (probe batch of 2048 sites against split3, accepted with <= 0.5 %% of the sites beyond 1e-5 and none "
+                                                   "beyond 5e-5: split-mx max %.1e, %.2f %% beyond 1e-5%s)") % (
+                dm.probe_error, 100.0 * dm.probe_tail,
+                "" if dm.probe_error_hybrid < 0 else "; hybrid max %.1e, %.2f %% beyond 1e-5" % (dm.probe_error_hybrid, 100.0 * dm.probe_tail_hybrid))
             print("[main]arithmetic: %s%s" % ({3: "split3 (three fp16 passes)", 4: "split-mx", 5: "hybrid (split-mx input part, three-pass "
                                                "recurrent part)"}.get(dm.precision, dm.precision), probe), file=log)
         # --batch_size (reference default 512) is the reference's sites per model call.  On the GPU-extraction paths a launch wants
         # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
-        # (every site's initial state is a function of the seed and its running index), so the flag is only a lower bound there.
+        # (every site's initial state is a function of the seed, its read's name and its position there), so the flag is only a lower bound there.
         chunk_sites = max(args.batch_size, 12288) if args.extract == "device" else args.batch_size
         pipe = CallModsPipeline(model._dev, batch_size=chunk_sites, seed=args.tseed, extract=args.extract)
     holeids_e = None if args.holeids_e is None else _get_holes(args.holeids_e)          # extract_features.py:561-562
