@@ -382,7 +382,6 @@ def call_mods(args, log=sys.stderr, pipe=None):
                             cur["n"] += b.n_reads
                             return ("batch", b, cur["k"])
                     nxt = rpool.submit(fetch)
-                    pending = None
 
                     def write(b, first, locs, prob1, tagged):
                         n = wr.write_batch(b, first, locs, prob1, tagged, rm_pulse)
@@ -394,6 +393,31 @@ def call_mods(args, log=sys.stderr, pipe=None):
                         e = wr.flush()
                         runs.append((k, a, e, wr.take_index()))
                         return 0
+                    streaming = hasattr(pipe, "feed_native_batch")
+                    todo = []                          # what still has to go to the writer, in order: ("batch", job | result, b, window) | ("end", chunk)
+                    state = dict(pending=None)
+
+                    def to_writer(fn, *a):
+                        nonlocal cnt_mm
+                        if state["pending"] is not None:
+                            cnt_mm += state["pending"].result()
+                        state["pending"] = wpool.submit(fn, *a)
+
+                    def drain_todo():
+                        nonlocal cnt_w, cnt_sites, cnt_failed
+                        while todo:
+                            act = todo.pop(0)
+                            if act[0] == "end":
+                                to_writer(end_run, act[1])
+                                continue
+                            _, res, b, window = act
+                            first, locs, prob1, tagged, failed = pipe.finish_native_batch(res) if streaming else res
+                            if window is not None:
+                                first, locs, prob1, tagged = _filter_sites_by_window(first, locs, prob1, tagged, window)
+                            to_writer(write, b, first, locs, prob1, tagged)
+                            cnt_w += b.n_reads
+                            cnt_sites += len(locs)
+                            cnt_failed += failed
                     while True:
                         item = nxt.result()
                         if item is None:
@@ -402,23 +426,22 @@ def call_mods(args, log=sys.stderr, pipe=None):
                         if item[0] == "end":
                             _, k, v0, v1, n = item
                             chunk_log.append((k, v0, v1, n))
-                            if pending is not None:
-                                cnt_mm += pending.result()
-                            pending = wpool.submit(end_run, k)
+                            todo.append(("end", k))        # closes the run behind the chunk's last batch, whenever that one is written
                             continue
                         b = item[1]
                         skip, window, _ = filters(b)
-                        first, locs, prob1, tagged, failed = pipe.run_native_batch(b, skip)
-                        if window is not None:
-                            first, locs, prob1, tagged = _filter_sites_by_window(first, locs, prob1, tagged, window)
-                        if pending is not None:
-                            cnt_mm += pending.result()
-                        pending = wpool.submit(write, b, first, locs, prob1, tagged)
-                        cnt_w += b.n_reads
-                        cnt_sites += len(locs)
-                        cnt_failed += failed
-                    if pending is not None:
-                        cnt_mm += pending.result()
+                        if streaming:
+                            # the batch's launches are queued behind the previous batch's last ones - the GPU does not drain between
+                            # hole-batches, nor between the chunks of the input - and what was queued before it is complete by then
+                            job = pipe.feed_native_batch(b, skip)
+                            drain_todo()
+                            todo.append(("batch", job, b, window))
+                        else:
+                            todo.append(("batch", pipe.run_native_batch(b, skip), b, window))
+                            drain_todo()
+                    drain_todo()
+                    if state["pending"] is not None:
+                        cnt_mm += state["pending"].result()
                     if world == 1:
                         end_run(0)
                 work_inflated = rd.inflated_bytes - header_inflated

@@ -55,9 +55,12 @@ class CallModsPipeline:
         dev = torch.device("cuda", device_model.device)
         self._streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
         self._slots = [_Slot(device_model, self.batch_size, s.cuda_stream) for s in self._streams]
-        self._site_counter = 0
+        self._inflight = []                             # [(workspace slot, job, selection)] of the native-batch path, oldest first
+        self._turn = 0
 
     def close(self):
+        while self._inflight:
+            self._collect_one()
         for s in self._slots:
             s.ws.close()
         if self._rws is not None:
@@ -145,12 +148,11 @@ class CallModsPipeline:
             pos += k
 
     # ---- native BAM batches (ccsmeth_amd/bamnative.py): no per-read Python objects ------------------------------------------
-    def run_native_batch(self, batch, skip=None):
-        """One bamnative.Batch through ccsm_submit_reads_host / ccsm_wait_reads_host, in chunks of whole reads holding
-        <= batch_size sites, double-buffered over two workspaces and two streams: chunk k+1 is copied, extracted and queued
-        while chunk k runs (the reader's site counts make the submit non-blocking).
-        Returns (first_site int32 (n_reads+1), locs int32, prob1 float32, tagged uint8 (n_reads), n_failed) in the batch's read
-        order, i.e. exactly the arguments of NativeBamWriter.write_batch."""
+    def feed_native_batch(self, batch, skip=None):
+        """Queue one bamnative.Batch: chunks of whole reads holding <= batch_size sites go through ccsm_submit_reads_host, double-buffered
+        over two workspaces and two streams (the reader's site counts make the submit non-blocking).  At most two chunks are in flight;
+        submitting a third first collects the oldest, which may belong to the PREVIOUS batch: the GPU does not drain between
+        hole-batches.  Returns a job for finish_native_batch; `batch` may be released once this returns (submit copies the arrays)."""
         nr = batch.n_reads
         cnt = np.where(batch.length > 0, batch.n_sites, 0).astype(np.int64)
         if skip is not None:                            # reads excluded by name (--holeids_e / --holeids_ne): no features
@@ -158,30 +160,18 @@ class CallModsPipeline:
         first = np.zeros(nr + 1, np.int32)
         np.cumsum(cnt, out=first[1:])
         total = int(first[-1])
-        locs = np.empty(total, np.int32)
-        prob1 = np.empty(total, np.float32)
-        tagged = (cnt > 0).astype(np.uint8)
+        job = dict(first=first, cnt=cnt, locs=np.empty(total, np.int32), prob1=np.empty(total, np.float32), tagged=(cnt > 0).astype(np.uint8),
+                   pending=0, failed=int(nr - np.count_nonzero(cnt > 0)))
         idx = np.flatnonzero(cnt > 0)
-        inflight = []                                   # [(workspace slot, selection)]
-
-        def collect():
-            k, sel = inflight.pop(0)
-            f, lc, _, pr = self._rwss[k].wait_reads()
-            if not np.array_equal(np.diff(f), cnt[sel]):
-                raise RuntimeError("device and host site counts disagree")
-            a = int(first[sel[0]])
-            locs[a:a + len(lc)] = lc                      # sel is a run of consecutive usable reads: their spans are adjacent
-            prob1[a:a + len(lc)] = prob1_norm_round6(pr)
-
-        start, turn = 0, 0
+        start = 0
         while start < len(idx):
             csum = np.cumsum(cnt[idx[start:]])
             take = max(1, int(np.searchsorted(csum, self.batch_size, side="right")))
             sel = idx[start:start + take]
             csites = int(cnt[sel].sum())
-            k = turn & 1
-            if len(inflight) == 2:
-                collect()
+            k = self._turn & 1
+            if len(self._inflight) == 2:
+                self._collect_one()
             if self._rwss[k] is None or self._rwss[k].max_sites < csites:
                 if self._rwss[k] is not None:
                     self._rwss[k].close()
@@ -189,12 +179,32 @@ class CallModsPipeline:
             self._rwss[k].submit_reads_arrays(batch.offset[sel], batch.length[sel], batch.seq, batch.fi, batch.ri, batch.fp, batch.rp,
                                               batch.fn[sel], batch.rn[sel], site_counts=cnt[sel], seed=self.seed,
                                               stream=self._slots[k].stream, read_keys=batch.name_hash[sel])
-            inflight.append((k, sel))
+            self._inflight.append((k, job, sel))
+            job["pending"] += 1
             start += take
-            turn += 1
-        while inflight:
-            collect()
-        return first, locs, prob1, tagged, int(nr - len(idx))
+            self._turn += 1
+        return job
+
+    def _collect_one(self):
+        k, job, sel = self._inflight.pop(0)
+        f, lc, _, pr = self._rwss[k].wait_reads()
+        if not np.array_equal(np.diff(f), job["cnt"][sel]):
+            raise RuntimeError("device and host site counts disagree")
+        a = int(job["first"][sel[0]])
+        job["locs"][a:a + len(lc)] = lc                 # sel is a run of consecutive usable reads: their spans are adjacent
+        job["prob1"][a:a + len(lc)] = prob1_norm_round6(pr)
+        job["pending"] -= 1
+
+    def finish_native_batch(self, job):
+        """-> (first_site int32 (n_reads+1), locs int32, prob1 float32, tagged uint8 (n_reads), n_failed) of a fed batch, in its read
+        order: exactly the arguments of NativeBamWriter.write_batch.  Blocks only for chunks of this job that are still in flight."""
+        while job["pending"]:
+            self._collect_one()
+        return job["first"], job["locs"], job["prob1"], job["tagged"], job["failed"]
+
+    def run_native_batch(self, batch, skip=None):
+        """feed + finish in one call (drains the GPU at the end of the batch)."""
+        return self.finish_native_batch(self.feed_native_batch(batch, skip))
 
     # ---- host side ------------------------------------------------------------------------------------------------
     def run(self, reads):

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # the driver's command; under rocprofv3 without the secondary measurements (their launches have other shapes and would mix into the
 # per-kernel averages) and without the CPU leg
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_plain.json 2> $O/bench_plain.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --extras none --cpu-seconds 0 > $O/bench_under_rocprof.json 2> $O/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --extras none --cpu-seconds 0 --ceiling-seconds 0 > $O/bench_under_rocprof.json 2> $O/rocprof.err
 cp $(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 python $R/tools/kernel_trace_by_shape.py $(find /tmp/prof_stats -name "*kernel_trace.csv" | head -1) $O/bench_kernel_by_shape.md 3 > /dev/null
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
