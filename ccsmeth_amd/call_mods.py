@@ -500,7 +500,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
             print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
             print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d GPU(s); ccsmeth_amd %s)" %
                   (time.time() - t0, cnt_failed, world, __version__), file=log)
-            if os.environ.get("CCSM_CALLMODS_REPORT"):      # machine-readable run summary (tools/e2e_multirank_probe.py, tools/host_feed_probe.py)
+            if os.environ.get("CCSM_CALLMODS_REPORT"):      # machine-readable run summary (tools/host_feed_probe.py)
                 import json
                 with open(os.environ["CCSM_CALLMODS_REPORT"], "w") as rf:
                     json.dump(dict({k: v for k, v in stats.items() if k != "output"}, seconds=time.time() - t0, world=world), rf)
