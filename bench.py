@@ -402,6 +402,61 @@ def extras(weights, dm, dev, pool, grp):
     return out
 
 
+def call_mods_multi_gpu(nranks, reads_per_rank=24000, timeout_s=900):
+    """`python -m torch.distributed.run --nproc-per-node N -m ccsmeth_amd call_mods` on a synthetic HiFi BAM (8000 generated reads, their
+    records 3 N times over: 18 M sites and 1.25 GiB per GPU), one process per GPU: BASELINE configs[3] scaled to what a bench run may take
+    (~20 s of generation, ~10 s of run)."""
+    import shutil
+    import tempfile
+    import torch
+    from collections import OrderedDict
+    from ccsmeth_amd.utils import benchdata, synth
+    tmp = tempfile.mkdtemp(prefix="ccsm_bench_mg_")
+    try:
+        base, inp, ckpt, rep = (os.path.join(tmp, f) for f in ("base.bam", "in.bam", "m.ckpt", "report.json"))
+        gen_s, _ = benchdata.write_synthetic_hifi_bam(base, 8000, 15000)
+        times = max(1, reads_per_rank * nranks // 8000)
+        size = benchdata.replicate_bam(base, inp, times)
+        os.remove(base)
+        torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
+        cores = len(os.sched_getaffinity(0))
+        try:
+            q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                cores = min(cores, max(1, int(int(q) / int(p))))
+        except (OSError, ValueError):
+            pass
+        threads = max(2, min(16, cores // nranks))
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        drop = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS")
+        env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_", "CCSM_BENCH_"))}
+        env.update(CCSM_CALLMODS_REPORT=rep, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   PYTHONPATH=os.path.dirname(os.path.abspath(__file__)) + os.pathsep + env.get("PYTHONPATH", ""))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), "-m", "ccsmeth_amd", "call_mods", "-i", inp, "-m", ckpt, "-o", os.path.join(tmp, "out"),
+               "--batch_size", "12288", "--threads", str(threads)]
+        t0 = time.time()
+        p = subprocess.run(cmd, env=env, cwd=os.path.dirname(os.path.abspath(__file__)), capture_output=True, text=True, timeout=timeout_s)
+        wall = time.time() - t0
+        if p.returncode != 0 or not os.path.exists(rep):
+            return {"error": "rc %d: %s" % (p.returncode, (p.stderr or "")[-600:])}
+        d = json.load(open(rep))
+        work = max(d.get("rank_seconds_work", [d.get("seconds_work", 0.0)]))
+        return {"value": d["sites"] / d["seconds"], "unit": "sites/s", "ranks": nranks, "reads": d["reads"], "sites": d["sites"], "input_GiB": size / 2 ** 30,
+                "seconds": d["seconds"], "seconds_work_slowest_rank": work, "work_phase_sites_per_s": d["sites"] / max(work, 1e-9),
+                "seconds_stitch": d.get("seconds_stitch"), "seconds_index": d.get("seconds_index"), "rank_chunks": d.get("rank_chunks"),
+                "threads_per_rank": threads, "host_cores": cores, "process_wall_s": wall,
+                "what": "BASELINE configs[3] scaled down: python -m torch.distributed.run --nproc-per-node %d -m ccsmeth_amd call_mods on a synthetic "
+                        "BAM (8000 generated 15-kb reads x %d), one process per GPU, chunk queue, one stitched modbam + index; `value` = sites / "
+                        "in-run seconds incl. model set-up and the gather / stitch / index tail, `work_phase_sites_per_s` = sites / the slowest "
+                        "rank's reading-to-writing phase" % (nranks, times)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -526,12 +581,22 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
         if n_gpus == 1 and a.extras == "all":
             line["extras"] = extras(weights, dm, dev, pool, grp)
-        print(json.dumps(line), flush=True)
     runner.close()
     dm.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # N > 1: the line above is device-resident weak scaling; BASELINE configs[3] is the BAM -> modbam path on N GPUs.  With this
+        # job's own ranks gone (they have nothing left to do), rank 0 runs that path once as its own torch.distributed.run job on a
+        # synthetic BAM and reports it beside the headline - bounded by a timeout, never instead of the line
+        legs = int(os.environ.get("CCSM_BENCH_MULTI_LEG_RANKS", n_gpus if n_gpus > 1 else 0))
+        if legs > 1 and a.extras == "all":
+            try:
+                line.setdefault("extras", {})["call_mods_multi_gpu"] = call_mods_multi_gpu(legs)
+            except Exception as e:      # noqa: BLE001
+                line.setdefault("extras", {})["call_mods_multi_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
