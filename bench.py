@@ -45,7 +45,9 @@ PEAK_HBM = 8.0e12
 # read from inside this process)
 TRAFFIC = {4: ((2 * 1209100 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_coalesced.md"),
            5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced_hybrid.md"),
+           6: (None, None),
            3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
+ARITH_NAME = {3: "split3", 4: "split-mx", 5: "hybrid", 6: "split-mx-d"}
 ARITH = {4: ("f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate",
              "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp4 e2m1 for the "
              "recurrent part and the r, z gates' input part, fp6 e2m3 for the n gate's input part, per-(row, 32-k) E8M0 scales, fp6 e2m3 "
@@ -54,6 +56,9 @@ ARITH = {4: ("f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate",
              "GRU layers: the input part as in split-mx (hi*hi on v_mfma_f32_32x32x16_f16 + one block-scaled fp6/fp4 x fp6 correction MFMA per "
              "32 k), the recurrent part in three fp16 passes (hi*hi+hi*lo+lo*hi) on an fp16 hi + lo state; attention pool: fp8 e4m3 x fp8 "
              "correction; one fp32 accumulator", (512 * 99.0 / 64.0 + 256 * 3.0) / 768.0),
+         6: ("f16 + MX(fp6 x fp6, per-row scales) split operands, f32 accumulate",
+             "split-mx with fp6 e2m3 weight blobs for the recurrent part as well, and the state's fp6 correction blob scaled per (row, 32-k block) "
+             "from the block's own largest magnitude (E8M0 from the fp16 hi fragments) instead of one fixed exponent", 99.0 / 64.0),
          3: ("f16x3 split operands, f32 accumulate", "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate", 3.0)}
 
 
@@ -65,7 +70,7 @@ def parse():
     ap.add_argument("--coalesce", type=int, default=6,
                     help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
                          "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds)")
-    ap.add_argument("--precision", type=int, default=0, choices=(0, 3, 4, 5),
+    ap.add_argument("--precision", type=int, default=0, choices=(0, 3, 4, 5, 6),
                     help="0 = the library's default: the fastest of split-mx (fp16 main product + MX correction product), the hybrid (split-mx input\n"
                          "part, three-pass recurrent part) and split3 whose probe batch through ccsm_create on these weights leaves at most 0.5 %% of\n"
                          "the sites beyond 1e-5 and none beyond 5e-5 of split3; 4 = split-mx forced; 5 = hybrid forced; 3 = split-fp16 x3 (fp32-class)")
@@ -280,9 +285,9 @@ def extras(weights, dm, dev, pool, grp):
         _, ref = c_oracle.forward(wt, sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"], h1, h2,
                                   threads=c_oracle.usable_threads())
         d = np.abs(gpu - ref)[:, 1]
-        res = {"value": steps * BATCH / dt, "unit": "sites/s", "arithmetic_selected": {3: "split3", 4: "split-mx", 5: "hybrid"}.get(dmt.precision, dmt.precision),
-               "probe": {"split_mx_max": dmt.probe_error, "split_mx_tail_gt_1e-5": dmt.probe_tail, "hybrid_max": dmt.probe_error_hybrid,
-                         "hybrid_tail_gt_1e-5": dmt.probe_tail_hybrid},
+        res = {"value": steps * BATCH / dt, "unit": "sites/s", "arithmetic_selected": ARITH_NAME.get(dmt.precision, dmt.precision),
+               "probe": {"split_mx_max": dmt.probe_error, "split_mx_tail_gt_1e-5": dmt.probe_tail, "split_mx_d_max": dmt.probe_error_mxd,
+                         "split_mx_d_tail_gt_1e-5": dmt.probe_tail_mxd, "hybrid_max": dmt.probe_error_hybrid, "hybrid_tail_gt_1e-5": dmt.probe_tail_hybrid},
                "launch_ms": float(np.mean(kt[1:3])), "roofline_frac": 2.0 * MAC_GRU12 * BATCH * grp / (float(np.mean(kt[1:3])) * 1e-3) / PEAK_F16_MFMA,
                "max_abs_dprob_vs_oracle": float(d.max()), "sites_checked": m, "sites_beyond_1e-5": int((d > 1e-5).sum()), "sites_beyond_5e-5": int((d > 5e-5).sum()),
                "frac_called_methylated": float((ref[:, 1] > 0.5).mean()), "train": {"steps": steps_t, "batch": n, "seed": wseed, "last_loss": float(loss), "seconds": t_train},
@@ -391,7 +396,7 @@ def extras(weights, dm, dev, pool, grp):
                 "what": "stock PyTorch %s CPU modules (nn.GRU 3 x bidirectional + attention + fc), fp32, torch.set_num_threads(%d), explicit h0"
                         % (torch.__version__, threads)}
 
-    for prec, name in ((5, "hybrid"), (3, "split3"), (4, "split-mx")):     # the arithmetics the probe did not select for these weights
+    for prec, name in ((6, "split-mx-d"), (5, "hybrid"), (3, "split3"), (4, "split-mx")):     # the arithmetics the probe did not select for these weights
         if prec != dm.precision:
             leg(name, other_arithmetic(prec))
     leg("trained", trained)
@@ -533,7 +538,7 @@ def main():
             "config": {"workload": "attbigru2s_b21 forward on synthetic 21-mer CpG batches (BASELINE.json configs[1])",
                        "batch": BATCH, "sites_per_step": BATCH, "coalesce": grp, "streams": 2 if runner.overlap else 1, "full_groups": full, "ragged_group_batches": rag,
                        "warmup_steps_run": w_steps, "h0": "device Philox N(0,1)", "arithmetic": arith,
-                       "arithmetic_selected": {3: "split3", 4: "split-mx", 5: "hybrid"}.get(dm.precision, dm.precision), "probe_max_abs_dprob": dm.probe_error,
+                       "arithmetic_selected": ARITH_NAME.get(dm.precision, dm.precision), "probe_max_abs_dprob": dm.probe_error,
                        "probe_max_abs_dprob_hybrid": dm.probe_error_hybrid,
                        "weights": ("state dict from %s" % a.weights) if a.weights else
                                   "synthetic random initialisation (seed 20260928); a TRAINED checkpoint typically makes the probe of ccsm_create "
@@ -542,7 +547,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
-                         "traffic": traffic * sites_per_launch, "traffic_source": traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled per site)",
+                         "traffic": None if traffic is None else traffic * sites_per_launch,
+                         "traffic_source": None if traffic is None else traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled per site)",
                          "launch_ms": dom_ms, "mfma_passes_per_flop": passes,
                          "issued_frac": achieved * passes / PEAK_F16_MFMA,
                          "power_note": "the kernel runs at the package power cap (sclk ~1.65-1.75 GHz of 2.4): profiles/r02_c_power_attribution.md; see peak_power_capped",

@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("CCSM_LIB_PATH") or os.path.join(_HERE, "lib", "libccs
 SEQ_LEN, HIDDEN, LAYERS, CLASSES = 21, 256, 3, 2
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_CAPACITY = range(6)
 H0_EXPLICIT, H0_ZERO, H0_DEVICE_RNG = 0, 1, 2
-PRECISION_SPLIT3, PRECISION_SPLIT_MX, PRECISION_HYBRID = 3, 4, 5      # ccsm_precision (include/ccsm.h); 0 = chosen by ccsm_create's probe
+PRECISION_SPLIT3, PRECISION_SPLIT_MX, PRECISION_HYBRID, PRECISION_SPLIT_MXD = 3, 4, 5, 6      # ccsm_precision (include/ccsm.h); 0 = chosen by ccsm_create's probe
 
 _FP = C.POINTER(C.c_float)
 
@@ -64,7 +64,7 @@ _lib = None
 # every symbol include/ccsm.h declares (checked by tests/test_cabi_symbols.py without a GPU)
 EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspace_destroy", "ccsm_forward_host",
            "ccsm_submit_host", "ccsm_wait_host", "ccsm_forward_device", "ccsm_last_error", "ccsm_version",
-           "ccsm_model_precision", "ccsm_model_probe_error", "ccsm_model_probe_error_hybrid", "ccsm_model_probe_tail", "ccsm_model_quant_error", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
+           "ccsm_model_precision", "ccsm_model_probe_error", "ccsm_model_probe_error_hybrid", "ccsm_model_probe_error_of", "ccsm_model_probe_tail", "ccsm_model_quant_error", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
            "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded", "ccsm_debug_rows_capacity",
            "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean",
            "ccsm_forward_reads_host", "ccsm_submit_reads_host", "ccsm_wait_reads_host", "ccsm_selftest_split_f8", "ccsm_selftest_split_mx",
@@ -103,6 +103,8 @@ def load():
     lib.ccsm_model_probe_error.restype = C.c_float
     lib.ccsm_model_probe_error_hybrid.argtypes = [vp]
     lib.ccsm_model_probe_error_hybrid.restype = C.c_float
+    lib.ccsm_model_probe_error_of.argtypes = [vp, C.c_int]
+    lib.ccsm_model_probe_error_of.restype = C.c_float
     lib.ccsm_model_probe_tail.argtypes = [vp, C.c_int]
     lib.ccsm_model_probe_tail.restype = C.c_float
     lib.ccsm_model_quant_error.argtypes = [vp]

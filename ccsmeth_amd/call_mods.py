@@ -84,12 +84,12 @@ def build_parser():
     p.add_argument("--io", default="native", choices=["native", "python"],
                    help="BAM reader/writer: libccsm_bam (threaded BGZF, whole read chunks straight to the GPU; implies --extract\n"
                         "device) or the pure-Python record-by-record implementation")
-    p.add_argument("--arithmetic", default="auto", choices=["auto", "split3", "hybrid", "split-mx"],
+    p.add_argument("--arithmetic", default="auto", choices=["auto", "split3", "hybrid", "split-mx-d", "split-mx"],
                    help="MFMA arithmetic of the model: auto (default) = the fastest of split-mx (fp16 main product + one block-scaled\n"
-                        "fp6/fp4 correction product), hybrid (split-mx for the GRUs' input part, three fp16 passes for their recurrent\n"
-                        "part) and split3 (three fp16 passes everywhere: fp32-class, max abs error < 1e-6) whose probe batch through THIS\n"
+                        "fp6/fp4 correction product), split-mx-d (the same with fp6 recurrent weights and the state's correction scaled\n"
+                        "per row), hybrid (split-mx for the GRUs' input part, three fp16 passes for their recurrent part) and split3 (three fp16 passes everywhere: fp32-class, max abs error < 1e-6) whose probe batch through THIS\n"
                         "checkpoint leaves at most 0.5 %% of the sites beyond 1e-5 and none beyond 5e-5 of split3.  Trained checkpoints\n"
-                        "usually end at hybrid: split-mx leaves ~0.1 %% of their sites beyond 1e-4.  The other values force one")
+                        "usually end at split-mx-d or hybrid: split-mx leaves ~0.1 %% of their sites beyond 1e-4.  The other values force one")
     p.add_argument("--extract", default="device", choices=["device", "host"],
                    help="where the 21-mer features are built: on the GPU from the raw read arrays (default) or NumPy on the host")
     return p
@@ -272,7 +272,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
             args.device = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)    # one process per GPU
         model = ModelAttRNN(args.seq_len, args.layer_rnn, args.class_num, args.dropout_rate, args.hid_rnn, is_npass=True,
                             model_type=args.model_type, device=args.device, seed=args.tseed, max_batch=args.batch_size,
-                            precision={"auto": 0, "split3": 3, "split-mx": 4, "hybrid": 5}[getattr(args, "arithmetic", "auto")])
+                            precision={"auto": 0, "split3": 3, "split-mx": 4, "hybrid": 5, "split-mx-d": 6}[getattr(args, "arithmetic", "auto")])
         para = _load_state_dict(args.model_file)
         try:
             model.load_state_dict(para)
@@ -284,9 +284,10 @@ def call_mods(args, log=sys.stderr, pipe=None):
             probe = "" if dm.probe_error < 0 else (" (probe batch of 2048 sites against split3, accepted with <= 0.5 %% of the sites beyond 1e-5 and none "
                                                    "beyond 5e-5: split-mx max %.1e, %.2f %% beyond 1e-5%s)") % (
                 dm.probe_error, 100.0 * dm.probe_tail,
-                "" if dm.probe_error_hybrid < 0 else "; hybrid max %.1e, %.2f %% beyond 1e-5" % (dm.probe_error_hybrid, 100.0 * dm.probe_tail_hybrid))
+                ("" if dm.probe_error_mxd < 0 else "; split-mx-d max %.1e, %.2f %% beyond 1e-5" % (dm.probe_error_mxd, 100.0 * dm.probe_tail_mxd)) +
+                ("" if dm.probe_error_hybrid < 0 else "; hybrid max %.1e, %.2f %% beyond 1e-5" % (dm.probe_error_hybrid, 100.0 * dm.probe_tail_hybrid)))
             print("[main]arithmetic: %s%s" % ({3: "split3 (three fp16 passes)", 4: "split-mx", 5: "hybrid (split-mx input part, three-pass "
-                                               "recurrent part)"}.get(dm.precision, dm.precision), probe), file=log)
+                                               "recurrent part)", 6: "split-mx-d (fp6 recurrent weights, per-row state scales)"}.get(dm.precision, dm.precision), probe), file=log)
         # --batch_size (reference default 512) is the reference's sites per model call.  On the GPU-extraction paths a launch wants
         # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
         # (every site's initial state is a function of the seed, its read's name and its position there), so the flag is only a lower bound there.

@@ -73,6 +73,8 @@ struct ccsm_model {
     float probe_err_hybrid = -1.f;                       // ... of the hybrid arithmetic (-1: not run: split-mx was accepted)
     float probe_tail = -1.f, probe_tail_hybrid = -1.f;   // fraction of the probe sites beyond kProbeTailAt
     float probe_err = -1.f;                              // max |dprob| split-mx vs split-fp16 on the probe batch of ccsm_create (-1: not run)
+    float probe_err_dyn = -1.f, probe_tail_dyn = -1.f;   // ... of split-mx-d (fp6 recurrent blobs + per-row dynamic activation scales)
+    uint4* wstmd[kLayers] = {nullptr, nullptr, nullptr};// split-mx-d weight streams (fp6 recurrent blobs)
     uint4* wstmx[kLayers] = {nullptr, nullptr, nullptr};// split-mx weight streams (ccsm_gru_mx.hip: hi fragments + MX correction blobs)
     uint4* wsthy[kLayers] = {nullptr, nullptr, nullptr};// hybrid weight streams (the same with fp16 lo fragments for the recurrent part)
     uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
@@ -304,10 +306,10 @@ inline void emit_hi_frag(_Float16* dst, int kb, const std::function<float(int, i
 
 // Split-mx weight stream of one layer (byte layouts: ccsm_gru_mx.hip).  Returns the relative RMS quantisation error of the layer's
 // correction blobs (the larger of the W_lo and W_hi halves).
-float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const float* const whh[2], bool hs3, std::vector<uint8_t>& out) {
+float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const float* const whh[2], bool hs3, std::vector<uint8_t>& out, bool dyn = false) {
     const int k_in = layer == 0 ? feat0 : 2 * kHidden;
-    const size_t wbytes = layer == 0 ? mx0_wbytes(hs3) : mx12_wbytes(hs3);
-    const size_t pair_b = mx_pair_b(hs3);
+    const size_t wbytes = layer == 0 ? mx0_wbytes(hs3, dyn) : mx12_wbytes(hs3, dyn);
+    const size_t pair_b = mx_pair_b(hs3, dyn);
     out.assign((size_t)2 * kWaves * wbytes, 0);
     BlobErr be;
     for (int dir = 0; dir < 2; ++dir)
@@ -335,7 +337,9 @@ float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const flo
                             hi_at(pb + (size_t)(3 * kbl + g) * 1024, wh(g), 2 * q + kbl);
                             if (hs3) lo_at(pb + (size_t)(6 + 3 * kbl + g) * 1024, wh(g), 2 * q + kbl);      // hybrid: fp16 residual fragments
                         }
-                    if (!hs3)
+                    if (dyn)          // split-mx-d: fp6 blobs [c0 x 3][c1 x 3][scales]
+                        for (int g = 0; g < 3; ++g) blob_at(pb + (size_t)(6 + g) * 1024, (long)(pb + 9 * 1024 + (size_t)g * 512), pb + 10 * 1024 + 512, g, kMxWFmtX, wh(g), q);
+                    else if (!hs3)
                         for (int g = 0; g < 3; ++g) blob_at(pb + (size_t)(6 + g) * 1024, -1, pb + 9 * 1024, g, kMxWFmtH, wh(g), q);
                 }
             };
@@ -353,7 +357,7 @@ float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const flo
                 }
                 phase_b(kMx12OffB);
                 for (int p = 0; p < kKB12 / 2; ++p) {
-                    const size_t pc = mx12_off_c(hs3) + (size_t)p * kMxPairC;
+                    const size_t pc = mx12_off_c(hs3, dyn) + (size_t)p * kMxPairC;
                     hi_at(pc, wx(2), 2 * p); hi_at(pc + 1024, wx(2), 2 * p + 1);
                     blob_at(pc + 2 * 1024, (long)(pc + 3 * 1024), pc + 3 * 1024 + 512, 0, kMxWFmtX, wx(2), p);
                 }
@@ -437,26 +441,27 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
 
 // GRU layers in split-mx arithmetic.  A build with -DCCSM_PHASE_STAMPS also holds the instantiations that record the cycle counter
 // at the phase boundaries of workgroup 0 (tools/gpu_phases.py); the product library is built without it.
-template <bool HS3>
+template <bool HS3, bool DYN>
 void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4* out, const uint4* wst, const float* bias, const float* h0,
                    int rows_p, unsigned long long* dbg) {
 #ifdef CCSM_PHASE_STAMPS
     if (dbg) {
-        if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<true, HS3>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
-        else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true, HS3>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
-        else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true, HS3>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<true, HS3, DYN>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
         return;
     }
 #endif
     (void)dbg;
-    if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, HS3>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
-    else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false, HS3>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
-    else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false, HS3>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);   // fp8 corr fragments for the attention kernel
+    if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, HS3, DYN>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
+    else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);   // fp8 corr fragments for the attention kernel
 }
 
 // Heavy kernels, once over every row used by the current slices, then the per-slice logits/softmax.
-// F8: the split-mx family (activations as [hi | blob] fragments); HS3: its hybrid member (recurrent part in three fp16 passes)
-template <bool F8, bool HS3 = false>
+// F8: the split-mx family (activations as [hi | blob] fragments); HS3: its hybrid member (recurrent part in three fp16 passes);
+// DYN: split-mx-d (fp6 recurrent blobs, per-row dynamic activation scales)
+template <bool F8, bool HS3 = false, bool DYN = false>
 ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
     const int rows_run = ((ws->rows_used + kRowPad - 1) / kRowPad) * kRowPad;
     const int tiles = rows_run / 32;
@@ -471,12 +476,12 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     constexpr int dbg_layer = -1;
 #endif
     if constexpr (F8) {
-        uint4* const* wst = HS3 ? m->wsthy : m->wstmx;
-        launch_gru_mx<HS3>(0, ggrid, st, ws->x0, ws->act[0], wst[0], m->bias[0], ws->h0buf, ws->rows_p, dbg_layer == 0 ? ws->dbg : nullptr);
+        uint4* const* wst = HS3 ? m->wsthy : DYN ? m->wstmd : m->wstmx;
+        launch_gru_mx<HS3, DYN>(0, ggrid, st, ws->x0, ws->act[0], wst[0], m->bias[0], ws->h0buf, ws->rows_p, dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
-        launch_gru_mx<HS3>(1, ggrid, st, ws->act[0], ws->act[1], wst[1], m->bias[1], ws->h0buf + slab, ws->rows_p, dbg_layer == 1 ? ws->dbg : nullptr);
+        launch_gru_mx<HS3, DYN>(1, ggrid, st, ws->act[0], ws->act[1], wst[1], m->bias[1], ws->h0buf + slab, ws->rows_p, dbg_layer == 1 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-        launch_gru_mx<HS3>(2, ggrid, st, ws->act[1], ws->act[0], wst[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, dbg_layer == 2 ? ws->dbg : nullptr);
+        launch_gru_mx<HS3, DYN>(2, ggrid, st, ws->act[1], ws->act[0], wst[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, dbg_layer == 2 ? ws->dbg : nullptr);
     } else {
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
                            m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p);
@@ -523,9 +528,10 @@ ccsm_status dispatch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st
     switch (m->precision) {
         case CCSM_PRECISION_SPLIT_F8: return launch_run<true>(m, ws, st);
         case CCSM_PRECISION_HYBRID: return launch_run<true, true>(m, ws, st);
+        case CCSM_PRECISION_SPLIT_MXD: return launch_run<true, false, true>(m, ws, st);
         case CCSM_PRECISION_SPLIT3: return launch_run<false>(m, ws, st);
     }
-    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 3 (split-fp16), 4 (split-mx) or 5 (hybrid)");
+    return fail(CCSM_ERR_UNSUPPORTED, "precision must be 3 (split-fp16), 4 (split-mx), 5 (hybrid) or 6 (split-mx-d)");
 }
 
 // add one slice (device pointers) to the workspace
@@ -650,13 +656,14 @@ ccsm_status probe_arithmetic(ccsm_model* m) {
     std::memset(&h0, 0, sizeof(h0));
     h0.mode = CCSM_H0_DEVICE_RNG;
     h0.seed = 20260928;
-    // reference = three fp16 passes; candidates in order of speed: split-mx, then the hybrid (recurrent part in three passes)
+    // reference = three fp16 passes; candidates in order of speed: split-mx, split-mx-d (fp6 recurrent blobs + dynamic activation
+    // scales), then the hybrid (recurrent part in three passes)
     std::vector<float> lg((size_t)kProbeSites * 2), pa(lg.size()), pb(lg.size());
     const int wanted = m->precision;
     m->precision = CCSM_PRECISION_SPLIT3;
     st = ccsm_forward_host(m, ws, kProbeSites, &b, &h0, lg.data(), pb.data(), nullptr);
     int chosen = CCSM_PRECISION_SPLIT3;
-    for (int cand : {(int)CCSM_PRECISION_SPLIT_F8, (int)CCSM_PRECISION_HYBRID}) {
+    for (int cand : {(int)CCSM_PRECISION_SPLIT_F8, (int)CCSM_PRECISION_SPLIT_MXD, (int)CCSM_PRECISION_HYBRID}) {
         if (st != CCSM_OK) break;
         m->precision = cand;
         st = ccsm_forward_host(m, ws, kProbeSites, &b, &h0, lg.data(), pa.data(), nullptr);
@@ -669,8 +676,8 @@ ccsm_status probe_arithmetic(ccsm_model* m) {
             beyond += d > kProbeTailAt;
         }
         const float tail = (float)beyond / (float)kProbeSites;
-        (cand == CCSM_PRECISION_SPLIT_F8 ? m->probe_err : m->probe_err_hybrid) = err;
-        (cand == CCSM_PRECISION_SPLIT_F8 ? m->probe_tail : m->probe_tail_hybrid) = tail;
+        (cand == CCSM_PRECISION_SPLIT_F8 ? m->probe_err : cand == CCSM_PRECISION_SPLIT_MXD ? m->probe_err_dyn : m->probe_err_hybrid) = err;
+        (cand == CCSM_PRECISION_SPLIT_F8 ? m->probe_tail : cand == CCSM_PRECISION_SPLIT_MXD ? m->probe_tail_dyn : m->probe_tail_hybrid) = tail;
         if ((tail <= kProbeTailFrac && err <= kProbeMaxErr) || std::getenv("CCSM_NO_PRECISION_FALLBACK") != nullptr) { chosen = cand; break; }
     }
     m->precision = st == CCSM_OK ? chosen : wanted;
@@ -696,8 +703,8 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         return fail(CCSM_ERR_UNSUPPORTED, "this build takes at most 16 input columns (is_npass + is_stds + is_sn together need 17)");
     const int prec = cfg->precision == 0 ? 4 : cfg->precision;
     const bool auto_prec = cfg->precision == 0;
-    if (prec != CCSM_PRECISION_SPLIT3 && prec != CCSM_PRECISION_SPLIT_F8 && prec != CCSM_PRECISION_HYBRID)
-        return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default: chosen by a probe batch), 3 (split-fp16), 4 (split-mx) or 5 (hybrid)");
+    if (prec != CCSM_PRECISION_SPLIT3 && prec != CCSM_PRECISION_SPLIT_F8 && prec != CCSM_PRECISION_HYBRID && prec != CCSM_PRECISION_SPLIT_MXD)
+        return fail(CCSM_ERR_INVALID_ARG, "precision must be 0 (default: chosen by a probe batch), 3 (split-fp16), 4 (split-mx), 5 (hybrid) or 6 (split-mx-d)");
     if (!w->embed_weight || !w->att_wa || !w->att_ua || !w->att_va || !w->fc1_weight || !w->fc1_bias)
         return fail(CCSM_ERR_INVALID_ARG, "weights: NULL tensor");
     for (int l = 0; l < kLayers; ++l)
@@ -729,6 +736,13 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             const float qe = pack_wstream_mx(l, m->feat0, w->weight_ih[l], w->weight_hh[l], true, bbuf);
             if (prec == 5) m->mx_quant_err = std::fmax(m->mx_quant_err, qe);
             st = upload(&m->wsthy[l], bbuf.data(), bbuf.size());
+            if (st != CCSM_OK) break;
+        }
+        if (prec == 6 || auto_prec) {
+            std::vector<uint8_t> bbuf;
+            const float qe = pack_wstream_mx(l, m->feat0, w->weight_ih[l], w->weight_hh[l], false, bbuf, true);
+            if (prec == 6) m->mx_quant_err = std::fmax(m->mx_quant_err, qe);
+            st = upload(&m->wstmd[l], bbuf.data(), bbuf.size());
             if (st != CCSM_OK) break;
         }
         pack_bias(w->bias_ih[l], w->bias_hh[l], fbuf);
@@ -763,6 +777,9 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, true>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, true>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false, true>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false, true>), kMx12Lds);
 #ifdef CCSM_PHASE_STAMPS
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, false>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, false>), kMx12Lds);
@@ -770,6 +787,9 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, true>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, true>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true, true>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, false, true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, false, true>), kMx12Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true, false, true>), kMx12Lds);
 #endif
             set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttF8Lds);
         }
@@ -788,8 +808,13 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
 
 float ccsm_model_probe_error(const ccsm_model* m) { return m ? m->probe_err : -1.f; }
 float ccsm_model_probe_error_hybrid(const ccsm_model* m) { return m ? m->probe_err_hybrid : -1.f; }
+float ccsm_model_probe_error_of(const ccsm_model* m, int precision) {
+    return !m ? -1.f : precision == CCSM_PRECISION_SPLIT_F8 ? m->probe_err : precision == CCSM_PRECISION_HYBRID ? m->probe_err_hybrid
+              : precision == CCSM_PRECISION_SPLIT_MXD ? m->probe_err_dyn : -1.f;
+}
 float ccsm_model_probe_tail(const ccsm_model* m, int precision) {
-    return !m ? -1.f : precision == CCSM_PRECISION_SPLIT_F8 ? m->probe_tail : precision == CCSM_PRECISION_HYBRID ? m->probe_tail_hybrid : -1.f;
+    return !m ? -1.f : precision == CCSM_PRECISION_SPLIT_F8 ? m->probe_tail : precision == CCSM_PRECISION_HYBRID ? m->probe_tail_hybrid
+              : precision == CCSM_PRECISION_SPLIT_MXD ? m->probe_tail_dyn : -1.f;
 }
 float ccsm_model_quant_error(const ccsm_model* m) { return m ? m->mx_quant_err : -1.f; }
 
@@ -799,6 +824,7 @@ void ccsm_destroy(ccsm_model* m) {
     for (int l = 0; l < kLayers; ++l) {
         (void)hipFree(m->wst2[l]);
         (void)hipFree(m->wstmx[l]);
+        (void)hipFree(m->wstmd[l]);
         (void)hipFree(m->wsthy[l]);
         (void)hipFree(m->bias[l]);
     }

@@ -47,6 +47,36 @@ constexpr float kMxLoScale = 65536.0f;             // a wave's private fp8 resid
 typedef _Float16 half32 __attribute__((ext_vector_type(32)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
+// ---- "split-mx-d" (DYN): the recurrent part's activation blobs with one E8M0 scale per (row, 32-k block) instead of the fixed x_hi * 4.
+// On TRAINED checkpoints the fixed scale is what gives split-mx its tail (state values below 0.25 are fp6 subnormals there; together with
+// the fp4 recurrent weights: 0.2-1.7e-4 max |dprob|; emulated with fp6 weights and per-block scales: 1.4-3.3e-5,
+// profiles/r03_y_dynamic_scale_emulation.log).  The block scale needs no storage: it is a function of the block's largest |x_hi| as
+// fp16, and every lane that reads a blob also holds 16 of the block's 32 fp16 hi values (its hi fragments of the pair's two k-blocks),
+// its half-wave partner the other 16 - the writer (step tail) and every reader derive the same exponent E:
+//     m = max |x_hi| (fp16 bits e, mantissa f):  E = max(e, 1) - 17 + (f > 0x380)      so that  |x_hi| / 2^E <= 7.5  (fp6 e2m3's top)
+//     hi lanes (g = 0) hold x_hi / 2^E, scale byte 127 + E;   lo lanes (g = 1) hold x_lo / 2^(E - 11), scale byte 127 + E - 11
+//     (|x_lo| <= half an ulp of the block's largest value = 2^(e - 26): at most 4 after the division).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t absmax8(uint4 f) {                 // eight fp16 of one fragment lane -> max |.| pair-wise (two u16 lanes)
+    const uint32_t a = f.x & 0x7fff7fffu, b = f.y & 0x7fff7fffu, c = f.z & 0x7fff7fffu, d = f.w & 0x7fff7fffu;
+    const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)),
+                                              __builtin_elementwise_max(__builtin_bit_cast(u16x2, c), __builtin_bit_cast(u16x2, d)));
+    return __builtin_bit_cast(uint32_t, m);                            // (positive fp16 bit patterns order like unsigned integers)
+}
+__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+// pm = pair-wise max of this lane's 16 values; returns E of the (row, block): the partner lane (n, 1 - g) holds the other 16
+__device__ __forceinline__ int dyn_block_exp(uint32_t pm) {
+    uint32_t m = pm & 0xffffu, h = pm >> 16;
+    m = m > h ? m : h;
+    uint32_t x = m, y = m;
+    swap32(x, y);                                                      // lower lanes: y = partner's m; upper lanes: x = partner's m
+    m = x > y ? x : y;
+    const int e = (int)(m >> 10);
+    return (e > 1 ? e : 1) - 17 + ((m & 0x3ffu) > 0x380u ? 1 : 0);
+}
+
 // correction MFMA of one pair: fp4 weight blob w (16 bytes per lane), its scale = byte G of ws, activation blob (x0, x1)
 template <int G>
 __device__ __forceinline__ f32x16 mfma_corr_mx(uint4 w, uint32_t ws, uint4 x0, uint2 x1, f32x16 c, int scale_b) {
@@ -76,8 +106,10 @@ __device__ __forceinline__ void blob_of(const uint32_t (&p)[16], float scale, ui
 //   c0, c1   : this lane's activation blob (lower lanes: x_hi of all 32 units, upper lanes: x_lo)
 //   lo8      : fp8 (x 2^16) residuals of this lane's own 16 values, C-layout order (the wave's private copy)
 // SCALE = what the blob's values are divided by (0.25 for GRU outputs; kMxH0Div for initial states).
-template <bool CLAMP>
-__device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, uint4& hi0, uint4& hi1, uint4& c0, uint2& c1, uint4& lo8) {
+// DYNB: additionally the blob with the block's own scale (dyn_block_exp of the 32 hi values) in d0 / d1 - always from the unclamped values.
+template <bool CLAMP, bool DYNB = false>
+__device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, uint4& hi0, uint4& hi1, uint4& c0, uint2& c1, uint4& lo8,
+                                             uint4* d0 = nullptr, uint2* d1 = nullptr, int upper = 0 /* lane >> 5 (DYNB) */) {
     typedef _Float16 half2p __attribute__((ext_vector_type(2)));
     uint32_t hp[8], hq[8], lp[8];     // hi (fragments), hi as it goes into the blob, lo * 2^12
     float lf[16];
@@ -123,6 +155,20 @@ __device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, 
         swap32(a1, b1);
         hi1 = make_uint4(a0, a1, b0, b1);
     }
+    if constexpr (DYNB) {
+        // the block's own scale from its 32 fp16 hi values; the lo lanes hold lo * 2^12 here and want x_lo / 2^(E - 11) = that / 2^(E + 1)
+        uint32_t pm = hp[0] & 0x7fff7fffu;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) pm = pkmax(pm, hp[j] & 0x7fff7fffu);
+        const int E = dyn_block_exp(pm);
+        uint32_t hu[8], lu[8];                                          // unclamped copies (CLAMP only concerns the fixed-scale blob)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hu[j] = hp[j]; lu[j] = pack2((_Float16)(lf[2 * j] * 4096.0f), (_Float16)(lf[2 * j + 1] * 4096.0f)); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) swap32(hu[j], lu[j]);
+        const uint32_t pd[16] = {hu[0], hu[1], hu[2], hu[3], hu[4], hu[5], hu[6], hu[7], lu[0], lu[1], lu[2], lu[3], lu[4], lu[5], lu[6], lu[7]};
+        blob_of(pd, __builtin_bit_cast(float, (uint32_t)(127 + E + upper) << 23), *d0, *d1);
+    }
     // blob: lower lanes end up with (own hi | partner's hi), upper lanes with (partner's lo | own lo): kMxPerm order
 #pragma unroll
     for (int j = 0; j < 8; ++j) swap32(hq[j], lp[j]);
@@ -159,7 +205,7 @@ constexpr int kMxHBytes = kKBH * kMxNB * 2 * 1024;
 __device__ __forceinline__ int mx_hfrag(int kb, int bt, int f) { return ((kb * kMxNB + bt) * 2 + f) << 10; }
 
 // ---- h0 -> LDS: hi fragments, blobs (coarse scale) and residuals of this wave's own two k-blocks, every batch tile
-template <bool HS3>
+template <bool HS3, bool DYN = false>
 __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float* __restrict__ h0d, int tile0, int wave, int lane) {
     const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
@@ -182,6 +228,10 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
         }
         uint4 hi0, hi1, c0, lo8;
         uint2 c1;
+        if constexpr (DYN) {            // the blob carries its own scale: any magnitude, no coarse first-step scale
+            uint4 f0; uint2 f1;
+            pack_pair_mx<false, true>(v, 0.25f, hi0, hi1, f0, f1, lo8, &c0, &c1, hh);
+        } else
         pack_pair_mx<true>(v, kMxH0Div, hi0, hi1, c0, c1, lo8);
         *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 0) + lane * 16) = hi0;
         *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 0) + lane * 16) = hi1;
@@ -194,7 +244,7 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
 // ---- step tail: n = tanh(N); h' = n + z (h_{t-1} - n) for this wave's own units; fragments and blobs for the next step (LDS)
 // and the next layer (HBM).  accz = sigmoid(Z) already, accn = N.  OUT_FP8: the layer feeding the attention kernel writes fp8 corr
 // fragments (attn_fc_f8_kernel's format) instead of blobs.  t16 = lane * 16 (an opaque copy: see lane16_here in the kernels).
-template <bool OUT_FP8, bool HS3>
+template <bool OUT_FP8, bool HS3, bool DYN = false>
 __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&accz)[kMxNB], const f32x16 (&accn)[kMxNB], uint4* __restrict__ out,
                                         int tile0, int t, int dir, int wave, int t16) {
     const int own_off = wave * (2 * kMxNB * 2 * 1024);                          // mx_hfrag(2 wave, 0, 0)
@@ -234,7 +284,10 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
         }
         uint4 hi0, hi1, c0, lo8;
         uint2 c1;
-        pack_pair_mx<false>(hn, 0.25f, hi0, hi1, c0, c1, lo8);
+        uint4 d0 = make_uint4(0, 0, 0, 0);
+        uint2 d1 = make_uint2(0, 0);
+        if constexpr (DYN) pack_pair_mx<false, true>(hn, 0.25f, hi0, hi1, c0, c1, lo8, &d0, &d1, t16 >> 9);   // (from the opaque lane copy: a hoisted 110 + upper got spilled)      // next layer: fixed scale; own state: block scale
+        else pack_pair_mx<false>(hn, 0.25f, hi0, hi1, c0, c1, lo8);
         const uint4 c1w = make_uint4(c1.x, c1.y, lo8.x, lo8.y);
         *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 0)) = hi0;
         *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 0)) = hi1;
@@ -243,13 +296,17 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
             pack_pair_hl(hn, h0_, h1_, lo0, lo1);
             *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = lo0;
             *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = lo1;
+        } else if constexpr (DYN) {
+            *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = d0;
+            *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = make_uint4(d1.x, d1.y, lo8.x, lo8.y);
+            *reinterpret_cast<uint2*>(t_lo + bt * (64 * 8)) = make_uint2(lo8.z, lo8.w);
         } else {
             *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = c0;
             *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = c1w;
             *reinterpret_cast<uint2*>(t_lo + bt * (64 * 8)) = make_uint2(lo8.z, lo8.w);
         }
         // streaming stores: the next reader is another kernel 0.5 GB later, keep the L2 for the weight stream
-        char* o = reinterpret_cast<char*>(out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + 2 * wave)) * 2 * kFragU4) + t16;
+        char* o = reinterpret_cast<char*>(out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + 2 * wave)) * 2 * kFragU4) + (uint32_t)t16;   // uniform base + 32-bit lane offset
         nt_store(hi0, reinterpret_cast<uint4*>(o));
         nt_store(hi1, reinterpret_cast<uint4*>(o + 2048));
         if constexpr (OUT_FP8) {
@@ -289,11 +346,14 @@ constexpr int kMxPairA = 6 * 1024 + 256, kMxPairB = 9 * 1024 + 256, kMxPairC = 3
 // accuracy (it is applied 21 times per layer): emulated on trained weights, max |dprob| 1.8e-5 with the hybrid against 1.2e-4 with split-mx
 // throughout.  Its phase-B pair: hi (kbl, g) at (3 kbl + g) KiB | fp16 lo (kbl, g) at (6 + 3 kbl + g) KiB = 12 KiB.
 constexpr int kMxPairBH = 12 * 1024;
-constexpr int mx_pair_b(bool hs3) { return hs3 ? kMxPairBH : kMxPairB; }
-constexpr int mx0_wbytes(bool hs3) { return 4 * 1024 + (kKBH / 2) * mx_pair_b(hs3) + 2 * 1024; }   // layer 0: [r hi, r lo, z hi, z lo] [B] [n hi, n lo]
+// split-mx-d (DYN): the recurrent weight blobs in fp6.  Its phase-B pair: hi (kbl, g) at (3 kbl + g) KiB | fp6 blob (g): bytes 0-15 at (6 + g) KiB,
+// bytes 16-23 at 9 KiB + g * 512 | scales at 10.5 KiB = 11008 B
+constexpr int kMxPairBD = 10 * 1024 + 512 + 256;
+constexpr int mx_pair_b(bool hs3, bool dyn = false) { return hs3 ? kMxPairBH : dyn ? kMxPairBD : kMxPairB; }
+constexpr int mx0_wbytes(bool hs3, bool dyn = false) { return 4 * 1024 + (kKBH / 2) * mx_pair_b(hs3, dyn) + 2 * 1024; }   // layer 0: [r hi, r lo, z hi, z lo] [B] [n hi, n lo]
 constexpr int kMx12OffB = (kKB12 / 2) * kMxPairA;
-constexpr int mx12_off_c(bool hs3) { return kMx12OffB + (kKBH / 2) * mx_pair_b(hs3); }
-constexpr int mx12_wbytes(bool hs3) { return mx12_off_c(hs3) + (kKB12 / 2) * kMxPairC; }
+constexpr int mx12_off_c(bool hs3, bool dyn = false) { return kMx12OffB + (kKBH / 2) * mx_pair_b(hs3, dyn); }
+constexpr int mx12_wbytes(bool hs3, bool dyn = false) { return mx12_off_c(hs3, dyn) + (kKB12 / 2) * kMxPairC; }
 
 // G gates of the pair's correction product: weight blobs W[g] with scale bytes g of WS, activation blobs xc0 / xc1
 #define CCSM_CORR_G(G, W, WS, SB)                                                                             \
@@ -317,13 +377,14 @@ constexpr int mx12_wbytes(bool hs3) { return mx12_off_c(hs3) + (kKB12 / 2) * kMx
 constexpr int kMx0XOff = kMxHBytes, kMx0LoOff = kMx0XOff + 2 * kMxNB * 2 * 1024, kMx0BiasOff = kMx0LoOff + kWaves * kMxNB * 64 * 8;
 constexpr int kMx0Lds = kMx0BiasOff + kWaves * 4 * 32 * 4;
 
-template <bool DBG, bool HS3>
+template <bool DBG, bool HS3, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                 const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                 const float* __restrict__ h0, int rows_p,
                                                                 unsigned long long* __restrict__ dbg) {
     constexpr int NB = kMxNB;
-    constexpr int PB = mx_pair_b(HS3);
+    static_assert(!(HS3 && DYN), "one or the other");
+    constexpr int PB = mx_pair_b(HS3, DYN);
     constexpr int OFF_B = 4 * 1024, OFF_C = OFF_B + (kKBH / 2) * PB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -337,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 
     if (threadIdx.x < kWaves * 4 * 32 / 4)
         reinterpret_cast<float4*>(smem + kMx0BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
-    mx_h0_to_lds<HS3>(smem, kMx0LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
+    mx_h0_to_lds<HS3, DYN>(smem, kMx0LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     // x staging: 6 fragments per step (bt x hi|lo), waves 0-5 move one each
     const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * 2 * kFragU4);     // per-workgroup base: see gru_layer12_mx_kernel
@@ -348,15 +409,21 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
         const int soff = (((bt * kSeqLen + t) * 2 + hl) << 10);
         dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + ((buf * 6 + f) << 10))));
     };
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx0_wbytes(HS3));
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx0_wbytes(HS3, DYN));
     const int bias_off = kMx0BiasOff + wave * 4 * 32 * 4;
     auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
     auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
+    auto w8_at = [&](int off) -> uint2 {            // bytes 16-23 of an fp6 blob: lane * 8
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, off, 0);
+        return make_uint2(v[0], v[1]);
+    };
 
     uint4 wxa[2][2];                                                // phase A: [gate r,z][hi, lo]
     uint4 wxc[2];                                                   // phase C: n gate [hi, lo]
     uint4 wbh[2][3], wbb[3];                                        // phase B resident pair: [kb in pair][gate] hi ; [gate] blob
     uint32_t wbs = 0;                                               //                        scale bytes
+    uint2 wbb1[3];                                                  // split-mx-d: bytes 16-23 of the fp6 blobs
     uint4 wbl[2][3];                                                // hybrid arithmetic: [kb in pair][gate] fp16 lo instead of the blobs
     auto ld_first = [&]() {                                         // everything a step needs before its second phase-B pair: 14 (16) requests
 #pragma unroll
@@ -366,12 +433,14 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
             wbh[0][g] = w_at(OFF_B + (g << 10)); wbh[1][g] = w_at(OFF_B + ((3 + g) << 10));
             if constexpr (HS3) { wbl[0][g] = w_at(OFF_B + ((6 + g) << 10)); wbl[1][g] = w_at(OFF_B + ((9 + g) << 10)); }
             else wbb[g] = w_at(OFF_B + ((6 + g) << 10));
+            if constexpr (DYN) wbb1[g] = w8_at(OFF_B + (9 << 10) + g * 512);
         }
-        if constexpr (!HS3) wbs = ws_at(OFF_B + (9 << 10));
+        if constexpr (!HS3) wbs = ws_at(OFF_B + (DYN ? (10 << 10) + 512 : (9 << 10)));
     };
     stage_load(dir ? kSeqLen - 1 : 0, 0);
     ld_first();
     if constexpr (HS3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (DYN) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");          // the first transfer (older than the 14 weight requests)
 
     for (int s = 0; s < kSeqLen; ++s) {
@@ -407,6 +476,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
         // ---------------- phase A: R, Z += W_i{r,z} x_t (three fp16 passes) -------------------------------------------------
         // the transfer of this step's x (issued one step ago) is older than the 14 weight requests and 12 output stores of the tail
         if constexpr (HS3) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // (16 weight requests there)
+        else if constexpr (DYN) asm volatile("s_waitcnt vmcnt(29)" ::: "memory");   // (17)
         else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
         __syncthreads();                                            // x_t in LDS; everybody's h_{t-1} fragments written
         stage_load(tn, (s + 1) & 1);
@@ -477,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
             constexpr int Q = decltype(QC)::value;
             constexpr bool LAST = Q == kKBH / 2 - 1;
             constexpr int NXT = OFF_B + (Q + 1) * PB;
+            uint32_t pm[NB];                                            // split-mx-d: running max |x_hi| of the pair's block, this lane's values
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 0) + lane * 16);
@@ -489,6 +560,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 #pragma unroll
                 for (int g = 0; g < 3; ++g) acc[g][bt] = mfma16(wbh[0][g], xh[bt], acc[g][bt]);
             CCSM_FENCE;
+            if constexpr (DYN) {
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) pm[bt] = absmax8(xh[bt]);
+            }
             if constexpr (!LAST) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbh[0][g] = w_at(NXT + (g << 10));
@@ -505,11 +580,30 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbh[1][g] = w_at(NXT + ((3 + g) << 10));
             }
-            CCSM_CORR_G(3, wbb, wbs, sbh);
+            if constexpr (DYN) {
+                // the block scales of the three row tiles (vector ALU in the shadow of the main MFMAs above), then the correction products
+                int sbd[NB];
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) sbd[bt] = 127 + dyn_block_exp(pkmax(pm[bt], absmax8(xh[bt]))) - (hh ? 11 : 0);
+                CCSM_FENCE;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    acc[0][bt] = mfma_corr_mx6<0>(wbb[0], wbb1[0], wbs, xc0[bt], xc1[bt], acc[0][bt], sbd[bt]);
+                    acc[1][bt] = mfma_corr_mx6<1>(wbb[1], wbb1[1], wbs, xc0[bt], xc1[bt], acc[1][bt], sbd[bt]);
+                    acc[2][bt] = mfma_corr_mx6<2>(wbb[2], wbb1[2], wbs, xc0[bt], xc1[bt], acc[2][bt], sbd[bt]);
+                }
+                CCSM_FENCE;
+            } else {
+                CCSM_CORR_G(3, wbb, wbs, sbh);
+            }
             if constexpr (!LAST) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbb[g] = w_at(NXT + ((6 + g) << 10));
-                wbs = ws_at(NXT + (9 << 10));
+                if constexpr (DYN) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) wbb1[g] = w8_at(NXT + (9 << 10) + g * 512);
+                }
+                wbs = ws_at(NXT + (DYN ? (10 << 10) + 512 : (9 << 10)));
             }
             CCSM_FENCE;
         });
@@ -543,7 +637,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
         __syncthreads();                                            // every wave has read h_{t-1} (phase B) before anybody overwrites its fragments
-        mx_tail<false, HS3>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        mx_tail<false, HS3, DYN>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         stamp(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no transfer may still be writing LDS when the workgroup retires
@@ -575,13 +669,15 @@ constexpr int kMxSlotBytes = 2 * kMxNB * 2 * 1024;
 constexpr int kMx12XOff = kMxHBytes, kMx12LoOff = kMx12XOff + kMxRS * kMxSlotBytes, kMx12BiasOff = kMx12LoOff + kWaves * kMxNB * 64 * 8;
 constexpr int kMx12Lds = kMx12BiasOff + kWaves * 4 * 32 * 4;
 
-template <bool OUT_FP8, bool DBG, bool HS3>
+template <bool OUT_FP8, bool DBG, bool HS3, bool DYN = false>
 __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                  const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                  const float* __restrict__ h0, int rows_p,
                                                                  unsigned long long* __restrict__ dbg) {
     constexpr int NB = kMxNB, KX = kKB12, NPAIR = KX / 2, RS = kMxRS, SLOT_BYTES = kMxSlotBytes;
-    constexpr int PA = kMxPairA, PB = mx_pair_b(HS3), PC = kMxPairC, OFF_B = kMx12OffB, OFF_C = mx12_off_c(HS3);
+    static_assert(!(HS3 && DYN), "one or the other");
+    constexpr int PA = kMxPairA, PB = mx_pair_b(HS3, DYN), PC = kMxPairC, OFF_B = kMx12OffB, OFF_C = mx12_off_c(HS3, DYN);
+    constexpr int OFF_BS = DYN ? (10 << 10) + 512 : (9 << 10);      // scale dwords of a phase-B pair
     constexpr int X_OFF = kMx12XOff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -594,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 
     if (threadIdx.x < kWaves * 4 * 32 / 4)
         reinterpret_cast<float4*>(smem + kMx12BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
-    mx_h0_to_lds<HS3>(smem, kMx12LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
+    mx_h0_to_lds<HS3, DYN>(smem, kMx12LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     // ---- x transfers: fragment f = (kbl * NB + bt) * 2 + hl of a ring slot; wave w moves fragment w, waves 0-3 also w + 8
     // the descriptor starts at THIS workgroup's first tile (64-bit address arithmetic): its 2 GiB range and the 32-bit offsets below
@@ -626,7 +722,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         else asm volatile("s_waitcnt vmcnt(" #NLO ")" ::: "memory");                     \
     } while (0)
 
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx12_wbytes(HS3));
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx12_wbytes(HS3, DYN));
     const int bias_off = kMx12BiasOff + wave * 4 * 32 * 4;
     auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
     auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
@@ -642,6 +738,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     uint32_t was[3];
     uint4 wbh[2][3], wbb[3];
     uint32_t wbs = 0;
+    uint2 wbb1[3];                                  // split-mx-d: bytes 16-23 of the resident phase-B pair's fp6 blobs
     uint4 wbl[2][3];                                // hybrid arithmetic: fp16 lo fragments of the resident phase-B pair instead of the blobs
     uint4 wch[4][2], wcb[4];
     uint2 wcb1[4];
@@ -736,19 +833,21 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             if constexpr (P + 3 < NPAIR) ldAh(wah[WS][0], P + 3, 0);
             else if constexpr (P == 13) { wbh[0][0] = w_at(OFF_B + (0 << 10)); wbh[0][1] = w_at(OFF_B + (1 << 10)); }
             else if constexpr (P == 14) {
-                if constexpr (HS3) wbl[1][0] = w_at(OFF_B + (9 << 10)); else wbs = ws_at(OFF_B + (9 << 10));
+                if constexpr (HS3) wbl[1][0] = w_at(OFF_B + (9 << 10)); else wbs = ws_at(OFF_B + OFF_BS);
             }
             rdx_blob(xs);
             CCSM_MAIN(wah[WS][1], xh1, 2, 0);
             if constexpr (P + 3 < NPAIR) ldAh(wah[WS][1], P + 3, 1);
             else if constexpr (P == 13) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); }
             else if constexpr (P == 14 && HS3) { wbl[1][1] = w_at(OFF_B + (10 << 10)); wbl[1][2] = w_at(OFF_B + (11 << 10)); }
+            else if constexpr (P == 14 && DYN) { wbb1[0] = w8_at(OFF_B + (9 << 10)); wbb1[1] = w8_at(OFF_B + (9 << 10) + 512); wbb1[2] = w8_at(OFF_B + (9 << 10) + 1024); }
             // this wave's part of the next pair's transfer has landed.  Operations the wave has issued since that refill (it sits right
             // behind its pair's barrier): the 3 blob / scale requests of that pair, two pairs of 7 + d, 4 of this pair; pair 13 requests
             // phase B's first pair instead (9), pair 14 one more of it, pair 15 nothing
-            // (hybrid arithmetic: pair 14 requests three fragments of phase B's first pair instead of one)
-            if constexpr (P == NPAIR - 1) { if constexpr (HS3) CCSM_WAIT_XFER(17, 19); else CCSM_WAIT_XFER(15, 17); }
-            else if constexpr (P == NPAIR - 2) { if constexpr (HS3) CCSM_WAIT_XFER(24, 26); else CCSM_WAIT_XFER(22, 24); }
+            // (hybrid arithmetic: pair 14 requests three fragments of phase B's first pair instead of one; split-mx-d: four - the scale
+            // dword and the three 8-byte ends of the fp6 blobs)
+            if constexpr (P == NPAIR - 1) { if constexpr (HS3) CCSM_WAIT_XFER(17, 19); else if constexpr (DYN) CCSM_WAIT_XFER(18, 20); else CCSM_WAIT_XFER(15, 17); }
+            else if constexpr (P == NPAIR - 2) { if constexpr (HS3) CCSM_WAIT_XFER(24, 26); else if constexpr (DYN) CCSM_WAIT_XFER(25, 27); else CCSM_WAIT_XFER(22, 24); }
             else CCSM_WAIT_XFER(23, 25);
             __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
             if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once (0.4 pair more
@@ -821,6 +920,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             constexpr int Q = decltype(QC)::value;
             constexpr bool LAST = Q == kKBH / 2 - 1;
             constexpr int NXT = OFF_B + (Q + 1) * PB;
+            uint32_t pm[NB];                                            // split-mx-d: running max |x_hi| of the pair's block, this lane's values
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 0) + lane * 16);
@@ -828,6 +928,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag(2 * Q + 1, bt, 1) + lane * 16);
             }
             CCSM_MAIN(wbh[0], xh, 3, 0);
+            if constexpr (DYN) {
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) pm[bt] = absmax8(xh[bt]);
+            }
             if constexpr (!LAST) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbh[0][g] = w_at(NXT + (g << 10));
@@ -843,11 +947,30 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             } else {
                 wcb1[0] = w8_at(OFF_C + 0 * PC + (3 << 10)); wcs[0] = ws_at(OFF_C + 0 * PC + (3 << 10) + 512); wch[1][0] = w_at(OFF_C + 1 * PC + (0 << 10));
             }
-            CCSM_CORR_G(3, wbb, wbs, sbh);
+            if constexpr (DYN) {
+                // the block scales of the three row tiles (vector ALU in the shadow of the main MFMAs above), then the correction products
+                int sbd[NB];
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) sbd[bt] = 127 + dyn_block_exp(pkmax(pm[bt], absmax8(xh[bt]))) - (hh ? 11 : 0);
+                CCSM_FENCE;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) {
+                    acc[0][bt] = mfma_corr_mx6<0>(wbb[0], wbb1[0], wbs, xc0[bt], xc1[bt], acc[0][bt], sbd[bt]);
+                    acc[1][bt] = mfma_corr_mx6<1>(wbb[1], wbb1[1], wbs, xc0[bt], xc1[bt], acc[1][bt], sbd[bt]);
+                    acc[2][bt] = mfma_corr_mx6<2>(wbb[2], wbb1[2], wbs, xc0[bt], xc1[bt], acc[2][bt], sbd[bt]);
+                }
+                CCSM_FENCE;
+            } else {
+                CCSM_CORR_G(3, wbb, wbs, sbh);
+            }
             if constexpr (!LAST) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbb[g] = w_at(NXT + ((6 + g) << 10));
-                wbs = ws_at(NXT + (9 << 10));
+                if constexpr (DYN) {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) wbb1[g] = w8_at(NXT + (9 << 10) + g * 512);
+                }
+                wbs = ws_at(NXT + OFF_BS);
             } else {
                 wch[1][1] = w_at(OFF_C + 1 * PC + (1 << 10));
             }
@@ -928,7 +1051,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         });
 #undef CCSM_MAIN
         stamp(3);
-        mx_tail<OUT_FP8, HS3>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        mx_tail<OUT_FP8, HS3, DYN>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         CCSM_FENCE;
         ldA_slot(2, 2);                                             // the third weight slot of the next step (needed two pairs in): not live across the tail
         CCSM_FENCE;

@@ -53,6 +53,8 @@ class DeviceModel:
         self.probe_error_hybrid = float(lib.ccsm_model_probe_error_hybrid(handle))     # -1: split-mx was accepted (or a precision forced)
         self.probe_tail = float(lib.ccsm_model_probe_tail(handle, 4))                  # fraction of the probe sites beyond 1e-5
         self.probe_tail_hybrid = float(lib.ccsm_model_probe_tail(handle, 5))
+        self.probe_error_mxd = float(lib.ccsm_model_probe_error_of(handle, 6))         # split-mx-d (-1: not run)
+        self.probe_tail_mxd = float(lib.ccsm_model_probe_tail(handle, 6))
         self.quant_error = float(lib.ccsm_model_quant_error(handle))
         self._workspaces = []
 

@@ -43,8 +43,11 @@ typedef enum {
  * SPLIT_F8: hi*hi on the fp16 MFMA, the two correction products hi*lo + lo*hi with fp8 (e4m3) operands on the gfx950
  *         block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) into the same fp32 accumulators: 2/3 of SPLIT3's MFMA
  *         cycles, max |dprob| ~4e-6 on the parity suite, 20x inside the 1e-4 bar (GRU layers and attention pool; only
- *         layer 0's K = 11 input projection keeps three fp16 passes).  The default. */
-typedef enum { CCSM_PRECISION_SPLIT_F8 = 4, CCSM_PRECISION_SPLIT3 = 3, CCSM_PRECISION_HYBRID = 5 } ccsm_precision;
+ *         layer 0's K = 11 input projection keeps three fp16 passes).  The default.
+ * HYBRID: SPLIT_F8 for the GRUs' input part, three fp16 passes and an fp16 hi + lo state for their recurrent part.
+ * SPLIT_MXD: SPLIT_F8 with fp6 (instead of fp4) recurrent weight blobs and the state's correction blob scaled per (row, 32-value
+ *         block) from the values themselves instead of by one fixed exponent: between SPLIT_F8 and HYBRID in cost and accuracy. */
+typedef enum { CCSM_PRECISION_SPLIT_F8 = 4, CCSM_PRECISION_SPLIT3 = 3, CCSM_PRECISION_HYBRID = 5, CCSM_PRECISION_SPLIT_MXD = 6 } ccsm_precision;
 
 /* Mirrors ModelAttRNN.__init__ (models.py:18-22) as called from call_modifications.py:315-323. */
 typedef struct {
@@ -203,14 +206,15 @@ const char* ccsm_last_error(void);
 const char* ccsm_version(void);
 int ccsm_model_precision(const ccsm_model* m);
 /* precision 0 (default) picks the arithmetic by measurement: ccsm_create runs a 2048-site probe batch through SPLIT3 and then through the
- * candidates in order of speed - SPLIT_F8 (split-mx), then HYBRID (split-mx for the GRUs' input part, three fp16 passes and an fp16
- * hi + lo state for their recurrent part: what a trained checkpoint usually needs) - and keeps the first one that leaves at most 0.5 % of
+ * candidates in order of speed - SPLIT_F8 (split-mx), SPLIT_MXD (split-mx-d), then HYBRID (split-mx for the GRUs' input part, three fp16
+ * passes and an fp16 hi + lo state for their recurrent part) - and keeps the first one that leaves at most 0.5 % of
  * the probe sites more than 1e-5 and none more than 5e-5 away from SPLIT3's probabilities, else SPLIT3.
- * ccsm_model_probe_error / _hybrid = the candidate's max |dprob| over the probe batch, ccsm_model_probe_tail(m, precision) = its fraction of
- * sites beyond 1e-5 (-1: that candidate was not run), ccsm_model_precision = the arithmetic in use, ccsm_model_quant_error = relative RMS
+ * ccsm_model_probe_error_of(m, precision) (and the older _error = SPLIT_F8's, _error_hybrid) = the candidate's max |dprob| over the probe
+ * batch, ccsm_model_probe_tail(m, precision) = its fraction of sites beyond 1e-5 (-1: that candidate was not run), ccsm_model_precision = the arithmetic in use, ccsm_model_quant_error = relative RMS
  * quantisation error of the weight correction blobs (worst layer). */
 float ccsm_model_probe_error(const ccsm_model* m);
 float ccsm_model_probe_error_hybrid(const ccsm_model* m);
+float ccsm_model_probe_error_of(const ccsm_model* m, int precision);
 float ccsm_model_probe_tail(const ccsm_model* m, int precision);
 float ccsm_model_quant_error(const ccsm_model* m);
 size_t ccsm_workspace_bytes(const ccsm_workspace* ws);

@@ -26,14 +26,15 @@ DEFAULT_TOL = 1e-5   # what the default (split-mx) arithmetic has to hold on wel
 SPLIT3_TOL = 1e-6    # the fp32-class fallback (measured: 2-3e-7)
 
 
-@pytest.fixture(scope="module", params=[0, 5, 3], ids=["default-split-mx", "hybrid", "split3"])
+@pytest.fixture(scope="module", params=[0, 6, 5, 3], ids=["default-split-mx", "split-mx-d", "hybrid", "split3"])
 def model7(request):
-    """Every test on this fixture runs in the default arithmetic (split-mx, CCSM_PRECISION_SPLIT_F8), in the hybrid (split-mx input part,
-    three-pass recurrent part: what the probe selects for trained checkpoints) and in the three-pass fp16 split."""
+    """Every test on this fixture runs in the default arithmetic (split-mx, CCSM_PRECISION_SPLIT_F8), in split-mx-d (fp6 recurrent weights,
+    per-row state scales) and the hybrid (split-mx input part, three-pass recurrent part) - what the probe selects for trained
+    checkpoints - and in the three-pass fp16 split."""
     from ccsmeth_amd.models import DeviceModel
     w = synth.synth_weights(7)
     dm = DeviceModel(w, device=0, precision=request.param)
-    assert dm.precision == {0: 4, 5: 5, 3: 3}[request.param]
+    assert dm.precision == {0: 4, 6: 6, 5: 5, 3: 3}[request.param]
     yield w, dm
     dm.close()
 
@@ -90,8 +91,11 @@ def _cascade(dm):
     5e-5 of the three-pass one."""
     ok = lambda err, tail: 0 <= err <= 5e-5 and 0 <= tail <= 0.005     # noqa: E731
     if ok(dm.probe_error, dm.probe_tail):
-        assert dm.probe_error_hybrid < 0 and dm.probe_tail_hybrid < 0   # not run
+        assert dm.probe_error_hybrid < 0 and dm.probe_tail_hybrid < 0 and dm.probe_error_mxd < 0   # not run
         return 4
+    if ok(dm.probe_error_mxd, dm.probe_tail_mxd):
+        assert dm.probe_error_hybrid < 0
+        return 6
     return 5 if ok(dm.probe_error_hybrid, dm.probe_tail_hybrid) else 3
 
 
