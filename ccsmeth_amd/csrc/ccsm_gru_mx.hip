@@ -78,18 +78,19 @@ __device__ __forceinline__ int dyn_block_exp(uint32_t pm) {
 }
 
 // correction MFMA of one pair: fp4 weight blob w (16 bytes per lane), its scale = byte G of ws, activation blob (x0, x1)
-template <int G>
+// (SBB: the byte of scale_b the instruction takes)
+template <int G, int SBB = 0>
 __device__ __forceinline__ f32x16 mfma_corr_mx(uint4 w, uint32_t ws, uint4 x0, uint2 x1, f32x16 c, int scale_b) {
     const i32x8 a = {(int)w.x, (int)w.y, (int)w.z, (int)w.w, 0, 0, 0, 0};
     const i32x8 b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, 0, 0};
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, kMxWFmtH, kMxBFmt, G, (int)ws, 0, scale_b);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, kMxWFmtH, kMxBFmt, G, (int)ws, SBB, scale_b);
 }
 // the same with an fp6 weight blob (24 bytes per lane: w0 | w1)
-template <int G>
+template <int G, int SBB = 0>
 __device__ __forceinline__ f32x16 mfma_corr_mx6(uint4 w0, uint2 w1, uint32_t ws, uint4 x0, uint2 x1, f32x16 c, int scale_b) {
     const i32x8 a = {(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, 0, 0};
     const i32x8 b = {(int)x0.x, (int)x0.y, (int)x0.z, (int)x0.w, (int)x1.x, (int)x1.y, 0, 0};
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, kMxWFmtX, kMxBFmt, G, (int)ws, 0, scale_b);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, kMxWFmtX, kMxBFmt, G, (int)ws, SBB, scale_b);
 }
 
 // 32 fp16 values (16 packed registers) / scale -> one fp6 blob
@@ -106,10 +107,12 @@ __device__ __forceinline__ void blob_of(const uint32_t (&p)[16], float scale, ui
 //   c0, c1   : this lane's activation blob (lower lanes: x_hi of all 32 units, upper lanes: x_lo)
 //   lo8      : fp8 (x 2^16) residuals of this lane's own 16 values, C-layout order (the wave's private copy)
 // SCALE = what the blob's values are divided by (0.25 for GRU outputs; kMxH0Div for initial states).
-// DYNB: additionally the blob with the block's own scale (dyn_block_exp of the 32 hi values) in d0 / d1 - always from the unclamped values.
+// DYNB: the blob carries the block's own scale (dyn_block_exp of the 32 hi values) instead: *dscale = this lane's E8M0 scale (byte 0 of the
+// dword the MX instruction takes: 127 + E in the hi lanes, 127 + E - 11 in the lo lanes); `scale` is then unused.
 template <bool CLAMP, bool DYNB = false>
 __device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, uint4& hi0, uint4& hi1, uint4& c0, uint2& c1, uint4& lo8,
-                                             uint4* d0 = nullptr, uint2* d1 = nullptr, int upper = 0 /* lane >> 5 (DYNB) */) {
+                                             uint32_t* dscale = nullptr, int upper = 0 /* lane >> 5 (DYNB) */) {
+    static_assert(!(CLAMP && DYNB), "a block-scaled blob needs no clamp");
     typedef _Float16 half2p __attribute__((ext_vector_type(2)));
     uint32_t hp[8], hq[8], lp[8];     // hi (fragments), hi as it goes into the blob, lo * 2^12
     float lf[16];
@@ -157,17 +160,13 @@ __device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, 
     }
     if constexpr (DYNB) {
         // the block's own scale from its 32 fp16 hi values; the lo lanes hold lo * 2^12 here and want x_lo / 2^(E - 11) = that / 2^(E + 1)
+        // (the blob conversion divides by `scale`)
         uint32_t pm = hp[0] & 0x7fff7fffu;
 #pragma unroll
         for (int j = 1; j < 8; ++j) pm = pkmax(pm, hp[j] & 0x7fff7fffu);
         const int E = dyn_block_exp(pm);
-        uint32_t hu[8], lu[8];                                          // unclamped copies (CLAMP only concerns the fixed-scale blob)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { hu[j] = hp[j]; lu[j] = pack2((_Float16)(lf[2 * j] * 4096.0f), (_Float16)(lf[2 * j + 1] * 4096.0f)); }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) swap32(hu[j], lu[j]);
-        const uint32_t pd[16] = {hu[0], hu[1], hu[2], hu[3], hu[4], hu[5], hu[6], hu[7], lu[0], lu[1], lu[2], lu[3], lu[4], lu[5], lu[6], lu[7]};
-        blob_of(pd, __builtin_bit_cast(float, (uint32_t)(127 + E + upper) << 23), *d0, *d1);
+        scale = __builtin_bit_cast(float, (uint32_t)(127 + E + upper) << 23);
+        *dscale = (uint32_t)(127 + E - 11 * upper);
     }
     // blob: lower lanes end up with (own hi | partner's hi), upper lanes with (partner's lo | own lo): kMxPerm order
 #pragma unroll
@@ -229,8 +228,8 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
         uint4 hi0, hi1, c0, lo8;
         uint2 c1;
         if constexpr (DYN) {            // the blob carries its own scale: any magnitude, no coarse first-step scale
-            uint4 f0; uint2 f1;
-            pack_pair_mx<false, true>(v, 0.25f, hi0, hi1, f0, f1, lo8, &c0, &c1, hh);
+            uint32_t sc;
+            pack_pair_mx<false, true>(v, 0.25f, hi0, hi1, c0, c1, lo8, &sc, hh);
         } else
         pack_pair_mx<true>(v, kMxH0Div, hi0, hi1, c0, c1, lo8);
         *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 0) + lane * 16) = hi0;
@@ -247,11 +246,13 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
 template <bool OUT_FP8, bool HS3, bool DYN = false>
 __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&accz)[kMxNB], const f32x16 (&accn)[kMxNB], uint4* __restrict__ out,
                                         int tile0, int t, int dir, int wave, int t16) {
+    constexpr bool XD = HS3 || DYN;     // block-scaled blobs for the next layer's input part (every arithmetic but plain split-mx)
     const int own_off = wave * (2 * kMxNB * 2 * 1024);                          // mx_hfrag(2 wave, 0, 0)
     char* t_wr = smem + (own_off + t16);                                        // + lane * 16       (fragment writes)
     const char* t_rd = smem + (own_off + (t16 & 0x1f0) + ((t16 >> 9) << 3));    // + n * 16 + hh * 8 (own-unit reads, C layout)
     char* t_lo = smem + (lo_off + wave * (kMxNB * 64 * 8) + (t16 >> 1));        // + lane * 8
     auto own_frag = [&](int kbl, int bt, int f) -> int { return ((kbl * kMxNB + bt) * 2 + f) << 10; };
+    uint32_t bsc_all = 0;
 #pragma unroll
     for (int bt = 0; bt < kMxNB; ++bt) {
         float hn[16];
@@ -284,9 +285,10 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
         }
         uint4 hi0, hi1, c0, lo8;
         uint2 c1;
-        uint4 d0 = make_uint4(0, 0, 0, 0);
-        uint2 d1 = make_uint2(0, 0);
-        if constexpr (DYN) pack_pair_mx<false, true>(hn, 0.25f, hi0, hi1, c0, c1, lo8, &d0, &d1, t16 >> 9);   // (from the opaque lane copy: a hoisted 110 + upper got spilled)      // next layer: fixed scale; own state: block scale
+        uint32_t bsc = 0;               // XD: this lane's E8M0 scale of the blob (the next layer reads it beside the blob)
+        // XD: ONE block-scaled blob, for the own state (DYN) and for the next layer (`upper` from the opaque lane copy: the hoisted
+        // 110 + upper got spilled)
+        if constexpr (XD) pack_pair_mx<false, true>(hn, 0.25f, hi0, hi1, c0, c1, lo8, &bsc, t16 >> 9);
         else pack_pair_mx<false>(hn, 0.25f, hi0, hi1, c0, c1, lo8);
         const uint4 c1w = make_uint4(c1.x, c1.y, lo8.x, lo8.y);
         *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 0)) = hi0;
@@ -296,10 +298,6 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
             pack_pair_hl(hn, h0_, h1_, lo0, lo1);
             *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = lo0;
             *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = lo1;
-        } else if constexpr (DYN) {
-            *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = d0;
-            *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = make_uint4(d1.x, d1.y, lo8.x, lo8.y);
-            *reinterpret_cast<uint2*>(t_lo + bt * (64 * 8)) = make_uint2(lo8.z, lo8.w);
         } else {
             *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = c0;
             *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = c1w;
@@ -320,7 +318,10 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
             }
         } else {
             nt_store(c0, reinterpret_cast<uint4*>(o + 1024));
-            nt_store(c1w, reinterpret_cast<uint4*>(o + 3072));
+            // (bytes 8-15 are spare in HBM: the scales of row tiles 0..bt in bytes 0..bt of one dword - the reader takes the last tile's, one
+            // register for the three row tiles, the instruction's op_sel picks the byte)
+            if constexpr (XD) bsc_all |= bsc << (8 * bt);
+            nt_store(XD ? make_uint4(c1.x, c1.y, bsc_all, 0u) : c1w, reinterpret_cast<uint4*>(o + 3072));
         }
     }
 }
@@ -679,6 +680,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     constexpr int PA = kMxPairA, PB = mx_pair_b(HS3, DYN), PC = kMxPairC, OFF_B = kMx12OffB, OFF_C = mx12_off_c(HS3, DYN);
     constexpr int OFF_BS = DYN ? (10 << 10) + 512 : (9 << 10);      // scale dwords of a phase-B pair
     constexpr int X_OFF = kMx12XOff;
+    constexpr bool XD = HS3 || DYN;                                 // the layer below wrote block-scaled blobs (mx_tail)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -796,6 +798,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 
         uint4 xh[NB], xh1[NB], xc0[NB];
         uint2 xc1[NB];
+        int xsc = 0;                                                // XD: the x blobs' E8M0 scales, byte bt = row tile bt (written beside the blob by the layer below)
         auto rdx = [&](uint4 (&x)[NB], int xs, int kbl, int f) {    // xs = byte offset of the slot + lane * 16
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((kbl * NB + bt) * 2 + f) << 10));
@@ -806,6 +809,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 xc0[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((0 * NB + bt) * 2 + 1) << 10));
                 xc1[bt] = *reinterpret_cast<const uint2*>(smem + xs + (((1 * NB + bt) * 2 + 1) << 10));
             }
+            if constexpr (XD) xsc = *reinterpret_cast<const int*>(smem + xs + (((1 * NB + (NB - 1)) * 2 + 1) << 10) + 8);   // bytes 0..2: row tiles 0..2
         };
         auto slot_off = [&](int sl) -> int { return X_OFF + sl * SLOT_BYTES + lane16; };
 #define CCSM_MAIN(W, X, G, S0)                                                                                \
@@ -854,10 +858,18 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                                                                                       // lead than as the pair's youngest operation: +1.4 %)
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
             CCSM_FENCE;
+            if constexpr (XD) {
+                static_for<0, NB>([&](auto BC) {
+                    constexpr int bt = decltype(BC)::value;
+                    acc[0][bt] = mfma_corr_mx<0, bt>(wab[WS][0], was[WS], xc0[bt], xc1[bt], acc[0][bt], xsc);
+                    acc[1][bt] = mfma_corr_mx<1, bt>(wab[WS][1], was[WS], xc0[bt], xc1[bt], acc[1][bt], xsc);
+                });
+            } else {
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) {
-                acc[0][bt] = mfma_corr_mx<0>(wab[WS][0], was[WS], xc0[bt], xc1[bt], acc[0][bt], sb);
-                acc[1][bt] = mfma_corr_mx<1>(wab[WS][1], was[WS], xc0[bt], xc1[bt], acc[1][bt], sb);
+                for (int bt = 0; bt < NB; ++bt) {
+                    acc[0][bt] = mfma_corr_mx<0>(wab[WS][0], was[WS], xc0[bt], xc1[bt], acc[0][bt], sb);
+                    acc[1][bt] = mfma_corr_mx<1>(wab[WS][1], was[WS], xc0[bt], xc1[bt], acc[1][bt], sb);
+                }
             }
             CCSM_FENCE;
             if constexpr (P + 3 < NPAIR) ldAb(WS, P + 3);
@@ -1037,8 +1049,15 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             dma_ahead(slot, s, NPAIR + P);                              // the vacated slot is refilled at once
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
             CCSM_FENCE;
+            if constexpr (XD) {
+                static_for<0, NB>([&](auto BC) {
+                    constexpr int bt = decltype(BC)::value;
+                    acc[2][bt] = mfma_corr_mx6<0, bt>(wcb[WS], wcb1[WS], wcs[WS], xc0[bt], xc1[bt], acc[2][bt], xsc);
+                });
+            } else {
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma_corr_mx6<0>(wcb[WS], wcb1[WS], wcs[WS], xc0[bt], xc1[bt], acc[2][bt], sb);
+                for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma_corr_mx6<0>(wcb[WS], wcb1[WS], wcs[WS], xc0[bt], xc1[bt], acc[2][bt], sb);
+            }
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) { wcb[WS] = w_at(OFF_C + (P + 4) * PC + (2 << 10)); wcb1[WS] = w8_at(OFF_C + (P + 4) * PC + (3 << 10));
                                            wcs[WS] = ws_at(OFF_C + (P + 4) * PC + (3 << 10) + 512); }
