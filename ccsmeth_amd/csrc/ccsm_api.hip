@@ -70,6 +70,7 @@ struct ccsm_model {
     float mx_quant_err = 0.f;                            // relative RMS quantisation error of the weight correction blobs (worst layer)
     int feat = kFeatNpass;                               // optional input features of the variant (kFeat* bits); feat0 = columns of weight_ih_l0
     int feat0 = kFeat0;
+    int fold = 0;                                        // 1: embedding folded into the layer-0 matrix, rows are [one-hot(5) | features] (pack_x0_kernel)
     float probe_err_hybrid = -1.f;                       // ... of the hybrid arithmetic (-1: not run: split-mx was accepted)
     float probe_tail = -1.f, probe_tail_hybrid = -1.f;   // fraction of the probe sites beyond kProbeTailAt
     float probe_err = -1.f;                              // max |dprob| split-mx vs split-fp16 on the probe batch of ccsm_create (-1: not run)
@@ -434,7 +435,7 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
                        seed, offset, sk.key, sk.sub);
     const int total = 2 * n_sites * kSeqLen * 2;
     hipLaunchKernelGGL(pack_x0_kernel, dim3((total + 255) / 256), dim3(256), 0, st, ws->x0, s1, s2, m->embed, n_sites, row_base,
-                       kmer_is_f32, npass_per_base, m->feat);
+                       kmer_is_f32, npass_per_base, m->feat, m->fold);
     HIP_TRY(hipGetLastError());
     return CCSM_OK;
 }
@@ -696,11 +697,12 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     if (cfg->seq_len != kSeqLen || cfg->num_layers != kLayers || cfg->num_classes != kClasses || cfg->hidden_size != kHidden)
         return fail(CCSM_ERR_UNSUPPORTED, "this build implements seq_len 21, layer_rnn 3, class_num 2, hid_rnn 256");
     // [embedding(8) | ipd | pw | npass? | ipd_std, pw_std? | sn(4)? | map?] (models.py:39-47): the layer-0 kernels take one 16-wide
-    // k-block, which holds every variant except is_npass + is_stds + is_sn (17 or 18 columns)
+    // k-block, which holds every variant except is_npass + is_stds + is_sn (17 or 18 columns); for those the embedding is folded into
+    // the matrix below ([one-hot(5) | features] = 14 or 15 columns)
     const int feat = (cfg->is_npass ? kFeatNpass : 0) | (cfg->is_stds ? kFeatStds : 0) | (cfg->is_sn ? kFeatSn : 0) | (cfg->is_map ? kFeatMap : 0);
     const int feat0 = kEmbed + 2 + (cfg->is_npass ? 1 : 0) + (cfg->is_stds ? 2 : 0) + (cfg->is_sn ? 4 : 0) + (cfg->is_map ? 1 : 0);
-    if (feat0 > 16)
-        return fail(CCSM_ERR_UNSUPPORTED, "this build takes at most 16 input columns (is_npass + is_stds + is_sn together need 17)");
+    const bool fold = feat0 > 16;
+    const int k0 = fold ? feat0 - kEmbed + kVocab : feat0;         // columns of the layer-0 matrix as the kernels see it
     const int prec = cfg->precision == 0 ? 4 : cfg->precision;
     const bool auto_prec = cfg->precision == 0;
     if (prec != CCSM_PRECISION_SPLIT3 && prec != CCSM_PRECISION_SPLIT_F8 && prec != CCSM_PRECISION_HYBRID && prec != CCSM_PRECISION_SPLIT_MXD)
@@ -717,30 +719,49 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     m->device = device;
     m->precision = prec;
     m->feat = feat;
-    m->feat0 = feat0;
+    m->feat0 = k0;
+    m->fold = fold ? 1 : 0;
+    // W'[:, c] = W[:, 0:8] E[c] (c < 5), then the feature columns: W[:, 0:8] E[code] + W[:, 8:] f = W' [one-hot(code) | f]
+    std::vector<float> wfold[2];
+    const float* wih_l0[2] = {w->weight_ih[0][0], w->weight_ih[0][1]};
+    if (fold)
+        for (int d = 0; d < 2; ++d) {
+            wfold[d].resize((size_t)kGates * kHidden * k0);
+            for (int r = 0; r < kGates * kHidden; ++r) {
+                const float* src = w->weight_ih[0][d] + (size_t)r * feat0;
+                for (int c = 0; c < kVocab; ++c) {
+                    double a = 0.0;
+                    for (int j = 0; j < kEmbed; ++j) a += (double)src[j] * (double)w->embed_weight[c * kEmbed + j];
+                    wfold[d][(size_t)r * k0 + c] = (float)a;
+                }
+                for (int c = kVocab; c < k0; ++c) wfold[d][(size_t)r * k0 + c] = src[kEmbed + (c - kVocab)];
+            }
+            wih_l0[d] = wfold[d].data();
+        }
     ccsm_status st = CCSM_OK;
     std::vector<_Float16> hbuf;
     std::vector<float> fbuf;
     for (int l = 0; l < kLayers && st == CCSM_OK; ++l) {
-        pack_wstream_v2(l, m->feat0, w->weight_ih[l], w->weight_hh[l], hbuf);
+        const float* const* wih = l == 0 ? wih_l0 : w->weight_ih[l];
+        pack_wstream_v2(l, m->feat0, wih, w->weight_hh[l], hbuf);
         st = upload(&m->wst2[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
         if (st != CCSM_OK) break;
         if (prec == 4) {
             std::vector<uint8_t> bbuf;
-            m->mx_quant_err = std::fmax(m->mx_quant_err, pack_wstream_mx(l, m->feat0, w->weight_ih[l], w->weight_hh[l], false, bbuf));
+            m->mx_quant_err = std::fmax(m->mx_quant_err, pack_wstream_mx(l, m->feat0, wih, w->weight_hh[l], false, bbuf));
             st = upload(&m->wstmx[l], bbuf.data(), bbuf.size());
             if (st != CCSM_OK) break;
         }
         if (prec == 5 || auto_prec) {
             std::vector<uint8_t> bbuf;
-            const float qe = pack_wstream_mx(l, m->feat0, w->weight_ih[l], w->weight_hh[l], true, bbuf);
+            const float qe = pack_wstream_mx(l, m->feat0, wih, w->weight_hh[l], true, bbuf);
             if (prec == 5) m->mx_quant_err = std::fmax(m->mx_quant_err, qe);
             st = upload(&m->wsthy[l], bbuf.data(), bbuf.size());
             if (st != CCSM_OK) break;
         }
         if (prec == 6 || auto_prec) {
             std::vector<uint8_t> bbuf;
-            const float qe = pack_wstream_mx(l, m->feat0, w->weight_ih[l], w->weight_hh[l], false, bbuf, true);
+            const float qe = pack_wstream_mx(l, m->feat0, wih, w->weight_hh[l], false, bbuf, true);
             if (prec == 6) m->mx_quant_err = std::fmax(m->mx_quant_err, qe);
             st = upload(&m->wstmd[l], bbuf.data(), bbuf.size());
             if (st != CCSM_OK) break;

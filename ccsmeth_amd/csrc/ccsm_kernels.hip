@@ -188,8 +188,11 @@ struct StrandDev {
 // [embedding(8) | ipd | pw] in a row of the layer-0 input, in the reference's concatenation order (models.py:100-123)
 constexpr int kFeatNpass = 1, kFeatStds = 2, kFeatSn = 4, kFeatMap = 8;
 
+// fold: the 17- and 18-column variants (is_npass + is_stds + is_sn [+ is_map]) do not fit the 16-wide k-block as [embedding(8) | features];
+// for them ccsm_create folds the embedding table into the layer-0 matrix (W'[:, c] = W[:, 0:8] E[c] for the N_VOCAB = 5 codes) and the
+// row becomes [one-hot(5) | features] = 14 or 15 columns: the same product, W[:, 0:8] E[code] = W'[:, code].
 __global__ void pack_x0_kernel(uint4* __restrict__ x0, StrandDev s1, StrandDev s2, const float* __restrict__ embed,
-                               int n_sites, int row_base, int kmer_is_f32, int npass_per_base, int feat) {
+                               int n_sites, int row_base, int kmer_is_f32, int npass_per_base, int feat, int fold) {
     const int total = 2 * n_sites * kSeqLen * 2;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int g = i & 1;
@@ -198,25 +201,39 @@ __global__ void pack_x0_kernel(uint4* __restrict__ x0, StrandDev s1, StrandDev s
         const int row = row_base + rl;
         const int tile = row >> 5, lane = (row & 31) + 32 * g;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float f[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // the columns behind the embedding
         const int strand = rl >= n_sites;
         const int site = rl - strand * n_sites;
         const StrandDev& s = strand ? s2 : s1;
         const size_t e = (size_t)site * kSeqLen + t;
+        if (g == 1 || fold) {
+            f[0] = s.ipd[e];
+            f[1] = s.pw[e];
+            int k = 2;
+            if (feat & kFeatNpass) f[k++] = npass_per_base ? s.npass[e] : s.npass[site];
+            if (feat & kFeatStds) { f[k++] = s.ipd_std[e]; f[k++] = s.pw_std[e]; }
+            if (feat & kFeatSn)
+                for (int j = 0; j < 4; ++j) f[k++] = s.sn[(size_t)site * 4 + j];    // one signal-to-noise quadruple per site, every position
+            if (feat & kFeatMap) f[k++] = s.map[e];
+        }
         if (g == 0) {
             int code = kmer_is_f32 ? (int)reinterpret_cast<const float*>(s.kmer)[e]
                                    : (int)reinterpret_cast<const uint8_t*>(s.kmer)[e];
             code = code < 0 ? 0 : (code >= kVocab ? kVocab - 1 : code);
+            if (fold) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = embed[code * kEmbed + j];
+                for (int j = 0; j < kVocab; ++j) v[j] = j == code ? 1.f : 0.f;
+                v[5] = f[0]; v[6] = f[1]; v[7] = f[2];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = embed[code * kEmbed + j];
+            }
+        } else if (fold) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = f[3 + j];                   // columns 8..14
         } else {
-            v[0] = s.ipd[e];
-            v[1] = s.pw[e];
-            int k = 2;                                                  // at most 6 optional features (checked by ccsm_create)
-            if (feat & kFeatNpass) v[k++] = npass_per_base ? s.npass[e] : s.npass[site];
-            if (feat & kFeatStds) { v[k++] = s.ipd_std[e]; v[k++] = s.pw_std[e]; }
-            if (feat & kFeatSn)
-                for (int j = 0; j < 4; ++j) v[k++] = s.sn[(size_t)site * 4 + j];    // one signal-to-noise quadruple per site, every position
-            if (feat & kFeatMap) v[k++] = s.map[e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = f[j];                       // at most 6 optional features without the fold (checked by ccsm_create)
         }
         _Float16 hi[8], lo[8];
 #pragma unroll

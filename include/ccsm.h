@@ -56,9 +56,9 @@ typedef struct {
     int32_t num_classes; /* 2 */
     int32_t hidden_size; /* 256 */
     int32_t is_npass;    /* 1 */
-    int32_t is_sn;       /* 0   the optional input features of models.py:39-47, 100-123: any combination with at most 16 input */
-    int32_t is_map;      /* 0   columns (8 + 2 + npass 1 + stds 2 + sn 4 + map 1), i.e. all but is_npass + is_stds + is_sn together */
-    int32_t is_stds;     /* 0 */
+    int32_t is_sn;       /* 0   the optional input features of models.py:39-47, 100-123: any combination (8 + 2 + npass 1 + stds 2 + */
+    int32_t is_map;      /* 0   sn 4 + map 1 columns; the 17- and 18-column ones run as [one-hot(5) | features] against a layer-0 matrix */
+    int32_t is_stds;     /* 0   with the embedding table folded in: the same product in 14 or 15 columns) */
     const char* model_type; /* "attbigru2s" */
     int32_t precision;   /* ccsm_precision; 0 = default (SPLIT_F8) */
 } ccsm_config;

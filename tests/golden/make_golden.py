@@ -99,10 +99,11 @@ def gen_forward():
     json.dump(meta, open(os.path.join(HERE, "forward_golden.json"), "w"), indent=1, sort_keys=True)
 
 
-VARIANTS = [  # name, (is_npass, is_stds, is_sn, is_map): every combination with at most 16 input columns that differs from the default
+VARIANTS = [  # name, (is_npass, is_stds, is_sn, is_map): combinations that differ from the default, the 17- and 18-column ones included
     ("sn", (True, False, True, False)), ("map", (True, False, False, True)), ("stds", (True, True, False, False)),
     ("stds_map", (True, True, False, True)), ("sn_map", (True, False, True, True)), ("nonpass", (False, False, False, False)),
     ("nonpass_stds_sn", (False, True, True, False)), ("nonpass_stds_sn_map", (False, True, True, True)),
+    ("stds_sn", (True, True, True, False)), ("stds_sn_map", (True, True, True, True)),       # 17 and 18 input columns
 ]
 
 

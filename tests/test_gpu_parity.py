@@ -203,20 +203,19 @@ def test_forward_vs_reference_goldens():
             assert np.abs(logits - fwd[name + "_logits"]).max() < LOGIT_TOL, (name, prec)
 
 
-@pytest.mark.parametrize("prec", [0, 5, 3])
+@pytest.mark.parametrize("prec", [0, 6, 5, 3])
 def test_model_variants_vs_reference_goldens(prec):
-    """is_stds / is_sn / is_map / no is_npass (models.py:39-47, 100-123): every combination that fits the 16 input columns of the layer-0
-    kernels against the reference's own outputs, through the raw workspace and through ModelAttRNN.forward's 16-argument signature;
-    the 17-column combinations are rejected by ccsm_create."""
+    """is_stds / is_sn / is_map / no is_npass (models.py:39-47, 100-123) against the reference's own outputs, through the raw workspace and
+    through ModelAttRNN.forward's 16-argument signature.  The 17- and 18-column combinations (is_stds + is_sn + one or two more) do not
+    fit the layer-0 kernels' 16-wide k-block as [embedding(8) | features]: ccsm_create folds the embedding table into the matrix and feeds
+    [one-hot(5) | features] = 14 or 15 columns - the same product - so they run in every arithmetic like the others."""
     from ccsmeth_amd.models import DeviceModel, ModelAttRNN
     from test_oracle_golden import VAR, VAR_META, variant_inputs
+    wide = 0
     for name, meta in sorted(VAR_META.items()):
         w, s, h1, h2, ex, feats = variant_inputs(meta)
         kw = dict(is_npass=feats[0], is_stds=feats[1], is_sn=feats[2], is_map=feats[3])
-        if 8 + synth.feas_ccs_of(*feats) > 16:                      # is_stds + is_sn + one more: 17 columns
-            with pytest.raises(RuntimeError, match="16 input columns"):
-                DeviceModel(w, device=0, precision=prec, **kw)
-            continue
+        wide += 8 + synth.feas_ccs_of(*feats) > 16
         dm = DeviceModel(w, device=0, precision=prec, **kw)
         ws = dm.workspace(meta["n"])
         logits, probs = ws.forward_host(s["kmer1"], s["ipd1"], s["pw1"], s["npass1"] if feats[0] else None, s["kmer2"], s["ipd2"], s["pw2"],
@@ -239,8 +238,9 @@ def test_model_variants_vs_reference_goldens(prec):
                       g(ex[1], "sn"), g(ex[1], "map"), h0=(h1, h2))
             m._release()
             assert np.abs(np.asarray(p2) - VAR[name + "_probs"]).max() < DEFAULT_TOL, name
-    with pytest.raises(RuntimeError, match="16 input columns"):
-        DeviceModel(synth.synth_weights(1, feas_ccs=9), device=0, is_npass=True, is_stds=True, is_sn=True)
+    assert wide == 3                                                 # 17, 17 and 18 columns
+    with pytest.raises(ValueError, match="columns"):                 # matrix and flags must agree
+        DeviceModel(synth.synth_weights(1, feas_ccs=9), device=0, is_npass=True, is_stds=True, is_sn=False)
 
 
 def test_input_layout_variants_agree(model7):
