@@ -45,7 +45,7 @@ PEAK_HBM = 8.0e12
 # read from inside this process)
 TRAFFIC = {4: ((2 * 1209100 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_coalesced.md"),
            5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced_hybrid.md"),
-           6: (None, None),
+           6: ((2 * 1217200 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_prec6.md"),
            3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
 ARITH_NAME = {3: "split3", 4: "split-mx", 5: "hybrid", 6: "split-mx-d"}
 ARITH = {4: ("f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate",
@@ -71,9 +71,10 @@ def parse():
                     help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
                          "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds)")
     ap.add_argument("--precision", type=int, default=0, choices=(0, 3, 4, 5, 6),
-                    help="0 = the library's default: the fastest of split-mx (fp16 main product + MX correction product), the hybrid (split-mx input\n"
-                         "part, three-pass recurrent part) and split3 whose probe batch through ccsm_create on these weights leaves at most 0.5 %% of\n"
-                         "the sites beyond 1e-5 and none beyond 5e-5 of split3; 4 = split-mx forced; 5 = hybrid forced; 3 = split-fp16 x3 (fp32-class)")
+                    help="0 = the library's default: the fastest of split-mx (fp16 main product + MX correction product), split-mx-d (the same with\n"
+                         "fp6 recurrent weights and block-scaled activation blobs), the hybrid (split-mx input part, three-pass recurrent part)\n"
+                         "and split3 whose probe batch through ccsm_create on these weights leaves at most 0.5 %% of the sites beyond 1e-5 and none\n"
+                         "beyond 5e-5 of split3; 4 = split-mx forced; 6 = split-mx-d forced; 5 = hybrid forced; 3 = split-fp16 x3 (fp32-class)")
     ap.add_argument("--weights", default=None,
                     help="an .npz of state_dict arrays (e.g. SAVE_TRAINED=<file> python tests/diag/gpu_trained_weights_parity.py) instead of\n"
                          "the contract's random initialisation: what the probe selects for THAT checkpoint, and its speed")
