@@ -7,6 +7,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include <functional>
 
@@ -312,9 +313,13 @@ float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const flo
     const size_t wbytes = layer == 0 ? mx0_wbytes(hs3, dyn) : mx12_wbytes(hs3, dyn);
     const size_t pair_b = mx_pair_b(hs3, dyn);
     out.assign((size_t)2 * kWaves * wbytes, 0);
-    BlobErr be;
+    // one task per (direction, wave): their byte ranges and error sums are disjoint (0.24 s single-threaded for the three layers)
+    BlobErr bes[2 * kWaves];
+    std::vector<std::thread> pool;
     for (int dir = 0; dir < 2; ++dir)
-        for (int wave = 0; wave < kWaves; ++wave) {
+        for (int wave = 0; wave < kWaves; ++wave)
+            pool.emplace_back([&, dir, wave] {
+            BlobErr& be = bes[dir * kWaves + wave];
             uint8_t* base = out.data() + (size_t)(dir * kWaves + wave) * wbytes;
             auto wx = [&](int g) { return [=](int i, int k) -> float { return k < k_in ? wih[dir][(size_t)(g * kHidden + kUnitTile * wave + i) * k_in + k] : 0.f; }; };
             auto wh = [&](int g) { return [=](int i, int k) -> float { return whh[dir][(size_t)(g * kHidden + kUnitTile * wave + i) * kHidden + k]; }; };
@@ -363,7 +368,11 @@ float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const flo
                     blob_at(pc + 2 * 1024, (long)(pc + 3 * 1024), pc + 3 * 1024 + 512, 0, kMxWFmtX, wx(2), p);
                 }
             }
-        }
+            });
+    for (std::thread& t : pool) t.join();
+    BlobErr be;
+    for (const BlobErr& b : bes)
+        for (int g = 0; g < 2; ++g) { be.e2[g] += b.e2[g]; be.r2[g] += b.r2[g]; }
     const double a = be.r2[0] > 0 ? std::sqrt(be.e2[0] / be.r2[0]) : 0.0, b = be.r2[1] > 0 ? std::sqrt(be.e2[1] / be.r2[1]) : 0.0;
     return (float)std::fmax(a, b);
 }
@@ -615,7 +624,8 @@ constexpr float kProbeMaxErr = 5.0e-5f;
 constexpr float kMxH0Limit = 6.0f;
 constexpr int kProbeSites = 2048;
 
-ccsm_status probe_arithmetic(ccsm_model* m) {
+// ensure(candidate): packs and uploads that arithmetic's weight streams (only the candidates the probe gets to are ever packed)
+ccsm_status probe_arithmetic(ccsm_model* m, const std::function<ccsm_status(int)>& ensure) {
     ccsm_workspace* ws = nullptr;
     ccsm_status st = ccsm_workspace_create(m, kProbeSites, &ws);
     if (st != CCSM_OK) return st;
@@ -665,6 +675,8 @@ ccsm_status probe_arithmetic(ccsm_model* m) {
     st = ccsm_forward_host(m, ws, kProbeSites, &b, &h0, lg.data(), pb.data(), nullptr);
     int chosen = CCSM_PRECISION_SPLIT3;
     for (int cand : {(int)CCSM_PRECISION_SPLIT_F8, (int)CCSM_PRECISION_SPLIT_MXD, (int)CCSM_PRECISION_HYBRID}) {
+        if (st != CCSM_OK) break;
+        st = ensure(cand);
         if (st != CCSM_OK) break;
         m->precision = cand;
         st = ccsm_forward_host(m, ws, kProbeSites, &b, &h0, lg.data(), pa.data(), nullptr);
@@ -746,26 +758,6 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         pack_wstream_v2(l, m->feat0, wih, w->weight_hh[l], hbuf);
         st = upload(&m->wst2[l], hbuf.data(), hbuf.size() * sizeof(_Float16));
         if (st != CCSM_OK) break;
-        if (prec == 4) {
-            std::vector<uint8_t> bbuf;
-            m->mx_quant_err = std::fmax(m->mx_quant_err, pack_wstream_mx(l, m->feat0, wih, w->weight_hh[l], false, bbuf));
-            st = upload(&m->wstmx[l], bbuf.data(), bbuf.size());
-            if (st != CCSM_OK) break;
-        }
-        if (prec == 5 || auto_prec) {
-            std::vector<uint8_t> bbuf;
-            const float qe = pack_wstream_mx(l, m->feat0, wih, w->weight_hh[l], true, bbuf);
-            if (prec == 5) m->mx_quant_err = std::fmax(m->mx_quant_err, qe);
-            st = upload(&m->wsthy[l], bbuf.data(), bbuf.size());
-            if (st != CCSM_OK) break;
-        }
-        if (prec == 6 || auto_prec) {
-            std::vector<uint8_t> bbuf;
-            const float qe = pack_wstream_mx(l, m->feat0, wih, w->weight_hh[l], false, bbuf, true);
-            if (prec == 6) m->mx_quant_err = std::fmax(m->mx_quant_err, qe);
-            st = upload(&m->wstmd[l], bbuf.data(), bbuf.size());
-            if (st != CCSM_OK) break;
-        }
         pack_bias(w->bias_ih[l], w->bias_hh[l], fbuf);
         st = upload(&m->bias[l], fbuf.data(), fbuf.size() * sizeof(float));
     }
@@ -816,9 +808,24 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         }
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     }
-    if (st == CCSM_OK && auto_prec) {
-        st = probe_arithmetic(m);      // leaves the fastest arithmetic within the margin in m->precision
-    }
+    // the weight streams of one arithmetic of the split-mx family (a forced precision: that one; the default: what the probe gets to)
+    float qerr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto ensure_streams = [&](int which) -> ccsm_status {
+        uint4** dst = which == CCSM_PRECISION_SPLIT_F8 ? m->wstmx : which == CCSM_PRECISION_HYBRID ? m->wsthy : m->wstmd;
+        if (dst[0]) return CCSM_OK;
+        std::vector<uint8_t> bbuf;
+        for (int l = 0; l < kLayers; ++l) {
+            const float* const* wih = l == 0 ? wih_l0 : w->weight_ih[l];
+            qerr[which] = std::fmax(qerr[which], pack_wstream_mx(l, m->feat0, wih, w->weight_hh[l], which == CCSM_PRECISION_HYBRID, bbuf,
+                                                                which == CCSM_PRECISION_SPLIT_MXD));
+            const ccsm_status s2 = upload(&dst[l], bbuf.data(), bbuf.size());
+            if (s2 != CCSM_OK) return s2;
+        }
+        return CCSM_OK;
+    };
+    if (st == CCSM_OK && prec >= CCSM_PRECISION_SPLIT_F8 && !auto_prec) st = ensure_streams(prec);
+    if (st == CCSM_OK && auto_prec) st = probe_arithmetic(m, ensure_streams);      // leaves the fastest arithmetic within the margin in m->precision
+    if (st == CCSM_OK && m->precision >= CCSM_PRECISION_SPLIT_F8) m->mx_quant_err = qerr[m->precision];
     if (st != CCSM_OK) {
         ccsm_destroy(m);
         return st;
