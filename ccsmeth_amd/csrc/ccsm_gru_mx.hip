@@ -56,20 +56,19 @@ typedef int i32x6 __attribute__((ext_vector_type(6)));
 //     m = max |x_hi| (fp16 bits e, mantissa f):  E = max(e, 1) - 17 + (f > 0x380)      so that  |x_hi| / 2^E <= 7.5  (fp6 e2m3's top)
 //     hi lanes (g = 0) hold x_hi / 2^E, scale byte 127 + E;   lo lanes (g = 1) hold x_lo / 2^(E - 11), scale byte 127 + E - 11
 //     (|x_lo| <= half an ulp of the block's largest value = 2^(e - 26): at most 4 after the division).
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t absmax8(uint4 f) {                 // eight fp16 of one fragment lane -> max |.| pair-wise (two u16 lanes)
-    const uint32_t a = f.x & 0x7fff7fffu, b = f.y & 0x7fff7fffu, c = f.z & 0x7fff7fffu, d = f.w & 0x7fff7fffu;
-    const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)),
-                                              __builtin_elementwise_max(__builtin_bit_cast(u16x2, c), __builtin_bit_cast(u16x2, d)));
-    return __builtin_bit_cast(uint32_t, m);                            // (positive fp16 bit patterns order like unsigned integers)
+// max |.| of the eight fp16 of one fragment lane and of `prev` (an fp16 in the low half): four v_max3_f16 with |.| source modifiers
+// and half selectors (masking and a packed-max tree cost 7 + 3 for the final unpack).  Writer and readers use the same routine.
+__device__ __forceinline__ uint32_t absmax8(uint4 f, uint32_t prev) {
+    uint32_t a, b, c, m;
+    asm("v_max3_f16 %0, |%1|, |%1|, |%2| op_sel:[0,1,0,0]" : "=v"(a) : "v"(f.x), "v"(f.y));     // x.lo x.hi y.lo
+    asm("v_max3_f16 %0, |%1|, |%2|, |%2| op_sel:[1,0,1,0]" : "=v"(b) : "v"(f.y), "v"(f.z));     // y.hi z.lo z.hi
+    asm("v_max3_f16 %0, |%1|, |%1|, %2 op_sel:[0,1,0,0]" : "=v"(c) : "v"(f.w), "v"(a));         // w.lo w.hi a
+    asm("v_max3_f16 %0, %1, %2, %3" : "=v"(m) : "v"(b), "v"(c), "v"(prev));
+    return m;                                                          // (the high half is not defined)
 }
-__device__ __forceinline__ uint32_t pkmax(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
-}
-// pm = pair-wise max of this lane's 16 values; returns E of the (row, block): the partner lane (n, 1 - g) holds the other 16
-__device__ __forceinline__ int dyn_block_exp(uint32_t pm) {
-    uint32_t m = pm & 0xffffu, h = pm >> 16;
-    m = m > h ? m : h;
+// m = max |.| of this lane's 16 values as fp16 bits (low half); returns E of the (row, block): the partner lane (n, 1 - g) holds the other 16
+__device__ __forceinline__ int dyn_block_exp(uint32_t m16) {
+    uint32_t m = m16 & 0xffffu;                                        // (positive fp16 bit patterns order like unsigned integers)
     uint32_t x = m, y = m;
     swap32(x, y);                                                      // lower lanes: y = partner's m; upper lanes: x = partner's m
     m = x > y ? x : y;
@@ -161,9 +160,7 @@ __device__ __forceinline__ void pack_pair_mx(const float (&v)[16], float scale, 
     if constexpr (DYNB) {
         // the block's own scale from its 32 fp16 hi values; the lo lanes hold lo * 2^12 here and want x_lo / 2^(E - 11) = that / 2^(E + 1)
         // (the blob conversion divides by `scale`)
-        uint32_t pm = hp[0] & 0x7fff7fffu;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) pm = pkmax(pm, hp[j] & 0x7fff7fffu);
+        const uint32_t pm = absmax8(make_uint4(hp[4], hp[5], hp[6], hp[7]), absmax8(make_uint4(hp[0], hp[1], hp[2], hp[3]), 0u));
         const int E = dyn_block_exp(pm);
         scale = __builtin_bit_cast(float, (uint32_t)(127 + E + upper) << 23);
         *dscale = (uint32_t)(127 + E - 11 * upper);
@@ -563,7 +560,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
             CCSM_FENCE;
             if constexpr (DYN) {
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) pm[bt] = absmax8(xh[bt]);
+                for (int bt = 0; bt < NB; ++bt) pm[bt] = absmax8(xh[bt], 0u);
             }
             if constexpr (!LAST) {
 #pragma unroll
@@ -585,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
                 // the block scales of the three row tiles (vector ALU in the shadow of the main MFMAs above), then the correction products
                 int sbd[NB];
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) sbd[bt] = 127 + dyn_block_exp(pkmax(pm[bt], absmax8(xh[bt]))) - (hh ? 11 : 0);
+                for (int bt = 0; bt < NB; ++bt) sbd[bt] = 127 + dyn_block_exp(absmax8(xh[bt], pm[bt])) - (hh ? 11 : 0);
                 CCSM_FENCE;
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
@@ -942,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             CCSM_MAIN(wbh[0], xh, 3, 0);
             if constexpr (DYN) {
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) pm[bt] = absmax8(xh[bt]);
+                for (int bt = 0; bt < NB; ++bt) pm[bt] = absmax8(xh[bt], 0u);
             }
             if constexpr (!LAST) {
 #pragma unroll
@@ -963,7 +960,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 // the block scales of the three row tiles (vector ALU in the shadow of the main MFMAs above), then the correction products
                 int sbd[NB];
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) sbd[bt] = 127 + dyn_block_exp(pkmax(pm[bt], absmax8(xh[bt]))) - (hh ? 11 : 0);
+                for (int bt = 0; bt < NB; ++bt) sbd[bt] = 127 + dyn_block_exp(absmax8(xh[bt], pm[bt])) - (hh ? 11 : 0);
                 CCSM_FENCE;
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
