@@ -42,7 +42,7 @@ ccsm_status fail(ccsm_status st, const std::string& msg) {
 
 constexpr size_t kReadTableBytes = 8 + 64 + 4 * 5 + 4 + 8;   // per read: offset | stats | length, fn, rn, nsites, first_site | spare | h0 key
 constexpr int kNBGru2 = 3;   // batch tiles (of 32 rows) per workgroup of the GRU kernels
-constexpr int kRowPad = 32 * kNBGru2;           // rows are padded to whole workgroups
+constexpr int kRowPad = 192;                    // rows are padded to whole workgroups of 96 AND of 64 rows (the split-mx family's small-launch form)
 // GRU kernels' dynamic LDS: h fragments + x chunk ring + 4 KiB bias table
 constexpr int gru2_lds(int kx) { return (kKBH * kNBGru2 * 2 + 2 * (kx >= 4 ? 4 : kx) * kNBGru2 * 2) * 1024 + kWaves * 4 * 32 * 4; }
 // attention kernel dynamic LDS: 2 staging buffers x 28 KiB + e partials + fc partials + fc1.weight
@@ -451,11 +451,11 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
 
 // GRU layers in split-mx arithmetic.  A build with -DCCSM_PHASE_STAMPS also holds the instantiations that record the cycle counter
 // at the phase boundaries of workgroup 0 (tools/gpu_phases.py); the product library is built without it.
-template <bool HS3, bool DYN>
+template <bool HS3, bool DYN, int NB = kMxNB>
 void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4* out, const uint4* wst, const float* bias, const float* h0,
                    int rows_p, unsigned long long* dbg) {
 #ifdef CCSM_PHASE_STAMPS
-    if (dbg) {
+    if (dbg && NB == kMxNB) {
         if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<true, HS3, DYN>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
         else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
         else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
@@ -463,9 +463,9 @@ void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4
     }
 #endif
     (void)dbg;
-    if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, HS3, DYN>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
-    else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);
-    else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, nullptr);   // fp8 corr fragments for the attention kernel
+    if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, HS3, DYN, NB>), grid, dim3(512), mx0_lds(NB), st, xin, out, wst, bias, h0, rows_p, nullptr);
+    else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false, HS3, DYN, NB>), grid, dim3(512), mx12_lds(NB), st, xin, out, wst, bias, h0, rows_p, nullptr);
+    else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false, HS3, DYN, NB>), grid, dim3(512), mx12_lds(NB), st, xin, out, wst, bias, h0, rows_p, nullptr);   // fp8 corr fragments for the attention kernel
 }
 
 // Heavy kernels, once over every row used by the current slices, then the per-slice logits/softmax.
@@ -473,13 +473,20 @@ void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4
 // DYN: split-mx-d (fp6 recurrent blobs, per-row dynamic activation scales)
 template <bool F8, bool HS3 = false, bool DYN = false>
 ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
-    const int rows_run = ((ws->rows_used + kRowPad - 1) / kRowPad) * kRowPad;
+    // Workgroups of 96 rows (kMxNB = 3 tiles) amortise the weight stream best; where they would leave compute units idle - a lone
+    // batch (86 workgroups), a ragged group of two (172) - the split-mx family runs its 64-row form instead: a workgroup's step takes
+    // ~0.74 of the time and more of the 256 CUs have one.  Picked by rounds of 256 workgroups.
+    const int w96 = 2 * ((ws->rows_used + 95) / 96), w64 = 2 * ((ws->rows_used + 63) / 64);
+    const bool no64 = std::getenv("CCSM_NO_64ROW") != nullptr;             // (A/B switch, read per launch: tests run both forms in one process)
+    const bool small = F8 && !no64 && 0.74 * ((w64 + 255) / 256) < (double)((w96 + 255) / 256);
+    const int wg_rows = small ? 64 : 96;
+    const int rows_run = ((ws->rows_used + wg_rows - 1) / wg_rows) * wg_rows;
     const int tiles = rows_run / 32;
     const bool tm = ws->timing && ws->ev_ok;
     if (tm) ws->ev = ws->evs[ws->ev_runs % ccsm_workspace::kEvSets];
     if (tm) HIP_TRY(hipEventRecord(ws->ev[1], st));
     const size_t slab = (size_t)2 * ws->rows_p * kHidden;  // floats per layer (two directions)
-    const dim3 ggrid(2 * (tiles / kNBGru2));
+    const dim3 ggrid(2 * (rows_run / wg_rows));
 #ifdef CCSM_PHASE_STAMPS
     static const int dbg_layer = std::getenv("CCSM_PHASE_LAYER") ? std::atoi(std::getenv("CCSM_PHASE_LAYER")) : 1;
 #else
@@ -487,11 +494,15 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
 #endif
     if constexpr (F8) {
         uint4* const* wst = HS3 ? m->wsthy : DYN ? m->wstmd : m->wstmx;
-        launch_gru_mx<HS3, DYN>(0, ggrid, st, ws->x0, ws->act[0], wst[0], m->bias[0], ws->h0buf, ws->rows_p, dbg_layer == 0 ? ws->dbg : nullptr);
+        auto layer = [&](int l, const uint4* in, uint4* out_, unsigned long long* dbg) {
+            if (small) launch_gru_mx<HS3, DYN, 2>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
+            else launch_gru_mx<HS3, DYN>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, dbg);
+        };
+        layer(0, ws->x0, ws->act[0], dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
-        launch_gru_mx<HS3, DYN>(1, ggrid, st, ws->act[0], ws->act[1], wst[1], m->bias[1], ws->h0buf + slab, ws->rows_p, dbg_layer == 1 ? ws->dbg : nullptr);
+        layer(1, ws->act[0], ws->act[1], dbg_layer == 1 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
-        launch_gru_mx<HS3, DYN>(2, ggrid, st, ws->act[1], ws->act[0], wst[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p, dbg_layer == 2 ? ws->dbg : nullptr);
+        layer(2, ws->act[1], ws->act[0], dbg_layer == 2 ? ws->dbg : nullptr);
     } else {
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
                            m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p);
@@ -793,6 +804,16 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, true>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false, true>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false, true>), kMx12Lds);
+            // the 64-row forms
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, false, 2>), mx0_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false, false, 2>), mx12_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false, false, 2>), mx12_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 2>), mx0_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, true, false, 2>), mx12_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, true, false, 2>), mx12_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, true, 2>), mx0_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false, true, 2>), mx12_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false, true, 2>), mx12_lds(2));
 #ifdef CCSM_PHASE_STAMPS
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, false>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, false>), kMx12Lds);

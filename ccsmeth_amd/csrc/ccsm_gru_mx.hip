@@ -196,16 +196,19 @@ __device__ __forceinline__ void pack_pair_hl(const float (&v)[16], uint4& hi0, u
 // LDS byte offsets shared by the two kernels: h fragments [kb 16][bt 3][hi | corr] x 1 KiB at 0 (96 KiB).  The fp8 residuals of a
 // wave's own units (16 B per lane and batch tile) live half in the unused second half of the lane's slot in the corr fragment
 // of the wave's second k-block (bytes 8-15) and half in a 12 KiB region at LO_OFF: [wave][bt][lane] x 8 B.
+// NB = row tiles per workgroup: 3 (96 rows) in full launches; 2 (64 rows) where 96-row workgroups would leave compute units idle (a lone
+// batch, a ragged group): the same code with two thirds of the rows per weight stream (ccsm_api.hip picks per launch).
 constexpr int kMxNB = 3;
-constexpr int kMxHBytes = kKBH * kMxNB * 2 * 1024;
-__device__ __forceinline__ int mx_hfrag(int kb, int bt, int f) { return ((kb * kMxNB + bt) * 2 + f) << 10; }
+constexpr int mx_hbytes(int nb) { return kKBH * nb * 2 * 1024; }
+template <int NB = kMxNB>
+__device__ __forceinline__ int mx_hfrag(int kb, int bt, int f) { return ((kb * NB + bt) * 2 + f) << 10; }
 
 // ---- h0 -> LDS: hi fragments, blobs (coarse scale) and residuals of this wave's own two k-blocks, every batch tile
-template <bool HS3, bool DYN = false>
+template <bool HS3, bool DYN = false, int NB = kMxNB>
 __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float* __restrict__ h0d, int tile0, int wave, int lane) {
     const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
-    for (int bt = 0; bt < kMxNB; ++bt) {
+    for (int bt = 0; bt < NB; ++bt) {
         const float* src = h0d + ((size_t)(tile0 + bt) * 32 + n) * kHidden + 32 * wave;
         float v[16];                                                // C layout: v[4q + e] = unit 8q + 4hh + e
 #pragma unroll
@@ -216,10 +219,10 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
         if constexpr (HS3) {            // exact: fp16 hi and fp16 lo fragments, any magnitude
             uint4 hi0, hi1, lo0, lo1;
             pack_pair_hl(v, hi0, hi1, lo0, lo1);
-            *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 0) + lane * 16) = hi0;
-            *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 0) + lane * 16) = hi1;
-            *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 1) + lane * 16) = lo0;
-            *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 1) + lane * 16) = lo1;
+            *reinterpret_cast<uint4*>(smem + mx_hfrag<NB>(2 * wave, bt, 0) + lane * 16) = hi0;
+            *reinterpret_cast<uint4*>(smem + mx_hfrag<NB>(2 * wave + 1, bt, 0) + lane * 16) = hi1;
+            *reinterpret_cast<uint4*>(smem + mx_hfrag<NB>(2 * wave, bt, 1) + lane * 16) = lo0;
+            *reinterpret_cast<uint4*>(smem + mx_hfrag<NB>(2 * wave + 1, bt, 1) + lane * 16) = lo1;
             continue;
         }
         uint4 hi0, hi1, c0, lo8;
@@ -229,29 +232,29 @@ __device__ __forceinline__ void mx_h0_to_lds(char* smem, int lo_off, const float
             pack_pair_mx<false, true>(v, 0.25f, hi0, hi1, c0, c1, lo8, &sc, hh);
         } else
         pack_pair_mx<true>(v, kMxH0Div, hi0, hi1, c0, c1, lo8);
-        *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 0) + lane * 16) = hi0;
-        *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 0) + lane * 16) = hi1;
-        *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave, bt, 1) + lane * 16) = c0;
-        *reinterpret_cast<uint4*>(smem + mx_hfrag(2 * wave + 1, bt, 1) + lane * 16) = make_uint4(c1.x, c1.y, lo8.x, lo8.y);
-        *reinterpret_cast<uint2*>(smem + lo_off + ((wave * kMxNB + bt) * 64 + lane) * 8) = make_uint2(lo8.z, lo8.w);
+        *reinterpret_cast<uint4*>(smem + mx_hfrag<NB>(2 * wave, bt, 0) + lane * 16) = hi0;
+        *reinterpret_cast<uint4*>(smem + mx_hfrag<NB>(2 * wave + 1, bt, 0) + lane * 16) = hi1;
+        *reinterpret_cast<uint4*>(smem + mx_hfrag<NB>(2 * wave, bt, 1) + lane * 16) = c0;
+        *reinterpret_cast<uint4*>(smem + mx_hfrag<NB>(2 * wave + 1, bt, 1) + lane * 16) = make_uint4(c1.x, c1.y, lo8.x, lo8.y);
+        *reinterpret_cast<uint2*>(smem + lo_off + ((wave * NB + bt) * 64 + lane) * 8) = make_uint2(lo8.z, lo8.w);
     }
 }
 
 // ---- step tail: n = tanh(N); h' = n + z (h_{t-1} - n) for this wave's own units; fragments and blobs for the next step (LDS)
 // and the next layer (HBM).  accz = sigmoid(Z) already, accn = N.  OUT_FP8: the layer feeding the attention kernel writes fp8 corr
 // fragments (attn_fc_f8_kernel's format) instead of blobs.  t16 = lane * 16 (an opaque copy: see lane16_here in the kernels).
-template <bool OUT_FP8, bool HS3, bool DYN = false>
-__device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&accz)[kMxNB], const f32x16 (&accn)[kMxNB], uint4* __restrict__ out,
+template <bool OUT_FP8, bool HS3, bool DYN = false, int NB = kMxNB>
+__device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&accz)[NB], const f32x16 (&accn)[NB], uint4* __restrict__ out,
                                         int tile0, int t, int dir, int wave, int t16) {
     constexpr bool XD = HS3 || DYN;     // block-scaled blobs for the next layer's input part (every arithmetic but plain split-mx)
-    const int own_off = wave * (2 * kMxNB * 2 * 1024);                          // mx_hfrag(2 wave, 0, 0)
+    const int own_off = wave * (2 * NB * 2 * 1024);                          // mx_hfrag(2 wave, 0, 0)
     char* t_wr = smem + (own_off + t16);                                        // + lane * 16       (fragment writes)
     const char* t_rd = smem + (own_off + (t16 & 0x1f0) + ((t16 >> 9) << 3));    // + n * 16 + hh * 8 (own-unit reads, C layout)
-    char* t_lo = smem + (lo_off + wave * (kMxNB * 64 * 8) + (t16 >> 1));        // + lane * 8
-    auto own_frag = [&](int kbl, int bt, int f) -> int { return ((kbl * kMxNB + bt) * 2 + f) << 10; };
+    char* t_lo = smem + (lo_off + wave * (NB * 64 * 8) + (t16 >> 1));        // + lane * 8
+    auto own_frag = [&](int kbl, int bt, int f) -> int { return ((kbl * NB + bt) * 2 + f) << 10; };
     uint32_t bsc_all = 0;
 #pragma unroll
-    for (int bt = 0; bt < kMxNB; ++bt) {
+    for (int bt = 0; bt < NB; ++bt) {
         float hn[16];
         uint2 la = make_uint2(0, 0), lb = make_uint2(0, 0);
         if constexpr (!HS3) {
@@ -372,15 +375,19 @@ constexpr int mx12_wbytes(bool hs3, bool dyn = false) { return mx12_off_c(hs3, d
 //   xin : [tile][t][hi|lo][64] uint4          out : [tile][t][32 kb][hi | corr][64] uint4 (activation blobs in the corr fragments)
 // LDS : h fragments 96 KiB | x ring 2 x 6 KiB | residuals 12 KiB | biases 4 KiB
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kMx0XOff = kMxHBytes, kMx0LoOff = kMx0XOff + 2 * kMxNB * 2 * 1024, kMx0BiasOff = kMx0LoOff + kWaves * kMxNB * 64 * 8;
-constexpr int kMx0Lds = kMx0BiasOff + kWaves * 4 * 32 * 4;
+constexpr int mx0_xoff(int nb) { return mx_hbytes(nb); }
+constexpr int mx0_looff(int nb) { return mx0_xoff(nb) + 2 * nb * 2 * 1024; }
+constexpr int mx0_biasoff(int nb) { return mx0_looff(nb) + kWaves * nb * 64 * 8; }
+constexpr int mx0_lds(int nb) { return mx0_biasoff(nb) + kWaves * 4 * 32 * 4; }
+constexpr int kMx0Lds = mx0_lds(kMxNB);
 
-template <bool DBG, bool HS3, bool DYN = false>
+template <bool DBG, bool HS3, bool DYN = false, int NB_ = kMxNB>
 __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                 const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                 const float* __restrict__ h0, int rows_p,
                                                                 unsigned long long* __restrict__ dbg) {
-    constexpr int NB = kMxNB;
+    constexpr int NB = NB_;
+    constexpr int kMx0XOff = mx0_xoff(NB), kMx0LoOff = mx0_looff(NB), kMx0BiasOff = mx0_biasoff(NB);
     static_assert(!(HS3 && DYN), "one or the other");
     constexpr int PB = mx_pair_b(HS3, DYN);
     constexpr int OFF_B = 4 * 1024, OFF_C = OFF_B + (kKBH / 2) * PB;
@@ -396,16 +403,16 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 
     if (threadIdx.x < kWaves * 4 * 32 / 4)
         reinterpret_cast<float4*>(smem + kMx0BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
-    mx_h0_to_lds<HS3, DYN>(smem, kMx0LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
+    mx_h0_to_lds<HS3, DYN, NB>(smem, kMx0LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     // x staging: 6 fragments per step (bt x hi|lo), waves 0-5 move one each
     const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * 2 * kFragU4);     // per-workgroup base: see gru_layer12_mx_kernel
     const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + kMx0XOff);
     auto stage_load = [&](int t, int buf) {
-        const int f = wave < 6 ? wave : 5;                          // waves 6, 7 re-stage fragment 5 (same bytes, same place)
+        const int f = wave < 2 * NB ? wave : 2 * NB - 1;            // the other waves re-stage the last fragment (same bytes, same place)
         const int hl = f & 1, bt = f >> 1;
         const int soff = (((bt * kSeqLen + t) * 2 + hl) << 10);
-        dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + ((buf * 6 + f) << 10))));
+        dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + ((buf * 2 * NB + f) << 10))));
     };
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx0_wbytes(HS3, DYN));
     const int bias_off = kMx0BiasOff + wave * 4 * 32 * 4;
@@ -472,18 +479,17 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
             for (int bt = 0; bt < NB; ++bt) { acc[0][bt] = b0; acc[1][bt] = b1; }
         }
         // ---------------- phase A: R, Z += W_i{r,z} x_t (three fp16 passes) -------------------------------------------------
-        // the transfer of this step's x (issued one step ago) is older than the 14 weight requests and 12 output stores of the tail
-        if constexpr (HS3) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // (16 weight requests there)
-        else if constexpr (DYN) asm volatile("s_waitcnt vmcnt(29)" ::: "memory");   // (17)
-        else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+        // the transfer of this step's x (issued one step ago) is older than the 14 weight requests and 4 NB output stores of the tail
+        // (4 NB stores; the hybrid has 16 weight requests there, split-mx-d 17)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((HS3 ? 16 : DYN ? 17 : 14) + 4 * NB) : "memory");
         __syncthreads();                                            // x_t in LDS; everybody's h_{t-1} fragments written
         stage_load(tn, (s + 1) & 1);
         auto rd_x0 = [&](uint4 (&x0)[NB][2]) {
             const int l16 = lane16_here();
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
-                x0[bt][0] = *reinterpret_cast<const uint4*>(smem + kMx0XOff + ((((s & 1) * 3 + bt) * 2 + 0) << 10) + l16);
-                x0[bt][1] = *reinterpret_cast<const uint4*>(smem + kMx0XOff + ((((s & 1) * 3 + bt) * 2 + 1) << 10) + l16);
+                x0[bt][0] = *reinterpret_cast<const uint4*>(smem + kMx0XOff + ((((s & 1) * NB + bt) * 2 + 0) << 10) + l16);
+                x0[bt][1] = *reinterpret_cast<const uint4*>(smem + kMx0XOff + ((((s & 1) * NB + bt) * 2 + 1) << 10) + l16);
             }
         };
         {
@@ -521,8 +527,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
                 constexpr int NXT = OFF_B + (Q + 1) * PB;
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
-                    xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(KB, bt, 0) + lane * 16);
-                    xl[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(KB, bt, 1) + lane * 16);
+                    xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(KB, bt, 0) + lane * 16);
+                    xl[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(KB, bt, 1) + lane * 16);
                 }
                 CCSM_FENCE;
 #pragma unroll
@@ -548,9 +554,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
             uint32_t pm[NB];                                            // split-mx-d: running max |x_hi| of the pair's block, this lane's values
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
-                xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 0) + lane * 16);
-                xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 1) + lane * 16);
-                xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag(2 * Q + 1, bt, 1) + lane * 16);
+                xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, bt, 0) + lane * 16);
+                xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, bt, 1) + lane * 16);
+                xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag<NB>(2 * Q + 1, bt, 1) + lane * 16);
             }
             CCSM_FENCE;
 #pragma unroll
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
                 for (int g = 0; g < 3; ++g) wbh[0][g] = w_at(NXT + (g << 10));
             }
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q + 1, bt, 0) + lane * 16);
+            for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q + 1, bt, 0) + lane * 16);
             CCSM_FENCE;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt)
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
         __syncthreads();                                            // every wave has read h_{t-1} (phase B) before anybody overwrites its fragments
-        mx_tail<false, HS3, DYN>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        mx_tail<false, HS3, DYN, NB>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         stamp(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no transfer may still be writing LDS when the workgroup retires
@@ -663,16 +669,20 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 // LDS : h fragments 96 KiB | x ring 4 x 12 KiB | residuals 12 KiB | biases 4 KiB = 160 KiB
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMxRS = 4;
-constexpr int kMxSlotBytes = 2 * kMxNB * 2 * 1024;
-constexpr int kMx12XOff = kMxHBytes, kMx12LoOff = kMx12XOff + kMxRS * kMxSlotBytes, kMx12BiasOff = kMx12LoOff + kWaves * kMxNB * 64 * 8;
-constexpr int kMx12Lds = kMx12BiasOff + kWaves * 4 * 32 * 4;
+constexpr int mx_slot_bytes(int nb) { return 2 * nb * 2 * 1024; }
+constexpr int mx12_xoff(int nb) { return mx_hbytes(nb); }
+constexpr int mx12_looff(int nb) { return mx12_xoff(nb) + kMxRS * mx_slot_bytes(nb); }
+constexpr int mx12_biasoff(int nb) { return mx12_looff(nb) + kWaves * nb * 64 * 8; }
+constexpr int mx12_lds(int nb) { return mx12_biasoff(nb) + kWaves * 4 * 32 * 4; }
+constexpr int kMx12Lds = mx12_lds(kMxNB);
 
-template <bool OUT_FP8, bool DBG, bool HS3, bool DYN = false>
+template <bool OUT_FP8, bool DBG, bool HS3, bool DYN = false, int NB_ = kMxNB>
 __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                  const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                  const float* __restrict__ h0, int rows_p,
                                                                  unsigned long long* __restrict__ dbg) {
-    constexpr int NB = kMxNB, KX = kKB12, NPAIR = KX / 2, RS = kMxRS, SLOT_BYTES = kMxSlotBytes;
+    constexpr int NB = NB_, KX = kKB12, NPAIR = KX / 2, RS = kMxRS, SLOT_BYTES = mx_slot_bytes(NB);
+    constexpr int kMx12XOff = mx12_xoff(NB), kMx12LoOff = mx12_looff(NB), kMx12BiasOff = mx12_biasoff(NB);
     static_assert(!(HS3 && DYN), "one or the other");
     constexpr int PA = kMxPairA, PB = mx_pair_b(HS3, DYN), PC = kMxPairC, OFF_B = kMx12OffB, OFF_C = mx12_off_c(HS3, DYN);
     constexpr int OFF_BS = DYN ? (10 << 10) + 512 : (9 << 10);      // scale dwords of a phase-B pair
@@ -689,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 
     if (threadIdx.x < kWaves * 4 * 32 / 4)
         reinterpret_cast<float4*>(smem + kMx12BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];
-    mx_h0_to_lds<HS3, DYN>(smem, kMx12LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
+    mx_h0_to_lds<HS3, DYN, NB>(smem, kMx12LoOff, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     // ---- x transfers: fragment f = (kbl * NB + bt) * 2 + hl of a ring slot; wave w moves fragment w, waves 0-3 also w + 8
     // the descriptor starts at THIS workgroup's first tile (64-bit address arithmetic): its 2 GiB range and the 32-bit offsets below
@@ -705,8 +715,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff),
                       __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT_BYTES + (f << 10))));
         };
-        one(wave);
-        if (wave < 4) one(wave + 8);
+        one(wave);                                                  // 4 NB fragments per pair
+        if (4 * NB > kWaves && wave < 4 * NB - kWaves) one(wave + 8);
     };
     // the transfer of consumption jj + RS of step s (jj: 0-15 phase A pairs, 16-31 phase C pairs) goes into the slot consumption jj
     // just vacated
@@ -717,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     // wait until this wave's part of a transfer has landed: at most NLO (waves 4-7) / NHI (waves 0-3) younger operations
 #define CCSM_WAIT_XFER(NLO, NHI)                                                        \
     do {                                                                                \
-        if (wave < 4) asm volatile("s_waitcnt vmcnt(" #NHI ")" ::: "memory");            \
+        if (4 * NB > kWaves && wave < 4 * NB - kWaves) asm volatile("s_waitcnt vmcnt(" #NHI ")" ::: "memory"); \
         else asm volatile("s_waitcnt vmcnt(" #NLO ")" ::: "memory");                     \
     } while (0)
 
@@ -898,8 +908,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 constexpr int NXT = OFF_B + (Q + 1) * PB;
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
-                    xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(KB, bt, 0) + lane * 16);
-                    xl[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(KB, bt, 1) + lane * 16);
+                    xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(KB, bt, 0) + lane * 16);
+                    xl[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(KB, bt, 1) + lane * 16);
                 }
                 CCSM_FENCE;
 #pragma unroll
@@ -932,9 +942,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             uint32_t pm[NB];                                            // split-mx-d: running max |x_hi| of the pair's block, this lane's values
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
-                xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 0) + lane * 16);
-                xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q, bt, 1) + lane * 16);
-                xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag(2 * Q + 1, bt, 1) + lane * 16);
+                xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, bt, 0) + lane * 16);
+                xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, bt, 1) + lane * 16);
+                xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag<NB>(2 * Q + 1, bt, 1) + lane * 16);
             }
             CCSM_MAIN(wbh[0], xh, 3, 0);
             if constexpr (DYN) {
@@ -948,7 +958,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 wch[0][0] = w_at(OFF_C + 0 * PC + (0 << 10)); wch[0][1] = w_at(OFF_C + 0 * PC + (1 << 10)); wcb[0] = w_at(OFF_C + 0 * PC + (2 << 10));
             }
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag(2 * Q + 1, bt, 0) + lane * 16);
+            for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q + 1, bt, 0) + lane * 16);
             CCSM_MAIN(wbh[1], xh, 3, 0);
             if constexpr (!LAST) {
 #pragma unroll
@@ -1063,11 +1073,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             slot = slot_n;
             if constexpr (P == 1) zwork(0);
             if constexpr (P == 5) zwork(1);
-            if constexpr (P == 9) zwork(2);
+            if constexpr (P == 9 && NB > 2) zwork(2);
         });
 #undef CCSM_MAIN
         stamp(3);
-        mx_tail<OUT_FP8, HS3, DYN>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        mx_tail<OUT_FP8, HS3, DYN, NB>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         CCSM_FENCE;
         ldA_slot(2, 2);                                             // the third weight slot of the next step (needed two pairs in): not live across the tail
         CCSM_FENCE;
