@@ -474,12 +474,22 @@ void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4
 template <bool F8, bool HS3 = false, bool DYN = false>
 ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) {
     // Workgroups of 96 rows (kMxNB = 3 tiles) amortise the weight stream best; where they would leave compute units idle - a lone
-    // batch (86 workgroups), a ragged group of two (172) - the split-mx family runs its 64-row form instead: a workgroup's step takes
-    // ~0.74 of the time and more of the 256 CUs have one.  Picked by rounds of 256 workgroups.
-    const int w96 = 2 * ((ws->rows_used + 95) / 96), w64 = 2 * ((ws->rows_used + 63) / 64);
-    const bool no64 = std::getenv("CCSM_NO_64ROW") != nullptr;             // (A/B switch, read per launch: tests run both forms in one process)
-    const bool small = F8 && !no64 && 0.74 * ((w64 + 255) / 256) < (double)((w96 + 255) / 256);
-    const int wg_rows = small ? 64 : 96;
+    // batch (86 workgroups), a ragged group of two (172) - the split-mx family runs its 64-row or 32-row form instead: a workgroup's
+    // step takes ~0.74 / ~0.55 of the time and more of the 256 CUs have one.  Picked by rounds of 256 workgroups; CCSM_WG_TILES = 1 | 2 | 3
+    // forces a form (A/B runs and tests; read per launch).
+    int nb_run = 3;
+    if (F8) {
+        static const double kStepCost[4] = {0.0, 0.55, 0.74, 1.0};
+        double best = 1e30;
+        for (int nb = 3; nb >= 1; --nb) {
+            const int wgs = 2 * ((ws->rows_used + 32 * nb - 1) / (32 * nb));
+            const double cost = kStepCost[nb] * ((wgs + 255) / 256);
+            if (cost < best - 1e-9) { best = cost; nb_run = nb; }
+        }
+        const char* force = std::getenv("CCSM_WG_TILES");
+        if (force && force[0] >= '1' && force[0] <= '3') nb_run = force[0] - '0';
+    }
+    const int wg_rows = 32 * nb_run;
     const int rows_run = ((ws->rows_used + wg_rows - 1) / wg_rows) * wg_rows;
     const int tiles = rows_run / 32;
     const bool tm = ws->timing && ws->ev_ok;
@@ -495,7 +505,8 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     if constexpr (F8) {
         uint4* const* wst = HS3 ? m->wsthy : DYN ? m->wstmd : m->wstmx;
         auto layer = [&](int l, const uint4* in, uint4* out_, unsigned long long* dbg) {
-            if (small) launch_gru_mx<HS3, DYN, 2>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
+            if (nb_run == 1) launch_gru_mx<HS3, DYN, 1>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
+            else if (nb_run == 2) launch_gru_mx<HS3, DYN, 2>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
             else launch_gru_mx<HS3, DYN>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, dbg);
         };
         layer(0, ws->x0, ws->act[0], dbg_layer == 0 ? ws->dbg : nullptr);
@@ -814,6 +825,15 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, true, 2>), mx0_lds(2));
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false, true, 2>), mx12_lds(2));
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false, true, 2>), mx12_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, false, 1>), mx0_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false, false, 1>), mx12_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false, false, 1>), mx12_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 1>), mx0_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, true, false, 1>), mx12_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, true, false, 1>), mx12_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, true, 1>), mx0_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false, true, 1>), mx12_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false, true, 1>), mx12_lds(1));
 #ifdef CCSM_PHASE_STAMPS
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, false>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, false>), kMx12Lds);

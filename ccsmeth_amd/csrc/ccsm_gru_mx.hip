@@ -407,7 +407,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 
     // x staging: 6 fragments per step (bt x hi|lo), waves 0-5 move one each
     const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * 2 * kFragU4);     // per-workgroup base: see gru_layer12_mx_kernel
-    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + kMx0XOff);
+    // (the 32-row form casts first: its offset otherwise trips a backend check, "Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base";
+    //  the other forms keep the expression their tuned code was generated from: cast-first gives them 10 % fewer instructions and, A/B on
+    //  MI355X, the same 2.47 M sites/s - the kernels are bound by energy, not by issue slots)
+    const unsigned sx_base = NB == 1 ? (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)kMx0XOff
+                                     : (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + kMx0XOff);
     auto stage_load = [&](int t, int buf) {
         const int f = wave < 2 * NB ? wave : 2 * NB - 1;            // the other waves re-stage the last fragment (same bytes, same place)
         const int hl = f & 1, bt = f >> 1;
@@ -705,7 +709,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     // the descriptor starts at THIS workgroup's first tile (64-bit address arithmetic): its 2 GiB range and the 32-bit offsets below
     // then never see more than three tiles, whatever the size of the launch (a layer output passes 2 GiB at 24960 sites)
     const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * KX * 2 * kFragU4);
-    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + X_OFF);
+    const unsigned sx_base = NB == 1 ? (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)X_OFF      // (see gru_layer0_mx_kernel)
+                                     : (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + X_OFF);
     auto dma_pair = [&](int slot, int sd, int jd) {                 // wave-uniform: ring slot, step (clamped), pair of x_t(sd)
         const int sc_ = sd < kSeqLen ? sd : kSeqLen - 1;
         const int td = dir ? kSeqLen - 1 - sc_ : sc_;
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff),
                       __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT_BYTES + (f << 10))));
         };
-        one(wave);                                                  // 4 NB fragments per pair
+        if (4 * NB >= kWaves || wave < 4 * NB) one(wave);           // 4 NB fragments per pair (NB = 1: waves 4-7 move nothing)
         if (4 * NB > kWaves && wave < 4 * NB - kWaves) one(wave + 8);
     };
     // the transfer of consumption jj + RS of step s (jj: 0-15 phase A pairs, 16-31 phase C pairs) goes into the slot consumption jj
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 #define CCSM_WAIT_XFER(NLO, NHI)                                                        \
     do {                                                                                \
         if (4 * NB > kWaves && wave < 4 * NB - kWaves) asm volatile("s_waitcnt vmcnt(" #NHI ")" ::: "memory"); \
-        else asm volatile("s_waitcnt vmcnt(" #NLO ")" ::: "memory");                     \
+        else if (4 * NB >= kWaves || wave < 4 * NB) asm volatile("s_waitcnt vmcnt(" #NLO ")" ::: "memory");   \
     } while (0)
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx12_wbytes(HS3, DYN));
@@ -1072,7 +1077,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             CCSM_FENCE;
             slot = slot_n;
             if constexpr (P == 1) zwork(0);
-            if constexpr (P == 5) zwork(1);
+            if constexpr (P == 5 && NB > 1) zwork(1);
             if constexpr (P == 9 && NB > 2) zwork(2);
         });
 #undef CCSM_MAIN

@@ -243,24 +243,26 @@ def test_model_variants_vs_reference_goldens(prec):
         DeviceModel(synth.synth_weights(1, feas_ccs=9), device=0, is_npass=True, is_stds=True, is_sn=False)
 
 
-def test_64_row_and_96_row_workgroups_agree_bitwise(model7, monkeypatch):
+def test_workgroup_forms_agree_bitwise(model7, monkeypatch):
     """Launches that would leave compute units idle with 96-row workgroups (a lone batch: 86 of them, a ragged group) run the split-mx
-    family's 64-row form (ccsm_api.hip::launch_run).  A row's arithmetic does not depend on which rows share its workgroup, so both
-    forms must produce the same bits - for a lone 2048-site batch, a ragged size, and a size whose 64-row grid is not a multiple of
-    the 96-row one; CCSM_NO_64ROW=1 forces the 96-row form (read per launch)."""
+    family's 64-row or 32-row form (ccsm_api.hip::launch_run picks by rounds of 256 workgroups).  A row's arithmetic does not depend on
+    which rows share its workgroup, so all three forms must produce the same bits - for a lone 2048-site batch, a ragged size, and a
+    tiny one; CCSM_WG_TILES = 1 | 2 | 3 forces a form (read per launch)."""
     w, dm = model7
     for n in (2048, 700, 33):
         s = synth.synth_sites(n, 77 + n)
         h1, h2 = synth.synth_h0(n, 78 + n)
         ws = dm.workspace(n)
-        monkeypatch.delenv("CCSM_NO_64ROW", raising=False)
+        monkeypatch.delenv("CCSM_WG_TILES", raising=False)
         la, pa = _fwd(ws, s, (h1, h2))
-        monkeypatch.setenv("CCSM_NO_64ROW", "1")
-        lb, pb = _fwd(ws, s, (h1, h2))
-        monkeypatch.delenv("CCSM_NO_64ROW", raising=False)
+        la, pa = np.array(la), np.array(pa)
+        for form in ("1", "2", "3"):
+            monkeypatch.setenv("CCSM_WG_TILES", form)
+            lb, pb = _fwd(ws, s, (h1, h2))
+            assert np.array_equal(la, np.asarray(lb)) and np.array_equal(pa, np.asarray(pb)), (n, form, dm.precision)
+        monkeypatch.delenv("CCSM_WG_TILES", raising=False)
         ws.close()
-        assert np.array_equal(np.asarray(la), np.asarray(lb)) and np.array_equal(np.asarray(pa), np.asarray(pb)), (n, dm.precision)
-        err = np.abs(np.asarray(pa) - _oracle(w, s, h1, h2)[1]).max()
+        err = np.abs(pa - _oracle(w, s, h1, h2)[1]).max()
         assert err < (DEFAULT_TOL if dm.precision >= 4 else SPLIT3_TOL), (n, err)
 
 
