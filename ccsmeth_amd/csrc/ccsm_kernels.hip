@@ -64,7 +64,12 @@ __device__ __forceinline__ u32x4_t dma_rsrc(const void* base) {
                    0x7fffffffu, 0x00020000u};
 }
 __device__ __forceinline__ void dma16_buf(u32x4_t rsrc, int voff, int soff, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
+    // cache policy of the transfers (A/B builds: -DCCSM_DMA_POLICY="\" nt\""): measured on MI355X, `nt` costs 3.4 % (phase C's second read of
+    // x_t finds less of it in L2), `sc1` nothing: profiles/r03_u_dma_policy.log
+#ifndef CCSM_DMA_POLICY
+#define CCSM_DMA_POLICY ""
+#endif
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" CCSM_DMA_POLICY " lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
                  : "memory");
 }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
