@@ -47,12 +47,17 @@ constexpr float kMxLoScale = 65536.0f;             // a wave's private fp8 resid
 typedef _Float16 half32 __attribute__((ext_vector_type(32)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
-// ---- "split-mx-d" (DYN): the recurrent part's activation blobs with one E8M0 scale per (row, 32-k block) instead of the fixed x_hi * 4.
-// On TRAINED checkpoints the fixed scale is what gives split-mx its tail (state values below 0.25 are fp6 subnormals there; together with
-// the fp4 recurrent weights: 0.2-1.7e-4 max |dprob|; emulated with fp6 weights and per-block scales: 1.4-3.3e-5,
-// profiles/r03_y_dynamic_scale_emulation.log).  The block scale needs no storage: it is a function of the block's largest |x_hi| as
-// fp16, and every lane that reads a blob also holds 16 of the block's 32 fp16 hi values (its hi fragments of the pair's two k-blocks),
-// its half-wave partner the other 16 - the writer (step tail) and every reader derive the same exponent E:
+// ---- "split-mx-d" (DYN): fp6 instead of fp4 recurrent weight blobs, and activation blobs with one E8M0 scale per (row, 32-k block)
+// instead of the fixed x_hi * 4.  On TRAINED checkpoints the fixed scale is what gives split-mx its tail (state values below 0.25 are fp6
+// subnormals there; together with the fp4 recurrent weights: 0.2-1.7e-4 max |dprob|; with fp6 weights and per-block scales 1.3-4.7e-5 over
+// 8192 sites, profiles/r03_y_dynamic_scale_emulation.log and r03_w_split_mx_d_trained_checkpoints.log).
+//   * The STATE's block scale needs no storage (the LDS is full): it is a function of the block's largest |x_hi| as fp16, and every lane
+//     that reads a blob also holds 16 of the block's 32 fp16 hi values (its hi fragments of the pair's two k-blocks), its half-wave
+//     partner the other 16 - the writer (step tail) and every reader derive the same exponent E (below).
+//   * For the NEXT layer's input part (XD = DYN or the hybrid: every arithmetic but plain split-mx) the same blob goes to HBM with the
+//     lane's scale byte in the spare bytes 8-11 of the pair's second corr fragment - byte bt = row tile bt of the writing workgroup, bytes
+//     0..bt filled by tile bt, so the reader takes ONE dword (the last tile's) per pair and the instruction's op_sel picks the byte.
+// The exponent:
 //     m = max |x_hi| (fp16 bits e, mantissa f):  E = max(e, 1) - 17 + (f > 0x380)      so that  |x_hi| / 2^E <= 7.5  (fp6 e2m3's top)
 //     hi lanes (g = 0) hold x_hi / 2^E, scale byte 127 + E;   lo lanes (g = 1) hold x_lo / 2^(E - 11), scale byte 127 + E - 11
 //     (|x_lo| <= half an ulp of the block's largest value = 2^(e - 26): at most 4 after the division).
