@@ -511,9 +511,15 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         };
         layer(0, ws->x0, ws->act[0], dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
+#ifdef CCSM_PWR_L0ONLY          // power diagnostics build (tools/gpu_power.py): layer 0 on its own - results are wrong on purpose
+        layer(0, ws->x0, ws->act[1], nullptr);
+        if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
+        layer(0, ws->x0, ws->act[1], nullptr);
+#else
         layer(1, ws->act[0], ws->act[1], dbg_layer == 1 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
         layer(2, ws->act[1], ws->act[0], dbg_layer == 2 ? ws->dbg : nullptr);
+#endif
     } else {
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
                            m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p);
