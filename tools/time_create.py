@@ -1,5 +1,7 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Wall time of ccsm_create per arithmetic (0 = the probe decides): weight-stream packing on 16 threads, only for the arithmetics the
+probe reaches.  The first call also pays the device initialisation.   usage: python tools/time_create.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from ccsmeth_amd.models import DeviceModel
 from ccsmeth_amd.utils import synth
