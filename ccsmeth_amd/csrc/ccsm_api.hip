@@ -362,8 +362,9 @@ float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const flo
                     for (int g = 0; g < 2; ++g) blob_at(pa + (size_t)(4 + g) * 1024, -1, pa + 6 * 1024, g, kMxWFmtH, wx(g), p);     // r, z: fp4 (see ccsm_gru_mx.hip)
                 }
                 phase_b(kMx12OffB);
-                for (int p = 0; p < kKB12 / 2; ++p) {
-                    const size_t pc = mx12_off_c(hs3, dyn) + (size_t)p * kMxPairC;
+                for (int pp = 0; pp < kKB12 / 2; ++pp) {
+                    const size_t pc = mx12_off_c(hs3, dyn) + (size_t)pp * kMxPairC;
+                    const int p = kMxZigZag ? kKB12 / 2 - 1 - pp : pp;          // the pair phase C consumes at position pp
                     hi_at(pc, wx(2), 2 * p); hi_at(pc + 1024, wx(2), 2 * p + 1);
                     blob_at(pc + 2 * 1024, (long)(pc + 3 * 1024), pc + 3 * 1024 + 512, 0, kMxWFmtX, wx(2), p);
                 }

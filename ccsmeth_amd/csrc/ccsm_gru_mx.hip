@@ -204,6 +204,15 @@ __device__ __forceinline__ void pack_pair_hl(const float (&v)[16], uint4& hi0, u
 // NB = row tiles per workgroup: 3 (96 rows) in full launches; 2 (64 rows) where 96-row workgroups would leave compute units idle (a lone
 // batch, a ragged group): the same code with two thirds of the rows per weight stream (ccsm_api.hip picks per launch).
 constexpr int kMxNB = 3;
+// Phase C's second pass over x_t runs in REVERSE pair order (15 .. 0): a cyclic pass over more bytes than the XCD's L2 holds (32
+// workgroups x 192 KiB of x_t beside 2.4 MB of weights in 4 MiB) finds none of them again under LRU, a zig-zag pass finds the most
+// recent ones.  +0.7 % (three alternating A/B runs, profiles/r03_s_zigzag.log); the host packs the n gate's input weights in the same
+// order.  -DCCSM_NO_ZIGZAG builds the forward order.
+#ifdef CCSM_NO_ZIGZAG
+constexpr bool kMxZigZag = false;
+#else
+constexpr bool kMxZigZag = true;
+#endif
 constexpr int mx_hbytes(int nb) { return kKBH * nb * 2 * 1024; }
 template <int NB = kMxNB>
 __device__ __forceinline__ int mx_hfrag(int kb, int bt, int f) { return ((kb * NB + bt) * 2 + f) << 10; }
@@ -732,7 +741,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     // just vacated
     auto dma_ahead = [&](int slot, int s, int jj) {
         const int g = jj + RS;
-        dma_pair(slot, s + (g >> 5), g & (NPAIR - 1));
+        const int c = g & (2 * NPAIR - 1);                           // consumption within its step: 0-15 phase A, 16-31 phase C
+        dma_pair(slot, s + (g >> 5), kMxZigZag && c >= NPAIR ? 2 * NPAIR - 1 - c : c & (NPAIR - 1));
     };
     // wait until this wave's part of a transfer has landed: at most NLO (waves 4-7) / NHI (waves 0-3) younger operations
 #define CCSM_WAIT_XFER(NLO, NHI)                                                        \
