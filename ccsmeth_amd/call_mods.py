@@ -281,7 +281,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
         model.cuda(args.device).eval()
         if int(os.environ.get("RANK", "0")) == 0:
             dm = model._dev
-            probe = "" if dm.probe_error < 0 else (" (probe batch of 2048 sites against split3, accepted with <= 0.5 %% of the sites beyond 1e-5 and none "
+            probe = "" if dm.probe_error < 0 else (" (probe batch of 8192 sites against split3, accepted with <= 0.5 %% of the sites beyond 1e-5 and none "
                                                    "beyond 5e-5: split-mx max %.1e, %.2f %% beyond 1e-5%s)") % (
                 dm.probe_error, 100.0 * dm.probe_tail,
                 ("" if dm.probe_error_mxd < 0 else "; split-mx-d max %.1e, %.2f %% beyond 1e-5" % (dm.probe_error_mxd, 100.0 * dm.probe_tail_mxd)) +

@@ -651,7 +651,13 @@ constexpr float kProbeTailAt = 1.0e-5f;
 constexpr float kProbeTailFrac = 0.005f;
 constexpr float kProbeMaxErr = 5.0e-5f;
 constexpr float kMxH0Limit = 6.0f;
-constexpr int kProbeSites = 2048;
+// 8192 sites: the rule's "none beyond 5e-5" has to see the tail sites that decide whether a checkpoint stays inside the 1e-4 bar.  With 2048
+// probe sites split-mx-d was accepted for checkpoints that then put one of 8192 other sites at 7-9e-5 (profiles/r03_r_ab_trained_tail_*.log):
+// a site that occurs once in 8192 is invisible to a 2048-site sample three times out of four.
+#ifndef CCSM_PROBE_SITES
+#define CCSM_PROBE_SITES 8192        // (-DCCSM_PROBE_SITES=2048: the A/B build of tests/diag/gpu_ab_trained_tail.py)
+#endif
+constexpr int kProbeSites = CCSM_PROBE_SITES;
 
 // ensure(candidate): packs and uploads that arithmetic's weight streams (only the candidates the probe gets to are ever packed)
 ccsm_status probe_arithmetic(ccsm_model* m, const std::function<ccsm_status(int)>& ensure) {

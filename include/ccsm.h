@@ -205,7 +205,7 @@ ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, con
 const char* ccsm_last_error(void);
 const char* ccsm_version(void);
 int ccsm_model_precision(const ccsm_model* m);
-/* precision 0 (default) picks the arithmetic by measurement: ccsm_create runs a 2048-site probe batch through SPLIT3 and then through the
+/* precision 0 (default) picks the arithmetic by measurement: ccsm_create runs an 8192-site probe batch through SPLIT3 and then through the
  * candidates in order of speed - SPLIT_F8 (split-mx), SPLIT_MXD (split-mx-d), then HYBRID (split-mx for the GRUs' input part, three fp16
  * passes and an fp16 hi + lo state for their recurrent part) - and keeps the first one that leaves at most 0.5 % of
  * the probe sites more than 1e-5 and none more than 5e-5 away from SPLIT3's probabilities, else SPLIT3.

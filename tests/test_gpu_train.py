@@ -155,7 +155,9 @@ def test_trained_checkpoint_tail_over_8192_sites(wseed, steps):
     a checkpoint trained here goes through ccsm_create's probe, and whatever arithmetic the probe selects must keep all of 8192 fresh
     sites within the north-star bar (1e-4) of the C oracle - and close to the selection rule's own bound on this other, four times larger
     sample (the rule: none of 2048 probe sites beyond 5e-5 and at most 0.5 % beyond 1e-5; here: at most 2 of 8192 beyond 5e-5 and at
-    most 1 % beyond 1e-5; the trainer's float atomics make every run's checkpoint a slightly different one).  split-mx forced on the same checkpoint is reported
+    most 1 % beyond 1e-5; the trainer's float atomics make every run's checkpoint a slightly different one, and the selected arithmetic
+    can land close to the bar: 16 checkpoints gave max 4.9e-6 ... 9.1e-5, profiles/r03_q_ab_probe_size.log - this test has failed once in about
+    14 suite runs; a failure is information about the selection rule's margin, not a reason to move the bar).  split-mx forced on the same checkpoint is reported
     beside it: it is the arithmetic the probe exists to reject (its tail is what `bench.py` extras.trained.probe shows)."""
     from ccsmeth_amd.models import DeviceModel
     from ccsmeth_amd.train import Trainer
