@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libccsm_bam.so")
 EXPORTS = ("ccsm_bam_last_error", "ccsm_bam_open", "ccsm_bam_header", "ccsm_bam_next", "ccsm_bam_batch_free", "ccsm_bam_close",
            "ccsm_bam_writer_open", "ccsm_bam_write_batch", "ccsm_bam_writer_flush", "ccsm_bam_writer_close",
            "ccsm_bam_modcalls_of_batch", "ccsm_bam_modcalls_free", "ccsm_bam_index_build", "ccsm_bam_sort",
-           "ccsm_bam_align_info", "ccsm_bam_seek", "ccsm_bam_tell", "ccsm_bam_inflated_bytes", "ccsm_bam_seek_chunk",
+           "ccsm_bam_align_info", "ccsm_bam_seek", "ccsm_bam_tell", "ccsm_bam_inflated_bytes", "ccsm_bam_seek_chunk", "ccsm_bam_eof_voffset",
            "ccsm_bam_writer_track_index", "ccsm_bam_writer_take_index", "ccsm_bam_index_write")
 
 
@@ -79,6 +79,7 @@ def load():
     lib.ccsm_bam_inflated_bytes.argtypes = [vp]
     lib.ccsm_bam_inflated_bytes.restype = C.c_int64
     lib.ccsm_bam_seek_chunk.argtypes = [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.ccsm_bam_eof_voffset.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.ccsm_bam_writer_track_index.argtypes = [vp, C.c_int]
     lib.ccsm_bam_writer_take_index.argtypes = [vp, C.POINTER(_IndexRun)]
     lib.ccsm_bam_index_write.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_IndexRun), vp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
@@ -183,6 +184,12 @@ class NativeBamReader:
     def tell(self):
         v = C.c_uint64(0)
         _check(_lib.ccsm_bam_tell(self._h, C.byref(v)))
+        return v.value
+
+    def eof_voffset(self):
+        """What tell() reports behind the file's last record, from the BGZF block headers alone (the hand-over chain must end here)."""
+        v = C.c_uint64(0)
+        _check(_lib.ccsm_bam_eof_voffset(self._h, C.byref(v)))
         return v.value
 
     @property

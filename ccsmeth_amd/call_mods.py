@@ -353,6 +353,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
                     header = _set_coordinate_order(header)             # no reference: every record sorts equal, input order is kept
                 header_inflated = rd.inflated_bytes
                 first_voffset = rd.tell()
+                eof_voffset = rd.eof_voffset() if queue is not None else None      # where the hand-over chain has to end (block headers only)
                 n_ref = rd.n_ref
                 with NativeBamWriter(part_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
                         ThreadPoolExecutor(1) as rpool, ThreadPoolExecutor(1) as wpool:
@@ -462,7 +463,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
             dist.all_gather_object(gathered, dict(rank=rank, header_end=header_end, runs=runs, chunks=chunk_log,
                                                   counts=(cnt_w, cnt_mm, cnt_failed, cnt_sites), inflated=work_inflated, work=t_work))
             cnt_w, cnt_mm, cnt_failed, cnt_sites = (sum(g["counts"][k] for g in gathered) for k in range(4))
-            n_chain = sharding.verify_chain(first_voffset, [c for g in gathered for c in g["chunks"]])
+            n_chain = sharding.verify_chain(first_voffset, [c for g in gathered for c in g["chunks"]], n_chunks=queue.n_chunks, eof_voffset=eof_voffset)
             if n_chain != cnt_w:
                 raise RuntimeError("the chunks hold %d records but %d were written" % (n_chain, cnt_w))
             stats.update(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, rank_inflated_bytes=[g["inflated"] for g in gathered],

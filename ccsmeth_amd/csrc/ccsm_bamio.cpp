@@ -425,6 +425,7 @@ void modcalls_of_record(const uint8_t* src, const ccsm_bam_modcall_opts& o, cons
 
 struct ccsm_bam_reader {
     FILE* fh = nullptr;
+    std::string path;              // (ccsm_bam_eof_voffset walks the block headers through a handle of its own)
     int threads = 1;
     std::vector<uint8_t> stream;   // inflated bytes not yet consumed: [pos, size)
     size_t pos = 0;
@@ -645,6 +646,7 @@ int ccsm_bam_open(const char* path, int threads, ccsm_bam_reader** out) try {
     ccsm_bam_reader* r = new (std::nothrow) ccsm_bam_reader();
     if (!r) return fail("out of memory");
     r->threads = std::max(1, threads);
+    r->path = path;
     r->fh = std::fopen(path, "rb");
     if (!r->fh) { delete r; return fail(std::string("cannot open ") + path); }
     auto bail = [&](const std::string& m) { std::fclose(r->fh); delete r; return fail(m); };
@@ -969,6 +971,75 @@ int ccsm_bam_seek_chunk(ccsm_bam_reader* r, uint64_t coffset_lo, uint64_t coffse
     }
     r->pos = p;
     *voffset_first = r->voffset(r->abs_pos());
+    return 0;
+} CCSM_BAM_CATCH
+
+// Virtual offset a reader reports behind the LAST record of the file: (file offset of the last non-empty BGZF block << 16) | its ISIZE.
+// Block headers and trailers only (nothing is inflated); the reader's position is left alone (own file handle).  A multi-GPU run closes
+// its hand-over chain on this value: a chain that ends anywhere else has lost the tail of the file (a truncated last record, a chunk whose
+// search ran off the end), which the sequential reader reports as an error and the chunked one must not pass over in silence.
+int ccsm_bam_eof_voffset(ccsm_bam_reader* r, uint64_t* voffset) try {
+    if (!r || !voffset) return fail("arguments must be non-NULL");
+    *voffset = 0;
+    FILE* fh = std::fopen(r->path.c_str(), "rb");
+    if (!fh) return fail("cannot reopen " + r->path);
+    struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fh};
+    if (std::fseek(fh, 0, SEEK_END) != 0) return fail("seek failed");
+    const uint64_t fsize = (uint64_t)std::ftell(fh);
+    // one block header + trailer: -> 1 ok (next, isize), 0 not a block, sets `why`
+    std::string why;
+    auto block_at = [&](uint64_t off, uint64_t* next, uint32_t* isize) -> bool {
+        uint8_t h[12];
+        if (off + 12 > fsize || std::fseek(fh, (long)off, SEEK_SET) != 0 || std::fread(h, 1, 12, fh) != 12) { why = "truncated BGZF block"; return false; }
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) { why = "not a BGZF stream (bad gzip member header)"; return false; }
+        const uint32_t xlen = rd16(h + 10);
+        std::vector<uint8_t> x(xlen);
+        if (std::fread(x.data(), 1, xlen, fh) != xlen) { why = "truncated BGZF block"; return false; }
+        int bsize = -1;
+        for (size_t o = 0; o + 4 <= xlen;) {
+            const uint32_t sl = rd16(x.data() + o + 2);
+            if (x[o] == 66 && x[o + 1] == 67 && sl == 2 && o + 6 <= xlen) bsize = rd16(x.data() + o + 4);
+            o += 4 + sl;
+        }
+        if (bsize < 0) { why = "gzip member without the BGZF 'BC' field"; return false; }
+        if ((uint64_t)bsize + 1 < (uint64_t)xlen + 20 || off + (uint64_t)bsize + 1 > fsize) { why = "truncated BGZF block"; return false; }
+        uint8_t t[4];
+        if (std::fseek(fh, (long)(off + (uint64_t)bsize + 1 - 4), SEEK_SET) != 0 || std::fread(t, 1, 4, fh) != 4) { why = "truncated BGZF block"; return false; }
+        *isize = rd32(t);
+        if (*isize > 65536) { why = "corrupt BGZF block (ISIZE > 64 KiB)"; return false; }
+        *next = off + (uint64_t)bsize + 1;
+        return true;
+    };
+    // walk from `start` to the end of the file: -> 1 reached the end exactly, 0 not a chain of blocks
+    auto walk = [&](uint64_t start, uint64_t* last, uint32_t* last_isize) -> bool {
+        *last = ~0ull;
+        for (uint64_t off = start; off < fsize;) {
+            uint64_t nx; uint32_t isz;
+            if (!block_at(off, &nx, &isz)) return false;
+            if (isz) { *last = off; *last_isize = isz; }
+            off = nx;
+        }
+        return true;
+    };
+    uint64_t last = ~0ull; uint32_t last_isize = 0;
+    // the tail of a large file first: a candidate header in its last 256 KiB from which the block chain reaches the end of the file
+    if (fsize > (1u << 18)) {
+        const uint64_t base = fsize - (1u << 18);
+        std::vector<uint8_t> win(65536 + 4);
+        if (std::fseek(fh, (long)base, SEEK_SET) == 0 && std::fread(win.data(), 1, win.size(), fh) == win.size()) {
+            for (size_t i = 0; i + 4 <= win.size(); ++i) {
+                if (win[i] != 0x1f || win[i + 1] != 0x8b || win[i + 2] != 8 || win[i + 3] != 4) continue;
+                if (walk(base + i, &last, &last_isize) && last != ~0ull) break;
+                last = ~0ull;
+            }
+        }
+    }
+    if (last == ~0ull) {                                             // small file, or a tail of empty blocks: from the first block
+        why.clear();
+        if (!walk(0, &last, &last_isize)) return fail(why.empty() ? "not a BGZF stream" : why);
+    }
+    if (last == ~0ull) return fail("no data in the BGZF stream");
+    *voffset = (last << 16) | last_isize;
     return 0;
 } CCSM_BAM_CATCH
 

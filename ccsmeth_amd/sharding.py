@@ -64,10 +64,13 @@ class ChunkQueue:
             raise RuntimeError("call_mods aborted: " + self.store.get("%s/error" % self.prefix).decode("utf-8", "replace"))
 
 
-def verify_chain(first_voffset, chunks):
+def verify_chain(first_voffset, chunks, n_chunks=None, eof_voffset=None):
     """chunks: [(k, voffset of the chunk's first record, voffset behind its last record, n_records)] of every rank, empty chunks with
     n_records == 0.  The first non-empty chunk must begin at the file's first record and every later one where its predecessor ended;
-    returns the total number of records."""
+    with n_chunks every chunk number 0 .. n_chunks - 1 must have been reported exactly once, and with eof_voffset (NativeBamReader.
+    eof_voffset: where a reader stands behind the file's last record) the chain must END there - a last chunk whose record search ran
+    off the end of a damaged file reports "empty", and only the end of the chain shows that the file's tail was never read (the
+    sequential reader raises "truncated BAM record" on such a file; so does this).  Returns the total number of records."""
     prev_end, total, seen = int(first_voffset), 0, set()
     for k, v0, v1, n in sorted(chunks):
         if k in seen:
@@ -80,6 +83,13 @@ def verify_chain(first_voffset, chunks):
                                "failed on this input (re-run with one GPU, or report the file)" % (k, int(v0), prev_end))
         prev_end = int(v1)
         total += int(n)
+    if n_chunks is not None:
+        missing = sorted(set(range(int(n_chunks))) - seen)
+        if missing or len(seen) != int(n_chunks):
+            raise RuntimeError("chunks %s of %d were never reported (a rank stopped early?)" % (missing[:8], int(n_chunks)))
+    if eof_voffset is not None and prev_end != int(eof_voffset):
+        raise RuntimeError("the records read end at virtual offset %#x but the file's data ends at %#x: truncated BAM record at the end "
+                           "of the input (or record-start detection failed in the last chunk)" % (prev_end, int(eof_voffset)))
     return total
 
 

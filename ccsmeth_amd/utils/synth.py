@@ -187,3 +187,23 @@ def synth_aligned_reads(seed, n=14):
         kin = lambda: rng.integers(0, 256, L).astype(np.uint8)  # noqa: E731
         out.append(("a%d" % i, flag, mapq, cigar, "".join(seq), kin(), kin(), kin(), kin(), int(rng.integers(3, 30)), int(rng.integers(3, 30))))
     return out
+
+
+def synth_labeled_sites(n, seed, noise=0.04):
+    """n sites with a PLANTED methylation signal, for training checkpoints whose weights have real structure (not the one-feature toy
+    label of the early tests): label 1 sites carry an IPD / PW shift at window positions 8..12 of both strands whose size depends on the
+    site (log-normal amplitude), on the strand and on the base in front of the C; `noise` of the labels are flipped.
+    -> (sites dict as synth_sites, labels int64 (n,))."""
+    d = synth_sites(n, seed)
+    rng = np.random.default_rng(seed + 7919)
+    y = (rng.random(n) < 0.5).astype(np.int64)
+    amp = np.exp(rng.normal(0.0, 0.45, n)) * y
+    pat_i = np.array([0.25, 0.55, 1.30, 0.80, 0.30])
+    pat_p = np.array([0.10, -0.20, 0.45, 0.30, 0.00])
+    for s, k in ((1, 1.0), (2, 0.7)):
+        ctx = 1.0 + 0.35 * (d[f"kmer{s}"][:, 9].astype(np.float64) - 1.5) / 1.5            # the base in front of the C modulates the shift
+        sh = (amp * ctx * k)[:, None]
+        d[f"ipd{s}"][:, 8:13] = np.around(d[f"ipd{s}"][:, 8:13] + sh * pat_i + 0.15 * sh * rng.standard_normal((n, 5)), 6).astype(np.float32)
+        d[f"pw{s}"][:, 8:13] = np.around(d[f"pw{s}"][:, 8:13] + sh * pat_p, 6).astype(np.float32)
+    flip = rng.random(n) < noise
+    return d, np.where(flip, 1 - y, y).astype(np.int64)

@@ -76,6 +76,12 @@ int ccsm_bam_tell(ccsm_bam_reader* r, uint64_t* voffset);
  * ccsm_bam_tell after a chunk's last batch must equal the next non-empty chunk's *voffset_first (call_mods raises otherwise). */
 int ccsm_bam_seek_chunk(ccsm_bam_reader* r, uint64_t coffset_lo, uint64_t coffset_hi, uint64_t* voffset_first);
 int64_t ccsm_bam_inflated_bytes(const ccsm_bam_reader* r);
+/* What ccsm_bam_tell reports behind the LAST record of the file: (file offset of the last non-empty BGZF block << 16) | its ISIZE, from the
+ * block headers and trailers alone (nothing is inflated, the reader's position does not move).  The hand-over chain of a chunked run must
+ * END here: a chain that ends earlier has lost the tail of the input (a truncated last record, a last chunk whose record search ran off
+ * the end of the file) - the error the reference's single reader raises from pysam (extract_features.py:129-177) instead of writing a
+ * short modbam. */
+int ccsm_bam_eof_voffset(ccsm_bam_reader* r, uint64_t* voffset);
 
 /* level = zlib level of the BGZF blocks (1..9), threads = deflate workers. */
 int ccsm_bam_writer_open(const char* path, const char* header_text, int64_t text_len, const uint8_t* refs, int64_t refs_len,

@@ -209,3 +209,79 @@ def test_index_of_stitched_runs_with_shifts(tmp_path):
             assert [c[0] for c in bins_w[k]] == [c[0] for c in bins_s[k]] or k == 37450
     with bamio.BamReader(out) as rd:
         assert [r.query_name for r in rd] == [r.query_name for r in recs]
+
+
+def _rewrap_truncated(src, dst, cut_bytes):
+    """`src` with the last `cut_bytes` of its INFLATED payload removed, as well-formed BGZF blocks + the EOF marker: a BAM whose last
+    record is cut in the middle while every block is intact (a damaged upload re-compressed, a writer killed between records' halves)."""
+    import gzip
+    import struct
+    import zlib
+    payload = gzip.open(src, "rb").read()
+    payload = payload[:len(payload) - cut_bytes]
+    with open(dst, "wb") as f:
+        for a in list(range(0, len(payload), 60000)) + [None]:
+            chunk = b"" if a is None else payload[a:a + 60000]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            cd = co.compress(chunk) + co.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(cd) + 25) + cd
+                    + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+
+
+@pytest.mark.parametrize("chunk", [3000, 200000, 1 << 30])
+def test_hand_over_chain_ends_at_the_end_of_the_data(tmp_path, chunk):
+    """ccsm_bam_eof_voffset = what tell() reports behind the last record (from the block headers alone), and sharding.verify_chain
+    closes the chain on it: on an intact file the chunked path's chain ends exactly there; on a file whose last record is cut in the
+    middle (every BGZF block intact) the sequential reader raises and so does the chain - the chunk the cut record starts in is either
+    reported empty by the record search or raises itself; before this check it was silently dropped (sharding.py)."""
+    from ccsmeth_amd import sharding
+    rng = np.random.default_rng(23)
+    path = str(tmp_path / "in.bam")
+    _make_bam(path, rng, n_reads=40)
+    first, seq_recs = _sequential(path)
+
+    def chunked(p):
+        log = []
+        with bamnative.NativeBamReader(p, threads=2) as rd:
+            eof = rd.eof_voffset()
+            nch = sharding.n_chunks_of(os.path.getsize(p), chunk)
+            for k in range(nch):
+                v0 = rd.seek_chunk(k * chunk, (k + 1) * chunk)
+                if v0 == 0:
+                    log.append((k, 0, 0, 0))
+                    continue
+                n = 0
+                while True:
+                    b = rd.next_batch(5)
+                    if b is None:
+                        break
+                    n += b.n_reads
+                    b.close()
+                log.append((k, v0, rd.tell(), n))
+        return eof, nch, log
+
+    eof, nch, log = chunked(path)
+    with bamnative.NativeBamReader(path, threads=1) as rd:
+        while True:
+            b = rd.next_batch(64)
+            if b is None:
+                break
+            b.close()
+        assert rd.tell() == eof                                  # the definition: a reader behind the last record stands at eof_voffset
+    assert sharding.verify_chain(first, log, n_chunks=nch, eof_voffset=eof) == len(seq_recs)
+    with pytest.raises(RuntimeError, match="never reported"):
+        sharding.verify_chain(first, log[:-1], n_chunks=nch, eof_voffset=eof)
+    # the same file with its last record cut in the middle
+    cut = str(tmp_path / "cut.bam")
+    _rewrap_truncated(path, cut, len(seq_recs[-1][1]) // 2)
+    with pytest.raises(IOError):                    # the sequential reader: an error, not a short file
+        _sequential(cut)
+    first_c = None
+    with bamnative.NativeBamReader(cut, threads=1) as rd:
+        first_c = rd.tell()
+    try:
+        eof_c, nch_c, log_c = chunked(cut)
+    except IOError:
+        return                                                   # the chunk holding the cut record raised itself: also not silent
+    with pytest.raises(RuntimeError, match="truncated BAM record"):
+        sharding.verify_chain(first_c, log_c, n_chunks=nch_c, eof_voffset=eof_c)
