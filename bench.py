@@ -15,7 +15,7 @@ path (weak scaling).  With --gpus N > 1 and no torch.distributed environment, th
 torch.distributed.run with N ranks; it refuses to run if fewer than N GPUs are visible.
 
 Besides BASELINE's metric the line carries (rank 0, N = 1; `--extras none` skips them): the same forward in the arithmetics
-the probe did not select (hybrid: what a trained checkpoint gets; split3: fp32-class), the PCIe-inclusive rate through ccsm_submit_host / ccsm_wait_host, `call_mods` end to end on a scaled-down
+the rule did not select (split3: fp32-class, what a trained checkpoint gets - `extras.trained` runs a committed one), the PCIe-inclusive rate through ccsm_submit_host / ccsm_wait_host, `call_mods` end to end on a scaled-down
 configs[2] BAM, and the aggregate kernel on configs[4]'s 50 M sites.
 """
 import argparse
@@ -48,18 +48,18 @@ TRAFFIC = {4: ((2 * 995710 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_coales
            6: ((2 * 1002900 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_prec6.md"),
            3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
 ARITH_NAME = {3: "split3", 4: "split-mx", 5: "hybrid", 6: "split-mx-d"}
-ARITH = {4: ("f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate",
+ARITH = {4: ("fp32 reference; computed as f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate (within 1e-4 on this config's random-init weights)",
              "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp4 e2m1 for the "
              "recurrent part and the r, z gates' input part, fp6 e2m3 for the n gate's input part, per-(row, 32-k) E8M0 scales, fp6 e2m3 "
              "activation blobs; attention pool: fp8 e4m3 x fp8), one fp32 accumulator", 99.0 / 64.0),
-         5: ("f16 + MX(fp6|fp4 x fp6) input part, f16x3 recurrent part, f32 accumulate",
+         5: ("fp32 reference; computed as f16 + MX(fp6|fp4 x fp6) input part, f16x3 recurrent part, f32 accumulate",
              "GRU layers: the input part as in split-mx (hi*hi on v_mfma_f32_32x32x16_f16 + one block-scaled fp6/fp4 x fp6 correction MFMA per "
              "32 k), the recurrent part in three fp16 passes (hi*hi+hi*lo+lo*hi) on an fp16 hi + lo state; attention pool: fp8 e4m3 x fp8 "
              "correction; one fp32 accumulator", (512 * 99.0 / 64.0 + 256 * 3.0) / 768.0),
-         6: ("f16 + MX(fp6 x fp6, per-row scales) split operands, f32 accumulate",
+         6: ("fp32 reference; computed as f16 + MX(fp6 x fp6, per-row scales) split operands, f32 accumulate",
              "split-mx with fp6 e2m3 weight blobs for the recurrent part as well, and the state's fp6 correction blob scaled per (row, 32-k block) "
              "from the block's own largest magnitude (E8M0 from the fp16 hi fragments) instead of one fixed exponent", 99.0 / 64.0),
-         3: ("f16x3 split operands, f32 accumulate", "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate", 3.0)}
+         3: ("fp32 reference; computed as f16x3 split operands (hi + lo), f32 accumulate: fp32-class", "split-fp16 x3 MFMA (hi*hi+hi*lo+lo*hi), fp32 accumulate", 3.0)}
 
 
 def parse():
@@ -71,10 +71,9 @@ def parse():
                     help="batches run per launch of the heavy kernels (micro-batching).  6 x 2048 sites = 24576 strand rows = 512 GRU\n"
                          "workgroups (2 full rounds of the 256 CUs) and 768 attention workgroups (3 full rounds)")
     ap.add_argument("--precision", type=int, default=0, choices=(0, 3, 4, 5, 6),
-                    help="0 = the library's default: the fastest of split-mx (fp16 main product + MX correction product), split-mx-d (the same with\n"
-                         "fp6 recurrent weights and block-scaled activation blobs), the hybrid (split-mx input part, three-pass recurrent part)\n"
-                         "and split3 whose probe batch through ccsm_create on these weights leaves at most 0.5 %% of the sites beyond 1e-5 and none\n"
-                         "beyond 5e-5 of split3; 4 = split-mx forced; 6 = split-mx-d forced; 5 = hybrid forced; 3 = split-fp16 x3 (fp32-class)")
+                    help="0 = the library's default: split-mx (fp16 main product + MX correction product) if ccsm_create's 65536-site probe of these\n"
+                         "weights against split3 is clean (max <= 1.25e-5, light tail: true of the contract's random initialisation), else split3\n"
+                         "(three fp16 passes, fp32-class: what trained checkpoints get); 4 = split-mx forced; 6 = split-mx-d forced; 5 = hybrid forced; 3 = split3")
     ap.add_argument("--weights", default=None,
                     help="an .npz of state_dict arrays (e.g. SAVE_TRAINED=<file> python tests/diag/gpu_trained_weights_parity.py) instead of\n"
                          "the contract's random initialisation: what the probe selects for THAT checkpoint, and its speed")
@@ -250,35 +249,25 @@ def extras(weights, dm, dev, pool, grp):
         return run
 
     def trained():
-        # What a user's checkpoint gets: one deterministic checkpoint trained HERE (seed 41, 960 steps of libccsm_train at batch 512 on
-        # a learnable synthetic labelling, ~6 s), served in whatever arithmetic ccsm_create's probe selects for it; its rate on the
-        # benchmark's workload, and its probabilities against the C oracle on 8192 fresh sites (h0 pinned).
+        # What a user's TRAINED checkpoint gets: the committed checkpoint tests/golden/trained/planted7_5000.npz (5000 steps of libccsm_train
+        # on the planted-signal label; fixed weights, so this leg is the same every run), served through ccsm_create(precision 0): the
+        # arithmetic the rule selects for it (the three-pass one: on trained weights split-mx's probe is not clean), its rate on the
+        # benchmark's workload, and its probabilities against the C oracle on 8192 sites (h0 pinned).
         from ccsmeth_amd.models import DeviceModel
-        from ccsmeth_amd.train import Trainer
         from ccsmeth_amd.utils import synth
         from oracle import c_oracle
-        n, steps_t, wseed = 512, 960, 41
-        tpool = synth.synth_sites(n * 8, 42)
-        lab = lambda q: (q["ipd1"][:, 10] + q["ipd2"][:, 10] > 0).astype(np.int64)  # noqa: E731
+        path = os.path.join(ROOT, "tests", "golden", "trained", "planted7_5000.npz")
+        wt = dict(np.load(path))
         t0 = time.perf_counter()
-        tr = Trainer(synth.synth_weights(wseed), device=dev.index, max_sites=n)
-        loss = float("nan")
-        for k in range(steps_t):
-            i = (k % 8) * n
-            q = {key: v[i:i + n] for key, v in tpool.items()}
-            loss, _ = tr.forward_backward(q, lab(q), h0=None, dropout_rate=0.5, seed=wseed, step=k)
-            tr.step(1e-3)
-        wt = tr.state_dict()
-        tr.close()
-        t_train = time.perf_counter() - t0
         dmt = DeviceModel(wt, device=dev.index, precision=0)
+        t_create = time.perf_counter() - t0
         r = Runner(dmt, pool, dev, grp, 0)
         steps = 4 * grp
         dt, _, _, _ = timed(r, steps, grp, fence)
         kt, _ = r.kernel_times()
         r.close()
         m = 8192
-        sv = synth.synth_sites(m, 143)
+        sv = synth.synth_labeled_sites(m, 143)[0]
         h1, h2 = synth.synth_h0(m, 144)
         ws = dmt.workspace(m)
         _, gpu = ws.forward_host(sv["kmer1"], sv["ipd1"], sv["pw1"], sv["npass1"], sv["kmer2"], sv["ipd2"], sv["pw2"], sv["npass2"], h0=(h1, h2))
@@ -287,13 +276,13 @@ def extras(weights, dm, dev, pool, grp):
                                   threads=c_oracle.usable_threads())
         d = np.abs(gpu - ref)[:, 1]
         res = {"value": steps * BATCH / dt, "unit": "sites/s", "arithmetic_selected": ARITH_NAME.get(dmt.precision, dmt.precision),
-               "probe": {"split_mx_max": dmt.probe_error, "split_mx_tail_gt_1e-5": dmt.probe_tail, "split_mx_d_max": dmt.probe_error_mxd,
-                         "split_mx_d_tail_gt_1e-5": dmt.probe_tail_mxd, "hybrid_max": dmt.probe_error_hybrid, "hybrid_tail_gt_1e-5": dmt.probe_tail_hybrid},
+               "probe": {"sites_run": dmt.probe_sites, "split_mx_max": dmt.probe_error, "split_mx_q999": dmt.probe_q999, "split_mx_tail_gt_1e-5": dmt.probe_tail,
+                         "rule": "split-mx iff max <= 1.25e-5 and max <= 3 x q99.9 over 65536 probe sites, else split3"},
                "launch_ms": float(np.mean(kt[1:3])), "roofline_frac": 2.0 * MAC_GRU12 * BATCH * grp / (float(np.mean(kt[1:3])) * 1e-3) / PEAK_F16_MFMA,
                "max_abs_dprob_vs_oracle": float(d.max()), "sites_checked": m, "sites_beyond_1e-5": int((d > 1e-5).sum()), "sites_beyond_5e-5": int((d > 5e-5).sum()),
-               "frac_called_methylated": float((ref[:, 1] > 0.5).mean()), "train": {"steps": steps_t, "batch": n, "seed": wseed, "last_loss": float(loss), "seconds": t_train},
-               "what": "a checkpoint trained in this process by libccsm_train, served through ccsm_create(precision 0): the arithmetic the probe selects, "
-                       "its rate on the benchmark's workload, max |dprob| against oracle/attbigru2s_oracle.c over 8192 sites (explicit h0)"}
+               "frac_called_methylated": float((ref[:, 1] > 0.5).mean()), "checkpoint": "tests/golden/trained/planted7_5000.npz", "create_seconds": t_create,
+               "what": "a committed checkpoint trained by libccsm_train (recipe: tests/golden/make_trained_fixtures.py), served through ccsm_create(precision 0): "
+                       "the arithmetic the rule selects, its rate on the benchmark's workload, max |dprob| against oracle/attbigru2s_oracle.c over 8192 sites (explicit h0)"}
         dmt.close()
         return res
 
@@ -397,10 +386,10 @@ def extras(weights, dm, dev, pool, grp):
                 "what": "stock PyTorch %s CPU modules (nn.GRU 3 x bidirectional + attention + fc), fp32, torch.set_num_threads(%d), explicit h0"
                         % (torch.__version__, threads)}
 
-    for prec, name in ((6, "split-mx-d"), (5, "hybrid"), (3, "split3"), (4, "split-mx")):     # the arithmetics the probe did not select for these weights
+    leg("trained", trained)
+    for prec, name in ((3, "split3"), (6, "split-mx-d"), (5, "hybrid"), (4, "split-mx")):     # the arithmetics the rule did not select for these weights
         if prec != dm.precision:
             leg(name, other_arithmetic(prec))
-    leg("trained", trained)
     leg("torch_cpu_path", torch_cpu)
     leg("pcie_inclusive", pcie)
     leg("call_mods_end_to_end", call_mods_e2e)
@@ -540,10 +529,11 @@ def main():
                        "batch": BATCH, "sites_per_step": BATCH, "coalesce": grp, "streams": 2 if runner.overlap else 1, "full_groups": full, "ragged_group_batches": rag,
                        "warmup_steps_run": w_steps, "h0": "device Philox N(0,1)", "arithmetic": arith,
                        "arithmetic_selected": ARITH_NAME.get(dm.precision, dm.precision), "probe_max_abs_dprob": dm.probe_error,
-                       "probe_max_abs_dprob_hybrid": dm.probe_error_hybrid,
+                       "probe_q999_abs_dprob": dm.probe_q999, "probe_sites": dm.probe_sites,
                        "weights": ("state dict from %s" % a.weights) if a.weights else
-                                  "synthetic random initialisation (seed 20260928); a TRAINED checkpoint typically makes the probe of ccsm_create "
-                                  "select the hybrid arithmetic (extras.hybrid): DESIGN.md section 2",
+                                  "synthetic random initialisation (seed 20260928), as BASELINE.json configs[1] defines the benchmark.  NOT what a trained "
+                                  "checkpoint is served with: see trained_checkpoint below (ccsm_create serves trained weights in split3)",
+                       "trained_checkpoint": "not measured (--extras none or N > 1)",
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
             "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
@@ -588,6 +578,11 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "sites/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
         if n_gpus == 1 and a.extras == "all":
             line["extras"] = extras(weights, dm, dev, pool, grp)
+            tr_ = line["extras"].get("trained", {})
+            if "value" in tr_:      # next to the headline: the rate and arithmetic a TRAINED checkpoint gets (the headline is random-init weights)
+                line["config"]["trained_checkpoint"] = {"arithmetic_selected": tr_["arithmetic_selected"], "sites_per_s": tr_["value"],
+                                                        "max_abs_dprob_vs_oracle": tr_["max_abs_dprob_vs_oracle"], "checkpoint": tr_["checkpoint"]}
+                line["value_trained_checkpoint"] = tr_["value"]
     runner.close()
     dm.close()
     if use_dist:

@@ -85,11 +85,13 @@ def build_parser():
                    help="BAM reader/writer: libccsm_bam (threaded BGZF, whole read chunks straight to the GPU; implies --extract\n"
                         "device) or the pure-Python record-by-record implementation")
     p.add_argument("--arithmetic", default="auto", choices=["auto", "split3", "hybrid", "split-mx-d", "split-mx"],
-                   help="MFMA arithmetic of the model: auto (default) = the fastest of split-mx (fp16 main product + one block-scaled\n"
-                        "fp6/fp4 correction product), split-mx-d (the same with fp6 recurrent weights and the state's correction scaled\n"
-                        "per row), hybrid (split-mx for the GRUs' input part, three fp16 passes for their recurrent part) and split3 (three fp16 passes everywhere: fp32-class, max abs error < 1e-6) whose probe batch through THIS\n"
-                        "checkpoint leaves at most 0.5 %% of the sites beyond 1e-5 and none beyond 5e-5 of split3.  Trained checkpoints\n"
-                        "usually end at split-mx-d or hybrid: split-mx leaves ~0.1 %% of their sites beyond 1e-4.  The other values force one")
+                   help="MFMA arithmetic of the model (the reference computes in fp32).  auto (default): split3 (three fp16 passes on\n"
+                        "hi + lo operands: fp32-class, max abs error < 1e-6) unless a 65536-site probe of THIS checkpoint against split3\n"
+                        "finds split-mx (fp16 main product + one block-scaled fp6/fp4 correction product, 1.5x faster) within 1.25e-5 at\n"
+                        "every site with a light tail - true of freshly initialised weights, not of trained checkpoints, whose split-mx /\n"
+                        "split-mx-d / hybrid errors are heavy-tailed (single sites beyond 1e-4 among 10^6).  The other values force one\n"
+                        "arithmetic: split-mx-d (fp6 recurrent weights, block-scaled state) and hybrid (three passes in the recurrent part)\n"
+                        "trade that tail for 1.25-1.4x split3's speed, at the caller's risk")
     p.add_argument("--extract", default="device", choices=["device", "host"],
                    help="where the 21-mer features are built: on the GPU from the raw read arrays (default) or NumPy on the host")
     return p
@@ -281,13 +283,11 @@ def call_mods(args, log=sys.stderr, pipe=None):
         model.cuda(args.device).eval()
         if int(os.environ.get("RANK", "0")) == 0:
             dm = model._dev
-            probe = "" if dm.probe_error < 0 else (" (probe batch of 8192 sites against split3, accepted with <= 0.5 %% of the sites beyond 1e-5 and none "
-                                                   "beyond 5e-5: split-mx max %.1e, %.2f %% beyond 1e-5%s)") % (
-                dm.probe_error, 100.0 * dm.probe_tail,
-                ("" if dm.probe_error_mxd < 0 else "; split-mx-d max %.1e, %.2f %% beyond 1e-5" % (dm.probe_error_mxd, 100.0 * dm.probe_tail_mxd)) +
-                ("" if dm.probe_error_hybrid < 0 else "; hybrid max %.1e, %.2f %% beyond 1e-5" % (dm.probe_error_hybrid, 100.0 * dm.probe_tail_hybrid)))
-            print("[main]arithmetic: %s%s" % ({3: "split3 (three fp16 passes)", 4: "split-mx", 5: "hybrid (split-mx input part, three-pass "
-                                               "recurrent part)", 6: "split-mx-d (fp6 recurrent weights, per-row state scales)"}.get(dm.precision, dm.precision), probe), file=log)
+            probe = "" if dm.probe_sites <= 0 else (" (probe of %d sites against split3: split-mx max %.1e, 99.9 %% %.1e, %.3f %% beyond 1e-5; split-mx is "
+                                                    "served only with max <= 1.25e-5 and max <= 3 x the 99.9th percentile over 65536 sites)") % (
+                dm.probe_sites, dm.probe_error, dm.probe_q999, 100.0 * dm.probe_tail)
+            print("[main]arithmetic: %s%s" % ({3: "split3 (three fp16 passes, fp32-class)", 4: "split-mx", 5: "hybrid (split-mx input part, three-pass "
+                                               "recurrent part; forced)", 6: "split-mx-d (fp6 recurrent weights, per-row state scales; forced)"}.get(dm.precision, dm.precision), probe), file=log)
         # --batch_size (reference default 512) is the reference's sites per model call.  On the GPU-extraction paths a launch wants
         # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
         # (every site's initial state is a function of the seed, its read's name and its position there), so the flag is only a lower bound there.
@@ -458,56 +458,66 @@ def call_mods(args, log=sys.stderr, pipe=None):
         ordered = [(k, part_path, a, e, ir) for k, a, e, ir in runs]
         t_stitch = time.time()
         if world > 1:
-            queue.check()
-            gathered = [None] * world
-            dist.all_gather_object(gathered, dict(rank=rank, header_end=header_end, runs=runs, chunks=chunk_log,
-                                                  counts=(cnt_w, cnt_mm, cnt_failed, cnt_sites), inflated=work_inflated, work=t_work))
-            cnt_w, cnt_mm, cnt_failed, cnt_sites = (sum(g["counts"][k] for g in gathered) for k in range(4))
-            n_chain = sharding.verify_chain(first_voffset, [c for g in gathered for c in g["chunks"]], n_chunks=queue.n_chunks, eof_voffset=eof_voffset)
-            if n_chain != cnt_w:
-                raise RuntimeError("the chunks hold %d records but %d were written" % (n_chain, cnt_w))
-            stats.update(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, rank_inflated_bytes=[g["inflated"] for g in gathered],
-                         rank_chunks=[len(g["runs"]) for g in gathered], rank_seconds_work=[g["work"] for g in gathered])
-            ordered = sorted((k, "%s.part%d" % (out_path, g["rank"]), a, e, ir) for g in gathered for k, a, e, ir in g["runs"])
-            spans = [(p, a, e) for _, p, a, e, _ in ordered]
-            dst, total = stitch_layout(header_end, spans)
-            if rank == 0:
-                stitch_create(out_path, part_path, header_end, total)
-            dist.barrier()
-            mine = [i for i, sp in enumerate(spans) if sp[0] == part_path]
-            stitch_copy(out_path, [spans[i] for i in mine], [dst[i] for i in mine])      # every rank moves its own runs, at the same time
-            dist.barrier()
-            os.remove(part_path)
+            # gather + the two barriers around the stitch go through the queue's store with its error key polled (ChunkQueue.rendezvous):
+            # a rank that fails anywhere from here on releases the others with its error instead of leaving them in a collective
+            try:
+                gathered = queue.rendezvous("gather", dict(rank=rank, header_end=header_end, runs=runs, chunks=chunk_log,
+                                                           counts=(cnt_w, cnt_mm, cnt_failed, cnt_sites), inflated=work_inflated, work=t_work))
+                cnt_w, cnt_mm, cnt_failed, cnt_sites = (sum(g["counts"][k] for g in gathered) for k in range(4))
+                n_chain = sharding.verify_chain(first_voffset, [c for g in gathered for c in g["chunks"]], n_chunks=queue.n_chunks, eof_voffset=eof_voffset)
+                if n_chain != cnt_w:
+                    raise RuntimeError("the chunks hold %d records but %d were written" % (n_chain, cnt_w))
+                stats.update(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, rank_inflated_bytes=[g["inflated"] for g in gathered],
+                             rank_chunks=[len(g["runs"]) for g in gathered], rank_seconds_work=[g["work"] for g in gathered])
+                ordered = sorted((k, "%s.part%d" % (out_path, g["rank"]), a, e, ir) for g in gathered for k, a, e, ir in g["runs"])
+                spans = [(p, a, e) for _, p, a, e, _ in ordered]
+                dst, total = stitch_layout(header_end, spans)
+                if rank == 0:
+                    stitch_create(out_path, part_path, header_end, total)
+                queue.rendezvous("stitch_created")
+                mine = [i for i, sp in enumerate(spans) if sp[0] == part_path]
+                stitch_copy(out_path, [spans[i] for i in mine], [dst[i] for i in mine])      # every rank moves its own runs, at the same time
+                queue.rendezvous("stitch_copied")
+                os.remove(part_path)
+            except BaseException as e:      # noqa: BLE001
+                queue.fail("%s: %s" % (type(e).__name__, e))
+                raise
             shifts = [d - a for d, (_, a, _) in zip(dst, spans)]
         else:
             shifts = [0] * len(ordered)
         t_stitch = time.time() - t_stitch
-        if rank == 0:
-            t_idx = time.time()
-            indexed = False
-            if not args.no_sort:
-                # the reference's samtools sort + index (call_modifications.py:592-607): records that are already in coordinate order
-                # (every unaligned HiFi BAM; a sorted aligned one) are indexed from the writers' run tables without reading the file
-                # back; only an unsorted input takes the real sort
-                try:
-                    indexed, _ = index_write(out_path + ".bai", n_ref, [ir for *_, ir in ordered], shifts)
-                except IOError as e:
-                    print("[post_process] WARNING: writing the index from the run tables failed (%s); falling back to a pass over the file" % e, file=log)
-                if indexed:
-                    print("[post_process] bam_sort_index costs %.2f seconds (already in order: indexed from the writers' run tables)" % (time.time() - t_idx),
-                          file=log)
-                else:
-                    _post_sort_index(out_path, args, log)
-            stats.update(seconds_stitch=t_stitch, seconds_index=time.time() - t_idx)
-            print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
-            print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d GPU(s); ccsmeth_amd %s)" %
-                  (time.time() - t0, cnt_failed, world, __version__), file=log)
-            if os.environ.get("CCSM_CALLMODS_REPORT"):      # machine-readable run summary (tools/host_feed_probe.py)
-                import json
-                with open(os.environ["CCSM_CALLMODS_REPORT"], "w") as rf:
-                    json.dump(dict({k: v for k, v in stats.items() if k != "output"}, seconds=time.time() - t0, world=world), rf)
+        try:
+            if rank == 0:
+                t_idx = time.time()
+                indexed = False
+                if not args.no_sort:
+                    # the reference's samtools sort + index (call_modifications.py:592-607): records that are already in coordinate order
+                    # (every unaligned HiFi BAM; a sorted aligned one) are indexed from the writers' run tables without reading the file
+                    # back; only an unsorted input takes the real sort
+                    try:
+                        indexed, _ = index_write(out_path + ".bai", n_ref, [ir for *_, ir in ordered], shifts)
+                    except IOError as e:
+                        print("[post_process] WARNING: writing the index from the run tables failed (%s); falling back to a pass over the file" % e, file=log)
+                    if indexed:
+                        print("[post_process] bam_sort_index costs %.2f seconds (already in order: indexed from the writers' run tables)" % (time.time() - t_idx),
+                              file=log)
+                    else:
+                        _post_sort_index(out_path, args, log)
+                stats.update(seconds_stitch=t_stitch, seconds_index=time.time() - t_idx)
+                print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
+                print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d GPU(s); ccsmeth_amd %s)" %
+                      (time.time() - t0, cnt_failed, world, __version__), file=log)
+                if os.environ.get("CCSM_CALLMODS_REPORT"):      # machine-readable run summary (tools/host_feed_probe.py)
+                    import json
+                    with open(os.environ["CCSM_CALLMODS_REPORT"], "w") as rf:
+                        json.dump(dict({k: v for k, v in stats.items() if k != "output"}, seconds=time.time() - t0, world=world), rf)
+        except BaseException as e:      # noqa: BLE001 - the other ranks wait for rank 0's index at "done"
+            if queue is not None:
+                queue.fail("%s: %s" % (type(e).__name__, e))
+            raise
         if world > 1:
-            dist.barrier()
+            queue.rendezvous("done")        # (error-aware: rank 0's index phase may have failed)
+            dist.barrier()                  # every rank has passed "done": rank 0, which hosts the store, may leave now
         return stats
     with BamReader(args.input) as rd:
         header = add_pg_line(rd.header_text, REF_VERSION, " ".join(sys.argv))

@@ -55,6 +55,8 @@ class DeviceModel:
         self.probe_tail_hybrid = float(lib.ccsm_model_probe_tail(handle, 5))
         self.probe_error_mxd = float(lib.ccsm_model_probe_error_of(handle, 6))         # split-mx-d (-1: not run)
         self.probe_tail_mxd = float(lib.ccsm_model_probe_tail(handle, 6))
+        self.probe_q999 = float(lib.ccsm_model_probe_q999(handle))                     # 99.9th percentile of |dprob| split-mx vs split3 over the probe sites
+        self.probe_sites = int(lib.ccsm_model_probe_sites(handle))                     # probe sites run (0: a precision was forced)
         self.quant_error = float(lib.ccsm_model_quant_error(handle))
         self._workspaces = []
 

@@ -13,7 +13,8 @@ The reference hands hole-batches (50 reads) to its call-workers through ONE shar
   * record-start detection inside a BGZF stream is a heuristic, so the ranks' reports are chained at the end: where chunk k's last
     record ended must be where the next non-empty chunk was found to begin (verify_chain) - any miss is an error, never a silently
     dropped or duplicated read.
-The only other communication is the end-of-run gather of the output runs, index tables and counters (gloo)."""
+The only other communication is the end-of-run gather of the output runs, index tables and counters and two barriers around the
+stitch, all on the same store (ChunkQueue.rendezvous: a failing rank releases the waiting ones with its error)."""
 
 
 def shard_indices(n_units, rank, world_size):
@@ -62,6 +63,24 @@ class ChunkQueue:
     def check(self):
         if self.store.check(["%s/error" % self.prefix]):
             raise RuntimeError("call_mods aborted: " + self.store.get("%s/error" % self.prefix).decode("utf-8", "replace"))
+
+    def rendezvous(self, tag, payload=None, poll_s=0.02, timeout_s=1800.0):
+        """Barrier + gather on the store, with the error key polled while waiting: every rank publishes `payload` under `tag` and gets
+        the list of all ranks' payloads once all are there.  A rank that has called fail() releases the others at once with the
+        error (a collective all_gather_object / barrier would keep them until the process group's timeout, 30 min by default)."""
+        import pickle
+        import time
+        self.check()
+        self.store.set("%s/%s/%d" % (self.prefix, tag, self.rank), pickle.dumps(payload))
+        keys = ["%s/%s/%d" % (self.prefix, tag, r) for r in range(self.world)]
+        t0 = time.time()
+        while not self.store.check(keys):
+            self.check()
+            if time.time() - t0 > timeout_s:
+                raise RuntimeError("call_mods: rank %d waited %.0f s at '%s' for ranks that never arrived" % (self.rank, timeout_s, tag))
+            time.sleep(poll_s)
+        self.check()
+        return [pickle.loads(self.store.get(k)) for k in keys]
 
 
 def verify_chain(first_voffset, chunks, n_chunks=None, eof_voffset=None):

@@ -37,16 +37,19 @@ typedef enum {
     CCSM_ERR_CAPACITY = 5     /* n_sites exceeds the workspace's max_sites */
 } ccsm_status;
 
-/* Arithmetic of the contraction (matmul) work; everything else is fp32.
- * SPLIT3: every fp32 operand v carried as fp16 pair (hi, lo); products hi*hi + hi*lo + lo*hi accumulate in fp32
- *         on v_mfma_f32_32x32x16_f16 (fp32-class accuracy: max |dprob| ~2e-7).
- * SPLIT_F8: hi*hi on the fp16 MFMA, the two correction products hi*lo + lo*hi with fp8 (e4m3) operands on the gfx950
- *         block-scaled MFMA (v_mfma_scale_f32_32x32x64_f8f6f4) into the same fp32 accumulators: 2/3 of SPLIT3's MFMA
- *         cycles, max |dprob| ~4e-6 on the parity suite, 20x inside the 1e-4 bar (GRU layers and attention pool; only
- *         layer 0's K = 11 input projection keeps three fp16 passes).  The default.
- * HYBRID: SPLIT_F8 for the GRUs' input part, three fp16 passes and an fp16 hi + lo state for their recurrent part.
- * SPLIT_MXD: SPLIT_F8 with fp6 (instead of fp4) recurrent weight blobs and the state's correction blob scaled per (row, 32-value
- *         block) from the values themselves instead of by one fixed exponent: between SPLIT_F8 and HYBRID in cost and accuracy. */
+/* Arithmetic of the contraction (matmul) work; everything else is fp32.  The reference computes in fp32 (models.py:125-130,
+ * utils/constants_torch.py:9-12); every operand v here is carried as fp16 hi = fp16(v) plus the residual lo = v - hi, fp32 accumulation.
+ * SPLIT3: hi*hi + lo*hi + hi*lo, three passes on v_mfma_f32_32x32x16_f16: fp32-class (max |dprob| <= 6e-7 against the oracle on every
+ *         checkpoint tried, trained ones included).  What `precision 0` serves to every checkpoint whose probe is not clean (below):
+ *         in practice every TRAINED checkpoint.
+ * SPLIT_F8 ("split-mx"; the enumerator's name is historical - round 1 used fp8 operands): hi*hi on the fp16 MFMA, both correction
+ *         products in ONE block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 per pair of k-blocks, weights fp4 e2m1 (fp6 for the n gate's
+ *         input part), activations fp6 e2m3, per-32-block E8M0 scales; 1.55 MFMA passes per flop.  4-9e-6 max |dprob| on the
+ *         synthetic initialisation (light-tailed: 8.5e-6 over 2^20 sites); on trained checkpoints a HEAVY tail (sites beyond 1e-4).
+ * SPLIT_MXD: SPLIT_F8 with fp6 recurrent weight blobs and activation blobs scaled per (row, 32-value block).
+ * HYBRID: SPLIT_MXD's input part; recurrent part in three fp16 passes on an exact fp16 hi + lo state.
+ *         Both are lighter-tailed than SPLIT_F8 and still leave single sites beyond 1e-4 on trained checkpoints
+ *         (profiles/r04_a_tail_study.log): explicit choices only, never selected by `precision 0`. */
 typedef enum { CCSM_PRECISION_SPLIT_F8 = 4, CCSM_PRECISION_SPLIT3 = 3, CCSM_PRECISION_HYBRID = 5, CCSM_PRECISION_SPLIT_MXD = 6 } ccsm_precision;
 
 /* Mirrors ModelAttRNN.__init__ (models.py:18-22) as called from call_modifications.py:315-323. */
@@ -60,7 +63,7 @@ typedef struct {
     int32_t is_map;      /* 0   sn 4 + map 1 columns; the 17- and 18-column ones run as [one-hot(5) | features] against a layer-0 matrix */
     int32_t is_stds;     /* 0   with the embedding table folded in: the same product in 14 or 15 columns) */
     const char* model_type; /* "attbigru2s" */
-    int32_t precision;   /* ccsm_precision; 0 = default (SPLIT_F8) */
+    int32_t precision;   /* ccsm_precision; 0 = default: SPLIT_F8 if the probe of ccsm_create is clean, else SPLIT3 (see ccsm_model_probe_*) */
 } ccsm_config;
 
 /* Host fp32 parameter tensors in the reference state_dict layout (models.py:32-61).
@@ -205,17 +208,21 @@ ccsm_status ccsm_forward_reads_host(const ccsm_model* m, ccsm_workspace* ws, con
 const char* ccsm_last_error(void);
 const char* ccsm_version(void);
 int ccsm_model_precision(const ccsm_model* m);
-/* precision 0 (default) picks the arithmetic by measurement: ccsm_create runs an 8192-site probe batch through SPLIT3 and then through the
- * candidates in order of speed - SPLIT_F8 (split-mx), SPLIT_MXD (split-mx-d), then HYBRID (split-mx for the GRUs' input part, three fp16
- * passes and an fp16 hi + lo state for their recurrent part) - and keeps the first one that leaves at most 0.5 % of
- * the probe sites more than 1e-5 and none more than 5e-5 away from SPLIT3's probabilities, else SPLIT3.
- * ccsm_model_probe_error_of(m, precision) (and the older _error = SPLIT_F8's, _error_hybrid) = the candidate's max |dprob| over the probe
- * batch, ccsm_model_probe_tail(m, precision) = its fraction of sites beyond 1e-5 (-1: that candidate was not run), ccsm_model_precision = the arithmetic in use, ccsm_model_quant_error = relative RMS
- * quantisation error of the weight correction blobs (worst layer). */
+/* precision 0 (default) picks the arithmetic by measurement, conservatively: ccsm_create runs up to 8 probe batches of 8192 synthetic sites
+ * (deterministic inputs and device-drawn initial states) through SPLIT3 and SPLIT_F8 and serves SPLIT_F8 only if over ALL 65536 sites
+ * max |dprob| <= 1.25e-5 (an eighth of the 1e-4 bar) AND max <= 3 x the 99.9th percentile (a light tail); otherwise SPLIT3.  The probe ends
+ * at the first batch that breaks the first condition.  SPLIT_MXD and HYBRID are never selected (explicit choices).  The same weights
+ * always get the same answer.  CCSM_NO_PRECISION_FALLBACK in the environment forces SPLIT_F8 and says so on stderr when the probe failed.
+ * ccsm_model_probe_error = max |dprob| over the probe sites run, _probe_q999 their 99.9th percentile, _probe_tail(m, 4) the share beyond
+ * 1e-5, _probe_sites how many were run (-1 / 0 when a precision was forced); _probe_error_hybrid / _error_of / _tail of 5, 6: -1 (those
+ * candidates left the probe in round 4; kept for the ABI); ccsm_model_precision = the arithmetic in use; ccsm_model_quant_error =
+ * relative RMS quantisation error of the weight correction blobs (worst layer). */
 float ccsm_model_probe_error(const ccsm_model* m);
 float ccsm_model_probe_error_hybrid(const ccsm_model* m);
 float ccsm_model_probe_error_of(const ccsm_model* m, int precision);
 float ccsm_model_probe_tail(const ccsm_model* m, int precision);
+float ccsm_model_probe_q999(const ccsm_model* m);
+int ccsm_model_probe_sites(const ccsm_model* m);
 float ccsm_model_quant_error(const ccsm_model* m);
 size_t ccsm_workspace_bytes(const ccsm_workspace* ws);
 /* Times (ms, HIP events on `stream`) of the kernels of the LAST forward issued on this workspace with timing

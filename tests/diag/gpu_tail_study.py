@@ -28,43 +28,15 @@ def say(*a):
     log.write(s + "\n"); log.flush()
 
 
-toy_lab = lambda q: (q["ipd1"][:, 10] + q["ipd2"][:, 10] > 0).astype(np.int64)  # noqa: E731
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import make_trained_fixtures as MTF
 
 
-def train(name, wseed, steps, kind, lr=1e-3, dropout=0.5, n=512):
-    from ccsmeth_amd.train import Trainer
-    t0 = time.time()
-    if kind == "toy":
-        pool = synth.synth_sites(n * 8, 42); labels = toy_lab(pool); nb = 8
-    else:
-        nb = 64
-        pool, labels = synth.synth_labeled_sites(n * nb, 1000 + wseed)
-    tr = Trainer(synth.synth_weights(wseed), device=0, max_sites=n)
-    losses = []
-    for k in range(steps):
-        i = (k % nb) * n
-        q = {key: v[i:i + n] for key, v in pool.items()}
-        loss, _ = tr.forward_backward(q, labels[i:i + n], h0=None, dropout_rate=dropout, seed=wseed, step=k)
-        tr.step(lr)
-        losses.append(loss)
-    if kind == "toy":
-        val = synth.synth_sites(2048, 43); vl = toy_lab(val)
-    else:
-        val, vl = synth.synth_labeled_sites(2048, 5000 + wseed)
-    hit = 0
-    for i in range(0, 2048, n):
-        _, logits = tr.evaluate({key: v[i:i + n] for key, v in val.items()}, vl[i:i + n], h0=None, seed=wseed, step=10 ** 6 + i)
-        hit += int((logits.argmax(1) == vl[i:i + n]).sum())
-    acc = hit / 2048.0
-    wt = tr.state_dict()
-    tr.close()
-    say("trained %-24s steps %5d lr %.0e dropout %.1f: loss %.3f -> %.3f, val acc %.3f, %.1f s | max|W_hh| %s rms %s" % (
-        name, steps, lr, dropout, np.mean(losses[:10]), np.mean(losses[-50:]), acc, time.time() - t0,
-        ["%.2f" % np.abs(wt["rnn.weight_hh_l%d" % l]).max() for l in range(3)], ["%.3f" % np.sqrt((wt["rnn.weight_hh_l%d" % l] ** 2).mean()) for l in range(3)]))
-    return wt
+def train(*a):
+    return MTF.train(*a, say=say)
 
 
-plan = [("toy41_960", 41, 960, "toy", 1e-3, 0.5), ("planted7_5000", 7, 5000, "planted", 1e-3, 0.5), ("planted11_12000_nodrop", 11, 12000, "planted", 2e-3, 0.0),
+plan = MTF.PLAN + [
         ("toy5_320", 5, 320, "toy", 1e-3, 0.5), ("planted13_2000", 13, 2000, "planted", 1e-3, 0.5), ("toy17_320", 17, 320, "toy", 1e-3, 0.5)]
 if args.quick:
     plan = [("toy41_960", 41, 960, "toy", 1e-3, 0.5), ("planted7_600", 7, 600, "planted", 1e-3, 0.5)]

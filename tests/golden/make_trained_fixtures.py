@@ -1,0 +1,64 @@
+"""Recipe of tests/golden/trained/*.npz: attbigru2s checkpoints TRAINED with libccsm_train on an MI355X (the reference ships none:
+/root/reference/.MISSING_LARGE_BLOBS; shapes models.py:32-61), committed as data so that every run of the suite sees the SAME weights -
+the trainer's reductions use float atomics, so re-training from the same seed gives a slightly different checkpoint every time, and the
+per-site error tail of the block-scaled arithmetics depends on exactly those weights.
+  toy41_960               the one-feature toy label of the early tests (ipd1[10] + ipd2[10] > 0), 960 steps
+  planted7_5000           the planted-signal label of synth.synth_labeled_sites (IPD / PW shift at window positions 8..12 of both strands,
+                          log-normal amplitude, sequence context, 4 % label noise), 5000 steps, dropout 0.5, lr 1e-3
+  planted11_12000_nodrop  the same label, 12000 steps at lr 2e-3 without dropout: long-trained, large recurrent matrices
+                          (max |W_hh| 1.7, rms 0.24 against 0.04 at initialisation) - the hostile-but-plausible one
+Run on a GPU box:  python tests/golden/make_trained_fixtures.py [out_dir]   (the committed files came out of
+tests/diag/gpu_tail_study.py, which calls train() below; profiles/r04_a_tail_study.log is that run)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from ccsmeth_amd.utils import synth  # noqa: E402
+
+PLAN = [("toy41_960", 41, 960, "toy", 1e-3, 0.5), ("planted7_5000", 7, 5000, "planted", 1e-3, 0.5),
+        ("planted11_12000_nodrop", 11, 12000, "planted", 2e-3, 0.0)]
+toy_lab = lambda q: (q["ipd1"][:, 10] + q["ipd2"][:, 10] > 0).astype(np.int64)  # noqa: E731
+
+
+def train(name, wseed, steps, kind, lr=1e-3, dropout=0.5, n=512, say=print):
+    from ccsmeth_amd.train import Trainer
+    t0 = time.time()
+    if kind == "toy":
+        pool = synth.synth_sites(n * 8, 42); labels = toy_lab(pool); nb = 8
+    else:
+        nb = 64
+        pool, labels = synth.synth_labeled_sites(n * nb, 1000 + wseed)
+    tr = Trainer(synth.synth_weights(wseed), device=0, max_sites=n)
+    losses = []
+    for k in range(steps):
+        i = (k % nb) * n
+        q = {key: v[i:i + n] for key, v in pool.items()}
+        loss, _ = tr.forward_backward(q, labels[i:i + n], h0=None, dropout_rate=dropout, seed=wseed, step=k)
+        tr.step(lr)
+        losses.append(loss)
+    if kind == "toy":
+        val = synth.synth_sites(2048, 43); vl = toy_lab(val)
+    else:
+        val, vl = synth.synth_labeled_sites(2048, 5000 + wseed)
+    hit = 0
+    for i in range(0, 2048, n):
+        _, logits = tr.evaluate({key: v[i:i + n] for key, v in val.items()}, vl[i:i + n], h0=None, seed=wseed, step=10 ** 6 + i)
+        hit += int((logits.argmax(1) == vl[i:i + n]).sum())
+    wt = tr.state_dict()
+    tr.close()
+    say("trained %-24s steps %5d lr %.0e dropout %.1f: loss %.3f -> %.3f, val acc %.3f, %.1f s | max|W_hh| %s rms %s" % (
+        name, steps, lr, dropout, np.mean(losses[:10]), np.mean(losses[-50:]), hit / 2048.0, time.time() - t0,
+        ["%.2f" % np.abs(wt["rnn.weight_hh_l%d" % l]).max() for l in range(3)], ["%.3f" % np.sqrt((wt["rnn.weight_hh_l%d" % l] ** 2).mean()) for l in range(3)]))
+    return wt
+
+
+if __name__ == "__main__":
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "trained")
+    os.makedirs(out, exist_ok=True)
+    for p in PLAN:
+        np.savez_compressed(os.path.join(out, p[0] + ".npz"), **train(*p))

@@ -87,29 +87,27 @@ def test_default_arithmetic_within_1e5_and_split3_within_1e6(model7):
 
 
 def _cascade(dm):
-    """What ccsm_create's probe has to select: the fastest arithmetic that leaves <= 0.5 % of the probe sites beyond 1e-5 and none beyond
-    5e-5 of the three-pass one."""
-    ok = lambda err, tail: 0 <= err <= 5e-5 and 0 <= tail <= 0.005     # noqa: E731
-    if ok(dm.probe_error, dm.probe_tail):
-        assert dm.probe_error_hybrid < 0 and dm.probe_tail_hybrid < 0 and dm.probe_error_mxd < 0   # not run
-        return 4
-    if ok(dm.probe_error_mxd, dm.probe_tail_mxd):
-        assert dm.probe_error_hybrid < 0
-        return 6
-    return 5 if ok(dm.probe_error_hybrid, dm.probe_tail_hybrid) else 3
+    """What ccsm_create's probe has to select (include/ccsm.h): split-mx iff all 65536 probe sites stay within 1.25e-5 of the three-pass
+    arithmetic and the maximum within 3 x the 99.9th percentile (a light tail); the three-pass arithmetic otherwise.  split-mx-d and the
+    hybrid are never probed."""
+    assert dm.probe_error_hybrid < 0 and dm.probe_tail_hybrid < 0 and dm.probe_error_mxd < 0
+    ok = dm.probe_sites == 65536 and 0 <= dm.probe_error <= 1.25e-5 and dm.probe_error <= 3.0 * dm.probe_q999
+    if not ok:
+        assert dm.probe_error > 1.25e-5 or dm.probe_sites == 65536     # the probe ends early only on the first condition
+    return 4 if ok else 3
 
 
 def test_default_arithmetic_is_chosen_by_the_probe():
-    """precision 0: ccsm_create measures split-mx, then the hybrid, against split-fp16 on a probe batch; the synthetic checkpoint keeps split-mx, the
-    hostile one (Student-t matrices with x50 outliers, gate-saturating biases) is served in whatever arithmetic the probe left, and
-    in either case holds the tolerance that arithmetic promises.  An explicit precision is never overridden."""
+    """precision 0: ccsm_create measures split-mx against split-fp16 on 65536 probe sites; the synthetic checkpoint keeps split-mx, the
+    hostile one (Student-t matrices with x50 outliers, gate-saturating biases) is served in whatever arithmetic the rule leaves, and
+    in either case holds the tolerance that arithmetic promises.  An explicit precision is never overridden and runs no probe."""
     from ccsmeth_amd.models import DeviceModel
     n = 512
     s = synth.synth_sites(n, 99)
     h1, h2 = synth.synth_h0(n, 98)
     w = synth.synth_weights(7)
     dm = DeviceModel(w, device=0)
-    assert dm.precision == 4 and 0 <= dm.probe_error < 1.5e-5 and dm.probe_tail == 0 and 0 < dm.quant_error < 0.2
+    assert dm.precision == 4 and 0 <= dm.probe_error <= 1.25e-5 and dm.probe_tail == 0 and dm.probe_sites == 65536 and 0 < dm.quant_error < 0.2
     dm.close()
     for seed in (7, 11):
         wh = synth.synth_weights_heavy(seed)
@@ -119,10 +117,10 @@ def test_default_arithmetic_is_chosen_by_the_probe():
         ws = dm.workspace(n)
         err = np.abs(_fwd(ws, s, (h1, h2))[1] - ref).max()
         assert dm.precision == _cascade(dm), (dm.precision, dm.probe_error, dm.probe_error_hybrid)
-        assert err < (5e-5 if dm.precision >= 4 else SPLIT3_TOL), (seed, dm.precision, dm.probe_error, err)
+        assert err < (2e-5 if dm.precision >= 4 else SPLIT3_TOL), (seed, dm.precision, dm.probe_error, err)
         dm.close()
         forced = DeviceModel(wh, device=0, precision=4)       # explicit split-mx on the hostile checkpoint: still inside the bar
-        assert forced.precision == 4 and forced.probe_error < 0
+        assert forced.precision == 4 and forced.probe_error < 0 and forced.probe_sites == 0
         ws = forced.workspace(n)
         err4 = np.abs(_fwd(ws, s, (h1, h2))[1] - ref).max()
         forced.close()

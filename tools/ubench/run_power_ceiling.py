@@ -9,7 +9,7 @@ import threading
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-exe = os.path.join(HERE, "_build", "mfma_power_ceiling")
+exe = os.path.join(HERE, "_build", os.environ.get("CCSM_UBENCH_EXE", "mfma_power_ceiling"))
 secs = sys.argv[1] if len(sys.argv) > 1 else "4"
 samples, stop = [], False
 
