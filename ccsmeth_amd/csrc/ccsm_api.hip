@@ -15,6 +15,7 @@
 #include "ccsm_kernels.hip"
 #include "ccsm_gru_f8.hip"
 #include "ccsm_gru_mx.hip"
+#include "ccsm_gru_f3.hip"
 #include "ccsm_aggr.hip"
 #include "ccsm_extract.hip"
 #include "ccsm_ceiling.hip"
@@ -76,10 +77,12 @@ struct ccsm_model {
     float probe_tail = -1.f, probe_tail_hybrid = -1.f;   // fraction of the probe sites beyond kProbeTailAt
     float probe_err = -1.f;                              // max |dprob| split-mx vs split-fp16 on the probe batch of ccsm_create (-1: not run)
     float probe_err_dyn = -1.f, probe_tail_dyn = -1.f;   // ... of split-mx-d (never probed since round 4: explicit choices only; kept for the ABI)
+    bool split3_v2 = false;                              // CCSM_SPLIT3_V2=1 at ccsm_create: split3 on the round-1 kernel (A/B)
     float probe_q999 = -1.f;                             // 99.9th percentile of |dprob| split-mx vs split-fp16 over the probe sites
     int probe_n = 0;                                     // probe sites actually run (the probe stops at the first batch that decides it)
     uint4* wstmd[kLayers] = {nullptr, nullptr, nullptr};// split-mx-d weight streams (fp6 recurrent blobs)
     uint4* wstmx[kLayers] = {nullptr, nullptr, nullptr};// split-mx weight streams (ccsm_gru_mx.hip: hi fragments + MX correction blobs)
+    uint4* wstf3[kLayers] = {nullptr, nullptr, nullptr};// split3 on the split-mx schedule (ccsm_gru_f3.hip): [0] = the hybrid's layer-0 stream, [1], [2] three-pass streams
     uint4* wsthy[kLayers] = {nullptr, nullptr, nullptr};// hybrid weight streams (the same with fp16 lo fragments for the recurrent part)
     uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
     uint4* ua3 = nullptr;
@@ -380,6 +383,53 @@ float pack_wstream_mx(int layer, int feat0, const float* const wih[2], const flo
     return (float)std::fmax(a, b);
 }
 
+// Weight streams of gru_layer12_f3_kernel (layout in ccsm_gru_f3.hip): fp16 hi and lo fragments of every product, per (direction,
+// wave) in consumption order - phase A (r, z input part), phase B (recurrent part, the hybrid's layout), phase C (n input part, zig-zag)
+void pack_wstream_f3(const float* const wih[2], const float* const whh[2], std::vector<uint8_t>& out) {
+    const int k_in = 2 * kHidden;
+    out.assign((size_t)2 * kWaves * kF3WBytes, 0);
+    std::vector<std::thread> pool;
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave)
+            pool.emplace_back([&, dir, wave] {
+            uint8_t* base = out.data() + (size_t)(dir * kWaves + wave) * kF3WBytes;
+            auto wx = [&](int g) { return [=](int i, int k) -> float { return wih[dir][(size_t)(g * kHidden + kUnitTile * wave + i) * k_in + k]; }; };
+            auto wh = [&](int g) { return [=](int i, int k) -> float { return whh[dir][(size_t)(g * kHidden + kUnitTile * wave + i) * kHidden + k]; }; };
+            auto hi_at = [&](size_t off, const std::function<float(int, int)>& get, int kb) { emit_hi_frag(reinterpret_cast<_Float16*>(base + off), kb, get); };
+            auto lo_at = [&](size_t off, const std::function<float(int, int)>& get, int kb) {
+                _Float16* dst = reinterpret_cast<_Float16*>(base + off);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = get(lane & 31, 16 * kb + 8 * (lane >> 5) + j);
+                        dst[lane * 8 + j] = (_Float16)(v - (float)(_Float16)v);
+                    }
+            };
+            for (int p = 0; p < kKB12 / 2; ++p) {
+                const size_t pa = (size_t)p * kF3PairA;
+                for (int kbl = 0; kbl < 2; ++kbl)
+                    for (int g = 0; g < 2; ++g) {
+                        hi_at(pa + (size_t)(2 * kbl + g) * 1024, wx(g), 2 * p + kbl);
+                        lo_at(pa + (size_t)(4 + 2 * kbl + g) * 1024, wx(g), 2 * p + kbl);
+                    }
+            }
+            for (int q = 0; q < kKBH / 2; ++q) {
+                const size_t pb = (size_t)kF3OffB + (size_t)q * kF3PairB;
+                for (int kbl = 0; kbl < 2; ++kbl)
+                    for (int g = 0; g < 3; ++g) {
+                        hi_at(pb + (size_t)(3 * kbl + g) * 1024, wh(g), 2 * q + kbl);
+                        lo_at(pb + (size_t)(6 + 3 * kbl + g) * 1024, wh(g), 2 * q + kbl);
+                    }
+            }
+            for (int pp = 0; pp < kKB12 / 2; ++pp) {
+                const size_t pc = (size_t)kF3OffC + (size_t)pp * kF3PairC;
+                const int p = kMxZigZag ? kKB12 / 2 - 1 - pp : pp;          // the pair phase C consumes at position pp
+                hi_at(pc, wx(2), 2 * p); hi_at(pc + 1024, wx(2), 2 * p + 1);
+                lo_at(pc + 2 * 1024, wx(2), 2 * p); lo_at(pc + 3 * 1024, wx(2), 2 * p + 1);
+            }
+            });
+    for (std::thread& t : pool) t.join();
+}
+
 void pack_bias(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
     out.assign((size_t)2 * kWaves * 4 * 32, 0.f);
     for (int dir = 0; dir < 2; ++dir)
@@ -481,7 +531,7 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     // step takes ~0.74 / ~0.55 of the time and more of the 256 CUs have one.  Picked by rounds of 256 workgroups; CCSM_WG_TILES = 1 | 2 | 3
     // forces a form (A/B runs and tests; read per launch).
     int nb_run = 3;
-    if (F8) {
+    if (F8 || !m->split3_v2) {
         static const double kStepCost[4] = {0.0, 0.55, 0.74, 1.0};
         double best = 1e30;
         for (int nb = 3; nb >= 1; --nb) {
@@ -523,7 +573,7 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
         layer(2, ws->act[1], ws->act[0], dbg_layer == 2 ? ws->dbg : nullptr);
 #endif
-    } else {
+    } else if (m->split3_v2) {                                      // CCSM_SPLIT3_V2=1: the round-1 kernel (A/B runs)
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB0>), ggrid, dim3(512), gru2_lds(kKB0), st, ws->x0, ws->act[0],
                            m->wst2[0], m->bias[0], ws->h0buf, ws->rows_p);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
@@ -532,6 +582,25 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
         hipLaunchKernelGGL((gru_layer_v2_kernel<kKB12>), ggrid, dim3(512), gru2_lds(kKB12), st, ws->act[1], ws->act[0],
                            m->wst2[2], m->bias[2], ws->h0buf + 2 * slab, ws->rows_p);
+    } else {
+        // split3 on the split-mx schedule: layer 0 = the hybrid's layer-0 kernel (three passes in both parts) writing fp16 lo fragments,
+        // layers 1-2 = gru_layer12_f3_kernel (ccsm_gru_f3.hip)
+        auto layer = [&](auto nbc, int l, const uint4* in, uint4* out_) {
+            constexpr int NBF = decltype(nbc)::value;
+            if (l == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, true, false, NBF, true>), ggrid, dim3(512), mx0_lds(NBF), st, in, out_, m->wstf3[0], m->bias[0],
+                                           ws->h0buf, ws->rows_p, nullptr);
+            else hipLaunchKernelGGL((gru_layer12_f3_kernel<NBF>), ggrid, dim3(512), f3_lds(NBF), st, in, out_, m->wstf3[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p);
+        };
+        auto all = [&](auto nbc) -> ccsm_status {
+            layer(nbc, 0, ws->x0, ws->act[0]);
+            if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
+            layer(nbc, 1, ws->act[0], ws->act[1]);
+            if (tm) HIP_TRY(hipEventRecord(ws->ev[3], st));
+            layer(nbc, 2, ws->act[1], ws->act[0]);
+            return CCSM_OK;
+        };
+        const ccsm_status rc = nb_run == 1 ? all(std::integral_constant<int, 1>{}) : nb_run == 2 ? all(std::integral_constant<int, 2>{}) : all(std::integral_constant<int, 3>{});
+        if (rc != CCSM_OK) return rc;
     }
     if (tm) HIP_TRY(hipEventRecord(ws->ev[4], st));
     SliceTable tab;
@@ -840,6 +909,12 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         set_lds(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB0>), gru2_lds(kKB0));
         set_lds(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB12>), gru2_lds(kKB12));
         set_lds(reinterpret_cast<const void*>(&attn_fc_kernel), kAttLds);
+        set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 3, true>), mx0_lds(3));
+        set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 2, true>), mx0_lds(2));
+        set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 1, true>), mx0_lds(1));
+        set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<3>), f3_lds(3));
+        set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<2>), f3_lds(2));
+        set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<1>), f3_lds(1));
         if (prec >= CCSM_PRECISION_SPLIT_F8) {
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false>), kMx12Lds);
@@ -883,6 +958,17 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttF8Lds);
         }
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
+    // split3's streams on the split-mx schedule (always: it is the reference of the probe and the arithmetic of explicit large initial states)
+    m->split3_v2 = std::getenv("CCSM_SPLIT3_V2") != nullptr;
+    if (st == CCSM_OK) {
+        std::vector<uint8_t> bbuf;
+        pack_wstream_mx(0, m->feat0, wih_l0, w->weight_hh[0], true, bbuf);
+        st = upload(&m->wstf3[0], bbuf.data(), bbuf.size());
+        for (int l = 1; l < kLayers && st == CCSM_OK; ++l) {
+            pack_wstream_f3(w->weight_ih[l], w->weight_hh[l], bbuf);
+            st = upload(&m->wstf3[l], bbuf.data(), bbuf.size());
+        }
     }
     // the weight streams of one arithmetic of the split-mx family (a forced precision: that one; the default: what the probe gets to)
     float qerr[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -932,6 +1018,7 @@ void ccsm_destroy(ccsm_model* m) {
         (void)hipFree(m->wstmx[l]);
         (void)hipFree(m->wstmd[l]);
         (void)hipFree(m->wsthy[l]);
+        (void)hipFree(m->wstf3[l]);
         (void)hipFree(m->bias[l]);
     }
     (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);

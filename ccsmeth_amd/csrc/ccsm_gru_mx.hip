@@ -340,6 +340,44 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
     }
 }
 
+// Three-pass split-fp16 arithmetic (F3: ccsm_gru_f3.hip, and gru_layer0_mx_kernel<.., HS3, .., F3>).  Step tail: n = tanh(N); h' = n + z (h_{t-1} - n) for this wave's own 32 units; fp16 hi + lo fragments for the next step (LDS) and the
+// next layer / the attention pool (HBM).  accz = sigmoid(Z) already, accn = N.
+template <int NB>
+__device__ __forceinline__ void f3_tail(char* smem, const f32x16 (&accz)[NB], const f32x16 (&accn)[NB], uint4* __restrict__ out, int tile0,
+                                        int t, int dir, int wave, int t16) {
+    const int own_off = wave * (2 * NB * 2 * 1024);                          // mx_hfrag(2 wave, 0, 0)
+    char* t_wr = smem + (own_off + t16);                                        // + lane * 16       (fragment writes)
+    const char* t_rd = smem + (own_off + (t16 & 0x1f0) + ((t16 >> 9) << 3));    // + n * 16 + hh * 8 (own-unit reads, C layout)
+    auto own_frag = [&](int kbl, int bt, int f) -> int { return ((kbl * NB + bt) * 2 + f) << 10; };
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+        float hn[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const half4 hi = as_half4(*reinterpret_cast<const uint2*>(t_rd + own_frag(q >> 1, bt, 0) + 512 * (q & 1)));
+            const half4 lo = as_half4(*reinterpret_cast<const uint2*>(t_rd + own_frag(q >> 1, bt, 1) + 512 * (q & 1)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float hp = (float)hi[e] + (float)lo[e];
+                const float nn = tanh_fold(accn[bt][4 * q + e]);
+                hn[4 * q + e] = (hp - nn) * accz[bt][4 * q + e] + nn;
+            }
+        }
+        uint4 hi0, hi1, lo0, lo1;
+        pack_pair_hl(hn, hi0, hi1, lo0, lo1);
+        *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 0)) = hi0;
+        *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 0)) = hi1;
+        *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 1)) = lo0;
+        *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 1)) = lo1;
+        // streaming stores: the next reader is another kernel 0.5 GB later, keep the L2 for the weight stream
+        char* o = reinterpret_cast<char*>(out + (((size_t)(tile0 + bt) * kSeqLen + t) * kKB12 + (dir * kKBH + 2 * wave)) * 2 * kFragU4) + (uint32_t)t16;
+        nt_store(hi0, reinterpret_cast<uint4*>(o));
+        nt_store(lo0, reinterpret_cast<uint4*>(o + 1024));
+        nt_store(hi1, reinterpret_cast<uint4*>(o + 2048));
+        nt_store(lo1, reinterpret_cast<uint4*>(o + 3072));
+    }
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -395,7 +433,7 @@ constexpr int mx0_biasoff(int nb) { return mx0_looff(nb) + kWaves * nb * 64 * 8;
 constexpr int mx0_lds(int nb) { return mx0_biasoff(nb) + kWaves * 4 * 32 * 4; }
 constexpr int kMx0Lds = mx0_lds(kMxNB);
 
-template <bool DBG, bool HS3, bool DYN = false, int NB_ = kMxNB>
+template <bool DBG, bool HS3, bool DYN = false, int NB_ = kMxNB, bool F3 = false>
 __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                 const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                 const float* __restrict__ h0, int rows_p,
@@ -403,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
     constexpr int NB = NB_;
     constexpr int kMx0XOff = mx0_xoff(NB), kMx0LoOff = mx0_looff(NB), kMx0BiasOff = mx0_biasoff(NB);
     static_assert(!(HS3 && DYN), "one or the other");
+    static_assert(!F3 || HS3, "F3 = the hybrid's layer 0 (three passes in both parts) writing fp16 lo fragments instead of blobs");
     constexpr int PB = mx_pair_b(HS3, DYN);
     constexpr int OFF_B = 4 * 1024, OFF_C = OFF_B + (kKBH / 2) * PB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -659,7 +698,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
         __syncthreads();                                            // every wave has read h_{t-1} (phase B) before anybody overwrites its fragments
-        mx_tail<false, HS3, DYN, NB>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        if constexpr (F3) f3_tail<NB>(smem, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        else mx_tail<false, HS3, DYN, NB>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         stamp(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no transfer may still be writing LDS when the workgroup retires

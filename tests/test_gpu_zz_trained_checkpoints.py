@@ -1,7 +1,7 @@
 """What a TRAINED checkpoint is served with, on committed weights (tests/golden/trained/*.npz; recipe tests/golden/make_trained_fixtures.py):
 the gate VERDICT r03 asked for - deterministic (fixed weights, fixed inputs, deterministic kernels), and about the arithmetic `precision 0`
 actually serves.  north_star: per-site probabilities within 1e-4 of the reference (fp32, models.py:125-130); this file holds the default to
-half of that (a quarter on the two ordinary checkpoints) at EVERY one of 16 x 8192 sites per checkpoint against the C oracle, and pins down
+a quarter of that on the two ordinary checkpoints at EVERY one of 16 x 8192 sites against the C oracle (BOUND below), and pins down
 why the default is the three-pass arithmetic there: the block-scaled arithmetics' error on these weights is heavy-tailed
 (profiles/r04_a_tail_study.log).  What "the reference" is worth on such weights: the C oracle (fp32, like the reference) itself sits
 2.4e-6 / 2.5e-6 / 1.1e-5 from the float64 NumPy oracle on 1024 sites of the three checkpoints - two fp32 evaluations of a trained model
@@ -17,9 +17,13 @@ from ccsmeth_amd.utils import synth
 
 pytestmark = pytest.mark.gpu
 FIXTURES = ["toy41_960", "planted7_5000", "planted11_12000_nodrop"]
-# max |dprob| of the default arithmetic against the C oracle over 16 x 8192 sites: a quarter of the bar; half of it for the long-trained
-# checkpoint (max |W_hh| 1.7: fp32 evaluations of it differ by 1e-5 among themselves)
-BOUND = {"toy41_960": 2.5e-5, "planted7_5000": 2.5e-5, "planted11_12000_nodrop": 5e-5}
+# max |dprob| of the default arithmetic against the C oracle (fp32) over 16 x 8192 sites: a quarter of the bar (measured 7e-6).  The
+# long-trained checkpoint (max |W_hh| 1.7) is held to the bar itself there, because fp32 evaluations of it differ by that much among
+# themselves: over its first 1024 sites the C oracle sits 1.6e-5 from the float64 oracle, this library 9.7e-6, and over 131072 sites the
+# two fp32 results are up to 6.8e-5 apart (measured, deterministic).  Against float64 arithmetic (1024 sites) every checkpoint is held
+# to a quarter of the bar.
+BOUND = {"toy41_960": 2.5e-5, "planted7_5000": 2.5e-5, "planted11_12000_nodrop": 1e-4}
+BOUND64 = 2.5e-5
 B = 8192
 
 
@@ -39,8 +43,8 @@ def _args(s):
 @pytest.mark.parametrize("name", FIXTURES)
 def test_default_arithmetic_on_a_trained_checkpoint_holds_the_bar_at_every_site(name):
     """precision 0 on fixed trained weights: the same selection and probe figures on two creations; 16 x 8192 sites (explicit initial
-    states) against the C oracle: none beyond BOUND (a quarter of the bar; half for the long-trained checkpoint); 1024 of them against
-    the float64 NumPy oracle as well, next to the C oracle's own distance from it."""
+    states) against the C oracle: none beyond BOUND (a quarter of the bar; the bar itself for the long-trained checkpoint, see BOUND); 1024
+    of them against the float64 NumPy oracle as well (a quarter of the bar), next to the C oracle's own distance from it."""
     from ccsmeth_amd.models import DeviceModel
     from oracle import c_oracle
     from oracle import attbigru2s_oracle as orc
@@ -70,7 +74,7 @@ def test_default_arithmetic_on_a_trained_checkpoint_holds_the_bar_at_every_site(
     dm.close()
     print("%s: precision 0 -> %d, probe max %.2e (99.9 %% %.2e, %d sites); 16 x 8192 sites vs C oracle (fp32): max %.2e, beyond 5e-5: %d; "
           "1024 sites vs float64 oracle: %.2e (the C oracle itself: %.2e)" % (name, dm.precision, dm.probe_error, dm.probe_q999, dm.probe_sites, worst, n5, own64, c64))
-    assert worst < BOUND[name] and own64 < BOUND[name], (worst, n5, own64, c64)
+    assert worst < BOUND[name] and own64 < BOUND64, (worst, n5, own64, c64)
     assert 0.05 < np.mean(frac) < 0.95                                # a model that discriminates
 
 
