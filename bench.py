@@ -43,7 +43,7 @@ PEAK_HBM = 8.0e12
 # HBM/fabric bytes of ONE launch of the dominant kernel per site, from rocprofv3 PMC passes on the launch shape timed here
 # (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
 # read from inside this process)
-TRAFFIC = {4: ((2 * 995710 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_coalesced.md"),       # (1209100 before phase C went zig-zag)
+TRAFFIC = {4: ((2 * 997200 + 516100) * 1024 / 6144.0, "profiles/r04_d_pmc.md"),       # (1209100 before phase C went zig-zag)
            5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced_hybrid.md"),
            6: ((2 * 1002900 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_prec6.md"),
            3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}

@@ -609,7 +609,7 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         tab.row_base[i] = i < ws->n_slices ? ws->slice_row[i] : 0;
         tab.n_sites[i] = i < ws->n_slices ? ws->slice_n[i] : 0;
     }
-    if constexpr (F8)
+    if constexpr (F8 && !HS3)       // (the hybrid's last layer writes fp16 hi + lo fragments: the three-pass attention pool)
         hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttF8Lds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fcw,
                            ws->part, tab, m->att_scale[0], m->att_scale[1]);
     else

@@ -765,12 +765,15 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * KX * 2 * kFragU4);
     const unsigned sx_base = NB == 1 ? (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)X_OFF      // (see gru_layer0_mx_kernel)
                                      : (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + X_OFF);
-    auto dma_pair = [&](int slot, int sd, int jd) {                 // wave-uniform: ring slot, step (clamped), pair of x_t(sd)
+    auto dma_pair = [&](int slot, int sd, int jd, bool last_read = false) {   // wave-uniform: ring slot, step (clamped), pair of x_t(sd)
         const int sc_ = sd < kSeqLen ? sd : kSeqLen - 1;
         const int td = dir ? kSeqLen - 1 - sc_ : sc_;
         auto one = [&](int f) {
             const int hl = f & 1, bt = (f >> 1) % NB, kbl = (f >> 1) / NB;
             const int soff = ((((bt * kSeqLen + td) * KX + (2 * jd + kbl)) * 2 + hl) << 10);
+#ifdef CCSM_DMA_C_NT
+            if (last_read) { dma16_buf_nt(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT_BYTES + (f << 10)))); return; }
+#endif
             dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff),
                       __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT_BYTES + (f << 10))));
         };
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     auto dma_ahead = [&](int slot, int s, int jj) {
         const int g = jj + RS;
         const int c = g & (2 * NPAIR - 1);                           // consumption within its step: 0-15 phase A, 16-31 phase C
-        dma_pair(slot, s + (g >> 5), kMxZigZag && c >= NPAIR ? 2 * NPAIR - 1 - c : c & (NPAIR - 1));
+        dma_pair(slot, s + (g >> 5), kMxZigZag && c >= NPAIR ? 2 * NPAIR - 1 - c : c & (NPAIR - 1), c >= NPAIR);
     };
     // wait until this wave's part of a transfer has landed: at most NLO (waves 4-7) / NHI (waves 0-3) younger operations
 #define CCSM_WAIT_XFER(NLO, NHI)                                                        \
@@ -797,7 +800,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
     auto w8_at = [&](int off) -> uint2 {            // bytes 16-23 of an fp6 blob: lane * 8
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(wrs, lane * 8, off, 0);
+        int v8 = lane * 8;
+        if constexpr (HS3) {        // the hybrid only needs it in phase C and has no register to keep it in through phases A and B (it was spilled:
+            v8 = lane16;            // 8-16 B of scratch, profiles/r03_z_isa.md): rebuilt from an opaque copy of lane * 16 at every use instead
+            asm volatile("" : "+v"(v8));
+            v8 >>= 1;
+        }
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(wrs, v8, off, 0);
         return make_uint2(v[0], v[1]);
     };
 
@@ -1137,7 +1146,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         });
 #undef CCSM_MAIN
         stamp(3);
-        mx_tail<OUT_FP8, HS3, DYN, NB>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        // (the hybrid's last layer hands the attention pool fp16 hi + lo fragments - attn_fc_kernel, three passes - instead of fp8 corr
+        // fragments: its fp8 tail had no registers left beside the exact state's and spilled, profiles/r03_z_isa.md)
+        if constexpr (HS3 && OUT_FP8) f3_tail<NB>(smem, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
+        else mx_tail<OUT_FP8, HS3, DYN, NB>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         CCSM_FENCE;
         ldA_slot(2, 2);                                             // the third weight slot of the next step (needed two pairs in): not live across the tail
         CCSM_FENCE;

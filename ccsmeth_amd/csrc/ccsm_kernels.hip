@@ -72,6 +72,11 @@ __device__ __forceinline__ void dma16_buf(u32x4_t rsrc, int voff, int soff, unsi
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" CCSM_DMA_POLICY " lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
                  : "memory");
 }
+// the same with the non-temporal policy: the LAST read of a line (experiment -DCCSM_DMA_C_NT: phase C's second pass over x_t)
+__device__ __forceinline__ void dma16_buf_nt(u32x4_t rsrc, int voff, int soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen nt lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
+                 : "memory");
+}
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ half8 as_half8(uint4 v) { return __builtin_bit_cast(half8, v); }
@@ -91,7 +96,11 @@ __device__ __forceinline__ uint32_t pack2(_Float16 a, _Float16 b) {
     return __builtin_bit_cast(uint32_t, t);
 }
 
+#ifdef CCSM_SIGMOID_EXP2   // experiment: exp2 on the pre-scaled argument, no range fix-up (exp2(+big) = inf -> rcp = 0, exp2(-big) = 0 -> rcp(1) = 1)
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f)); }
+#else
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+#endif
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 
 // Split-fp16 product of one k-block (CCSM_PRECISION_SPLIT3): hi*hi + hi*lo + lo*hi, fp32 accumulate.  Callers that hold several
