@@ -115,8 +115,8 @@ def _check_scope(args):
         raise ValueError("--ref does not exist")       # only --is_map yes reads the reference sequence (outside this build)
     if args.motifs.upper() != "CG" or args.mod_loc != 0:
         raise ValueError("this build implements --motifs CG --mod_loc 0")
-    if args.norm != "zscore" or args.no_decode:
-        raise ValueError("this build implements --norm zscore with CodecV1 decoding")
+    if args.norm not in ("zscore", "min-mean", "min-max", "mad", "none"):
+        raise ValueError("--norm must be one of zscore, min-mean, min-max, mad, none")         # the reference's choices (ccsmeth.py)
     if yes(args.use_compile):
         raise ValueError("--use_compile applies to the reference's torch model only")
 
@@ -263,6 +263,13 @@ def call_mods(args, log=sys.stderr, pipe=None):
     if not os.path.exists(args.input):
         raise ValueError("--input_file does not exist!")              # :486-488
     _check_scope(args)
+    if args.norm != "zscore" or args.no_decode:
+        # the device extraction kernels implement the default (z-score of the CodecV1-decoded kinetics: extract_features.py:181-199,
+        # 327-334); the other normalisations and raw codes go through the NumPy mirror of the reference's extraction and the
+        # record-level BAM path, single GPU
+        if args.extract != "host" or args.io != "python":
+            print("[main]--norm %s%s: feature extraction on the host (--extract host --io python)" % (args.norm, " --no_decode" if args.no_decode else ""), file=log)
+        args.extract, args.io = "host", "python"
     from collections import OrderedDict
     if pipe is None and os.environ.get("CCSM_NULL_MODEL") == "2":      # diagnostics: the host side alone (tools/host_feed_probe.py)
         from .pipeline import HostNullPipe
@@ -292,7 +299,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
         # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
         # (every site's initial state is a function of the seed, its read's name and its position there), so the flag is only a lower bound there.
         chunk_sites = max(args.batch_size, 12288) if args.extract == "device" else args.batch_size
-        pipe = CallModsPipeline(model._dev, batch_size=chunk_sites, seed=args.tseed, extract=args.extract)
+        pipe = CallModsPipeline(model._dev, batch_size=chunk_sites, seed=args.tseed, extract=args.extract, norm=args.norm, no_decode=args.no_decode)
     holeids_e = None if args.holeids_e is None else _get_holes(args.holeids_e)          # extract_features.py:561-562
     holeids_ne = None if args.holeids_ne is None else _get_holes(args.holeids_ne)
     name_filter = holeids_e is not None or holeids_ne is not None

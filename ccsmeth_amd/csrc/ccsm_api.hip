@@ -47,7 +47,7 @@ constexpr int kRowPad = 192;                    // rows are padded to whole work
 // GRU kernels' dynamic LDS: h fragments + x chunk ring + 4 KiB bias table
 constexpr int gru2_lds(int kx) { return (kKBH * kNBGru2 * 2 + 2 * (kx >= 4 ? 4 : kx) * kNBGru2 * 2) * 1024 + kWaves * 4 * 32 * 4; }
 // attention kernel dynamic LDS: 2 staging buffers x 28 KiB + e partials + fc partials + fc1.weight
-constexpr int kAttF8Lds = 2 * 28 * 1024 + kWaves * 7 * 32 * 4 + kSeqLen * 32 * 4 + kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4;   // attn_fc_f8_kernel: staging, one group's score partials, scores, fc partials, fc1.weight, va = 79.9 KiB
+constexpr int kAttF8Lds = 3 * 28 * 1024 + kWaves * 7 * 32 * 4 + kSeqLen * 32 * 4 + kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4 + kWaves * 4 * 64 * 16;   // attn_fc_f8_kernel: three staging buffers (14 hi + 7 lo fragments + 7 KiB derived fp8), one group's score partials, scores, fc partials, fc1.weight, va, q = 139.9 KiB
 constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kWaves * kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4;   // staging, e / fc partials, fc1.weight, va
 
 inline int rows_padded(int n_sites) { return ((2 * n_sites + kRowPad - 1) / kRowPad) * kRowPad; }

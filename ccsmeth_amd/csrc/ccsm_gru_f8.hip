@@ -110,30 +110,58 @@ __device__ __forceinline__ void pack_kb(const float (&v)[8], uint4& hi_out, uint
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Attention pool + FC partials in split-f8 arithmetic: attn_fc_kernel (ccsm_kernels.hip) with the activation and the
-// Wa / Ua fragments in [hi | corr] form.  One staged chunk (2 k-blocks) is exactly one pair: per timestep two main MFMAs and
-// one K = 64 corr MFMA instead of six fp16 MFMAs.  The fc1 partial dot products need the activations themselves: hi from the
-// main fragment in registers, the fp8 residual from the staged corr fragment (lane (n, 1), kCorrPerm order).
+// Attention pool + FC partials in split-f8 arithmetic: attn_fc_kernel (ccsm_kernels.hip) with the Wa / Ua fragments in [hi | corr]
+// form and the activations as the last GRU layer writes them for this kernel (mx_tail<OUT_FP8>): per pair of k-blocks the two fp16 hi
+// fragments and ONE compact fp8 residual fragment (lane (n, g) = the 16 residual bytes of k-block g, byte j <-> k = kCorrPerm[j]) -
+// 3 bytes per element instead of the 4 of two [fp8 x_hi | fp8 x_lo] corr fragments: the pool streams its input once at the rate the
+// CU's outstanding-request capacity allows, so its time is its bytes.  The fp8 copy of x_hi that the K = 64 correction
+// MFMA wants in its lower lanes is re-derived from the staged hi fragments, ONCE per staged chunk and workgroup (one 16-value item per
+// thread), into a third LDS region; a lane reads its half of a corr operand from
+//     base_g + tt * 1024 + kbl * 512 + n * 16,   base_0 = the derived region (CV), base_1 = the staged residual fragments (LO).
+// One staged chunk (2 k-blocks) is one pair: per timestep two main MFMAs and one K = 64 corr MFMA.  Three staging buffers: while chunk c
+// multiplies, chunk c + 1 (landed) is converted and chunk c + 2 is in flight; one barrier per chunk as before.
+//   out2 : [tile][t][32 kb][hi | corr][64] uint4 - of each pair only hi (kb0), lo (in kb0's corr slot) and hi (kb1) are written / read
 //   wa / ua : [wave][kb 32][hi|corr][64] uint4 ; sa_wa / sa_ua : E8M0 scales of their corr operands
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kAttF8TG = 7;                                          // timesteps per Ua pass (21 = 3 * 7)
+constexpr int kAttF8Frags = kAttF8TG * 3;                            // staged fragments per chunk: [kbl 2][tt] hi, then [tt] lo
+constexpr int kAttF8Buf = (kAttF8Frags + kAttF8TG) * 1024;           // + the derived region: [tt][kbl][32 rows] x 16 B = 7 KiB
+// packed pair of fp16 clamped to the e4m3 range of the x_hi copy (|x_hi| * 64 <= 448): the state is only bounded by max(1, |h0|) and the
+// conversion does not saturate (an overflow would be a NaN in the product)
+__device__ __forceinline__ uint32_t clamp_hi2(uint32_t h) {
+    typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+    const half2p lim = {(_Float16)(kF8Clamp / kCorrActHi), (_Float16)(kF8Clamp / kCorrActHi)};
+    half2p t = __builtin_bit_cast(half2p, h);
+    t = __builtin_elementwise_min(__builtin_elementwise_max(t, -lim), lim);
+    return __builtin_bit_cast(uint32_t, t);
+}
+__device__ __forceinline__ uint32_t cvt4_fp8_hc(uint32_t a, uint32_t b) { return cvt4_fp8_h(clamp_hi2(a), clamp_hi2(b)); }
+__device__ __forceinline__ uint4 cvt16_fp8_h(uint4 own, uint4 prt) {   // 16 fp16 of one k-block (own: k 0-7, prt: k 8-15) -> fp8 x 64, kCorrPerm order
+    return make_uint4(cvt4_fp8_hc(own.x, own.y), cvt4_fp8_hc(prt.x, prt.y), cvt4_fp8_hc(own.z, own.w), cvt4_fp8_hc(prt.z, prt.w));
+}
+// lane id recomputed where it is needed (two instructions, no input): what the loops' epilogues index with, instead of values the
+// compiler would have to keep through the accumulator-bound main loop (they were spilled)
+__device__ __forceinline__ int lane_now() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
                                                              const uint4* __restrict__ ua, const float* __restrict__ va,
                                                              const float* __restrict__ fcw, float* __restrict__ part,
                                                              SliceTable slices, int sa_wa, int sa_ua) {
-    constexpr int TG = 7;                      // timesteps per Ua pass (21 = 3 * 7)
+    constexpr int TG = kAttF8TG;
     constexpr int CK = 2;                      // k-blocks per staged chunk = one pair
     constexpr int NCHUNK = kKB12 / CK;
-    constexpr int CHUNK_FRAGS = CK * TG * 2;   // 28 fragments of 1 KiB
+    constexpr int NFR = kAttF8Frags;           // 21 fragments of 1 KiB per chunk
+    constexpr int BUF = kAttF8Buf;             // 28 KiB: H [kbl][tt] 14 KiB | LO [tt] 7 KiB | CV [tt][kbl][n] 7 KiB
+    constexpr int LO_OFF = 2 * TG * 1024, CV_OFF = 3 * TG * 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // 79.9 KiB in all (kAttF8Lds; round 2 kept per-wave score partials of all 21 timesteps and a per-wave fc1 array that was never
-    // indexed by wave: 129 KiB).  Occupancy is set by the registers (seven accumulator tiles: 250 VGPRs, two waves per SIMD, one
-    // workgroup per CU), not by this
-    char* s_stage = smem;                                                     // [2][CK][TG][hi|corr] fragments
-    float* s_epart = reinterpret_cast<float*>(smem + 2 * CHUNK_FRAGS * 1024);  // [wave][tt][32]: this timestep group's score partials
+    char* s_stage = smem;                                                     // [3] buffers
+    float* s_epart = reinterpret_cast<float*>(smem + 3 * BUF);                 // [wave][tt][32]: this timestep group's score partials
     float* s_e = s_epart + kWaves * TG * 32;                                   // [t][32]: scores, summed over the waves in a fixed order
     float* s_pfc = s_e + kSeqLen * 32;                                         // [t][32][2]
     float* s_fcw = s_pfc + kSeqLen * 32 * 2;                                   // [2][1024]
-    float* s_va = s_fcw + kClasses * 4 * kHidden;                              // [256]: in LDS, the 16 registers go to the operand pipeline
+    float* s_va = s_fcw + kClasses * 4 * kHidden;                              // [256]
+    float4* s_q = reinterpret_cast<float4*>(s_va + kHidden);                   // [wave][4][64] float4: q of this wave's units (re-read per timestep group:
+                                                                               // the accumulators of the group leave it no 16 registers)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -151,32 +179,37 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     f32x16 qacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
-    {   // operands of pairs p+1 .. p+3 are in flight while pair p multiplies (four register sets of 8 fragments: the activation
-        // fragments come from HBM, one pair of look-ahead left the loop at one round trip per pair)
-        uint4 qa[4][8];
+    {   // operands of pairs p+1 .. p+2 are in flight while pair p multiplies.  Per pair and lane: the Wa fragments, the own hi fragments and
+        // two more 16-byte pieces - lower lanes: the partner's hi (k 8-15) of both k-blocks, to derive the fp8 copy; upper lanes: the residual
+        // bytes of both k-blocks (lanes n and n + 32 of the compact fragment)
+        uint4 qa[3][8];
         auto ldq = [&](uint4 (&d)[8], int kb) {
             const int tq = kb < kKBH ? kSeqLen - 1 : 0;
-            const uint4* xp = otile + ((size_t)tq * kKB12 + kb) * 2 * kFragU4 + lane;
+            const uint4* xb = otile + ((size_t)tq * kKB12 + kb) * 2 * kFragU4;      // hi(kb) | lo(pair) | hi(kb + 1) | -
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d[i] = wap[(kb * 2 + i) * kFragU4];           // hi0, corr0, hi1, corr1
-                d[4 + i] = xp[i * kFragU4];
-            }
+            for (int i = 0; i < 4; ++i) d[i] = wap[(kb * 2 + i) * kFragU4];           // hi0, corr0, hi1, corr1
+            d[4] = xb[lane];
+            d[6] = xb[2 * kFragU4 + lane];
+            d[5] = hh ? xb[kFragU4 + n] : xb[n + 32];
+            d[7] = hh ? xb[kFragU4 + n + 32] : xb[2 * kFragU4 + n + 32];
         };
         ldq(qa[0], 0);
         ldq(qa[1], 2);
-        ldq(qa[2], 4);
 #pragma unroll
         for (int p = 0; p < kKB12 / 2; ++p) {
-            if (p + 3 < kKB12 / 2) ldq(qa[(p + 3) & 3], 2 * (p + 3));
+            if (p + 2 < kKB12 / 2) ldq(qa[(p + 2) % 3], 2 * (p + 2));
             asm volatile("" ::: "memory");
-            const uint4(&d)[8] = qa[p & 3];
+            const uint4(&d)[8] = qa[p % 3];
+            const uint4 c0 = cvt16_fp8_h(d[4], d[5]), c1 = cvt16_fp8_h(d[6], d[7]);
+            const uint4 x0c = hh ? d[5] : c0, x1c = hh ? d[7] : c1;
             qacc = mfma16(d[0], d[4], qacc);
             qacc = mfma16(d[2], d[6], qacc);
-            qacc = mfma_corr(d[1], d[3], d[5], d[7], qacc, sa_wa);
+            qacc = mfma_corr(d[1], d[3], x0c, x1c, qacc, sa_wa);
             asm volatile("" ::: "memory");
         }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_q[(wave * 4 + i) * 64 + lane] = make_float4(qacc[4 * i], qacc[4 * i + 1], qacc[4 * i + 2], qacc[4 * i + 3]);
     int strand = 0;   // which half of fc1.weight this lane's row multiplies: strand 2 rows are the upper half of a slice
     {
         const int row = tile * 32 + n;
@@ -185,16 +218,32 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                 strand = (row - slices.row_base[i]) >= slices.n_sites[i];
     }
 
-    // stage chunk `c` of timestep group t0 into buffer `buf`: fragment f = (kbl * TG + tt) * 2 + hl
+    // stage chunk `c` of timestep group t0 into buffer `buf`: fragments 0..13 = hi [kbl][tt], 14..20 = lo [tt]
     auto stage = [&](int t0, int c, int buf) {
 #pragma unroll
-        for (int i = 0; i < (CHUNK_FRAGS + kWaves - 1) / kWaves; ++i) {
+        for (int i = 0; i < (NFR + kWaves - 1) / kWaves; ++i) {
             const int f = wave + kWaves * i;
-            if (f < CHUNK_FRAGS) {
-                const int hl = f & 1, tt = (f >> 1) % TG, kbl = (f >> 1) / TG;
-                const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
-                dma16(src, __builtin_amdgcn_readfirstlane(
-                               (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024)));
+            if (f < NFR) {
+                const int lo = f >= 2 * TG;
+                const int tt = lo ? f - 2 * TG : f % TG, kbl = lo ? 0 : f / TG;
+                const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + lo) * kFragU4 + lane;
+                dma16(src, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_stage + buf * BUF + f * 1024)));
+            }
+        }
+    };
+    // derive the fp8 copy of x_hi of a landed chunk: item = (tt, kbl, row), one per thread (448 of 512)
+    auto convert = [&](int buf) {
+        const int it = threadIdx.x;
+        if (it < TG * 2 * 32) {
+            const int tt = it >> 6, kbl = (it >> 5) & 1, r = it & 31;
+            const char* hf = s_stage + buf * BUF + (kbl * TG + tt) * 1024 + r * 16;
+            char* cv = s_stage + buf * BUF + CV_OFF + tt * 1024 + kbl * 512 + r * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                  // in two halves (8 bytes of the result each): few registers live at a time
+                const uint2 own = *reinterpret_cast<const uint2*>(hf + 8 * h);
+                const uint2 prt = *reinterpret_cast<const uint2*>(hf + 512 + 8 * h);
+                *reinterpret_cast<uint2*>(cv + 8 * h) = make_uint2(cvt4_fp8_hc(own.x, own.y), cvt4_fp8_hc(prt.x, prt.y));
+                asm volatile("" ::: "memory");
             }
         }
     };
@@ -206,22 +255,34 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     for (int tg = 0; tg < kSeqLen / TG; ++tg) {
         const int t0 = tg * TG;
         f32x16 kacc[TG];
+        {
+            f32x16 q;                                        // (written by this lane itself: no barrier needed)
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt) kacc[tt] = qacc;     // accumulate K_t on top of q
-        // fc1 partials: wave w takes timestep t0 + w of the group for ALL k-blocks (w < 7): the work of every chunk is spread
-        // over seven waves instead of falling on the two that own its k-blocks (they made the other six wait at the barrier),
-        // and each (row, t) sum is complete in one wave's registers, in a fixed order
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = s_q[(wave * 4 + i) * 64 + lane];
+                q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt) kacc[tt] = q;    // accumulate K_t on top of q
+        }
+        // fc1 partials: wave w takes timestep t0 + w of the group for ALL k-blocks (w < 7); each (row, t) sum is complete in one wave's
+        // registers, in a fixed order
         float pf0 = 0.f, pf1 = 0.f;
 
         stage(t0, 0, 0);
+        stage(t0, 1, 1);
+        wait_dma();
+        __syncthreads();           // chunks 0 and 1 are in LDS (and every wave is done with the previous group's buffers: barrier at its end)
+        convert(0);
 #pragma unroll 1
         for (int c = 0; c < NCHUNK; ++c) {
             uint4 w[CK][2];
 #pragma unroll
             for (int kbl = 0; kbl < CK; ++kbl) { w[kbl][0] = wu[kbl][0]; w[kbl][1] = wu[kbl][1]; }
-            wait_dma();        // this wave's part of chunk c (and the Ua fragments above) has arrived ...
-            __syncthreads();   // ... and so has everybody else's: chunk c is in LDS; buffer (c+1)&1 is free
-            if (c + 1 < NCHUNK) stage(t0, c + 1, (c + 1) & 1);
+            wait_dma();        // this wave's part of chunk c + 1 (and the Ua fragments above) has arrived ...
+            __syncthreads();   // ... and everybody else's; chunk c's derived region is complete; buffer (c + 2) % 3 (chunk c - 1) is free
+            if (c + 2 < NCHUNK) stage(t0, c + 2, (c + 2) % 3);
+            if (c + 1 < NCHUNK) convert((c + 1) % 3);
             {
                 const int cn = c + 1 < NCHUNK ? c + 1 : 0;       // Ua is re-streamed for every timestep group
 #pragma unroll
@@ -230,37 +291,36 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                     wu[kbl][1] = uap[((cn * CK + kbl) * 2 + 1) * kFragU4];
                 }
             }
-            const char* sb0 = s_stage + (c & 1) * CHUNK_FRAGS * 1024;
+            const char* sb0 = s_stage + (c % 3) * BUF;
             const char* sb = sb0 + lane * 16;
-            // operands of timestep tt + 1 are read from LDS before the three MFMAs of timestep tt are issued (two register sets,
-            // pinned with compiler fences: left alone the compiler reads each operand right in front of its MFMA and every MFMA
-            // waits out an LDS round trip — 4.2 k cycles per chunk for 1.85 k of matrix work)
-            uint4 xo[2][4];
-            auto rdop = [&](uint4 (&d)[4], int tt) {
-                d[0] = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 0) * 1024);
-                d[1] = *reinterpret_cast<const uint4*>(sb + ((0 * TG + tt) * 2 + 1) * 1024);
-                d[2] = *reinterpret_cast<const uint4*>(sb + ((1 * TG + tt) * 2 + 0) * 1024);
-                d[3] = *reinterpret_cast<const uint4*>(sb + ((1 * TG + tt) * 2 + 1) * 1024);
+            const char* sc = sb0 + (hh ? LO_OFF : CV_OFF) + n * 16;     // this lane's half of the corr operands
+            // the hi operands of timestep tt + 1 are read from LDS before the MFMAs of timestep tt are issued (two register sets); the corr
+            // operands of timestep tt are read in front of its two main MFMAs and used behind them (one set: the kernel has no register to spare)
+            uint4 xo[2][2], xc[2];
+            auto rdhi = [&](uint4 (&d)[2], int tt) {
+                d[0] = *reinterpret_cast<const uint4*>(sb + (0 * TG + tt) * 1024);
+                d[1] = *reinterpret_cast<const uint4*>(sb + (1 * TG + tt) * 1024);
             };
-            rdop(xo[0], 0);
+            rdhi(xo[0], 0);
 #pragma unroll
             for (int tt = 0; tt < TG; ++tt) {
                 asm volatile("" ::: "memory");
-                if (tt + 1 < TG) rdop(xo[(tt + 1) & 1], tt + 1);
+                xc[0] = *reinterpret_cast<const uint4*>(sc + tt * 1024);
+                xc[1] = *reinterpret_cast<const uint4*>(sc + tt * 1024 + 512);
+                if (tt + 1 < TG) rdhi(xo[(tt + 1) & 1], tt + 1);
                 asm volatile("" ::: "memory");
-                const uint4 x0h = xo[tt & 1][0], x0c = xo[tt & 1][1], x1h = xo[tt & 1][2], x1c = xo[tt & 1][3];
+                const uint4 x0h = xo[tt & 1][0], x1h = xo[tt & 1][1];
                 kacc[tt] = mfma16(w[0][0], x0h, kacc[tt]);
                 kacc[tt] = mfma16(w[1][0], x1h, kacc[tt]);
-                kacc[tt] = mfma_corr(w[0][1], w[1][1], x0c, x1c, kacc[tt], sa_ua);
-                // fc1 partial of k-block (tt & 1) for timestep t0 + wave, issued behind this timestep's MFMAs (tt < 2): vector ALU
-                // and LDS work in the shadow of the matrix pipe instead of a serial block at the end of the chunk
+                kacc[tt] = mfma_corr(w[0][1], w[1][1], xc[0], xc[1], kacc[tt], sa_ua);
+                // fc1 partial of k-block (tt & 1) for timestep t0 + wave, issued behind this timestep's MFMAs (tt < 2)
                 if (tt < CK && wave < TG) {
                     const int kbl = tt;
                     const int kb = c * CK + kbl;
-                    const char* fr = sb0 + ((kbl * TG + wave) * 2) * 1024;
-                    const half8 xh = as_half8(*reinterpret_cast<const uint4*>(fr + lane * 16));
-                    const int la = *reinterpret_cast<const int*>(fr + 1024 + (n + 32) * 16 + 4 * hh);
-                    const int lb = *reinterpret_cast<const int*>(fr + 1024 + (n + 32) * 16 + 8 + 4 * hh);
+                    const half8 xh = as_half8(*reinterpret_cast<const uint4*>(sb0 + (kbl * TG + wave) * 1024 + lane * 16));
+                    const char* lr = sb0 + LO_OFF + wave * 1024 + kbl * 512 + n * 16;          // the 16 residual bytes of (row n, k-block kb), kCorrPerm order
+                    const int la = *reinterpret_cast<const int*>(lr + 4 * hh);
+                    const int lb = *reinterpret_cast<const int*>(lr + 8 + 4 * hh);
                     const float xl[8] = {__builtin_amdgcn_cvt_f32_fp8(la, 0), __builtin_amdgcn_cvt_f32_fp8(la, 1),
                                          __builtin_amdgcn_cvt_f32_fp8(la, 2), __builtin_amdgcn_cvt_f32_fp8(la, 3),
                                          __builtin_amdgcn_cvt_f32_fp8(lb, 0), __builtin_amdgcn_cvt_f32_fp8(lb, 1),
@@ -279,25 +339,27 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                 }
             }
         }
+        const int ln = lane_now(), n2 = ln & 31, hh2 = ln >> 5;
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
             float e = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e += s_va[(wave * 2 + hh) * 16 + r] * tanh_f(kacc[tt][r]);
+            for (int r = 0; r < 16; ++r) e += s_va[(wave * 2 + hh2) * 16 + r] * tanh_f(kacc[tt][r]);
             e += __shfl_xor(e, 32);
-            if (hh == 0) s_epart[(wave * TG + tt) * 32 + n] = e;
+            if (hh2 == 0) s_epart[(wave * TG + tt) * 32 + n2] = e;
         }
         if (wave < TG) {
             pf0 += __shfl_xor(pf0, 32);
             pf1 += __shfl_xor(pf1, 32);
-            if (hh == 0) {
-                s_pfc[((t0 + wave) * 32 + n) * 2 + 0] = pf0;
-                s_pfc[((t0 + wave) * 32 + n) * 2 + 1] = pf1;
+            if (hh2 == 0) {
+                s_pfc[((t0 + wave) * 32 + n2) * 2 + 0] = pf0;
+                s_pfc[((t0 + wave) * 32 + n2) * 2 + 1] = pf1;
             }
         }
-        __syncthreads();   // all waves are done with both staging buffers before the next group restages buffer 0
-        if (threadIdx.x < TG * 32) {       // the group's scores: the eight waves' partials in a fixed order (deterministic)
-            const int tt = threadIdx.x >> 5, rl = threadIdx.x & 31;
+        __syncthreads();   // all waves are done with the staging buffers before the next group restages them
+        const int tid2 = wave * 64 + ln;
+        if (tid2 < TG * 32) {       // the group's scores: the eight waves' partials in a fixed order (deterministic)
+            const int tt = tid2 >> 5, rl = tid2 & 31;
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) v += s_epart[(w * TG + tt) * 32 + rl];
@@ -307,8 +369,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     __syncthreads();
 
     // ---- softmax over t and the strand-half of the logits (fixed summation order: deterministic)
-    if (threadIdx.x < 32) {
-        const int rl = threadIdx.x;
+    if (wave == 0 && lane_now() < 32) {
+        const int rl = lane_now();
         const int row = tile * 32 + rl;
         float e[kSeqLen];
         float m = -3.0e38f;

@@ -322,14 +322,26 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
         nt_store(hi0, reinterpret_cast<uint4*>(o));
         nt_store(hi1, reinterpret_cast<uint4*>(o + 2048));
         if constexpr (OUT_FP8) {
+            // For the attention pool: ONE compact residual fragment per pair instead of two [fp8 x_hi | fp8 x_lo] corr fragments - lane
+            // (n, g) holds the 16 fp8 residuals (x 2^17) of k-block g of the pair, byte j <-> k = kCorrPerm[j]; the fp8 copy of x_hi is
+            // derivable from the hi fragments and attn_fc_f8_kernel re-derives it in LDS: 3 instead of 4 bytes per element cross HBM twice.
+            // This lane's values: hn[4q + e] = unit 8q + 4hh + e, i.e. q = 0, 1 -> k-block 0 (units 0-3, 8-11 (+ 4hh)), q = 2, 3 -> k-block 1.
+            typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+            uint32_t lq[4];
 #pragma unroll
-            for (int kbl = 0; kbl < 2; ++kbl) {
-                const float v8[8] = {hn[8 * kbl + 0], hn[8 * kbl + 1], hn[8 * kbl + 2], hn[8 * kbl + 3],
-                                     hn[8 * kbl + 4], hn[8 * kbl + 5], hn[8 * kbl + 6], hn[8 * kbl + 7]};
-                uint4 fh, fc;
-                pack_kb(v8, fh, fc);
-                nt_store(fc, reinterpret_cast<uint4*>(o + 1024 + 2048 * kbl));
+            for (int q = 0; q < 4; ++q) {
+                float lf[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = hn[4 * q + e];
+                    lf[e] = __builtin_amdgcn_fmed3f(v - (float)(_Float16)v, -kF8Clamp / kCorrActLo, kF8Clamp / kCorrActLo);
+                }
+                lq[q] = cvt4_fp8_l(hi0.x, lf[0], lf[1], lf[2], lf[3]);
             }
+            // lower lanes keep k-block 0 (own units 0-3, 8-11; the partner's 4-7, 12-15), upper lanes k-block 1
+            swap32(lq[0], lq[2]);       // lower: lq0 = own kb0 0-3, lq2 = partner's kb0 4-7 ; upper: lq0 = partner's kb1 0-3, lq2 = own kb1 4-7
+            swap32(lq[1], lq[3]);       // lower: lq1 = own kb0 8-11, lq3 = partner's kb0 12-15 ; upper: lq1 = partner's kb1 8-11, lq3 = own kb1 12-15
+            nt_store(make_uint4(lq[0], lq[1], lq[2], lq[3]), reinterpret_cast<uint4*>(o + 1024));
         } else {
             nt_store(c0, reinterpret_cast<uint4*>(o + 1024));
             // (bytes 8-15 are spare in HBM: the scales of row tiles 0..bt in bytes 0..bt of one dword - the reader takes the last tile's, one

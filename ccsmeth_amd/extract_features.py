@@ -15,13 +15,22 @@ _ASCII_C, _ASCII_G = ord("C"), ord("G")
 
 
 def _normalize_signals(signals, normalize_method="zscore"):
-    """extract_features.py:181-199 ('zscore' and 'none'; the other methods are not used by call_mods defaults)."""
+    """extract_features.py:181-199, every method: none | zscore | min-max | min-mean | mad (statsmodels.robust.scale.mad = median
+    absolute deviation from the median / Phi^-1(3/4)).  float64 like the reference; a zero scale gives all zeros."""
     signals = np.asarray(signals)
     if normalize_method == "none":
         return np.around(signals, decimals=6)
-    if normalize_method != "zscore":
-        raise ValueError("normalize_method '%s' is outside this build (zscore | none)" % normalize_method)
-    sshift, sscale = np.mean(signals), np.std(signals)
+    if normalize_method == "zscore":
+        sshift, sscale = np.mean(signals), np.std(signals)
+    elif normalize_method == "min-max":
+        sshift, sscale = np.min(signals), np.max(signals) - np.min(signals)
+    elif normalize_method == "min-mean":
+        sshift, sscale = np.min(signals), np.mean(signals)
+    elif normalize_method == "mad":
+        med = np.median(signals)
+        sshift, sscale = med, float(np.median(np.abs(signals - med)) / 0.6744897501960817)
+    else:
+        raise ValueError("")                                  # (the reference's own message)
     if sscale == 0.0:
         return np.zeros(len(signals), dtype=np.float64)
     return np.around((signals - sshift) / sscale, decimals=6)

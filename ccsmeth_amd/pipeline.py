@@ -40,7 +40,7 @@ class _Slot:
 
 
 class CallModsPipeline:
-    def __init__(self, device_model, batch_size=2048, seed=1234, extract="host"):
+    def __init__(self, device_model, batch_size=2048, seed=1234, extract="host", norm="zscore", no_decode=False):
         """extract="host": NumPy feature extraction + feature-level C-ABI (ccsm_submit_host / ccsm_wait_host);
         extract="device": raw read arrays go to the GPU, ccsm_forward_reads_host extracts there (include/ccsm.h)."""
         import torch
@@ -50,6 +50,9 @@ class CallModsPipeline:
         self.batch_size = int(batch_size)
         self.seed = seed
         self.extract = extract
+        self.norm, self.no_decode = norm, bool(no_decode)       # host extraction only (the device kernels: zscore on decoded codes)
+        if extract == "device" and (norm != "zscore" or no_decode):
+            raise ValueError("the device extraction kernels implement --norm zscore with CodecV1 decoding; use extract='host'")
         self._rws = None
         self._rwss = [None, None]                       # read-level workspaces of the double-buffered native path
         dev = torch.device("cuda", device_model.device)
@@ -233,7 +236,7 @@ class CallModsPipeline:
             meta, nsites = [], 0
 
         for ridx, read in enumerate(reads):
-            arr = extract_read_arrays(read.seq, read.fi, read.ri, read.fp, read.rp)
+            arr = extract_read_arrays(read.seq, read.fi, read.ri, read.fp, read.rp, no_decode=self.no_decode, norm=self.norm)
             if arr is None or len(arr["loc"]) == 0:
                 failed += 1                            # reference counts reads without features as failed (:416-429)
                 continue

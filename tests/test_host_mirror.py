@@ -108,8 +108,31 @@ def test_call_mods_cli_matches_reference_parser():
     base = ["-i", "a.bam", "-m", "m.ckpt", "-o", "out"]
     _check_scope(build_parser().parse_args(base + ["-p", "4", "--threads_call", "2", "--no_sort", "--keep_pulse"]))
     _check_scope(build_parser().parse_args(base + ["--mode", "align", "--mapq", "10", "--identity", "0.9", "--no_supplementary", "--skip_unmapped", "no"]))
+    for norm in ("zscore", "min-mean", "min-max", "mad", "none"):        # every normalisation of the reference, raw codes too (host extraction)
+        _check_scope(build_parser().parse_args(base + ["--norm", norm, "--no_decode"]))
     for extra in (["--seq_len", "20"], ["--mode", "reference"], ["--is_sn", "yes"], ["--model_type", "attbilstm2s"], ["--motifs", "CHG"],
-                  ["--norm", "min-max"], ["--no_decode"], ["--hid_rnn", "128"], ["--mode", "align", "--ref", "/nonexistent/g.fa"], ["--is_map", "yes"]):
+                  ["--norm", "median"], ["--hid_rnn", "128"], ["--mode", "align", "--ref", "/nonexistent/g.fa"], ["--is_map", "yes"]):
         with pytest.raises(ValueError):
             _check_scope(build_parser().parse_args(base + extra))
     assert isinstance(build_parser(), argparse.ArgumentParser)
+
+
+def test_every_kinetics_normalisation_matches_the_reference():
+    """extract_features.py:181-199: none | zscore | min-max | min-mean on raw (--no_decode) and CodecV1-decoded codes against values
+    generated by the reference's own function (tests/golden/make_norm_golden.py); a zero scale gives zeros.  `mad` against its
+    definition (statsmodels.robust.scale.mad; statsmodels is not installed in the build container, so there is no run to pin it to)."""
+    from ccsmeth_amd.extract_features import CODE2FRAMES, _normalize_signals
+    g = np.load(os.path.join(GOLDEN, "norm_golden.npz"))
+    for name in ("gamma", "flat", "short"):
+        codes = g["codes_" + name]
+        for dec in (0, 1):
+            sig = CODE2FRAMES[codes] if dec else codes
+            for method in ("none", "zscore", "min-max", "min-mean"):
+                assert np.array_equal(np.asarray(_normalize_signals(sig, method), np.float64), g["%s_%s_dec%d" % (name, method, dec)]), (name, method, dec)
+    x = CODE2FRAMES[g["codes_gamma"]].astype(np.float64)
+    med = np.median(x)
+    want = np.around((x - med) / (np.median(np.abs(x - med)) / 0.6744897501960817), 6)
+    assert np.array_equal(_normalize_signals(x, "mad"), want)
+    assert not np.any(_normalize_signals(CODE2FRAMES[g["codes_flat"]], "mad"))
+    with pytest.raises(ValueError):
+        _normalize_signals(x, "median")
