@@ -43,10 +43,10 @@ PEAK_HBM = 8.0e12
 # HBM/fabric bytes of ONE launch of the dominant kernel per site, from rocprofv3 PMC passes on the launch shape timed here
 # (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
 # read from inside this process)
-TRAFFIC = {4: ((2 * 997200 + 516100) * 1024 / 6144.0, "profiles/r04_d_pmc.md"),       # (1209100 before phase C went zig-zag)
+TRAFFIC = {4: ((2 * 1001600 + 451600) * 1024 / 6144.0, "profiles/r04_g_pmc.md"),       # mean of layers 1 and 2 (the last layer writes 3 of 4 fragments per pair)
            5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced_hybrid.md"),
            6: ((2 * 1002900 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_prec6.md"),
-           3: ((2 * 1241546 + 516096) * 1024 / 6144.0, "profiles/r01_c_pmc_coalesced.md")}
+           3: ((2 * 1049900 + 516100) * 1024 / 6144.0, "profiles/r04_g_pmc_split3.md")}
 ARITH_NAME = {3: "split3", 4: "split-mx", 5: "hybrid", 6: "split-mx-d"}
 ARITH = {4: ("fp32 reference; computed as f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate (within 1e-4 on this config's random-init weights)",
              "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp4 e2m1 for the "
@@ -332,6 +332,14 @@ def extras(weights, dm, dev, pool, grp):
         from ccsmeth_amd.utils import benchdata
         return benchdata.call_mods_end_to_end(n_reads=int(os.environ.get("CCSM_BENCH_READS", "8000")), read_len=15000)
 
+    def call_mods_e2e_trained():
+        # the same run on the committed trained checkpoint: what `call_mods --arithmetic auto` gives a user's model (split3)
+        from ccsmeth_amd.utils import benchdata
+        wt = dict(np.load(os.path.join(ROOT, "tests", "golden", "trained", "planted7_5000.npz")))
+        r = benchdata.call_mods_end_to_end(n_reads=int(os.environ.get("CCSM_BENCH_READS", "8000")), read_len=15000, weights=wt)
+        r["checkpoint"] = "tests/golden/trained/planted7_5000.npz (served in split3)"
+        return r
+
     def aggregate():
         from ccsmeth_amd.utils import benchdata
         return benchdata.aggregate_50m(dev)
@@ -393,6 +401,7 @@ def extras(weights, dm, dev, pool, grp):
     leg("torch_cpu_path", torch_cpu)
     leg("pcie_inclusive", pcie)
     leg("call_mods_end_to_end", call_mods_e2e)
+    leg("call_mods_end_to_end_trained", call_mods_e2e_trained)
     leg("aggregate_50M", aggregate)
     return out
 
@@ -535,7 +544,7 @@ def main():
                                   "checkpoint is served with: see trained_checkpoint below (ccsm_create serves trained weights in split3)",
                        "trained_checkpoint": "not measured (--extras none or N > 1)",
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else "gru_layer_v2_kernel<32>") + " (BiGRU layers 1-2)",
+            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else "gru_layer12_f3_kernel") + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
                          "traffic": None if traffic is None else traffic * sites_per_launch,

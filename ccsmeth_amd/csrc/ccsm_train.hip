@@ -1,12 +1,15 @@
 // libccsm_train: the attbigru2s training step (forward with saved activations, backward, Adam) for gfx950, fp32.
-// C-ABI in include/ccsm_train.h.  Dense products go to rocBLAS SGEMM / SGEMV; gates, attention, loss, embedding scatter,
-// dropout and the optimizer are the kernels below.  Activations are time-major: (T, M, features) with M = 2N rows
+// C-ABI in include/ccsm_train.h.  Dense products run on the matrix cores in the library's three-pass split-fp16 arithmetic
+// (ccsm_train_gemm.hip; rounds 1-3 called rocBLAS SGEMM here: a -DCCSM_TRAIN_WITH_ROCBLAS build still does, for A/B runs); the recurrent
+// part, gates, attention, loss, embedding scatter, dropout and the optimizer are the kernels below and in ccsm_train_seq.hip.  Activations are time-major: (T, M, features) with M = 2N rows
 // (strand 1 rows first), so that a timestep of a direction is one contiguous (M, H) block and both strands share every product.
 //
 // Reference equations: ModelAttRNN.forward (models.py:89-150), torch.nn.GRU cell (gate order r, z, n), Attention
 // (utils/attention.py:48-70), CrossEntropyLoss(weight) + clip_grad_norm_ + Adam (train_multigpu.py:212-216, 283-312).
 #include <hip/hip_runtime.h>
+#ifdef CCSM_TRAIN_WITH_ROCBLAS
 #include <rocblas/rocblas.h>
+#endif
 
 #include <cmath>
 #include <cstdint>
@@ -17,6 +20,14 @@
 #include <vector>
 
 #include "../../include/ccsm_train.h"
+#include "ccsm_train_gemm.hip"
+
+#ifndef CCSM_TRAIN_WITH_ROCBLAS
+// the product build has no BLAS library: what the rounds 1-3 code calls a handle is the stream its products run on
+typedef hipStream_t rocblas_handle;
+typedef hipError_t rocblas_status;
+constexpr hipError_t rocblas_status_success = hipSuccess;
+#endif
 
 namespace {
 
@@ -370,7 +381,8 @@ inline dim3 blocks(int64_t n, int per = 256) { return dim3((unsigned)((n + per -
 
 struct ccsm_trainer {
     int device = 0, max_sites = 0;
-    rocblas_handle blas = nullptr, blas1 = nullptr;
+    rocblas_handle blas = nullptr, blas1 = nullptr;    // (product build: the two streams themselves)
+    float* nrm_part = nullptr;                         // 1024 partial sums of squares + the norm (ccsm_train_step)
     hipStream_t stream = nullptr, stream1 = nullptr;       // stream1 / blas1: the backward direction of a layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
@@ -412,11 +424,26 @@ struct ccsm_trainer {
 
 namespace {
 
-// row-major C(MxN) (+)= op(A) op(B) through column-major rocBLAS
+// row-major C(MxN) (+)= op(A) op(B): tA = A is stored K x M, tB = B is stored N x K
 rocblas_status rm_gemm(rocblas_handle h, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
                        int ldb, float beta, float* C, int ldc) {
+#ifdef CCSM_TRAIN_WITH_ROCBLAS
     return rocblas_sgemm(h, tB ? rocblas_operation_transpose : rocblas_operation_none, tA ? rocblas_operation_transpose : rocblas_operation_none,
                          N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
+#else
+    return ccsm_train::gemm_s3(h, tA, tB, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1);
+#endif
+}
+// C_b (M x N) = A_b B_b for `batch` problems at element strides sA / sB / sC (row-major, no transposes)
+rocblas_status rm_gemm_batched(rocblas_handle h, int M, int N, int K, const float* A, int lda, long long sA, const float* B, int ldb, long long sB,
+                               float* C, int ldc, long long sC, int batch) {
+#ifdef CCSM_TRAIN_WITH_ROCBLAS
+    const float one = 1.f, zero = 0.f;
+    return rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, N, M, K, &one, B, ldb, (rocblas_stride)sB, A, lda,
+                                         (rocblas_stride)sA, &zero, C, ldc, (rocblas_stride)sC, batch);
+#else
+    return ccsm_train::gemm_s3(h, false, false, M, N, K, 1.f, A, lda, sA, B, ldb, sB, 0.f, C, ldc, sC, batch);
+#endif
 }
 
 // C (m x n) = sum over `parts` row blocks of A_blk^T B_blk, A_blk = rows_per_part x m (lda), B_blk = rows_per_part x n (ldb): one
@@ -424,10 +451,15 @@ rocblas_status rm_gemm(rocblas_handle h, bool tA, bool tB, int M, int N, int K, 
 // dimension fills the chip instead of 24 workgroups.  `extra` slots of scratch beyond `parts` are summed too (filled by the caller).
 rocblas_status atb_split(rocblas_handle h, hipStream_t st, int m, int n, int rows_per_part, int parts, const float* A, int lda, const float* B,
                          int ldb, float* scratch, int extra, float* C) {
+#ifdef CCSM_TRAIN_WITH_ROCBLAS
     const float one = 1.f, zero = 0.f;
     rocblas_status s = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, n, m, rows_per_part, &one, B, ldb,
                                                      (rocblas_stride)rows_per_part * ldb, A, lda, (rocblas_stride)rows_per_part * lda, &zero, scratch, n,
                                                      (rocblas_stride)m * n, parts);
+#else
+    rocblas_status s = ccsm_train::gemm_s3(h, true, false, m, n, rows_per_part, 1.f, A, lda, (long long)rows_per_part * lda, B, ldb,
+                                           (long long)rows_per_part * ldb, 0.f, scratch, n, (long long)m * n, parts);
+#endif
     if (s != rocblas_status_success) return s;
     sum_partials_kernel<<<blocks((int64_t)m * n), 256, 0, st>>>(scratch, C, parts + extra, (int64_t)m * n);
     return rocblas_status_success;
@@ -587,10 +619,8 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
                                                                        t->sav[l][d][1] + so, t->sav[l][d][2] + so, t->sav[l][d][3] + so, hprev, ld,
                                                                        dgi + (size_t)tt * M * G, dgh + (size_t)tt * M * G, M);
             if (s > 0) {
-                const float one = 1.f, zero = 0.f;      // cpart[g] (M x 256) = dgh_t[:, g*256 : (g+1)*256] W_hh[g*256 : (g+1)*256, :]
-                BLASCHK(rocblas_sgemm_strided_batched(blas, rocblas_operation_none, rocblas_operation_none, H, M, H, &one, P + kOff.w_hh[l][d], H,
-                                                      (rocblas_stride)H * H, dgh + (size_t)tt * M * G, G, (rocblas_stride)H, &zero, cpart, H,
-                                                      (rocblas_stride)M * H, 3));
+                // cpart[g] (M x 256) = dgh_t[:, g*256 : (g+1)*256] W_hh[g*256 : (g+1)*256, :]
+                BLASCHK(rm_gemm_batched(blas, M, H, H, dgh + (size_t)tt * M * G, G, H, P + kOff.w_hh[l][d], H, (long long)H * H, cpart, H, (long long)M * H, 3));
             }
         }
     }
@@ -693,6 +723,7 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
     HIPCHK(hipStreamCreate(&t->stream1));
     HIPCHK(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+#ifdef CCSM_TRAIN_WITH_ROCBLAS
     if (rocblas_create_handle(&t->blas) != rocblas_status_success || rocblas_create_handle(&t->blas1) != rocblas_status_success) {
         ccsm_train_destroy(t);
         return fail(CCSM_ERR_HIP, "rocblas_create_handle failed");
@@ -701,6 +732,12 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
     rocblas_set_stream(t->blas1, t->stream1);
     rocblas_set_pointer_mode(t->blas, rocblas_pointer_mode_host);
     rocblas_set_pointer_mode(t->blas1, rocblas_pointer_mode_host);
+#else
+    t->blas = t->stream;
+    t->blas1 = t->stream1;
+    HIPCHK(ccsm_train::gemm_s3_init());
+#endif
+    TRY(dalloc(&t->nrm_part, 1024 + 1));
     TRY(dalloc(&t->params, kOff.total));
     TRY(dalloc(&t->adam_m, kOff.total));
     TRY(dalloc(&t->adam_v, kOff.total));
@@ -781,8 +818,11 @@ void ccsm_train_destroy(ccsm_trainer* t) {
         for (int d = 0; d < 2; ++d)
             for (int k = 0; k < 4; ++k) if (t->sav[l][d][k]) (void)hipFree(t->sav[l][d][k]);
     }
+#ifdef CCSM_TRAIN_WITH_ROCBLAS
     if (t->blas) rocblas_destroy_handle(t->blas);
     if (t->blas1) rocblas_destroy_handle(t->blas1);
+#endif
+    if (t->nrm_part) (void)hipFree(t->nrm_part);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     if (t->stream1) (void)hipStreamDestroy(t->stream1);
@@ -880,7 +920,10 @@ ccsm_status ccsm_train_step(ccsm_trainer* t, float lr, float beta1, float beta2,
     if (!t) return fail(CCSM_ERR_INVALID_ARG, "trainer must be non-NULL");
     HIPCHK(hipSetDevice(t->device));
     float norm = 0.f;
-    BLASCHK(rocblas_snrm2(t->blas, (int)kOff.total, t->grads, 1, &norm));
+    // |g|_2: per-block partial sums and a final block, both in a fixed order (the same gradients always give the same clip coefficient)
+    ccsm_train::sumsq_partial_kernel<<<1024, 256, 0, t->stream>>>(t->grads, (long long)kOff.total, t->nrm_part);
+    ccsm_train::sumsq_final_kernel<<<1, 256, 0, t->stream>>>(t->nrm_part, 1024, t->nrm_part + 1024);
+    HIPCHK(hipMemcpyAsync(&norm, t->nrm_part + 1024, sizeof(float), hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     if (grad_norm) *grad_norm = norm;
     float clip = 1.f;

@@ -50,9 +50,10 @@ def replicate_bam(src, dst, times, threads=8):
     return os.path.getsize(dst)
 
 
-def call_mods_end_to_end(n_reads=4000, read_len=15000):
+def call_mods_end_to_end(n_reads=4000, read_len=15000, weights=None):
     """`call_mods --io native` on a synthetic BAM (BGZF inflate, parse, feature extraction + model on the GPU, MM/ML, BGZF deflate);
-    second of two runs (the first pays page-ins and library loads)."""
+    second of two runs (the first pays page-ins and library loads).  weights: a state dict (default: the synthetic initialisation,
+    which `--arithmetic auto` serves in split-mx; a trained checkpoint gets split3)."""
     import torch
     from collections import OrderedDict
     from ..call_mods import build_parser, call_mods
@@ -61,7 +62,7 @@ def call_mods_end_to_end(n_reads=4000, read_len=15000):
     inp = os.path.join(tmp, "in.bam")
     gen_s, nbytes = write_synthetic_hifi_bam(inp, n_reads, read_len)
     ckpt = os.path.join(tmp, "m.ckpt")
-    torch.save(OrderedDict((k, torch.from_numpy(v)) for k, v in synth.synth_weights(5).items()), ckpt)
+    torch.save(OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in (weights or synth.synth_weights(5)).items()), ckpt)
     res, dt = None, None
     for _ in range(2):
         args = build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", os.path.join(tmp, "out"), "--batch_size", "12288", "--no_sort"])
