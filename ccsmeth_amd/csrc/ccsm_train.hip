@@ -1,14 +1,18 @@
 // libccsm_train: the attbigru2s training step (forward with saved activations, backward, Adam) for gfx950, fp32.
-// C-ABI in include/ccsm_train.h.  Dense products run on the matrix cores in the library's three-pass split-fp16 arithmetic
-// (ccsm_train_gemm.hip; rounds 1-3 called rocBLAS SGEMM here: a -DCCSM_TRAIN_WITH_ROCBLAS build still does, for A/B runs); the recurrent
-// part, gates, attention, loss, embedding scatter, dropout and the optimizer are the kernels below and in ccsm_train_seq.hip.  Activations are time-major: (T, M, features) with M = 2N rows
+// C-ABI in include/ccsm_train.h.  Dense products: the library's three-pass split-fp16 MFMA kernel (ccsm_train_gemm.hip; no BLAS library
+// is linked - rounds 1-3 called rocBLAS SGEMM here, an A/B build still can: GemmCtx below); the recurrent part, gates, attention, loss,
+// embedding scatter, dropout and the optimizer are the kernels below and in ccsm_train_seq.hip.  Activations are time-major: (T, M, features) with M = 2N rows
 // (strand 1 rows first), so that a timestep of a direction is one contiguous (M, H) block and both strands share every product.
 //
 // Reference equations: ModelAttRNN.forward (models.py:89-150), torch.nn.GRU cell (gate order r, z, n), Attention
 // (utils/attention.py:48-70), CrossEntropyLoss(weight) + clip_grad_norm_ + Adam (train_multigpu.py:212-216, 283-312).
 #include <hip/hip_runtime.h>
-#ifdef CCSM_TRAIN_WITH_ROCBLAS
+#ifdef CCSM_TRAIN_WITH_ROCBLAS          // A/B build only (tools: hipcc -DCCSM_TRAIN_WITH_ROCBLAS ... -lrocblas): the product library links no BLAS
 #include <rocblas/rocblas.h>
+#else
+typedef void* rocblas_handle;
+typedef int rocblas_status;
+constexpr int rocblas_status_success = 0, rocblas_status_internal_error = 6;
 #endif
 
 #include <cmath>
@@ -22,12 +26,12 @@
 #include "../../include/ccsm_train.h"
 #include "ccsm_train_gemm.hip"
 
-#ifndef CCSM_TRAIN_WITH_ROCBLAS
-// the product build has no BLAS library: what the rounds 1-3 code calls a handle is the stream its products run on
-typedef hipStream_t rocblas_handle;
-typedef hipError_t rocblas_status;
-constexpr hipError_t rocblas_status_success = hipSuccess;
-#endif
+// Where a matrix product of the step runs.  The product library: ccsm_train_gemm.hip, the library's three-pass split-fp16 MFMA kernel, for
+// every product ("own": 5.35 / 12.4 ms per step at batch 512 / 2048 against 5.72 / 13.8 with rocBLAS SGEMM, profiles/r04_h_train_gemm.log).
+// A -DCCSM_TRAIN_WITH_ROCBLAS build (A/B runs) also holds the rounds 1-3 rocBLAS calls: CCSM_TRAIN_GEMM = own | rocblas | mixed (mixed: the
+// library's kernel for row-major A, rocBLAS for the A^T B weight gradients), read at ccsm_train_create.
+struct GemmCtx { hipStream_t st; unsigned* amax; rocblas_handle rb; int mode; };      // mode: 0 mixed, 1 own, 2 rocblas
+typedef GemmCtx* blas_t;
 
 namespace {
 
@@ -381,8 +385,11 @@ inline dim3 blocks(int64_t n, int per = 256) { return dim3((unsigned)((n + per -
 
 struct ccsm_trainer {
     int device = 0, max_sites = 0;
-    rocblas_handle blas = nullptr, blas1 = nullptr;    // (product build: the two streams themselves)
-    float* nrm_part = nullptr;                         // 1024 partial sums of squares + the norm (ccsm_train_step)
+    blas_t blas = nullptr, blas1 = nullptr;            // per stream: the stream, one scale word, the rocBLAS handle, the mode
+    GemmCtx gctx[2] = {{nullptr, nullptr, nullptr, 0}, {nullptr, nullptr, nullptr, 0}};
+    float* nrm_part = nullptr;                         // 1024 partial sums of squares + the norm (ccsm_train_step) + the scale words below
+    unsigned* amax_slot(int k) const { return reinterpret_cast<unsigned*>(nrm_part + 1027 + k); }    // 0, 1: dgi of direction 0 / 1; 2: dSpre; 3: dq
+    bool own_any() const { return gctx[0].mode != 2; }
     hipStream_t stream = nullptr, stream1 = nullptr;       // stream1 / blas1: the backward direction of a layer
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
@@ -425,41 +432,56 @@ struct ccsm_trainer {
 namespace {
 
 // row-major C(MxN) (+)= op(A) op(B): tA = A is stored K x M, tB = B is stored N x K
-rocblas_status rm_gemm(rocblas_handle h, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
-                       int ldb, float beta, float* C, int ldc) {
+inline rocblas_status hip2rb(hipError_t e) { return e == hipSuccess ? rocblas_status_success : rocblas_status_internal_error; }
+// row-major C(MxN) (+)= op(A) op(B): tA = A is stored K x M, tB = B is stored N x K.
+// grad_a: A holds gradients (every product with tA does: A = dg^T; the backward products through a weight matrix say so themselves)
+// amax_pre: a device word that already bounds max |A| (one scan of the gradient tensor serves every product that reads it)
+rocblas_status rm_gemm(blas_t h, bool tA, bool tB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                       int ldb, float beta, float* C, int ldc, bool grad_a = false, unsigned* amax_pre = nullptr) {
+    const bool own = h->mode == 1 || (h->mode == 0 && !tA && M >= 128);
+    if (own) return hip2rb(ccsm_train::gemm_s3(h->st, tA, tB, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1,
+                                               amax_pre ? amax_pre : (tA || grad_a) ? h->amax : nullptr, amax_pre == nullptr));
 #ifdef CCSM_TRAIN_WITH_ROCBLAS
-    return rocblas_sgemm(h, tB ? rocblas_operation_transpose : rocblas_operation_none, tA ? rocblas_operation_transpose : rocblas_operation_none,
+    return rocblas_sgemm(h->rb, tB ? rocblas_operation_transpose : rocblas_operation_none, tA ? rocblas_operation_transpose : rocblas_operation_none,
                          N, M, K, &alpha, B, ldb, A, lda, &beta, C, ldc);
 #else
-    return ccsm_train::gemm_s3(h, tA, tB, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1);
+    return rocblas_status_internal_error;
 #endif
 }
-// C_b (M x N) = A_b B_b for `batch` problems at element strides sA / sB / sC (row-major, no transposes)
-rocblas_status rm_gemm_batched(rocblas_handle h, int M, int N, int K, const float* A, int lda, long long sA, const float* B, int ldb, long long sB,
+// C_b (M x N) = A_b B_b for `batch` problems at element strides sA / sB / sC (row-major, no transposes; A = gate gradients)
+rocblas_status rm_gemm_batched(blas_t h, int M, int N, int K, const float* A, int lda, long long sA, const float* B, int ldb, long long sB,
                                float* C, int ldc, long long sC, int batch) {
+    if (h->mode == 1 || (h->mode == 0 && M >= 128))
+        return hip2rb(ccsm_train::gemm_s3(h->st, false, false, M, N, K, 1.f, A, lda, sA, B, ldb, sB, 0.f, C, ldc, sC, batch, h->amax));
 #ifdef CCSM_TRAIN_WITH_ROCBLAS
     const float one = 1.f, zero = 0.f;
-    return rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_none, N, M, K, &one, B, ldb, (rocblas_stride)sB, A, lda,
+    return rocblas_sgemm_strided_batched(h->rb, rocblas_operation_none, rocblas_operation_none, N, M, K, &one, B, ldb, (rocblas_stride)sB, A, lda,
                                          (rocblas_stride)sA, &zero, C, ldc, (rocblas_stride)sC, batch);
 #else
-    return ccsm_train::gemm_s3(h, false, false, M, N, K, 1.f, A, lda, sA, B, ldb, sB, 0.f, C, ldc, sC, batch);
+    return rocblas_status_internal_error;
 #endif
 }
 
 // C (m x n) = sum over `parts` row blocks of A_blk^T B_blk, A_blk = rows_per_part x m (lda), B_blk = rows_per_part x n (ldb): one
 // batched product per block into `scratch` (parts x m x n) and a reduction, so that a weight gradient with a 21504-long inner
 // dimension fills the chip instead of 24 workgroups.  `extra` slots of scratch beyond `parts` are summed too (filled by the caller).
-rocblas_status atb_split(rocblas_handle h, hipStream_t st, int m, int n, int rows_per_part, int parts, const float* A, int lda, const float* B,
-                         int ldb, float* scratch, int extra, float* C) {
+rocblas_status atb_split(blas_t h, hipStream_t st, int m, int n, int rows_per_part, int parts, const float* A, int lda, const float* B,
+                         int ldb, float* scratch, int extra, float* C, unsigned* amax_pre = nullptr) {
+    rocblas_status s;
+    if (h->mode == 1) {
+        s = hip2rb(ccsm_train::gemm_s3(h->st, true, false, m, n, rows_per_part, 1.f, A, lda, (long long)rows_per_part * lda, B, ldb,
+                                       (long long)rows_per_part * ldb, 0.f, scratch, n, (long long)m * n, parts, amax_pre ? amax_pre : h->amax,
+                                       amax_pre == nullptr));
+    } else {
 #ifdef CCSM_TRAIN_WITH_ROCBLAS
-    const float one = 1.f, zero = 0.f;
-    rocblas_status s = rocblas_sgemm_strided_batched(h, rocblas_operation_none, rocblas_operation_transpose, n, m, rows_per_part, &one, B, ldb,
-                                                     (rocblas_stride)rows_per_part * ldb, A, lda, (rocblas_stride)rows_per_part * lda, &zero, scratch, n,
-                                                     (rocblas_stride)m * n, parts);
+        const float one = 1.f, zero = 0.f;
+        s = rocblas_sgemm_strided_batched(h->rb, rocblas_operation_none, rocblas_operation_transpose, n, m, rows_per_part, &one, B, ldb,
+                                          (rocblas_stride)rows_per_part * ldb, A, lda, (rocblas_stride)rows_per_part * lda, &zero, scratch, n,
+                                          (rocblas_stride)m * n, parts);
 #else
-    rocblas_status s = ccsm_train::gemm_s3(h, true, false, m, n, rows_per_part, 1.f, A, lda, (long long)rows_per_part * lda, B, ldb,
-                                           (long long)rows_per_part * ldb, 0.f, scratch, n, (long long)m * n, parts);
+        s = rocblas_status_internal_error;
 #endif
+    }
     if (s != rocblas_status_success) return s;
     sum_partials_kernel<<<blocks((int64_t)m * n), 256, 0, st>>>(scratch, C, parts + extra, (int64_t)m * n);
     return rocblas_status_success;
@@ -524,7 +546,7 @@ ccsm_status join(ccsm_trainer* t) {
 
 ccsm_status forward_dir(ccsm_trainer* t, int M, int l, int d, const float* X, int in, bool train) {
     const float* P = t->params;
-    rocblas_handle blas = d == 0 ? t->blas : t->blas1;
+    blas_t blas = d == 0 ? t->blas : t->blas1;
     hipStream_t st = d == 0 ? t->stream : t->stream1;
     BLASCHK(rm_gemm(blas, false, true, T * M, G, in, 1.f, X, in, P + kOff.w_ih[l][d], in, 0.f, t->gi[d], G));
     if (!t->stepwise_for(M)) {     // all 21 steps in one launch (ccsm_train_seq.hip)
@@ -593,11 +615,13 @@ ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, bool have_la
 ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, const float* X, int in) {
     const float* P = t->params;
     float* Gd = t->grads;
-    rocblas_handle blas = d == 0 ? t->blas : t->blas1;
+    blas_t blas = d == 0 ? t->blas : t->blas1;
     hipStream_t st = d == 0 ? t->stream : t->stream1;
     float *dgi = t->dgi[d], *dgh = t->dgh[d], *carry = t->carry[d], *part = t->part[d];
     // timesteps per batched weight-gradient product: measured best 2 / 3 up to 1024 sites per step (6.98 vs 8.30 ms at 512), 4 / 3 above
-    const int sp20 = t->sp20 ? t->sp20 : (M <= 2048 ? 2 : 4), sp21 = t->sp21 ? t->sp21 : 3;
+    // (the library's own kernel: one timestep per partial product - 20 / 21 problems of (768 / 128) x (n / 128) workgroups fill the chip)
+    const bool own_atb = t->gctx[0].mode == 1;
+    const int sp20 = t->sp20 ? t->sp20 : own_atb ? 1 : (M <= 2048 ? 2 : 4), sp21 = t->sp21 ? t->sp21 : own_atb ? 1 : 3;
     float* cpart = t->cpart[d];
     if (!t->stepwise_bwd_for(M)) {     // all 21 steps in one launch (ccsm_train_seq.hip)
         gru_seq_bwd_kernel<<<(M + 31) / 32, 512, kSbLds, st>>>(dO + d * H, t->out[l] + d * H, t->h0 + (size_t)(2 * l + d) * M * H,
@@ -624,17 +648,23 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
             }
         }
     }
+    // one scan of this direction's gate gradients bounds every product that reads them (|dgh| <= |dgi| elementwise: dgh_n = r dgi_n)
+    unsigned* am = nullptr;
+    if (t->own_any()) {
+        am = t->amax_slot(d);
+        HIPCHK(ccsm_train::gemm_scan_amax(st, dgi, G, T * M, G, am));
+    }
     // weight gradients over all steps at once
     float* dWhh = Gd + kOff.w_hh[l][d];
     float* last = part + (size_t)((T - 1) / sp20) * G * H;      // the h0 step's product goes to the slot after the batched ones
     if (d == 0) {
-        BLASCHK(rm_gemm(blas, true, false, G, H, M, 1.f, dgh, G, t->h0 + (size_t)(2 * l) * M * H, H, 0.f, last, H));
-        BLASCHK(atb_split(blas, st, G, H, M * sp20, (T - 1) / sp20, dgh + (size_t)M * G, G, t->out[l], H2, part, 1, dWhh));
+        BLASCHK(rm_gemm(blas, true, false, G, H, M, 1.f, dgh, G, t->h0 + (size_t)(2 * l) * M * H, H, 0.f, last, H, true, am));
+        BLASCHK(atb_split(blas, st, G, H, M * sp20, (T - 1) / sp20, dgh + (size_t)M * G, G, t->out[l], H2, part, 1, dWhh, am));
     } else {
-        BLASCHK(rm_gemm(blas, true, false, G, H, M, 1.f, dgh + (size_t)(T - 1) * M * G, G, t->h0 + (size_t)(2 * l + 1) * M * H, H, 0.f, last, H));
-        BLASCHK(atb_split(blas, st, G, H, M * sp20, (T - 1) / sp20, dgh, G, t->out[l] + (size_t)M * H2 + H, H2, part, 1, dWhh));
+        BLASCHK(rm_gemm(blas, true, false, G, H, M, 1.f, dgh + (size_t)(T - 1) * M * G, G, t->h0 + (size_t)(2 * l + 1) * M * H, H, 0.f, last, H, true, am));
+        BLASCHK(atb_split(blas, st, G, H, M * sp20, (T - 1) / sp20, dgh, G, t->out[l] + (size_t)M * H2 + H, H2, part, 1, dWhh, am));
     }
-    BLASCHK(atb_split(blas, st, G, in, M * sp21, T / sp21, dgi, G, X, in, part, 0, Gd + kOff.w_ih[l][d]));
+    BLASCHK(atb_split(blas, st, G, in, M * sp21, T / sp21, dgi, G, X, in, part, 0, Gd + kOff.w_ih[l][d], am));
     if (t->stepwise_bwd_for(M)) {      // (the fused backward kernel has accumulated the bias gradients already)
         colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgi, Gd + kOff.b_ih[l][d], T * M, G);
         colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgh, Gd + kOff.b_hh[l][d], T * M, G);
@@ -660,11 +690,17 @@ ccsm_status backward(ccsm_trainer* t, int N, float rate) {
     att_dout_init_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(t->a, t->dc, dO, M);
     att_dpre_kernel<<<blocks((int64_t)T * M, 64), H, 0, st>>>(t->KS, t->e, P + kOff.va, Gd + kOff.va, T * M);   // KS <- dSpre
     att_dq_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(t->KS, t->dq, M);
-    { const int sp21 = t->sp21 ? t->sp21 : 3;
-      BLASCHK(atb_split(t->blas, st, H, H2, M * sp21, T / sp21, t->KS, H, O2, H2, t->part[0], 0, Gd + kOff.ua)); }
-    BLASCHK(rm_gemm(t->blas, false, false, T * M, H2, H, 1.f, t->KS, H, P + kOff.ua, H2, 1.f, dO, H2));
-    BLASCHK(rm_gemm(t->blas, true, false, H, H2, M, 1.f, t->dq, H, t->hn, H2, 0.f, Gd + kOff.wa, H2));
-    BLASCHK(rm_gemm(t->blas, false, false, M, H2, H, 1.f, t->dq, H, P + kOff.wa, H2, 0.f, t->dhn, H2));
+    unsigned *am_s = nullptr, *am_q = nullptr;
+    if (t->own_any()) {
+        am_s = t->amax_slot(2); am_q = t->amax_slot(3);
+        HIPCHK(ccsm_train::gemm_scan_amax(st, t->KS, H, T * M, H, am_s));
+        HIPCHK(ccsm_train::gemm_scan_amax(st, t->dq, H, M, H, am_q));
+    }
+    { const int sp21 = t->sp21 ? t->sp21 : t->gctx[0].mode == 1 ? 1 : 3;
+      BLASCHK(atb_split(t->blas, st, H, H2, M * sp21, T / sp21, t->KS, H, O2, H2, t->part[0], 0, Gd + kOff.ua, am_s)); }
+    BLASCHK(rm_gemm(t->blas, false, false, T * M, H2, H, 1.f, t->KS, H, P + kOff.ua, H2, 1.f, dO, H2, true, am_s));
+    BLASCHK(rm_gemm(t->blas, true, false, H, H2, M, 1.f, t->dq, H, t->hn, H2, 0.f, Gd + kOff.wa, H2, true, am_q));
+    BLASCHK(rm_gemm(t->blas, false, false, M, H2, H, 1.f, t->dq, H, P + kOff.wa, H2, 0.f, t->dhn, H2, true, am_q));
     scatter_dhn_kernel<<<blocks((int64_t)M * H2), 256, 0, st>>>(t->dhn, dO, M);
     // GRU layers, top down
     float* dX = t->dB;
@@ -680,7 +716,8 @@ ccsm_status backward(ccsm_trainer* t, int N, float rate) {
         s = join(t);
         if (s != CCSM_OK) return s;
         for (int d = 0; d < 2; ++d)
-            BLASCHK(rm_gemm(t->blas, false, false, T * M, in, G, 1.f, t->dgi[d], G, P + kOff.w_ih[l][d], in, d == 0 ? 0.f : 1.f, dX, in));
+            BLASCHK(rm_gemm(t->blas, false, false, T * M, in, G, 1.f, t->dgi[d], G, P + kOff.w_ih[l][d], in, d == 0 ? 0.f : 1.f, dX, in, true,
+                            t->own_any() ? t->amax_slot(d) : nullptr));
         if (l == 0) {
             embed_bwd_kernel<<<blocks((int64_t)T * M), 256, 0, st>>>(dX, t->kmer, Gd + kOff.embed, M);
         } else {
@@ -723,21 +760,31 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
     HIPCHK(hipStreamCreate(&t->stream1));
     HIPCHK(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    TRY(dalloc(&t->nrm_part, 1024 + 1 + 8));
+    {
+        int mode = 1;                                   // the library's own kernel
 #ifdef CCSM_TRAIN_WITH_ROCBLAS
-    if (rocblas_create_handle(&t->blas) != rocblas_status_success || rocblas_create_handle(&t->blas1) != rocblas_status_success) {
-        ccsm_train_destroy(t);
-        return fail(CCSM_ERR_HIP, "rocblas_create_handle failed");
-    }
-    rocblas_set_stream(t->blas, t->stream);
-    rocblas_set_stream(t->blas1, t->stream1);
-    rocblas_set_pointer_mode(t->blas, rocblas_pointer_mode_host);
-    rocblas_set_pointer_mode(t->blas1, rocblas_pointer_mode_host);
-#else
-    t->blas = t->stream;
-    t->blas1 = t->stream1;
-    HIPCHK(ccsm_train::gemm_s3_init());
+        const char* gm = std::getenv("CCSM_TRAIN_GEMM");
+        mode = gm && std::strcmp(gm, "mixed") == 0 ? 0 : gm && std::strcmp(gm, "rocblas") == 0 ? 2 : 1;
 #endif
-    TRY(dalloc(&t->nrm_part, 1024 + 1));
+        t->gctx[0] = GemmCtx{t->stream, reinterpret_cast<unsigned*>(t->nrm_part + 1025), nullptr, mode};
+        t->gctx[1] = GemmCtx{t->stream1, reinterpret_cast<unsigned*>(t->nrm_part + 1026), nullptr, mode};
+        t->blas = &t->gctx[0];
+        t->blas1 = &t->gctx[1];
+        HIPCHK(ccsm_train::gemm_s3_init());
+#ifdef CCSM_TRAIN_WITH_ROCBLAS
+        if (mode != 1) {
+            if (rocblas_create_handle(&t->gctx[0].rb) != rocblas_status_success || rocblas_create_handle(&t->gctx[1].rb) != rocblas_status_success) {
+                ccsm_train_destroy(t);
+                return fail(CCSM_ERR_HIP, "rocblas_create_handle failed");
+            }
+            rocblas_set_stream(t->gctx[0].rb, t->stream);
+            rocblas_set_stream(t->gctx[1].rb, t->stream1);
+            rocblas_set_pointer_mode(t->gctx[0].rb, rocblas_pointer_mode_host);
+            rocblas_set_pointer_mode(t->gctx[1].rb, rocblas_pointer_mode_host);
+        }
+#endif
+    }
     TRY(dalloc(&t->params, kOff.total));
     TRY(dalloc(&t->adam_m, kOff.total));
     TRY(dalloc(&t->adam_v, kOff.total));
@@ -819,8 +866,8 @@ void ccsm_train_destroy(ccsm_trainer* t) {
             for (int k = 0; k < 4; ++k) if (t->sav[l][d][k]) (void)hipFree(t->sav[l][d][k]);
     }
 #ifdef CCSM_TRAIN_WITH_ROCBLAS
-    if (t->blas) rocblas_destroy_handle(t->blas);
-    if (t->blas1) rocblas_destroy_handle(t->blas1);
+    for (int k = 0; k < 2; ++k)
+        if (t->gctx[k].rb) rocblas_destroy_handle(t->gctx[k].rb);
 #endif
     if (t->nrm_part) (void)hipFree(t->nrm_part);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
@@ -959,6 +1006,24 @@ ccsm_status ccsm_train_set_params(ccsm_trainer* t, const float* host_flat) {
     return CCSM_OK;
 }
 long ccsm_train_fused_fallbacks(const ccsm_trainer* t) { return t ? t->fused_fallbacks : 0; }
+
+ccsm_status ccsm_train_selftest_gemm(int device, int t_a, int t_b, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                                     int ldb, float beta, float* C, int ldc, int grad_a) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0) return fail(CCSM_ERR_INVALID_ARG, "selftest_gemm: bad arguments");
+    HIPCHK(hipSetDevice(device));
+    const size_t na = (size_t)(t_a ? K : M) * lda, nb = (size_t)(t_b ? N : K) * ldb, nc = (size_t)M * ldc;
+    float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    unsigned* amax = nullptr;
+    HIPCHK(hipMalloc(&dA, na * 4)); HIPCHK(hipMalloc(&dB, nb * 4)); HIPCHK(hipMalloc(&dC, nc * 4)); HIPCHK(hipMalloc(&amax, 4));
+    HIPCHK(hipMemcpy(dA, A, na * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dB, B, nb * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dC, C, nc * 4, hipMemcpyHostToDevice));
+    HIPCHK(ccsm_train::gemm_s3_init());
+    HIPCHK(ccsm_train::gemm_s3(nullptr, t_a != 0, t_b != 0, M, N, K, alpha, dA, lda, 0, dB, ldb, 0, beta, dC, ldc, 0, 1, grad_a ? amax : nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(C, dC, nc * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(amax);
+    return CCSM_OK;
+}
 
 ccsm_status ccsm_train_get_grads(ccsm_trainer* t, float* host_flat) {
     if (!t || !host_flat) return fail(CCSM_ERR_INVALID_ARG, "NULL argument");

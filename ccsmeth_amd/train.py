@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCSM_TRAIN_LIB_PATH") or os.path.join(_HERE, "lib", "libccsm_train.so")   # the variable: A/B builds (tools/)
 EXPORTS = ("ccsm_train_last_error", "ccsm_train_num_params", "ccsm_train_param_offsets", "ccsm_train_create", "ccsm_train_destroy",
            "ccsm_train_forward_backward", "ccsm_train_eval", "ccsm_train_step", "ccsm_train_grad_ptr", "ccsm_train_get_params",
-           "ccsm_train_set_params", "ccsm_train_get_grads", "ccsm_train_fused_fallbacks")
+           "ccsm_train_set_params", "ccsm_train_get_grads", "ccsm_train_fused_fallbacks", "ccsm_train_selftest_gemm")
 
 PARAM_NAMES = ["embed.weight"] + [f"rnn.{k}_l{l}{sfx}" for l in range(3) for sfx in ("", "_reverse")
                                   for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] + \
@@ -63,6 +63,7 @@ def load():
     lib.ccsm_train_get_grads.argtypes = [vp, vp]
     lib.ccsm_train_fused_fallbacks.argtypes = [vp]
     lib.ccsm_train_fused_fallbacks.restype = C.c_long
+    lib.ccsm_train_selftest_gemm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, C.c_int, C.c_float, vp, C.c_int, C.c_int]
     _tl = lib
     return lib
 
@@ -223,3 +224,18 @@ class Trainer:
         flat = np.concatenate([_f32(sd[k]).ravel() for k in PARAM_NAMES])
         assert flat.size == self.num_params
         _check(self._lib.ccsm_train_set_params(self.handle, flat.ctypes.data))
+
+
+def selftest_gemm(a, b, c=None, t_a=False, t_b=False, alpha=1.0, beta=0.0, grad_a=False, device=0):
+    """C = alpha op(A) op(B) + beta C through the training library's matrix-product kernel (include/ccsm_train.h); a, b: 2-D float32 arrays
+    as STORED (t_a: a is K x M; t_b: b is N x K), possibly non-contiguous views along the first axis (their row stride is passed)."""
+    lib = load()
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.dtype == np.float32 and b.dtype == np.float32 and a.strides[1] == 4 and b.strides[1] == 4
+    M, K = (a.shape[1], a.shape[0]) if t_a else a.shape
+    N = b.shape[0] if t_b else b.shape[1]
+    assert (b.shape[1] if t_b else b.shape[0]) == K
+    out = np.zeros((M, N), np.float32) if c is None else np.ascontiguousarray(c, np.float32).copy()
+    _check(lib.ccsm_train_selftest_gemm(int(device), int(t_a), int(t_b), M, N, K, float(alpha), a.ctypes.data, a.strides[0] // 4, b.ctypes.data,
+                                        b.strides[0] // 4, float(beta), out.ctypes.data, N, int(grad_a)))
+    return out

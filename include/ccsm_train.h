@@ -8,7 +8,8 @@
  * caller may supply it, e.g. the storage of a torch tensor) that is all-reduced over RCCL between
  * ccsm_train_forward_backward and ccsm_train_step.
  *
- * Arithmetic: fp32 throughout (rocBLAS SGEMM for the dense products, hand-written HIP kernels for everything else); the two
+ * Arithmetic: fp32 values throughout; every matrix product - the fused recurrent kernels and the plain ones (ccsm_train_gemm.hip) - runs on
+ * the matrix cores with fp16 hi + lo split operands (three passes, fp32 accumulation: fp32-class), hand-written; no BLAS library; the two
  * strands run as one batch of 2N rows through the shared GRU / attention weights, so their gradient contributions add up in
  * the same products.  Parameters, gradients and Adam moments are flat fp32 arrays in the order of model.parameters()
  * (= the state_dict order of SURVEY.md 8 a-4): embed.weight, then for l, sfx: weight_ih, weight_hh, bias_ih, bias_hh, then
@@ -59,6 +60,11 @@ ccsm_status ccsm_train_step(ccsm_trainer* t, float lr, float beta1, float beta2,
  * |gradient| = 14.6; a step in which one exceeds that (a sum-reduced loss, an extreme pos_weight) is detected on the device and its
  * backward pass is repeated step by step in fp32 before ccsm_train_forward_backward returns.  How often that has happened: */
 long ccsm_train_fused_fallbacks(const ccsm_trainer* t);
+/* Self-test of the training step's matrix-product kernel (ccsm_train_gemm.hip; the products torch autograd runs on a BLAS library
+ * inside train_multigpu.py:283-312): C (M x N, ldc) = alpha op(A) op(B) + beta C on `device`, HOST pointers, row-major storage; t_a: A
+ * is stored K x M; t_b: B is stored N x K; grad_a: treat A as a gradient operand (scaled into fp16's range by its maximum). */
+ccsm_status ccsm_train_selftest_gemm(int device, int t_a, int t_b, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+                                     int ldb, float beta, float* C, int ldc, int grad_a);
 
 /* Flat buffers: device pointer of the gradients (for the caller's all-reduce), and host copies in / out. */
 ccsm_status ccsm_train_grad_ptr(ccsm_trainer* t, float** d_grads);

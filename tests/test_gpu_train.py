@@ -346,3 +346,27 @@ def test_whole_chain_bam_extract_trainm_call_mods(tmp_path):
             ml = np.concatenate([r.get_tag("ML") for r in rd if r.has_tag("ML")])
         means.append(float(ml.mean()))
     assert means[1] > means[0] + 100, means                     # ML bytes: the trained model separates the two classes
+
+
+@pytest.mark.parametrize("t_a,t_b", [(False, True), (False, False), (True, False), (True, True)])
+def test_training_gemm_kernel_against_float64(t_a, t_b):
+    """The matrix-product kernel of the training step (ccsm_train_gemm.hip: three-pass split-fp16 MFMA, fp32 in / out) in its four storage
+    forms against NumPy float64: ragged shapes (K = 11 as in layer 0; M, N not multiples of the 128 x 128 tile), padded row strides,
+    alpha / beta, and a GRADIENT-sized operand (1e-7: far below fp16's normal range; scaled by its maximum inside the library).
+    Tolerance: 2^-20 of the product of the operands' magnitudes times sqrt(K) - fp32-class."""
+    from ccsmeth_amd.train import selftest_gemm
+    rng = np.random.default_rng(12)
+    for (M, N, K, pad, mag, grad) in ((200, 768, 11, 0, 1.0, False), (257, 130, 513, 3, 1.0, False), (96, 40, 2100, 0, 1.0, False),
+                                      (300, 512, 768, 0, 1e-7, True), (64, 11, 8400, 5, 3e-6, True)):
+        a_log = (rng.standard_normal((M, K)) * mag).astype(np.float32)          # op(A): M x K
+        b_log = (rng.standard_normal((K, N)) * 0.1).astype(np.float32)          # op(B): K x N
+        a_st = np.ascontiguousarray(a_log.T if t_a else a_log)
+        b_st = np.ascontiguousarray(b_log.T if t_b else b_log)
+        if pad:                                                                  # views with a row stride larger than the row
+            big = np.zeros((a_st.shape[0], a_st.shape[1] + pad), np.float32); big[:, :a_st.shape[1]] = a_st; a_st = big[:, :a_st.shape[1]]
+            big = np.zeros((b_st.shape[0], b_st.shape[1] + pad), np.float32); big[:, :b_st.shape[1]] = b_st; b_st = big[:, :b_st.shape[1]]
+        c0 = rng.standard_normal((M, N)).astype(np.float32) * mag
+        got = selftest_gemm(a_st, b_st, c0, t_a=t_a, t_b=t_b, alpha=0.5, beta=2.0, grad_a=grad)
+        want = 0.5 * (a_log.astype(np.float64) @ b_log.astype(np.float64)) + 2.0 * c0.astype(np.float64)
+        tol = 2.0 ** -20 * mag * 0.1 * np.sqrt(K) * 4 + 2.0 ** -22 * np.abs(want).max()
+        assert np.abs(got - want).max() <= tol, (t_a, t_b, M, N, K, float(np.abs(got - want).max()), tol)
