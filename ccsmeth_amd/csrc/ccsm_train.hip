@@ -250,8 +250,9 @@ __global__ void att_dscore_kernel(const float* a, float* da, int M) {
     for (int t = 0; t < T; ++t) s += a[(size_t)t * M + m] * da[(size_t)t * M + m];
     for (int t = 0; t < T; ++t) da[(size_t)t * M + m] = a[(size_t)t * M + m] * (da[(size_t)t * M + m] - s);
 }
-// dSpre[t][m][j] = de[t][m] va[j] (1 - S^2) in place of S; dva[j] += sum de S; dout2[t][m][k] = a[t][m] dc[m][k]
-__global__ void att_dpre_kernel(float* S, const float* de, const float* va, float* dva, int rows) {
+// dSpre[t][m][j] = de[t][m] va[j] (1 - S^2) in place of S; dva_part[block][j] = sum over the block's 64 rows of de S (added up in block
+// order by sum_partials_kernel: no float atomics anywhere in the step since round 4); dout2[t][m][k] = a[t][m] dc[m][k]
+__global__ void att_dpre_kernel(float* S, const float* de, const float* va, float* dva_part, int rows) {
     const int j = threadIdx.x;                       // blockDim.x == H
     const int r0 = blockIdx.x * 64, r1 = min(rows, r0 + 64);
     float acc = 0.f;
@@ -261,7 +262,7 @@ __global__ void att_dpre_kernel(float* S, const float* de, const float* va, floa
         acc += d * s;
         S[(size_t)r * H + j] = d * v * (1.0f - s * s);
     }
-    atomicAdd(dva + j, acc);
+    dva_part[(size_t)blockIdx.x * H + j] = acc;
 }
 __global__ void att_dq_kernel(const float* dS, float* dq, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,7 +283,7 @@ __global__ void att_dout_init_kernel(const float* a, const float* dc, float* dou
 // feat[n] = [c[n] | c[N + n]] (dropout1 applied when rate > 0); logits = feat fc^T + b; p = softmax; weighted CE
 //   loss_sum += w_y * -log p_y ; dlogits[n][c] = w_y (p_c - [c == y]) / wsum            (models.py:145-150, train_multigpu.py:212-214)
 __global__ void fc_loss_kernel(const float* c, const float* fcw, const float* fcb, const int32_t* labels, const Ctl* ctl, float rate,
-                               float* feat, float* logits, float* dlogits, float* loss_sum, int N) {
+                               float* feat, float* logits, float* dlogits, float* loss_site, int N) {
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
@@ -306,7 +307,7 @@ __global__ void fc_loss_kernel(const float* c, const float* fcw, const float* fc
             const float lse = mx + __logf(__expf(a0 - mx) + __expf(a1 - mx));
             const int y = labels[n] != 0;
             const float w = y ? pos_weight : 1.0f;
-            atomicAdd(loss_sum, w * (lse - (y ? a1 : a0)));
+            loss_site[n] = w * (lse - (y ? a1 : a0));         // added up in site order by sum_fixed_kernel
             if (dlogits != nullptr) {
                 dlogits[2 * n] = w * (__expf(a0 - lse) - (y ? 0.f : 1.f)) / wsum;
                 dlogits[2 * n + 1] = w * (__expf(a1 - lse) - (y ? 1.f : 0.f)) / wsum;
@@ -330,33 +331,55 @@ __global__ void fc_bwd_kernel(const float* dlogits, const float* fcw, float rate
     const int m = k < H2 ? n : N + n;
     dc[(size_t)m * H2 + (k % H2)] = g;
 }
-// dembed[kmer[m][t]][e] += dx0[t][m][e]
-__global__ void embed_bwd_kernel(const float* dx0, const uint8_t* kmer, float* dembed, int M) {
-    __shared__ float part[NV * NE];
-    if (threadIdx.x < NV * NE) part[threadIdx.x] = 0.f;
-    __syncthreads();
+// dembed_part[block][code][e] = sum over the block's 256 (t, m) entries with kmer[m][t] == code of dx0[t][m][e], each bin added up in
+// entry order by one thread (fixed order); sum_partials_kernel adds the blocks
+__global__ void embed_bwd_kernel(const float* dx0, const uint8_t* kmer, float* dembed_part, int M) {
+    __shared__ float val[256][NE];
+    __shared__ int code[256];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = -1;
     if (i < T * M) {
         const int t = i / M, m = i % M;
-        int b = kmer[m * T + t];
+        b = kmer[m * T + t];
         b = b > 4 ? 4 : b;
 #pragma unroll
-        for (int e = 0; e < NE; ++e) atomicAdd(&part[b * NE + e], dx0[(size_t)i * F0 + e]);
+        for (int e = 0; e < NE; ++e) val[threadIdx.x][e] = dx0[(size_t)i * F0 + e];
     }
+    code[threadIdx.x] = b;
     __syncthreads();
-    if (threadIdx.x < NV * NE) atomicAdd(dembed + threadIdx.x, part[threadIdx.x]);
+    if (threadIdx.x < NV * NE) {
+        const int bb = threadIdx.x / NE, e = threadIdx.x % NE;
+        float acc = 0.f;
+        for (int k = 0; k < 256; ++k)
+            if (code[k] == bb) acc += val[k][e];
+        dembed_part[(size_t)blockIdx.x * NV * NE + threadIdx.x] = acc;
+    }
 }
-// out[c] += sum over rows of a[r][c]  (bias gradients: column sums of the (T*M, 768) gate-gradient blocks); out pre-zeroed
-__global__ void colsum_kernel(const float* a, float* out, int rows, int cols) {
+// part[block][c] = sum over the block's 32 rows of a[r][c]  (bias gradients: column sums of the (T*M, 768) gate-gradient blocks; the blocks
+// are added up in order by sum_partials_kernel)
+__global__ void colsum_kernel(const float* a, float* part, int rows, int cols) {
     const int r0 = blockIdx.x * 32, r1 = min(rows, r0 + 32);
     for (int c = threadIdx.x; c < cols; c += blockDim.x) {
         float acc = 0.f;
 #pragma unroll 8
         for (int r = r0; r < r1; ++r) acc += a[(size_t)r * cols + c];
-        atomicAdd(out + c, acc);
+        part[(size_t)blockIdx.x * cols + c] = acc;
     }
 }
-// out[i] = sum_k part[k][i]   (the per-timestep partial products of a weight gradient)
+// out[0] = sum of x[0 .. n) in a fixed order (one block: strided partial sums, then a tree)
+__global__ void sum_fixed_kernel(const float* x, int n, float* out) {
+    __shared__ float s[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+// out[i] = sum_k part[k][i]   (the per-timestep partial products of a weight gradient; the per-block partial sums of the reductions above)
 __global__ void sum_partials_kernel(const float* part, float* out, int parts, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -408,6 +431,7 @@ struct ccsm_trainer {
           *carry[2] = {nullptr, nullptr}, *cpart[2] = {nullptr, nullptr};            // per direction
     float *hn = nullptr, *q = nullptr, *KS = nullptr, *e = nullptr, *a = nullptr, *c = nullptr, *feat = nullptr, *logits = nullptr,
           *dlogits = nullptr, *loss = nullptr;
+    float* red[2] = {nullptr, nullptr};               // per stream: per-block partial sums of the step's reductions (added up in a fixed order)
     float *dc = nullptr, *dq = nullptr, *dhn = nullptr, *dA = nullptr, *dB = nullptr;   // dA / dB: (T, M, 512) gradient ping-pong
     float* part[2] = {nullptr, nullptr};               // per direction: (T, 768, 512) per-timestep partial weight gradients
     std::vector<uint8_t> h_kmer;
@@ -607,7 +631,8 @@ ccsm_status forward(ccsm_trainer* t, int N, bool train, float rate, bool have_la
     att_context_kernel<<<blocks((int64_t)M * H2), 256, 0, st>>>(t->a, O2, t->c, M);
     HIPCHK(hipMemsetAsync(t->loss, 0, 2 * sizeof(float), st));      // [loss sum | saturation flag of the fused backward kernels]
     fc_loss_kernel<<<blocks(N, 4), 256, 0, st>>>(t->c, P + kOff.fcw, P + kOff.fcb, have_labels ? t->labels : nullptr, t->ctl,
-                                                 drop ? rate : 0.f, t->feat, t->logits, train ? t->dlogits : nullptr, t->loss, N);
+                                                 drop ? rate : 0.f, t->feat, t->logits, train ? t->dlogits : nullptr, t->red[0], N);
+    if (have_labels) sum_fixed_kernel<<<1, 256, 0, st>>>(t->red[0], N, t->loss);
     HIPCHK(hipGetLastError());
     return CCSM_OK;
 }
@@ -626,8 +651,9 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
     if (!t->stepwise_bwd_for(M)) {     // all 21 steps in one launch (ccsm_train_seq.hip)
         gru_seq_bwd_kernel<<<(M + 31) / 32, 512, kSbLds, st>>>(dO + d * H, t->out[l] + d * H, t->h0 + (size_t)(2 * l + d) * M * H,
                                                                t->whh_t_frag + (size_t)(2 * l + d) * kSqFragPerDir, t->sav[l][d][0], t->sav[l][d][1],
-                                                               t->sav[l][d][2], t->sav[l][d][3], dgi, dgh, Gd + kOff.b_ih[l][d], Gd + kOff.b_hh[l][d], M, d,
+                                                               t->sav[l][d][2], t->sav[l][d][3], dgi, dgh, t->red[d], M, d,
                                                                reinterpret_cast<int*>(t->loss + 1));
+        seq_bias_reduce_kernel<<<blocks(4 * H), 256, 0, st>>>(t->red[d], (M + 31) / 32, Gd + kOff.b_ih[l][d], Gd + kOff.b_hh[l][d]);
         HIPCHK(hipGetLastError());
     } else {
         HIPCHK(hipMemsetAsync(carry, 0, sizeof(float) * (size_t)M * H, st));
@@ -666,8 +692,11 @@ ccsm_status backward_dir(ccsm_trainer* t, int M, int l, int d, const float* dO, 
     }
     BLASCHK(atb_split(blas, st, G, in, M * sp21, T / sp21, dgi, G, X, in, part, 0, Gd + kOff.w_ih[l][d], am));
     if (t->stepwise_bwd_for(M)) {      // (the fused backward kernel has accumulated the bias gradients already)
-        colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgi, Gd + kOff.b_ih[l][d], T * M, G);
-        colsum_kernel<<<blocks((int64_t)T * M, 32), 256, 0, st>>>(dgh, Gd + kOff.b_hh[l][d], T * M, G);
+        const int nb = (int)blocks((int64_t)T * M, 32).x;
+        colsum_kernel<<<nb, 256, 0, st>>>(dgi, t->red[d], T * M, G);
+        sum_partials_kernel<<<blocks(G), 256, 0, st>>>(t->red[d], Gd + kOff.b_ih[l][d], nb, G);
+        colsum_kernel<<<nb, 256, 0, st>>>(dgh, t->red[d], T * M, G);
+        sum_partials_kernel<<<blocks(G), 256, 0, st>>>(t->red[d], Gd + kOff.b_hh[l][d], nb, G);
     }
     return CCSM_OK;
 }
@@ -688,7 +717,8 @@ ccsm_status backward(ccsm_trainer* t, int N, float rate) {
     att_dalpha_kernel<<<blocks((int64_t)T * M, 4), 256, 0, st>>>(t->dc, O2, t->e, M);        // e <- da
     att_dscore_kernel<<<blocks(M), 256, 0, st>>>(t->a, t->e, M);                             // e <- de
     att_dout_init_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(t->a, t->dc, dO, M);
-    att_dpre_kernel<<<blocks((int64_t)T * M, 64), H, 0, st>>>(t->KS, t->e, P + kOff.va, Gd + kOff.va, T * M);   // KS <- dSpre
+    att_dpre_kernel<<<blocks((int64_t)T * M, 64), H, 0, st>>>(t->KS, t->e, P + kOff.va, t->red[0], T * M);   // KS <- dSpre
+    sum_partials_kernel<<<blocks(H), 256, 0, st>>>(t->red[0], Gd + kOff.va, (int)blocks((int64_t)T * M, 64).x, H);
     att_dq_kernel<<<blocks((int64_t)M * H), 256, 0, st>>>(t->KS, t->dq, M);
     unsigned *am_s = nullptr, *am_q = nullptr;
     if (t->own_any()) {
@@ -719,7 +749,8 @@ ccsm_status backward(ccsm_trainer* t, int N, float rate) {
             BLASCHK(rm_gemm(t->blas, false, false, T * M, in, G, 1.f, t->dgi[d], G, P + kOff.w_ih[l][d], in, d == 0 ? 0.f : 1.f, dX, in, true,
                             t->own_any() ? t->amax_slot(d) : nullptr));
         if (l == 0) {
-            embed_bwd_kernel<<<blocks((int64_t)T * M), 256, 0, st>>>(dX, t->kmer, Gd + kOff.embed, M);
+            embed_bwd_kernel<<<blocks((int64_t)T * M), 256, 0, st>>>(dX, t->kmer, t->red[0], M);
+            sum_partials_kernel<<<1, 256, 0, st>>>(t->red[0], Gd + kOff.embed, (int)blocks((int64_t)T * M).x, NV * NE);
         } else {
             if (drop) dropout_kernel<<<blocks((int64_t)T * M * H2), 256, 0, st>>>(dX, dX, (int64_t)T * M * H2, rate, t->ctl, 0xd0 + (l - 1));
             float* tmp = dO; dO = dX; dX = tmp;
@@ -806,6 +837,7 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
         TRY(dalloc(&t->gi[d], T * M * G + 32 * G));     // + 32 rows of slack: gru_seq_fwd_kernel reads whole 32-row tiles
         TRY(dalloc(&t->gh[d], M * G)); TRY(dalloc(&t->dgi[d], T * M * G)); TRY(dalloc(&t->dgh[d], T * M * G));
         TRY(dalloc(&t->carry[d], M * H)); TRY(dalloc(&t->cpart[d], 3 * M * H)); TRY(dalloc(&t->part[d], (size_t)T * G * H2));
+        TRY(dalloc(&t->red[d], ((size_t)T * M / 32 + 2) * G));        // the largest user: colsum_kernel, 32 rows per block x 768 columns
     }
     TRY(dalloc(&t->hn, M * H2)); TRY(dalloc(&t->q, M * H)); TRY(dalloc(&t->KS, T * M * H)); TRY(dalloc(&t->e, T * M)); TRY(dalloc(&t->a, T * M));
     TRY(dalloc(&t->c, M * H2)); TRY(dalloc(&t->feat, (size_t)max_sites * 2 * H2)); TRY(dalloc(&t->logits, (size_t)max_sites * NC));
@@ -853,6 +885,7 @@ void ccsm_train_destroy(ccsm_trainer* t) {
     float* fl[] = {t->params, t->adam_m, t->adam_v, t->own_grads ? t->grads : nullptr, t->ipd, t->pw, t->npass, t->h0, t->x0, t->gi[0], t->gi[1], t->gh[0], t->gh[1], t->dgi[0],
                    t->dgi[1], t->dgh[0], t->dgh[1], t->carry[0], t->carry[1], t->cpart[0], t->cpart[1], t->part[0], t->part[1], t->hn, t->q, t->KS, t->e, t->a, t->c, t->feat, t->logits, t->dlogits, t->loss, t->dc, t->dq, t->dhn, t->dA, t->dB};
     for (float* p : fl) if (p) (void)hipFree(p);
+    for (int d = 0; d < 2; ++d) if (t->red[d]) (void)hipFree(t->red[d]);
     for (auto& c : t->graphs) if (c.exec) (void)hipGraphExecDestroy(c.exec);
     if (t->ctl) (void)hipFree(t->ctl);
     if (t->whh_frag) (void)hipFree(t->whh_frag);

@@ -215,8 +215,8 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
                                                             const float* __restrict__ h0, const uint4* __restrict__ wt,
                                                             const float* __restrict__ R, const float* __restrict__ Z,
                                                             const float* __restrict__ Nn, const float* __restrict__ HP,
-                                                            float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ db_ih,
-                                                            float* __restrict__ db_hh, int M, int reverse, int* __restrict__ saturated) {
+                                                            float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ db_part,
+                                                            int M, int reverse, int* __restrict__ saturated) {
     extern __shared__ __attribute__((aligned(16))) _Float16 sb_lds[];
     _Float16* t_hi = sb_lds;
     _Float16* t_lo = sb_lds + 32 * kSbRowHalfs;
@@ -335,10 +335,22 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
         for (int r = 0; r < 16; ++r) mm[r] = acc[r] * (1.0f / kSbScale);
         __syncthreads();                                            // every wave has read the tile before the next step overwrites it
     }
-    // bias gradients (pre-zeroed by the caller): both half-waves hold the same unit
+    // bias gradients: this workgroup's sums of its 32 rows, [workgroup][dr | dz | dn | dn r][unit]; seq_bias_reduce_kernel adds the
+    // workgroups in a fixed order (no float atomics: the same gradients every run).  Both half-waves hold the same unit.
     s_dr += __shfl_xor(s_dr, 32, 64); s_dz += __shfl_xor(s_dz, 32, 64); s_dn += __shfl_xor(s_dn, 32, 64); s_dnr += __shfl_xor(s_dnr, 32, 64);
     if (hh == 0) {
-        atomicAdd(db_ih + u, s_dr); atomicAdd(db_ih + H + u, s_dz); atomicAdd(db_ih + 2 * H + u, s_dn);
-        atomicAdd(db_hh + u, s_dr); atomicAdd(db_hh + H + u, s_dz); atomicAdd(db_hh + 2 * H + u, s_dnr);
+        float* p = db_part + (size_t)blockIdx.x * 4 * H + u;
+        p[0] = s_dr; p[H] = s_dz; p[2 * H] = s_dn; p[3 * H] = s_dnr;
     }
+}
+// db_ih = [sum dr | sum dz | sum dn], db_hh = [sum dr | sum dz | sum dn r] over the workgroups of gru_seq_bwd_kernel, in workgroup order
+__global__ void seq_bias_reduce_kernel(const float* __restrict__ part, int nwg, float* __restrict__ db_ih, float* __restrict__ db_hh) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;           // 4 H values
+    if (i >= 4 * H) return;
+    float acc = 0.f;
+    for (int w = 0; w < nwg; ++w) acc += part[(size_t)w * 4 * H + i];
+    const int k = i / H, u = i - k * H;
+    if (k < 3) db_ih[k * H + u] = acc;
+    if (k < 2) db_hh[k * H + u] = acc;
+    if (k == 3) db_hh[2 * H + u] = acc;
 }

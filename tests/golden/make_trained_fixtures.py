@@ -1,7 +1,9 @@
 """Recipe of tests/golden/trained/*.npz: attbigru2s checkpoints TRAINED with libccsm_train on an MI355X (the reference ships none:
 /root/reference/.MISSING_LARGE_BLOBS; shapes models.py:32-61), committed as data so that every run of the suite sees the SAME weights -
-the trainer's reductions use float atomics, so re-training from the same seed gives a slightly different checkpoint every time, and the
-per-site error tail of the block-scaled arithmetics depends on exactly those weights.
+when they were made the trainer's reductions used float atomics, so re-training from the same seed gave a slightly different checkpoint every
+time, and the per-site error tail of the block-scaled arithmetics depends on exactly those weights.  Since the end of
+round 4 the training step is bit-reproducible (tests/test_gpu_train.py::test_training_is_bit_reproducible): this recipe now yields the same
+files every run - other ones than the committed three, which stay what the tests pin.
   toy41_960               the one-feature toy label of the early tests (ipd1[10] + ipd2[10] > 0), 960 steps
   planted7_5000           the planted-signal label of synth.synth_labeled_sites (IPD / PW shift at window positions 8..12 of both strands,
                           log-normal amplitude, sequence context, 4 % label noise), 5000 steps, dropout 0.5, lr 1e-3
