@@ -589,7 +589,11 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
             constexpr int NBF = decltype(nbc)::value;
             if (l == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, true, false, NBF, true>), ggrid, dim3(512), mx0_lds(NBF), st, in, out_, m->wstf3[0], m->bias[0],
                                            ws->h0buf, ws->rows_p, nullptr);
-            else hipLaunchKernelGGL((gru_layer12_f3_kernel<NBF>), ggrid, dim3(512), f3_lds(NBF), st, in, out_, m->wstf3[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p);
+#ifdef CCSM_PHASE_STAMPS
+            else if (NBF == 3 && ws->dbg && l == (dbg_layer == 2 ? 2 : 1))
+                hipLaunchKernelGGL((gru_layer12_f3_kernel<3, true>), ggrid, dim3(512), f3_lds(3), st, in, out_, m->wstf3[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, ws->dbg);
+#endif
+            else hipLaunchKernelGGL((gru_layer12_f3_kernel<NBF>), ggrid, dim3(512), f3_lds(NBF), st, in, out_, m->wstf3[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
         };
         auto all = [&](auto nbc) -> ccsm_status {
             layer(nbc, 0, ws->x0, ws->act[0]);
@@ -915,6 +919,9 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<3>), f3_lds(3));
         set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<2>), f3_lds(2));
         set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<1>), f3_lds(1));
+#ifdef CCSM_PHASE_STAMPS
+        set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<3, true>), f3_lds(3));
+#endif
         if (prec >= CCSM_PRECISION_SPLIT_F8) {
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false>), kMx12Lds);

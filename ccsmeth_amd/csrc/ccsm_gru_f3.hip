@@ -7,7 +7,7 @@
 // (profiles/r02_i_phases_product_kernels.log) say where that kernel loses its time: its phase B (recurrent part, weights only) runs at
 // the MFMA rate, its phases A and C (input part: weights from L2 AND x_t from HBM through the CU's one vector-memory path, 55-74 B/clk
 // wanted of 64) at 59 % and 37 % of it.  With three fp16 passes per product the same bytes feed twice the MFMAs, so the phases that are
-// memory-path-bound in split-mx are MFMA-bound here: this kernel is that schedule - four-slot LDS-DMA ring for x_t, one barrier per
+// memory-path-bound in split-mx are MFMA-bound here: this kernel is that schedule - LDS-DMA ring for x_t (five slots here), one barrier per
 // pair of k-blocks, counted s_waitcnt, weights straight from L2 into registers one to two pairs ahead - with
 //     W x = W_hi x_hi + W_lo x_hi + W_hi x_lo        (all on v_mfma_f32_32x32x16_f16, fp32 accumulation; the state as fp16 hi + lo)
 // per k-block, the third product of a pair issued behind the pair's barrier (where split-mx has its correction product).
@@ -17,7 +17,7 @@
 //                 phase-A pair (r, z) : hi (kbl, g) at (2 kbl + g) KiB | lo (kbl, g) at (4 + 2 kbl + g) KiB                = 8 KiB  x 16
 //                 phase-B pair (r,z,n): hi (kbl, g) at (3 kbl + g) KiB | lo (kbl, g) at (6 + 3 kbl + g) KiB  (= the hybrid) = 12 KiB x 8
 //                 phase-C pair (n)    : hi (kbl) at kbl KiB | lo (kbl) at (2 + kbl) KiB, pairs in zig-zag order            = 4 KiB  x 16
-//   LDS       : h fragments [kb 16][bt NB][hi | lo] 32 NB KiB | x ring 4 x [kbl 2][bt NB][hi | lo] 4 NB KiB | biases 4 KiB  = 148 KiB at NB = 3
+//   LDS       : h fragments [kb 16][bt NB][hi | lo] 32 NB KiB | x ring RS x [kbl 2][bt NB][hi | lo] 4 NB KiB | biases 4 KiB  = 160 KiB at NB = 3, RS = 5
 // Vector-memory operations of a wave per pair (they set the counted waits; a wave's operations retire in order):
 //   phase A: 4 requests before the pair's barrier (the lo fragments of the slot's next pair), d transfer instructions and 4 requests
 //            (its hi fragments) behind it; phase C: 2 + d + 2; d = 2 for the waves that move two fragments of a ring slot, 1 for the others.
@@ -29,7 +29,10 @@ constexpr int kF3PairA = 8 * 1024, kF3PairB = 12 * 1024, kF3PairC = 4 * 1024;
 constexpr int kF3OffB = (kKB12 / 2) * kF3PairA;
 constexpr int kF3OffC = kF3OffB + (kKBH / 2) * kF3PairB;
 constexpr int kF3WBytes = kF3OffC + (kKB12 / 2) * kF3PairC;          // 288 KiB per (direction, wave)
-constexpr int kF3RS = 4;
+#ifndef CCSM_F3_RING
+#define CCSM_F3_RING 5               // ring slots of x_t: the kernel's LDS has room for five at 96 rows (96 + 5 x 12 + 4 = 160 KiB); -DCCSM_F3_RING=4: A/B
+#endif
+constexpr int kF3RS = CCSM_F3_RING;
 constexpr int f3_xoff(int nb) { return mx_hbytes(nb); }
 constexpr int f3_biasoff(int nb) { return f3_xoff(nb) + kF3RS * mx_slot_bytes(nb); }
 constexpr int f3_lds(int nb) { return f3_biasoff(nb) + kWaves * 4 * 32 * 4; }
@@ -39,9 +42,11 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 #define CCSM_FENCE asm volatile("" ::: "memory")
 
-template <int NB_ = kMxNB>
+// DBG (only instantiated in a -DCCSM_PHASE_STAMPS build): workgroup 0 records the cycle counter at step start / behind phase A / B / C / the tail
+template <int NB_ = kMxNB, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void gru_layer12_f3_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out, const uint4* __restrict__ wst,
-                                                                 const float* __restrict__ bias, const float* __restrict__ h0, int rows_p) {
+                                                                 const float* __restrict__ bias, const float* __restrict__ h0, int rows_p,
+                                                                 unsigned long long* __restrict__ dbg = nullptr) {
     constexpr int NB = NB_, KX = kKB12, NPAIR = KX / 2, RS = kF3RS, SLOT_BYTES = mx_slot_bytes(NB);
     constexpr int X_OFF = f3_xoff(NB), BIAS_OFF = f3_biasoff(NB);
     constexpr int PA = kF3PairA, PB = kF3PairB, PC = kF3PairC, OFF_B = kF3OffB, OFF_C = kF3OffC;
@@ -116,6 +121,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3_kernel(const uint4* __r
     int slot = 0;                                                   // ring slot of the next consumption (wave-uniform)
     for (int s = 0; s < kSeqLen; ++s) {
         const int t = dir ? (kSeqLen - 1 - s) : s;
+        auto stamp = [&](int k) {
+            if constexpr (DBG) {
+                if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[(s * kWaves + wave) * 5 + k] = __builtin_readcyclecounter();
+            }
+        };
+        stamp(0);
         f32x16 acc[3][NB];                                          // R, Z, N
         auto lane16_here = [&]() -> int {                           // opaque copy: per-lane addresses are rebuilt where a phase needs them
             int v = lane16;
@@ -183,12 +194,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3_kernel(const uint4* __r
             if constexpr (P + 2 < NPAIR) { wal[WS][1][0] = a_lo(P + 2, 1, 0); wal[WS][1][1] = a_lo(P + 2, 1, 1); }
             else if constexpr (P == NPAIR - 2) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbl[0][0] = w_at(OFF_B + (6 << 10)); }
             else { wbl[1][1] = w_at(OFF_B + (10 << 10)); wbl[1][2] = w_at(OFF_B + (11 << 10)); }
-            // this wave's part of the next pair's transfer (issued behind the barrier of pair P - 3) has landed.  Operations since:
-            // 4 behind that barrier, two pairs of 4 + d + 4, 4 of this pair = 24 + 2 d.  The first pairs of a step look back over the
-            // tail's 4 NB stores and phase C's lighter pairs: pair 0: 2 + 2 (2 + d + 2) + 4 NB + 4, pair 1: 2 + (2 + d + 2) + 4 NB + (4 + d + 4) + 4
-            if constexpr (P == 0) CCSM_XW((14 + 4 * NB < 24 ? 14 + 4 * NB : 24), 2);
-            else if constexpr (P == 1) CCSM_XW((18 + 4 * NB < 24 ? 18 + 4 * NB : 24), 2);
-            else CCSM_XW(24, 2);
+            // this wave's part of the next pair's transfer (issued behind the barrier of pair P - (RS - 1)) has landed.  Operations since:
+            // 4 behind that barrier, RS - 2 pairs of 4 + d + 4, 4 of this pair = 8 + (RS - 2)(8 + d).  The first RS - 1 pairs of a step look
+            // back over the tail's 4 NB stores and phase C's lighter pairs (2 + d + 2): 6 + 4 (RS - 2) + 4 P + 4 NB + (RS - 2) d
+            {
+                constexpr int FULL = 8 + 8 * (RS - 2), EARLY = 6 + 4 * (RS - 2) + 4 * P + 4 * NB;
+                CCSM_XW((P < RS - 1 && EARLY < FULL ? EARLY : FULL), RS - 2);
+            }
             __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
             if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once (pair 15: behind phase B)
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
@@ -211,6 +223,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3_kernel(const uint4* __r
             slot = slot_n;
         });
 
+        stamp(1);
         // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn): three passes per k-block on the fp16 hi + lo state;
         // one pair resident, each k-block's six fragments refilled with the next pair's right behind its MFMAs; the last pair's positions
         // take phase C's first two pair slots ----------------------------------------------------------------------------------------
@@ -275,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3_kernel(const uint4* __r
             }
         };
 
+        stamp(2);
         // ---------------- phase C: N += W_in x_t, pairs 0..15 (consumptions 16..31, zig-zag); pair P lives in slot P & 3, refilled with
         // pair P + 4 (1 + 1 requests before the barrier, 2 behind it); pairs 12..15 request the next step's phase-A slots instead ----------
         rdx(xh, slot_off(slot), 0, 0);
@@ -303,13 +317,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3_kernel(const uint4* __r
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) wcl[WS][1] = c_lo(P + 4, 1);
             else if constexpr (AH == 0) wal[AS][0][1] = a_lo(AS, 0, 1); else wah[AS][0][1] = a_hi(AS, 0, 1);
-            // operations since the awaited refill (behind the barrier of pair P - 3): 2 behind it, two pairs of 2 + d + 2, 2 of this pair
-            // = 12 + 2 d; the first pairs count from the deferred refill behind phase B (d instructions, nothing else since): pair 0 must not
-            // wait for it (d + 2), pair 1 looks back over pair 0 (d + (2 + d + 2) + 2), pair 2 waits for it (2 (2 + d + 2) + 2)
-            if constexpr (P == 0) CCSM_XW(2, 1);
-            else if constexpr (P == 1) CCSM_XW(6, 2);
-            else if constexpr (P == 2) CCSM_XW(10, 2);
-            else CCSM_XW(12, 2);
+            // operations since the awaited refill (behind the barrier of pair P - (RS - 1)): 2 behind it, RS - 2 pairs of 2 + d + 2, 2 of this
+            // pair = 4 + (RS - 2)(4 + d); the first pairs count from the deferred refill behind phase B (d instructions, nothing else since):
+            // pairs 0 .. RS - 3 must not wait for it (d + P (4 + d) + 2), pair RS - 2 waits for it ((RS - 2)(4 + d) + 2)
+            if constexpr (P < RS - 2) CCSM_XW(2 + 4 * P, P + 1);
+            else if constexpr (P == RS - 2) CCSM_XW(2 + 4 * (RS - 2), RS - 2);
+            else CCSM_XW(4 + 4 * (RS - 2), RS - 2);
             __syncthreads();
             dma_ahead(slot, s, NPAIR + P);                              // the vacated slot is refilled at once
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
@@ -328,8 +341,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3_kernel(const uint4* __r
             if constexpr (P == 5 && NB > 1) zwork(1);
             if constexpr (P == 9 && NB > 2) zwork(2);
         });
+        stamp(3);
         f3_tail<NB>(smem, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         CCSM_FENCE;
+        stamp(4);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no transfer may still be writing LDS when the workgroup retires
 #undef CCSM_XW
