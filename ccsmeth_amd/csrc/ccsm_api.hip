@@ -47,8 +47,8 @@ constexpr int kRowPad = 192;                    // rows are padded to whole work
 // GRU kernels' dynamic LDS: h fragments + x chunk ring + 4 KiB bias table
 constexpr int gru2_lds(int kx) { return (kKBH * kNBGru2 * 2 + 2 * (kx >= 4 ? 4 : kx) * kNBGru2 * 2) * 1024 + kWaves * 4 * 32 * 4; }
 // attention kernel dynamic LDS: 2 staging buffers x 28 KiB + e partials + fc partials + fc1.weight
-constexpr int kAttF8Lds = 3 * 28 * 1024 + kWaves * 7 * 32 * 4 + kSeqLen * 32 * 4 + kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4 + kWaves * 4 * 64 * 16;   // attn_fc_f8_kernel: three staging buffers (14 hi + 7 lo fragments + 7 KiB derived fp8), one group's score partials, scores, fc partials, fc1.weight, va, q = 139.9 KiB
-constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kWaves * kSeqLen * 32 * 2 * 4 + kClasses * 4 * kHidden * 4 + kHidden * 4;   // staging, e / fc partials, fc1.weight, va
+constexpr int kAttF8Lds = 3 * 28 * 1024 + kWaves * 7 * 32 * 4 + kSeqLen * 32 * 4 + kSeqLen * 32 * 2 * 4 + kAttFc3 * 16 + kHidden * 4 + kWaves * 4 * 64 * 16;   // attn_fc_f8_kernel: three staging buffers (14 hi + 7 lo fragments + 7 KiB derived fp8), one group's score partials, scores, fc partials, fc1 tile fragments, va, q = 139.9 KiB
+constexpr int kAttLds = 2 * 28 * 1024 + kWaves * kSeqLen * 32 * 4 + kSeqLen * 32 * 2 * 4 + kAttFc3 * 16 + kHidden * 4;   // staging, score partials, fc partials, fc1 tile fragments, va
 
 inline int rows_padded(int n_sites) { return ((2 * n_sites + kRowPad - 1) / kRowPad) * kRowPad; }
 
@@ -87,6 +87,9 @@ struct ccsm_model {
     uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
     uint4* ua3 = nullptr;
     int att_scale[2] = {127, 127};                       // E8M0 scales of the Wa / Ua corr operands
+    uint4* fc3 = nullptr;                                // fc1.weight as four rows (class x strand half) of split-f8 A fragments, compact: pack_fc_v3
+    int fc_scale = 127;
+    uint4* fc3s = nullptr;                               // the same tile as fp16 hi | lo fragments (attn_fc_kernel: three passes): pack_fc_s3
     float* bias[kLayers] = {nullptr, nullptr, nullptr};  // [dir][wave][4][hh][16]
     uint4* wa = nullptr;                                 // [wave][32][hl][64]
     uint4* ua = nullptr;
@@ -475,6 +478,47 @@ void pack_att_v3(const float* w, std::vector<_Float16>& out, int& scale) {
                            [&](int i, int k) { return w[(size_t)(kUnitTile * wave + i) * 2 * kHidden + k]; });
 }
 
+// fc1.weight (2, 1024) for the attention pool's MFMA: four virtual units u = class * 2 + strand half, W4[u][k] = fc1.weight[class][512 strand + k],
+// as the A operand of the same split-f8 product as Ua - rows 4..31 of the 32-row tile are zero and not stored: per fragment (k-block kb,
+// hi | corr) only lanes (i < 4, q) = 8 x 16 bytes, [kb 32][hi|corr][q 2][i 4] = 8 KiB, + one zero line for the other lanes.
+void pack_fc_v3(const float* fcw, std::vector<uint8_t>& out, int& scale) {
+    std::vector<float> w4((size_t)4 * 2 * kHidden);
+    for (int cls = 0; cls < kClasses; ++cls)
+        for (int sh = 0; sh < 2; ++sh)
+            for (int k = 0; k < 2 * kHidden; ++k) w4[(size_t)(cls * 2 + sh) * 2 * kHidden + k] = fcw[(size_t)cls * 4 * kHidden + sh * 2 * kHidden + k];
+    const int lg = corr_scale_log2(w4.data(), w4.size());
+    scale = 127 - 11 - lg;
+    out.assign((size_t)kKB12 * 2 * 8 * 16 + 16, 0);
+    std::vector<uint8_t> frag(1024);
+    for (int kb = 0; kb < kKB12; ++kb) {
+        for (int q = 0; q < 2; ++q)
+            for (int i = 0; i < 4; ++i) {
+                _Float16 h[8];
+                for (int j = 0; j < 8; ++j) h[j] = split_host(w4[(size_t)i * 2 * kHidden + 16 * kb + 8 * q + j]).hi;
+                std::memcpy(out.data() + ((size_t)(kb * 2 + 0) * 8 + q * 4 + i) * 16, h, 16);
+            }
+        emit_corr_frag(frag.data(), kb, lg, [&](int i, int k) { return i < 4 ? w4[(size_t)i * 2 * kHidden + k] : 0.0f; });
+        for (int q = 0; q < 2; ++q)
+            for (int i = 0; i < 4; ++i) std::memcpy(out.data() + ((size_t)(kb * 2 + 1) * 8 + q * 4 + i) * 16, frag.data() + (q * 32 + i) * 16, 16);
+    }
+}
+
+// The fc1 tile of pack_fc_v3 for the three-pass pool: [kb 32][hi|lo][q 2][i 4] x 16 bytes + one zero line
+void pack_fc_s3(const float* fcw, std::vector<uint8_t>& out) {
+    out.assign((size_t)kKB12 * 2 * 8 * 16 + 16, 0);
+    for (int kb = 0; kb < kKB12; ++kb)
+        for (int q = 0; q < 2; ++q)
+            for (int i = 0; i < 4; ++i) {
+                _Float16 h[8], l[8];
+                for (int j = 0; j < 8; ++j) {
+                    const HalfPair p = split_host(fcw[(size_t)(i >> 1) * 4 * kHidden + (i & 1) * 2 * kHidden + 16 * kb + 8 * q + j]);
+                    h[j] = p.hi; l[j] = p.lo;
+                }
+                std::memcpy(out.data() + ((size_t)(kb * 2 + 0) * 8 + q * 4 + i) * 16, h, 16);
+                std::memcpy(out.data() + ((size_t)(kb * 2 + 1) * 8 + q * 4 + i) * 16, l, 16);
+            }
+}
+
 template <typename T>
 ccsm_status upload(T** dst, const void* src, size_t bytes) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(dst), bytes));
@@ -614,10 +658,10 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         tab.n_sites[i] = i < ws->n_slices ? ws->slice_n[i] : 0;
     }
     if constexpr (F8 && !HS3)       // (the hybrid's last layer writes fp16 hi + lo fragments: the three-pass attention pool)
-        hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttF8Lds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fcw,
-                           ws->part, tab, m->att_scale[0], m->att_scale[1]);
+        hipLaunchKernelGGL(attn_fc_f8_kernel, dim3(tiles), dim3(512), kAttF8Lds, st, ws->act[0], m->wa3, m->ua3, m->va, m->fc3,
+                           ws->part, tab, m->att_scale[0], m->att_scale[1], m->fc_scale);
     else
-        hipLaunchKernelGGL(attn_fc_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fcw,
+        hipLaunchKernelGGL(attn_fc_kernel, dim3(tiles), dim3(512), kAttLds, st, ws->act[0], m->wa, m->ua, m->va, m->fc3s,
                            ws->part, tab);
     if (tm) HIP_TRY(hipEventRecord(ws->ev[5], st));
     for (int i = 0; i < ws->n_slices; ++i)
@@ -903,6 +947,16 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         st = upload(&m->va, fbuf.data(), fbuf.size() * sizeof(float));
     }
     if (st == CCSM_OK) st = upload(&m->fcw, w->fc1_weight, sizeof(float) * kClasses * 4 * kHidden);
+    if (st == CCSM_OK) {
+        std::vector<uint8_t> fb;
+        pack_fc_s3(w->fc1_weight, fb);
+        st = upload(&m->fc3s, fb.data(), fb.size());
+    }
+    if (st == CCSM_OK && prec >= 4) {
+        std::vector<uint8_t> fb;
+        pack_fc_v3(w->fc1_weight, fb, m->fc_scale);
+        st = upload(&m->fc3, fb.data(), fb.size());
+    }
     if (st == CCSM_OK) st = upload(&m->fcb, w->fc1_bias, sizeof(float) * kClasses);
     if (st == CCSM_OK) st = upload(&m->embed, w->embed_weight, sizeof(float) * kVocab * kEmbed);
     if (st == CCSM_OK) {
@@ -1029,7 +1083,7 @@ void ccsm_destroy(ccsm_model* m) {
         (void)hipFree(m->bias[l]);
     }
     (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);
-    (void)hipFree(m->wa3); (void)hipFree(m->ua3);
+    (void)hipFree(m->wa3); (void)hipFree(m->ua3); (void)hipFree(m->fc3); (void)hipFree(m->fc3s);
     (void)hipFree(m->fcw); (void)hipFree(m->fcb); (void)hipFree(m->embed);
     delete m;
 }

@@ -812,20 +812,24 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
     auto w8_at = [&](int off) -> uint2 {            // bytes 16-23 of an fp6 blob: lane * 8
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-        int v8 = lane * 8;
-        if constexpr (HS3) {        // the hybrid only needs it in phase C and has no register to keep it in through phases A and B (it was spilled:
-            v8 = lane16;            // 8-16 B of scratch, profiles/r03_z_isa.md): rebuilt from an opaque copy of lane * 16 at every use instead
-            asm volatile("" : "+v"(v8));
-            v8 >>= 1;
-        }
+        int v8 = lane16;            // only phases B / C need lane * 8 and no register is free to keep it through phase A (it was spilled: 8-16 B
+        asm volatile("" : "+v"(v8));// of scratch, profiles/r03_z_isa.md): rebuilt from an opaque copy of lane * 16 at every use instead
+        v8 >>= 1;
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(wrs, v8, off, 0);
         return make_uint2(v[0], v[1]);
     };
 
     // weight registers: phase A three pair slots: [slot][kb in pair][gate r,z] hi, [slot][gate] fp6 blobs (16 + 8 bytes), [slot] scale
     // bytes; phase B one resident pair (fp4 blobs); phase C four pair slots of the n gate: [slot][kb in pair] hi, [slot] fp6 blob, scale
-    uint4 wah[3][2][2], wab[3][2];
-    uint32_t was[3];
+    // (-DCCSM_MX_A_SLOTS=4 gives plain split-mx a fourth phase-A slot: measured in round 4, phase A -3 %, the step +3 % (the slot's
+    // load behind the tail and 8 B of scratch cost more than the look-ahead gains - phase A is bound by the CU's vector-memory path,
+    // not by latency: profiles/r04_j_a_slots.log); the default stays three)
+#ifndef CCSM_MX_A_SLOTS
+#define CCSM_MX_A_SLOTS 3
+#endif
+    constexpr int NSA = (HS3 || DYN) ? 3 : CCSM_MX_A_SLOTS;
+    uint4 wah[NSA][2][2], wab[NSA][2];
+    uint32_t was[NSA];
     uint4 wbh[2][3], wbb[3];
     uint32_t wbs = 0;
     uint2 wbb1[3];                                  // split-mx-d: bytes 16-23 of the resident phase-B pair's fp6 blobs
@@ -850,7 +854,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     ldA_slot(0, 0);
     ldA_slot(1, 1);
     ldA_slot(2, 2);
-    asm volatile("s_waitcnt vmcnt(21)" ::: "memory");               // all ring transfers (older than the 21 weight requests)
+    if constexpr (NSA == 4) ldA_slot(3, 3);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(7 * NSA) : "memory");   // all ring transfers (older than the 7 NSA weight requests)
     __syncthreads();                                                // ring, h0 fragments and biases are in LDS
 
     int slot = 0;                                                   // ring slot of the next consumption (wave-uniform)
@@ -917,19 +922,19 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         int slot_a15 = 0;
         static_for<0, NPAIR>([&](auto PC_) {
             constexpr int P = decltype(PC_)::value;
-            constexpr int WS = P % 3;
+            constexpr int WS = P % NSA;
             const int xs = slot_off(slot);
             const int slot_n = slot == RS - 1 ? 0 : slot + 1;
             rdx(xh1, xs, 1, 0);
             CCSM_MAIN(wah[WS][0], xh, 2, 0);
-            if constexpr (P + 3 < NPAIR) ldAh(wah[WS][0], P + 3, 0);
+            if constexpr (P + NSA < NPAIR) ldAh(wah[WS][0], P + NSA, 0);
             else if constexpr (P == 13) { wbh[0][0] = w_at(OFF_B + (0 << 10)); wbh[0][1] = w_at(OFF_B + (1 << 10)); }
             else if constexpr (P == 14) {
                 if constexpr (HS3) wbl[1][0] = w_at(OFF_B + (9 << 10)); else wbs = ws_at(OFF_B + OFF_BS);
             }
             rdx_blob(xs);
             CCSM_MAIN(wah[WS][1], xh1, 2, 0);
-            if constexpr (P + 3 < NPAIR) ldAh(wah[WS][1], P + 3, 1);
+            if constexpr (P + NSA < NPAIR) ldAh(wah[WS][1], P + NSA, 1);
             else if constexpr (P == 13) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); }
             else if constexpr (P == 14 && HS3) { wbl[1][1] = w_at(OFF_B + (10 << 10)); wbl[1][2] = w_at(OFF_B + (11 << 10)); }
             else if constexpr (P == 14 && DYN) { wbb1[0] = w8_at(OFF_B + (9 << 10)); wbb1[1] = w8_at(OFF_B + (9 << 10) + 512); wbb1[2] = w8_at(OFF_B + (9 << 10) + 1024); }
@@ -938,7 +943,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             // phase B's first pair instead (9), pair 14 one more of it, pair 15 nothing
             // (hybrid arithmetic: pair 14 requests three fragments of phase B's first pair instead of one; split-mx-d: four - the scale
             // dword and the three 8-byte ends of the fp6 blobs)
-            if constexpr (P == NPAIR - 1) { if constexpr (HS3) CCSM_WAIT_XFER(17, 19); else if constexpr (DYN) CCSM_WAIT_XFER(18, 20); else CCSM_WAIT_XFER(15, 17); }
+            // (four slots: pair 12 has nothing left to request, so the windows of pairs 12..15 hold 7 requests fewer each:
+            //  pair 12: 3 + 2 (7 + d) + 0; 13: 3 + (7 + d) + d + 4; 14: 3 + d + (9 + d) + 1; 15: (9 + d) + (1 + d))
+            if constexpr (NSA == 4 && P == NPAIR - 4) CCSM_WAIT_XFER(19, 21);
+            else if constexpr (NSA == 4 && P == NPAIR - 3) CCSM_WAIT_XFER(16, 18);
+            else if constexpr (NSA == 4 && P == NPAIR - 2) CCSM_WAIT_XFER(15, 17);
+            else if constexpr (NSA == 4 && P == NPAIR - 1) CCSM_WAIT_XFER(12, 14);
+            else if constexpr (P == NPAIR - 1) { if constexpr (HS3) CCSM_WAIT_XFER(17, 19); else if constexpr (DYN) CCSM_WAIT_XFER(18, 20); else CCSM_WAIT_XFER(15, 17); }
             else if constexpr (P == NPAIR - 2) { if constexpr (HS3) CCSM_WAIT_XFER(24, 26); else if constexpr (DYN) CCSM_WAIT_XFER(25, 27); else CCSM_WAIT_XFER(22, 24); }
             else CCSM_WAIT_XFER(23, 25);
             __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
@@ -960,7 +971,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 }
             }
             CCSM_FENCE;
-            if constexpr (P + 3 < NPAIR) ldAb(WS, P + 3);
+            if constexpr (P + NSA < NPAIR) ldAb(WS, P + NSA);
             else if constexpr (P == 13) {       // (hybrid: fragments 6-8 are the fp16 lo of the pair's first k-block)
                 wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10));
                 if constexpr (HS3) { wbl[0][0] = w_at(OFF_B + (6 << 10)); wbl[0][1] = w_at(OFF_B + (7 << 10)); wbl[0][2] = w_at(OFF_B + (8 << 10)); }
@@ -1164,6 +1175,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         else mx_tail<OUT_FP8, HS3, DYN, NB>(smem, kMx12LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         CCSM_FENCE;
         ldA_slot(2, 2);                                             // the third weight slot of the next step (needed two pairs in): not live across the tail
+        if constexpr (NSA == 4) ldA_slot(3, 3);
         CCSM_FENCE;
         stamp(4);
     }

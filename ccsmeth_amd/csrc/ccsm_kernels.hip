@@ -610,9 +610,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer_v2_kernel(const uint4* __res
 // (2 k-blocks x 7 timesteps x hi/lo = 28 KiB per chunk, double-buffered).
 //   wa / ua : [wave][kb 32][hl][64] uint4 ; va : [wave][hh][16] floats (C-row order) ; fcw : fc1.weight (2,1024) fp32
 // ---------------------------------------------------------------------------------------------------------
+constexpr int kAttFc3 = kKB12 * 2 * 8 + 1;        // uint4 items of the compact fc1 fragments + the zero line (attn_fc_kernel, attn_fc_f8_kernel)
 __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict__ out2, const uint4* __restrict__ wa,
                                                           const uint4* __restrict__ ua, const float* __restrict__ va,
-                                                          const float* __restrict__ fcw, float* __restrict__ part,
+                                                          const uint4* __restrict__ fc3, float* __restrict__ part,
                                                           SliceTable slices) {
     constexpr int TG = 7;                      // timesteps per Ua pass (21 = 3 * 7)
     constexpr int CK = 2;                      // k-blocks per staged chunk
@@ -621,15 +622,15 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* s_stage = smem;                                                     // [2][CK][TG][hl] fragments
     float* s_epart = reinterpret_cast<float*>(smem + 2 * CHUNK_FRAGS * 1024);  // [wave][t][32]
-    float* s_pfc = s_epart + kWaves * kSeqLen * 32;                            // [wave][t][32][2]
-    float* s_fcw = s_pfc + kWaves * kSeqLen * 32 * 2;                          // [2][1024]
+    float* s_pfc = s_epart + kWaves * kSeqLen * 32;                            // [t][32][2]: wave w < 7 owns timestep t0 + w of every group
+    uint4* s_fc3 = reinterpret_cast<uint4*>(s_pfc + kSeqLen * 32 * 2);         // fc1.weight as compact A fragments [kb 32][hi|lo][q 2][i 4] + one zero line (pack_fc_s3)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tile = blockIdx.x;
     const int n = lane & 31, hh = lane >> 5;
 
-    for (int i = threadIdx.x; i < kClasses * 4 * kHidden; i += blockDim.x) s_fcw[i] = fcw[i];
+    for (int i = threadIdx.x; i < kAttFc3; i += blockDim.x) s_fc3[i] = fc3[i];
 
     const uint4* wap = wa + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
     const uint4* uap = ua + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
@@ -647,9 +648,9 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
         const uint4 x[2] = {xp[0], xp[kFragU4]};
         qacc = mma_split3(w, x, qacc);
     }
-    float vav[16];
+    float vav[16], vsum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) vav[r] = va[(wave * 2 + hh) * 16 + r];
+    for (int r = 0; r < 16; ++r) { vav[r] = va[(wave * 2 + hh) * 16 + r]; vsum += vav[r]; }
     int strand = 0;   // which half of fc1.weight this lane's row multiplies: strand 2 rows are the upper half of a slice
     {
         const int row = tile * 32 + n;
@@ -658,20 +659,27 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
                 strand = (row - slices.row_base[i]) >= slices.n_sites[i];
     }
 
-    // stage chunk `c` of timestep group t0 into buffer `buf`: fragment f = (kbl * TG + tt) * 2 + hl
-    auto stage = [&](int t0, int c, int buf) {
-#pragma unroll
-        for (int i = 0; i < (CHUNK_FRAGS + kWaves - 1) / kWaves; ++i) {
-            const int f = wave + kWaves * i;
-            if (f < CHUNK_FRAGS) {
-                const int hl = f & 1, tt = (f >> 1) % TG, kbl = (f >> 1) / TG;
-                const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
-                dma16(src, __builtin_amdgcn_readfirstlane(
-                               (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024)));
-            }
+    // stage fragment f = wave + 8 i of chunk `c` of timestep group t0 into buffer `buf`: f = (kbl * TG + tt) * 2 + hl
+    auto stage_one = [&](int t0, int c, int buf, int i) {
+        const int f = wave + kWaves * i;
+        if (f < CHUNK_FRAGS) {
+            const int hl = f & 1, tt = (f >> 1) % TG, kbl = (f >> 1) / TG;
+            const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + hl) * kFragU4 + lane;
+            dma16(src, __builtin_amdgcn_readfirstlane(
+                           (unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_stage + (buf * CHUNK_FRAGS + f) * 1024)));
         }
     };
-
+    constexpr int NST = (CHUNK_FRAGS + kWaves - 1) / kWaves;      // 4 transfers per wave and chunk (waves 4-7: 3)
+    auto stage = [&](int t0, int c, int buf) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) stage_one(t0, c, buf, i);
+    };
+    // fc1 partials: wave w < 7 takes timestep t0 + w of the group for ALL k-blocks, as three more MFMAs per k-block on the operands it holds
+    // for that timestep anyway: fc1.weight is the A operand of a 33rd unit tile whose rows 0-3 are (class, strand half) and whose other rows
+    // are zero (lanes n >= 4 read the zero line).  Rounds 1-4 did this sum on the vector ALU of ONE wave per k-block (280 instructions that
+    // every other wave waited for at the chunk's barrier).
+    f32x16 facc;
+    const int fc_lane = n < 4 ? hh * 4 + n : -1;
     uint4 wu[CK][2];       // Ua fragments of the next chunk, requested one chunk ahead
 #pragma unroll
     for (int kbl = 0; kbl < CK; ++kbl) { wu[kbl][0] = uap[(kbl * 2 + 0) * kFragU4]; wu[kbl][1] = uap[(kbl * 2 + 1) * kFragU4]; }
@@ -681,9 +689,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
         f32x16 kacc[TG];
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) kacc[tt] = qacc;     // accumulate K_t on top of q
-        float pf[TG][2];
 #pragma unroll
-        for (int tt = 0; tt < TG; ++tt) pf[tt][0] = pf[tt][1] = 0.f;
+        for (int r = 0; r < 16; ++r) facc[r] = 0.f;
 
         stage(t0, 0, 0);
 #pragma unroll 1
@@ -696,57 +703,47 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
             for (int kbl = 0; kbl < CK; ++kbl) { w[kbl][0] = wu[kbl][0]; w[kbl][1] = wu[kbl][1]; }
             wait_dma();        // this wave's part of chunk c has arrived (see dma16)
             __syncthreads();   // chunk c has landed; buffer (c+1)&1 is free
-            if (c + 1 < NCHUNK) stage(t0, c + 1, (c + 1) & 1);
-            {
-                const int cn = c + 1 < NCHUNK ? c + 1 : 0;       // Ua is re-streamed for every timestep group
-#pragma unroll
-                for (int kbl = 0; kbl < CK; ++kbl) {
-                    wu[kbl][0] = uap[((cn * CK + kbl) * 2 + 0) * kFragU4];
-                    wu[kbl][1] = uap[((cn * CK + kbl) * 2 + 1) * kFragU4];
-                }
-            }
+            // The next chunk's requests - the wave's transfers and its four Ua fragments (Ua is re-streamed for every timestep group) - are
+            // issued one per timestep behind the MFMAs of this chunk's first k-block and the start of its second: in a block behind the barrier
+            // all eight waves queued on the CU's vector-memory path at once while no MFMA ran (profiles/r04_j_attn_stamps_before.log).
+            const int cn = c + 1 < NCHUNK ? c + 1 : 0;
             const char* sb = s_stage + (c & 1) * CHUNK_FRAGS * 1024 + lane * 16;
 #pragma unroll
             for (int kbl = 0; kbl < CK; ++kbl) {
                 const int kb = c * CK + kbl;
-                const bool fc_owner = (kb & (kWaves - 1)) == wave;   // wave-uniform: each k-block's fc partial taken once
-                float fw[2][8];
-                if (fc_owner) {
-#pragma unroll
-                    for (int cl = 0; cl < 2; ++cl)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) fw[cl][j] = s_fcw[cl * 4 * kHidden + strand * 2 * kHidden + kb * 16 + hh * 8 + j];
-                }
 #pragma unroll
                 for (int tt = 0; tt < TG; ++tt) {
                     const uint4 x[2] = {*reinterpret_cast<const uint4*>(sb + ((kbl * TG + tt) * 2 + 0) * 1024),
                                         *reinterpret_cast<const uint4*>(sb + ((kbl * TG + tt) * 2 + 1) * 1024)};
                     kacc[tt] = mma_split3(w[kbl], x, kacc[tt]);
-                    if (fc_owner) {
-                        const half8 xh = as_half8(x[0]), xl = as_half8(x[1]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float xv = (float)xh[j] + (float)xl[j];
-                            pf[tt][0] += fw[0][j] * xv;
-                            pf[tt][1] += fw[1][j] * xv;
-                        }
+                    if (wave == tt) {
+                        const uint4 fw[2] = {s_fc3[fc_lane < 0 ? kAttFc3 - 1 : (kb * 2 + 0) * 8 + fc_lane],
+                                             s_fc3[fc_lane < 0 ? kAttFc3 - 1 : (kb * 2 + 1) * 8 + fc_lane]};
+                        facc = mma_split3(fw, x, facc);
                     }
+                    const int slot = kbl * TG + tt;          // 0..13: transfers in slots 0..3, Ua fragments in slots 4..7
+                    if (slot < NST) { if (c + 1 < NCHUNK) stage_one(t0, c + 1, (c + 1) & 1, slot); }
+                    else if (slot < NST + CK * 2) {
+                        const int j = slot - NST;
+                        wu[j >> 1][j & 1] = uap[((cn * CK + (j >> 1)) * 2 + (j & 1)) * kFragU4];
+                    }
+                    asm volatile("" ::: "memory");
                 }
             }
         }
 #pragma unroll
         for (int tt = 0; tt < TG; ++tt) {
+            // sum_r va_r tanh(k_r) = sum_r va_r - 2 sum_r va_r / (e^{2 k_r} + 1)
             float e = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e += vav[r] * tanh_f(kacc[tt][r]);
+            for (int r = 0; r < 16; ++r) e += vav[r] * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(kacc[tt][r] * 2.8853900817779268f) + 1.0f);
+            e = vsum - 2.0f * e;
             e += __shfl_xor(e, 32);
             if (hh == 0) s_epart[(wave * kSeqLen + t0 + tt) * 32 + n] = e;
-#pragma unroll
-            for (int cl = 0; cl < 2; ++cl) {
-                float v = pf[tt][cl];
-                v += __shfl_xor(v, 32);
-                if (hh == 0) s_pfc[((wave * kSeqLen + t0 + tt) * 32 + n) * 2 + cl] = v;
-            }
+        }
+        if (wave < TG && hh == 0) {       // C rows 0-3 of the fc1 tile = registers 0-3 of the lower lanes: (class 0, strand), (class 1, strand)
+            s_pfc[((t0 + wave) * 32 + n) * 2 + 0] = strand ? facc[1] : facc[0];
+            s_pfc[((t0 + wave) * 32 + n) * 2 + 1] = strand ? facc[3] : facc[2];
         }
         __syncthreads();   // all waves are done with both staging buffers before the next group restages buffer 0
     }
@@ -773,14 +770,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_kernel(const uint4* __restrict
 #pragma unroll
         for (int t = 0; t < kSeqLen; ++t) {
             const float a = e[t] * inv;
-            float p0 = 0.f, p1 = 0.f;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) {
-                p0 += s_pfc[((w * kSeqLen + t) * 32 + rl) * 2 + 0];
-                p1 += s_pfc[((w * kSeqLen + t) * 32 + rl) * 2 + 1];
-            }
-            l0 += a * p0;
-            l1 += a * p1;
+            l0 += a * s_pfc[(t * 32 + rl) * 2 + 0];
+            l1 += a * s_pfc[(t * 32 + rl) * 2 + 1];
         }
         part[(size_t)row * 2 + 0] = l0;
         part[(size_t)row * 2 + 1] = l1;
