@@ -77,6 +77,7 @@ struct ccsm_model {
     float probe_tail = -1.f, probe_tail_hybrid = -1.f;   // fraction of the probe sites beyond kProbeTailAt
     float probe_err = -1.f;                              // max |dprob| split-mx vs split-fp16 on the probe batch of ccsm_create (-1: not run)
     float probe_err_dyn = -1.f, probe_tail_dyn = -1.f;   // ... of split-mx-d (never probed since round 4: explicit choices only; kept for the ABI)
+    bool l0_stag = true;                                 // layer 0 in its staggered form (96-row launches); CCSM_L0_LOCKSTEP=1 at ccsm_create: the lock-step form (A/B)
     bool split3_v2 = false;                              // CCSM_SPLIT3_V2=1 at ccsm_create: split3 on the round-1 kernel (A/B)
     float probe_q999 = -1.f;                             // 99.9th percentile of |dprob| split-mx vs split-fp16 over the probe sites
     int probe_n = 0;                                     // probe sites actually run (the probe stops at the first batch that decides it)
@@ -550,16 +551,23 @@ ccsm_status launch_prep(const ccsm_model* m, ccsm_workspace* ws, int n_sites, in
 // at the phase boundaries of workgroup 0 (tools/gpu_phases.py); the product library is built without it.
 template <bool HS3, bool DYN, int NB = kMxNB>
 void launch_gru_mx(int layer, dim3 grid, hipStream_t st, const uint4* xin, uint4* out, const uint4* wst, const float* bias, const float* h0,
-                   int rows_p, unsigned long long* dbg) {
+                   int rows_p, unsigned long long* dbg, bool stag = false) {
 #ifdef CCSM_PHASE_STAMPS
     if (dbg && NB == kMxNB) {
-        if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<true, HS3, DYN>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        if (layer == 0 && stag) hipLaunchKernelGGL((gru_layer0_mx_kernel<true, HS3, DYN, kMxNB, false, true>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
+        else if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<true, HS3, DYN>), grid, dim3(512), kMx0Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
         else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, true, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
         else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, true, HS3, DYN>), grid, dim3(512), kMx12Lds, st, xin, out, wst, bias, h0, rows_p, dbg);
         return;
     }
 #endif
     (void)dbg;
+    if constexpr (NB == kMxNB) {
+        if (layer == 0 && stag) {
+            hipLaunchKernelGGL((gru_layer0_mx_kernel<false, HS3, DYN, NB, false, true>), grid, dim3(512), mx0_lds(NB), st, xin, out, wst, bias, h0, rows_p, nullptr);
+            return;
+        }
+    }
     if (layer == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, HS3, DYN, NB>), grid, dim3(512), mx0_lds(NB), st, xin, out, wst, bias, h0, rows_p, nullptr);
     else if (layer == 1) hipLaunchKernelGGL((gru_layer12_mx_kernel<false, false, HS3, DYN, NB>), grid, dim3(512), mx12_lds(NB), st, xin, out, wst, bias, h0, rows_p, nullptr);
     else hipLaunchKernelGGL((gru_layer12_mx_kernel<true, false, HS3, DYN, NB>), grid, dim3(512), mx12_lds(NB), st, xin, out, wst, bias, h0, rows_p, nullptr);   // fp8 corr fragments for the attention kernel
@@ -604,7 +612,7 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         auto layer = [&](int l, const uint4* in, uint4* out_, unsigned long long* dbg) {
             if (nb_run == 1) launch_gru_mx<HS3, DYN, 1>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
             else if (nb_run == 2) launch_gru_mx<HS3, DYN, 2>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
-            else launch_gru_mx<HS3, DYN>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, dbg);
+            else launch_gru_mx<HS3, DYN>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, dbg, m->l0_stag);
         };
         layer(0, ws->x0, ws->act[0], dbg_layer == 0 ? ws->dbg : nullptr);
         if (tm) HIP_TRY(hipEventRecord(ws->ev[2], st));
@@ -631,7 +639,10 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         // layers 1-2 = gru_layer12_f3_kernel (ccsm_gru_f3.hip)
         auto layer = [&](auto nbc, int l, const uint4* in, uint4* out_) {
             constexpr int NBF = decltype(nbc)::value;
-            if (l == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, true, false, NBF, true>), ggrid, dim3(512), mx0_lds(NBF), st, in, out_, m->wstf3[0], m->bias[0],
+            if (l == 0 && NBF == 3 && m->l0_stag)
+                hipLaunchKernelGGL((gru_layer0_mx_kernel<false, true, false, 3, true, true>), ggrid, dim3(512), mx0_lds(3), st, in, out_, m->wstf3[0], m->bias[0],
+                                   ws->h0buf, ws->rows_p, nullptr);
+            else if (l == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, true, false, NBF, true>), ggrid, dim3(512), mx0_lds(NBF), st, in, out_, m->wstf3[0], m->bias[0],
                                            ws->h0buf, ws->rows_p, nullptr);
 #ifdef CCSM_PHASE_STAMPS
             else if (NBF == 3 && ws->dbg && l == (dbg_layer == 2 ? 2 : 1))
@@ -968,6 +979,7 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         set_lds(reinterpret_cast<const void*>(&gru_layer_v2_kernel<kKB12>), gru2_lds(kKB12));
         set_lds(reinterpret_cast<const void*>(&attn_fc_kernel), kAttLds);
         set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 3, true>), mx0_lds(3));
+        set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 3, true, true>), mx0_lds(3));
         set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 2, true>), mx0_lds(2));
         set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 1, true>), mx0_lds(1));
         set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<3>), f3_lds(3));
@@ -978,6 +990,9 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
 #endif
         if (prec >= CCSM_PRECISION_SPLIT_F8) {
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, false, 3, false, true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true, false, 3, false, true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false, true, 3, false, true>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, false, false>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, true>), kMx0Lds);
@@ -1007,6 +1022,9 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, false, false, true, 1>), mx12_lds(1));
 #ifdef CCSM_PHASE_STAMPS
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, false>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, false, false, 3, false, true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, true, false, 3, false, true>), kMx0Lds);
+            set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, false, true, 3, false, true>), kMx0Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, false>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true, false>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<true, true>), kMx0Lds);
@@ -1022,6 +1040,7 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     }
     // split3's streams on the split-mx schedule (always: it is the reference of the probe and the arithmetic of explicit large initial states)
     m->split3_v2 = std::getenv("CCSM_SPLIT3_V2") != nullptr;
+    m->l0_stag = std::getenv("CCSM_L0_LOCKSTEP") == nullptr;
     if (st == CCSM_OK) {
         std::vector<uint8_t> bbuf;
         pack_wstream_mx(0, m->feat0, wih_l0, w->weight_hh[0], true, bbuf);

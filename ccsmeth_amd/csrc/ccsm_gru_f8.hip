@@ -172,7 +172,6 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     if (threadIdx.x < kHidden) s_va[threadIdx.x] = va[threadIdx.x];
 
     const uint4* wap = wa + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
-    const uint4* uap = ua + (size_t)wave * kKB12 * 2 * kFragU4 + lane;
     const uint4* otile = out2 + (size_t)tile * kSeqLen * kKB12 * 2 * kFragU4;   // [t][kb][hi|corr][64]
 
     // ---- q = Wa h_n, h_n = [fwd final state = out[t=L-1][0:256] | bwd final state = out[t=0][256:512]] (models.py:135-137)
@@ -219,6 +218,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
     }
 
     // stage chunk `c` of timestep group t0 into buffer `buf`: fragments 0..13 = hi [kbl][tt], 14..20 = lo [tt]
+    const u32x4_t ors = dma_rsrc(otile);
+    const __amdgpu_buffer_rsrc_t urs = make_rsrc(ua + (size_t)wave * kKB12 * 2 * kFragU4);
     auto stage = [&](int t0, int c, int buf) {
 #pragma unroll
         for (int i = 0; i < (NFR + kWaves - 1) / kWaves; ++i) {
@@ -226,8 +227,10 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
             if (f < NFR) {
                 const int lo = f >= 2 * TG;
                 const int tt = lo ? f - 2 * TG : f % TG, kbl = lo ? 0 : f / TG;
-                const uint4* src = otile + (((size_t)(t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + lo) * kFragU4 + lane;
-                dma16(src, __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_stage + buf * BUF + f * 1024)));
+                // (descriptor + wave-uniform byte offset + lane * 16: no 64-bit per-lane address kept through the chunk loop - they were spilled)
+                const int soff = ((((t0 + tt) * kKB12 + (c * CK + kbl)) * 2 + lo) * kFragU4) * 16;
+                dma16_buf(ors, lane_now() * 16, __builtin_amdgcn_readfirstlane(soff),
+                          __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(s_stage + buf * BUF + f * 1024)));
             }
         }
     };
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
 
     uint4 wu[CK][2];       // Ua fragments of the next chunk, requested one chunk ahead
 #pragma unroll
-    for (int kbl = 0; kbl < CK; ++kbl) { wu[kbl][0] = uap[(kbl * 2 + 0) * kFragU4]; wu[kbl][1] = uap[(kbl * 2 + 1) * kFragU4]; }
+    for (int kbl = 0; kbl < CK; ++kbl) { wu[kbl][0] = buf_load(urs, lane * 16, (kbl * 2 + 0) * 1024); wu[kbl][1] = buf_load(urs, lane * 16, (kbl * 2 + 1) * 1024); }
 
     for (int tg = 0; tg < kSeqLen / TG; ++tg) {
         const int t0 = tg * TG;
@@ -292,8 +295,8 @@ __global__ __launch_bounds__(512, 2) void attn_fc_f8_kernel(const uint4* __restr
                 const int cn = c + 1 < NCHUNK ? c + 1 : 0;       // Ua is re-streamed for every timestep group
 #pragma unroll
                 for (int kbl = 0; kbl < CK; ++kbl) {
-                    wu[kbl][0] = uap[((cn * CK + kbl) * 2 + 0) * kFragU4];
-                    wu[kbl][1] = uap[((cn * CK + kbl) * 2 + 1) * kFragU4];
+                    wu[kbl][0] = buf_load(urs, lane_now() * 16, ((cn * CK + kbl) * 2 + 0) * 1024);
+                    wu[kbl][1] = buf_load(urs, lane_now() * 16, ((cn * CK + kbl) * 2 + 1) * 1024);
                 }
             }
             const char* sb0 = s_stage + (c % 3) * BUF;

@@ -445,7 +445,7 @@ constexpr int mx0_biasoff(int nb) { return mx0_looff(nb) + kWaves * nb * 64 * 8;
 constexpr int mx0_lds(int nb) { return mx0_biasoff(nb) + kWaves * 4 * 32 * 4; }
 constexpr int kMx0Lds = mx0_lds(kMxNB);
 
-template <bool DBG, bool HS3, bool DYN = false, int NB_ = kMxNB, bool F3 = false>
+template <bool DBG, bool HS3, bool DYN = false, int NB_ = kMxNB, bool F3 = false, bool STAG = false>
 __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __restrict__ xin, uint4* __restrict__ out,
                                                                 const uint4* __restrict__ wst, const float* __restrict__ bias,
                                                                 const float* __restrict__ h0, int rows_p,
@@ -483,6 +483,18 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
         const int soff = (((bt * kSeqLen + t) * 2 + hl) << 10);
         dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + ((buf * 2 * NB + f) << 10))));
     };
+    // STAG: the transfers are group 1's (waves 0-3), two per wave and step: fragments w and w + 4 (clamped: re-staged duplicates)
+    auto stage_load2 = [&](int t, int buf) {
+        if (wave < 4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int f = wave + 4 * i < 2 * NB ? wave + 4 * i : 2 * NB - 1;
+                const int hl = f & 1, bt = f >> 1;
+                const int soff = (((bt * kSeqLen + t) * 2 + hl) << 10);
+                dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + ((buf * 2 * NB + f) << 10))));
+            }
+        }
+    };
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx0_wbytes(HS3, DYN));
     const int bias_off = kMx0BiasOff + wave * 4 * 32 * 4;
     auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
@@ -511,11 +523,16 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
         }
         if constexpr (!HS3) wbs = ws_at(OFF_B + (DYN ? (10 << 10) + 512 : (9 << 10)));
     };
-    stage_load(dir ? kSeqLen - 1 : 0, 0);
+    if constexpr (STAG) stage_load2(dir ? kSeqLen - 1 : 0, 0);
+    else stage_load(dir ? kSeqLen - 1 : 0, 0);
     ld_first();
     if constexpr (HS3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (DYN) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");          // the first transfer (older than the 14 weight requests)
+    if constexpr (STAG) {
+        __syncthreads();                                            // x_0, the initial states and the biases in LDS
+        if (wave >= 4) __syncthreads();                             // group 2 runs one slot behind group 1 from here on
+    }
 
     for (int s = 0; s < kSeqLen; ++s) {
         const int t = dir ? (kSeqLen - 1 - s) : s;
@@ -550,9 +567,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
         // ---------------- phase A: R, Z += W_i{r,z} x_t (three fp16 passes) -------------------------------------------------
         // the transfer of this step's x (issued one step ago) is older than the 14 weight requests and 4 NB output stores of the tail
         // (4 NB stores; the hybrid has 16 weight requests there, split-mx-d 17)
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((HS3 ? 16 : DYN ? 17 : 14) + 4 * NB) : "memory");
-        __syncthreads();                                            // x_t in LDS; everybody's h_{t-1} fragments written
-        stage_load(tn, (s + 1) & 1);
+        if constexpr (!STAG) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((HS3 ? 16 : DYN ? 17 : 14) + 4 * NB) : "memory");
+            __syncthreads();                                        // x_t in LDS; everybody's h_{t-1} fragments written
+            stage_load(tn, (s + 1) & 1);
+        }
         auto rd_x0 = [&](uint4 (&x0)[NB][2]) {
             const int l16 = lane16_here();
 #pragma unroll
@@ -575,8 +594,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
                 }
             CCSM_FENCE;
         }
-        wxc[0] = w_at(OFF_C); wxc[1] = w_at(OFF_C + 1024);
-        stamp(1);
+        if constexpr (!STAG) { wxc[0] = w_at(OFF_C); wxc[1] = w_at(OFF_C + 1024); }
+        if constexpr (!STAG) stamp(1);
         // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn) ---------------------------------
         {
             const f32x16 b3 = bias_set(3);
@@ -594,6 +613,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
                 constexpr int KB = decltype(KC)::value;
                 constexpr int KBL = KB & 1, Q = KB >> 1;
                 constexpr int NXT = OFF_B + (Q + 1) * PB;
+                if constexpr (STAG && KB == kKBH - 2) stage_load2(tn, (s + 1) & 1);     // behind the phase's last weight request
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
                     xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(KB, bt, 0) + lane * 16);
@@ -614,6 +634,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
                     for (int g = 0; g < 3; ++g) { wbh[KBL][g] = w_at(NXT + ((3 * KBL + g) << 10)); wbl[KBL][g] = w_at(NXT + ((6 + 3 * KBL + g) << 10)); }
                 }
                 CCSM_FENCE;
+                // alpha: the other group's units of h_{t-1} are written.  (The scheduling barrier keeps this k-block's MFMAs in front of
+                // the workgroup barrier: moved behind it, the refilled fragments needed registers of their own - spills behind vmcnt(0).)
+                if constexpr (STAG && KB == kKBH / 2 - 1) { __builtin_amdgcn_sched_barrier(0); stamp(1); __syncthreads(); CCSM_FENCE; }
             });
         } else
         static_for<0, kKBH / 2>([&](auto QC) {
@@ -621,6 +644,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
             constexpr bool LAST = Q == kKBH / 2 - 1;
             constexpr int NXT = OFF_B + (Q + 1) * PB;
             uint32_t pm[NB];                                            // split-mx-d: running max |x_hi| of the pair's block, this lane's values
+            if constexpr (STAG && LAST) stage_load2(tn, (s + 1) & 1);   // behind the phase's last weight request
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, bt, 0) + lane * 16);
@@ -679,7 +703,16 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
                 wbs = ws_at(NXT + (DYN ? (10 << 10) + 512 : (9 << 10)));
             }
             CCSM_FENCE;
+            if constexpr (STAG && Q == kKBH / 4 - 1) { __builtin_amdgcn_sched_barrier(0); stamp(1); __syncthreads(); CCSM_FENCE; }   // alpha: the other group's units of h_{t-1} are written
         });
+        if constexpr (STAG) {
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(2);
+            __syncthreads();                                        // beta: both groups have read units 0-127 of h_{t-1}; group 1 may overwrite them
+            CCSM_FENCE;
+            wxc[0] = w_at(OFF_C); wxc[1] = w_at(OFF_C + 1024);      // (not held through phase B: in flight under the sigmoids)
+            stamp(3);
+        }
         // r = sigmoid(R) ; N = b_in + r * N
         {
             const f32x16 b2 = bias_set(2);
@@ -688,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
         }
-        stamp(2);
+        if constexpr (!STAG) stamp(2);
         // ---------------- phase C: N += W_in x_t (x_t is still in its ring buffer) -------------------------------------------
         {
             uint4 x0[NB][2];
@@ -702,17 +735,31 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
             }
             CCSM_FENCE;
         }
-        stamp(3);
+        if constexpr (!STAG) stamp(3);
         ld_first();                                                 // the next step's first weight fragments: in flight during the tail
         CCSM_FENCE;
 #pragma unroll
         for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[1][bt][r] = sigmoid_f(acc[1][bt][r]);
-        __syncthreads();                                            // every wave has read h_{t-1} (phase B) before anybody overwrites its fragments
+        if constexpr (!STAG) __syncthreads();                       // every wave has read h_{t-1} (phase B) before anybody overwrites its fragments
+        else __builtin_amdgcn_sched_barrier(0);                     // (keeps the tail's operand reads behind the sigmoids, as the barrier did)
         if constexpr (F3) f3_tail<NB>(smem, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
         else mx_tail<false, HS3, DYN, NB>(smem, kMx0LoOff, acc[1], acc[2], out, tile0, t, dir, wave, lane16_here());
-        stamp(4);
+        if constexpr (STAG) {
+            stamp(4);
+            // gamma: this group's units of h_t are written; group 1's transfer of x_{t+1} (older than the 2 + 14 weight requests and the
+            // 4 NB output stores issued since) has landed
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 + (HS3 ? 16 : DYN ? 17 : 14) + 4 * NB) : "memory");
+            __syncthreads();
+        }
+        if constexpr (!STAG) stamp(4);
+    }
+    if constexpr (STAG) {
+        if (wave < 4) __syncthreads();                              // group 1 keeps group 2's last barrier company
+    }
+    if constexpr (DBG) {            // where the wave ran: HW_ID (wave slot, SIMD, CU ...) behind the stamps
+        if (dbg != nullptr && blockIdx.x == 0 && lane == 0) dbg[kSeqLen * kWaves * 5 + wave] = __builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | (31 << 11));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // no transfer may still be writing LDS when the workgroup retires
 }
