@@ -264,6 +264,29 @@ def test_workgroup_forms_agree_bitwise(model7, monkeypatch):
         assert err < (DEFAULT_TOL if dm.precision >= 4 else SPLIT3_TOL), (n, err)
 
 
+def test_layer0_staggered_and_lock_step_agree_bitwise(model7, monkeypatch):
+    """96-row launches run layer 0 in its staggered form (waves 0-3 and 4-7 one slot apart, three barriers per step: DESIGN 7.3); a model
+    created with CCSM_L0_LOCKSTEP=1 runs the lock-step form.  Both issue the same products in the same order: same bits, in every
+    arithmetic, for a full coalesced-size launch and a ragged one (CCSM_WG_TILES=3 keeps both on 96-row workgroups)."""
+    from ccsmeth_amd.models import DeviceModel
+    w, dm = model7
+    monkeypatch.setenv("CCSM_L0_LOCKSTEP", "1")
+    dl = DeviceModel(w, device=0, precision=dm.precision)
+    monkeypatch.delenv("CCSM_L0_LOCKSTEP")
+    monkeypatch.setenv("CCSM_WG_TILES", "3")
+    try:
+        for n in (6144, 1000):
+            s = synth.synth_sites(n, 177 + n)
+            h1, h2 = synth.synth_h0(n, 178 + n)
+            wa, wb = dm.workspace(n), dl.workspace(n)
+            la, pa = _fwd(wa, s, (h1, h2))
+            lb, pb = _fwd(wb, s, (h1, h2))
+            wa.close(); wb.close()
+            assert np.array_equal(np.asarray(la), np.asarray(lb)) and np.array_equal(np.asarray(pa), np.asarray(pb)), (n, dm.precision)
+    finally:
+        dl.close()
+
+
 def test_input_layout_variants_agree(model7):
     """float32 k-mers and per-base npass (what the reference's FloatTensor call passes) == u8 k-mers + per-site npass."""
     w, dm = model7
