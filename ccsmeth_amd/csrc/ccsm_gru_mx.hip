@@ -833,6 +833,15 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 #ifdef CCSM_DMA_C_NT
             if (last_read) { dma16_buf_nt(xrs, lane16, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT_BYTES + (f << 10)))); return; }
 #endif
+#ifdef CCSM_PWR_NOXC        // diagnostic build (results wrong on purpose): phase C's transfers (the SECOND read of x_t) run with an empty exec mask - the
+                           // instruction issues and counts, nothing is fetched: the upper bound of what one pass over x_t could save in this schedule
+            if (last_read) {
+                asm volatile("s_mov_b32 m0, %3\n\ts_mov_b64 exec, 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds\n\ts_mov_b64 exec, -1"
+                             : : "v"(lane16), "s"(xrs), "s"(__builtin_amdgcn_readfirstlane(soff)),
+                                 "s"(__builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT_BYTES + (f << 10)))) : "memory");
+                return;
+            }
+#endif
 #ifdef CCSM_PWR_HALFCORR    // diagnostic build (results wrong on purpose): the blob fragments' transfers move their upper lanes only - what the layer
                            // input costs without the derivable fp6 copy of x_hi, before the cost of re-deriving it
             if (hl) {
