@@ -267,9 +267,20 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
     char* t_lo = smem + (lo_off + wave * (NB * 64 * 8) + (t16 >> 1));        // + lane * 8
     auto own_frag = [&](int kbl, int bt, int f) -> int { return ((kbl * NB + bt) * 2 + f) << 10; };
     uint32_t bsc_all = 0;
+#ifdef CCSM_PWR_TAIL1       // diagnostic build (results wrong on purpose): the tail's arithmetic (tanh, blend, packing) for row tile 0 only, its results
+                           // written for all three row tiles - LDS writes and output stores as shipped: what the tail's vector work costs
+    float hn[16];
+    uint4 hi0, hi1, c0, lo8;
+    uint2 c1;
+    uint32_t bsc = 0;
+#endif
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) {
+#ifdef CCSM_PWR_TAIL1
+        if (bt == 0) {
+#else
         float hn[16];
+#endif
         uint2 la = make_uint2(0, 0), lb = make_uint2(0, 0);
         if constexpr (!HS3) {
             la = *reinterpret_cast<const uint2*>(t_wr + own_frag(1, bt, 1) + 8);            // residuals of values 0..7
@@ -297,13 +308,24 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
                 hn[4 * q + e] = (hp[e] - nn) * accz[bt][4 * q + e] + nn;
             }
         }
+#ifndef CCSM_PWR_TAIL1
         uint4 hi0, hi1, c0, lo8;
         uint2 c1;
         uint32_t bsc = 0;               // XD: this lane's E8M0 scale of the blob (the next layer reads it beside the blob)
+#endif
         // XD: ONE block-scaled blob, for the own state (DYN) and for the next layer (`upper` from the opaque lane copy: the hoisted
         // 110 + upper got spilled)
         if constexpr (XD) pack_pair_mx<false, true>(hn, 0.25f, hi0, hi1, c0, c1, lo8, &bsc, t16 >> 9);
         else pack_pair_mx<false>(hn, 0.25f, hi0, hi1, c0, c1, lo8);
+#ifdef CCSM_PWR_TAIL1
+        } else {                    // (the accumulators of the other row tiles stay alive: their MFMAs and sigmoids must not be optimised away)
+#pragma unroll
+            for (int r = 0; r < 16; r += 8) {
+                asm volatile("" :: "v"(accn[bt][r]), "v"(accn[bt][r + 1]), "v"(accn[bt][r + 2]), "v"(accn[bt][r + 3]), "v"(accn[bt][r + 4]), "v"(accn[bt][r + 5]), "v"(accn[bt][r + 6]), "v"(accn[bt][r + 7]));
+                asm volatile("" :: "v"(accz[bt][r]), "v"(accz[bt][r + 1]), "v"(accz[bt][r + 2]), "v"(accz[bt][r + 3]), "v"(accz[bt][r + 4]), "v"(accz[bt][r + 5]), "v"(accz[bt][r + 6]), "v"(accz[bt][r + 7]));
+            }
+        }
+#endif
         const uint4 c1w = make_uint4(c1.x, c1.y, lo8.x, lo8.y);
         *reinterpret_cast<uint4*>(t_wr + own_frag(0, bt, 0)) = hi0;
         *reinterpret_cast<uint4*>(t_wr + own_frag(1, bt, 0)) = hi1;
@@ -785,6 +807,15 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 //   xin : [tile][t][32 kb][hi | corr][64] uint4      out : the same (OUT_FP8: fp8 corr fragments for the attention kernel)
 // LDS : h fragments 96 KiB | x ring 4 x 12 KiB | residuals 12 KiB | biases 4 KiB = 160 KiB
 // ---------------------------------------------------------------------------------------------------------
+// diagnostic build -DCCSM_PWR_LDS1 (results wrong on purpose): the layer-1/2 kernel reads the B operands of row tile 0 for all three row
+// tiles - one LDS read where there are three: what the activations' LDS reads cost
+//   = 1: every B operand; = 3: the hi fragments only (main MFMAs); = 2: all reads as shipped, but the main MFMAs take row tile 0's operand
+//   (the reads of tiles 1, 2 pinned behind them): 3 against 2 isolates the LDS reads from the operand toggling of the MFMAs
+#ifndef CCSM_PWR_LDS1
+#define CCSM_PWR_LDS1 0
+#endif
+constexpr int lds_bt(int bt) { return CCSM_PWR_LDS1 == 1 || CCSM_PWR_LDS1 == 3 ? 0 : bt; }        // hi fragments
+constexpr int lds_btc(int bt) { return CCSM_PWR_LDS1 == 1 ? 0 : bt; }                              // blob fragments
 constexpr int kMxRS = 4;
 constexpr int mx_slot_bytes(int nb) { return 2 * nb * 2 * 1024; }
 constexpr int mx12_xoff(int nb) { return mx_hbytes(nb); }
@@ -959,13 +990,13 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         int xsc = 0;                                                // XD: the x blobs' E8M0 scales, byte bt = row tile bt (written beside the blob by the layer below)
         auto rdx = [&](uint4 (&x)[NB], int xs, int kbl, int f) {    // xs = byte offset of the slot + lane * 16
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((kbl * NB + bt) * 2 + f) << 10));
+            for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((kbl * NB + lds_bt(bt)) * 2 + f) << 10));
         };
         auto rdx_blob = [&](int xs) {
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
-                xc0[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((0 * NB + bt) * 2 + 1) << 10));
-                xc1[bt] = *reinterpret_cast<const uint2*>(smem + xs + (((1 * NB + bt) * 2 + 1) << 10));
+                xc0[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((0 * NB + lds_btc(bt)) * 2 + 1) << 10));
+                xc1[bt] = *reinterpret_cast<const uint2*>(smem + xs + (((1 * NB + lds_btc(bt)) * 2 + 1) << 10));
             }
             if constexpr (XD) xsc = *reinterpret_cast<const int*>(smem + xs + (((1 * NB + (NB - 1)) * 2 + 1) << 10) + 8);   // bytes 0..2: row tiles 0..2
         };
@@ -974,7 +1005,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     do {                                                                                                      \
         CCSM_FENCE;                                                                                           \
         _Pragma("unroll") for (int bt = 0; bt < NB; ++bt) _Pragma("unroll") for (int g = 0; g < G; ++g)       \
-            acc[S0 + g][bt] = mfma16(W[g], X[bt], acc[S0 + g][bt]);                                           \
+            acc[S0 + g][bt] = mfma16(W[g], X[CCSM_PWR_LDS1 == 2 ? 0 : bt], acc[S0 + g][bt]);                  \
+        if constexpr (CCSM_PWR_LDS1 == 2) {                                                                   \
+            _Pragma("unroll") for (int bt = 1; bt < NB; ++bt)                                                 \
+                asm volatile("" :: "v"(X[bt].x), "v"(X[bt].y), "v"(X[bt].z), "v"(X[bt].w));                   \
+        }                                                                                                     \
         CCSM_FENCE;                                                                                           \
     } while (0)
 
@@ -1099,9 +1134,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             uint32_t pm[NB];                                            // split-mx-d: running max |x_hi| of the pair's block, this lane's values
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
-                xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, bt, 0) + lane * 16);
-                xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, bt, 1) + lane * 16);
-                xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag<NB>(2 * Q + 1, bt, 1) + lane * 16);
+                xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, lds_bt(bt), 0) + lane * 16);
+                xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, lds_btc(bt), 1) + lane * 16);
+                xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag<NB>(2 * Q + 1, lds_btc(bt), 1) + lane * 16);
             }
             CCSM_MAIN(wbh[0], xh, 3, 0);
             if constexpr (DYN) {
@@ -1115,7 +1150,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 wch[0][0] = w_at(OFF_C + 0 * PC + (0 << 10)); wch[0][1] = w_at(OFF_C + 0 * PC + (1 << 10)); wcb[0] = w_at(OFF_C + 0 * PC + (2 << 10));
             }
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q + 1, bt, 0) + lane * 16);
+            for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q + 1, lds_bt(bt), 0) + lane * 16);
             CCSM_MAIN(wbh[1], xh, 3, 0);
             if constexpr (!LAST) {
 #pragma unroll
@@ -1196,14 +1231,16 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             rdx(xh1, xs, 1, 0);
             CCSM_FENCE;
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][0], xh[bt], acc[2][bt]);
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][0], xh[CCSM_PWR_LDS1 == 2 ? 0 : bt], acc[2][bt]);
+            if constexpr (CCSM_PWR_LDS1 == 2) { asm volatile("" :: "v"(xh[NB - 1].x), "v"(xh[NB - 1].y), "v"(xh[NB - 1].z), "v"(xh[NB - 1].w), "v"(xh[NB > 1 ? 1 : 0].x), "v"(xh[NB > 1 ? 1 : 0].y), "v"(xh[NB > 1 ? 1 : 0].z), "v"(xh[NB > 1 ? 1 : 0].w)); }
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) wch[WS][0] = w_at(OFF_C + (P + 4) * PC + (0 << 10));
             else if constexpr (AF == 0) wah[AS][0][0] = w_at(AS * PA + (0 << 10)); else was[AS] = ws_at(AS * PA + (6 << 10));
             rdx_blob(xs);
             CCSM_FENCE;
 #pragma unroll
-            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][1], xh1[bt], acc[2][bt]);
+            for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][1], xh1[CCSM_PWR_LDS1 == 2 ? 0 : bt], acc[2][bt]);
+            if constexpr (CCSM_PWR_LDS1 == 2) { asm volatile("" :: "v"(xh1[NB - 1].x), "v"(xh1[NB - 1].y), "v"(xh1[NB - 1].z), "v"(xh1[NB - 1].w), "v"(xh1[NB > 1 ? 1 : 0].x), "v"(xh1[NB > 1 ? 1 : 0].y), "v"(xh1[NB > 1 ? 1 : 0].z), "v"(xh1[NB > 1 ? 1 : 0].w)); }
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) wch[WS][1] = w_at(OFF_C + (P + 4) * PC + (1 << 10));
             else if constexpr (AF == 0) wah[AS][0][1] = w_at(AS * PA + (1 << 10)); else wab[AS][1] = w_at(AS * PA + (5 << 10));
