@@ -904,7 +904,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)(dir * kWaves + wave) * mx12_wbytes(HS3, DYN));
     const int bias_off = kMx12BiasOff + wave * 4 * 32 * 4;
+#ifdef CCSM_PWR_W1          // diagnostic build (results wrong on purpose): every weight request of the layer-1/2 kernel reads one of the stream's first four
+                           // fragments (L1-resident): same requests, no L2 -> CU weight traffic - what the weight stream costs beyond its instructions
+    auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off & 0xc00); };
+#else
     auto w_at = [&](int off) -> uint4 { return buf_load(wrs, lane16, off); };
+#endif
     auto ws_at = [&](int off) -> uint32_t { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, off, 0); };
     auto w8_at = [&](int off) -> uint2 {            // bytes 16-23 of an fp6 blob: lane * 8
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
