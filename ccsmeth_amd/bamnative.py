@@ -278,6 +278,20 @@ class IndexRun:
         for k, v in zip(self.__slots__, st):
             setattr(self, k, v)
 
+    def to_wire(self):
+        """Plain-data form for the ranks' gather over the store (sharding.ChunkQueue.rendezvous: JSON, nothing executable)."""
+        import base64
+        return {"__index_run__": [self.n_records, self.n_unplaced, bool(self.sorted), list(self.first_key), list(self.last_key),
+                                  base64.b64encode(np.ascontiguousarray(self.entries, INDEX_ENTRY).tobytes()).decode("ascii"),
+                                  self.file_start, self.file_end]}
+
+    @classmethod
+    def from_wire(cls, d):
+        import base64
+        nr, nu, srt, fk, lk, ent, fs, fe = d["__index_run__"]
+        return cls(int(nr), int(nu), bool(srt), (int(fk[0]), int(fk[1])), (int(lk[0]), int(lk[1])),
+                   np.frombuffer(base64.b64decode(ent), INDEX_ENTRY).copy(), int(fs), int(fe))
+
 
 def index_write(bai_path, n_ref, runs, shifts=None):
     """Write <bai_path> from IndexRun tables given in final file order (shifts[i] = how far run i's bytes were moved when the part

@@ -267,6 +267,9 @@ def call_mods(args, log=sys.stderr, pipe=None):
         # the device extraction kernels implement the default (z-score of the CodecV1-decoded kinetics: extract_features.py:181-199,
         # 327-334); the other normalisations and raw codes go through the NumPy mirror of the reference's extraction and the
         # record-level BAM path, single GPU
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise ValueError("--norm %s%s are served by host extraction, which is single-GPU: run it without torch.distributed.run, "
+                             "or use --norm zscore on CodecV1 codes for the sharded path" % (args.norm, " / --no_decode" if args.no_decode else ""))
         if args.extract != "host" or args.io != "python":
             print("[main]--norm %s%s: feature extraction on the host (--extract host --io python)" % (args.norm, " --no_decode" if args.no_decode else ""), file=log)
         args.extract, args.io = "host", "python"
@@ -487,7 +490,13 @@ def call_mods(args, log=sys.stderr, pipe=None):
                 queue.rendezvous("stitch_copied")
                 os.remove(part_path)
             except BaseException as e:      # noqa: BLE001
-                queue.fail("%s: %s" % (type(e).__name__, e))
+                queue.fail("%s: %s" % (type(e).__name__, e))      # first failure wins: an echo of another rank's error does not replace it
+                for stale in (part_path, out_path if rank == 0 else None):      # no half-stitched output, no part files left behind
+                    try:
+                        if stale and os.path.exists(stale):
+                            os.remove(stale)
+                    except OSError:
+                        pass
                 raise
             shifts = [d - a for d, (_, a, _) in zip(dst, spans)]
         else:

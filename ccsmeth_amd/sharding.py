@@ -30,6 +30,22 @@ def n_chunks_of(file_size, chunk_bytes):
     return max(1, -(-int(file_size) // int(chunk_bytes)))
 
 
+def _to_wire(obj):
+    """json.dumps hook of ChunkQueue.rendezvous: run tables travel as plain data (bamnative.IndexRun.to_wire), NumPy scalars as numbers."""
+    if hasattr(obj, "to_wire"):
+        return obj.to_wire()
+    if hasattr(obj, "item") and getattr(obj, "shape", None) == ():
+        return obj.item()
+    raise TypeError("call_mods: %r does not travel between ranks" % type(obj).__name__)
+
+
+def _from_wire(d):
+    if "__index_run__" in d:
+        from .bamnative import IndexRun
+        return IndexRun.from_wire(d)
+    return d
+
+
 class ChunkQueue:
     """The shared work queue: chunk numbers 0 .. n_chunks - 1, each handed out once."""
 
@@ -56,7 +72,10 @@ class ChunkQueue:
     def fail(self, message):
         """Tell the other ranks that this one is giving up."""
         try:
-            self.store.set("%s/error" % self.prefix, ("rank %d: %s" % (self.rank, message)).encode("utf-8", "replace"))
+            # first failure wins: a rank that fails BECAUSE another one did (check() / rendezvous() raised the published error in it)
+            # must not replace the cause with its own echo of it
+            if self.store.add("%s/error_count" % self.prefix, 1) == 1:
+                self.store.set("%s/error" % self.prefix, ("rank %d: %s" % (self.rank, message)).encode("utf-8", "replace"))
         except Exception:   # noqa: BLE001 - the store may be what failed
             pass
 
@@ -68,10 +87,11 @@ class ChunkQueue:
         """Barrier + gather on the store, with the error key polled while waiting: every rank publishes `payload` under `tag` and gets
         the list of all ranks' payloads once all are there.  A rank that has called fail() releases the others at once with the
         error (a collective all_gather_object / barrier would keep them until the process group's timeout, 30 min by default)."""
-        import pickle
+        import json
         import time
         self.check()
-        self.store.set("%s/%s/%d" % (self.prefix, tag, self.rank), pickle.dumps(payload))
+        # JSON, not pickle: the payloads are numbers, strings and lists, and nothing read from a TCP store should be executable
+        self.store.set("%s/%s/%d" % (self.prefix, tag, self.rank), json.dumps(payload, default=_to_wire).encode("utf-8"))
         keys = ["%s/%s/%d" % (self.prefix, tag, r) for r in range(self.world)]
         t0 = time.time()
         while not self.store.check(keys):
@@ -80,7 +100,7 @@ class ChunkQueue:
                 raise RuntimeError("call_mods: rank %d waited %.0f s at '%s' for ranks that never arrived" % (self.rank, timeout_s, tag))
             time.sleep(poll_s)
         self.check()
-        return [pickle.loads(self.store.get(k)) for k in keys]
+        return [json.loads(self.store.get(k).decode("utf-8"), object_hook=_from_wire) for k in keys]
 
 
 def verify_chain(first_voffset, chunks, n_chunks=None, eof_voffset=None):
