@@ -5,6 +5,8 @@ import numpy as np
 
 from .utils.process_utils import base2code_dna
 
+COALESCE_SITES = 24576          # sites per launch when _call_mods2s coalesces the reference's batches: four full rounds of 256 workgroups x 96 strand rows
+
 
 def _batch_feature_list2s(feature_list):
     """22-field rows -> the reference's 18-tuple of parallel lists (call_modifications.py:73-123)."""
@@ -48,8 +50,16 @@ def _call_mods2s(features_batch, model, batch_size, device=0, h0_provider=None):
         rkmers, rpasss, ripdms, ripdsds, rpwms, rpwsds, rsns, rmaps, _ = features_batch
     pred_info = []
     batch_num = 0
-    for i in np.arange(0, len(sampleinfo), batch_size):
-        s, e = i, i + batch_size
+    # The reference cuts a hole-batch into model calls of `batch_size` sites (default 512: 11 of the 256 workgroups a launch of this
+    # library can hold).  All sites of the hole-batch are known before the first call and, with device-drawn initial states, a site's
+    # result does not depend on how the calls are cut (its random stream is keyed by its running index; every launch form computes the same
+    # bits), so against this library's model the loop below runs in launches of >= COALESCE_SITES sites and only COUNTS the reference's
+    # batches.  Pinned initial states (h0_provider: parity runs) keep the reference's cut.
+    coalesce = h0_provider is None and getattr(model, "coalesces_calls", False)
+    step = max(int(batch_size), COALESCE_SITES) if coalesce else batch_size
+    n_ref_batches = -(-len(sampleinfo) // int(batch_size)) if len(sampleinfo) else 0
+    for i in np.arange(0, len(sampleinfo), step):
+        s, e = i, i + step
         b_sampleinfo = sampleinfo[s:e]
         if len(b_sampleinfo) == 0:
             continue
@@ -64,4 +74,4 @@ def _call_mods2s(features_batch, model, batch_size, device=0, h0_provider=None):
             words = b_sampleinfo[idx].split("\t")
             pred_info.append((words[3], int(words[4]), p1[idx]))
         batch_num += 1
-    return pred_info, batch_num
+    return pred_info, (n_ref_batches if coalesce else batch_num)

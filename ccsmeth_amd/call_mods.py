@@ -62,6 +62,10 @@ def build_parser():
     p.add_argument("--methy_label", type=int, default=1, choices=[1, 0])
     p.add_argument("--norm", default="zscore")
     p.add_argument("--no_decode", action="store_true", default=False)
+    p.add_argument("--no_data_probe", action="store_true", default=False,
+                   help="--arithmetic auto picks split-mx only for a checkpoint whose 65536-site SYNTHETIC probe is clean; call_mods then\n"
+                        "repeats the comparison against split3 on the first <= 65536 sites of THIS input and falls back to split3 if\n"
+                        "split-mx is not clean on them as well (costs one extra pass over those sites).  This flag skips that second probe.")
     p.add_argument("--ref", default=None)
     p.add_argument("--mapq", type=int, default=1)
     p.add_argument("--identity", type=float, default=0.0)
@@ -254,6 +258,12 @@ def _read_of(rec):
                 np.asarray(tag("rp", [])), tag("fn", 0), tag("rn", 0), rec.is_reverse)
 
 
+def _print_data_probe(dm, log):
+    print("[main]arithmetic on this input: split-mx against split3 over its first %d sites: max %.1e, 99.9 %% %.1e -> %s" % (
+        dm.data_probe_sites, dm.data_probe_error, dm.data_probe_q999,
+        "split-mx is served" if dm.precision == 4 else "NOT clean on this input: split3 (three fp16 passes, fp32-class) is served"), file=log)
+
+
 def call_mods(args, log=sys.stderr, pipe=None):
     """`pipe`: an object with CallModsPipeline's run_native_batch / close (the CPU tests of the multi-rank hand-out pass a
     stand-in; None = the GPU pipeline on the checkpoint of --model_file)."""
@@ -274,6 +284,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
             print("[main]--norm %s%s: feature extraction on the host (--extract host --io python)" % (args.norm, " --no_decode" if args.no_decode else ""), file=log)
         args.extract, args.io = "host", "python"
     from collections import OrderedDict
+    probe_dm = None         # the device model whose default arithmetic (split-mx after a clean synthetic probe) is still to be probed on this input
     if pipe is None and os.environ.get("CCSM_NULL_MODEL") == "2":      # diagnostics: the host side alone (tools/host_feed_probe.py)
         from .pipeline import HostNullPipe
         pipe = HostNullPipe()
@@ -302,6 +313,7 @@ def call_mods(args, log=sys.stderr, pipe=None):
         # >= 12288 sites to fill the chip (256 workgroups of 96 strand rows), and the calls do not depend on how sites are chunked
         # (every site's initial state is a function of the seed, its read's name and its position there), so the flag is only a lower bound there.
         chunk_sites = max(args.batch_size, 12288) if args.extract == "device" else args.batch_size
+        probe_dm = model._dev if (model._dev.auto_precision and model._dev.precision == 4 and not args.no_data_probe) else None
         pipe = CallModsPipeline(model._dev, batch_size=chunk_sites, seed=args.tseed, extract=args.extract, norm=args.norm, no_decode=args.no_decode)
     holeids_e = None if args.holeids_e is None else _get_holes(args.holeids_e)          # extract_features.py:561-562
     holeids_ne = None if args.holeids_ne is None else _get_holes(args.holeids_ne)
@@ -353,6 +365,28 @@ def call_mods(args, log=sys.stderr, pipe=None):
                 dist.init_process_group("gloo", rank=rank, world_size=world)      # host-side bookkeeping only
             queue = sharding.ChunkQueue(sharding.open_board_store(world, rank), world, rank,
                                         sharding.n_chunks_of(os.path.getsize(args.input), chunk_bytes), dispatch=args.dispatch)
+        if probe_dm is not None:
+            # The selection rule on the ACTUAL input: the first <= 65536 called sites of the file go through split-mx and
+            # through split3, and split-mx stays only if it is clean on them too.  Rank 0 probes and publishes the verdict: one arithmetic
+            # for the whole run, whatever the number of ranks (the bytes written do not depend on the sharding).
+            if rank == 0:
+                with NativeBamReader(args.input, threads=min(args.threads, 4)) as prd:
+                    head, n_head = [], 0
+                    while n_head < 65536:
+                        b = prd.next_batch(min(holes_batch, 64))
+                        if b is None:
+                            break
+                        skip, _, sites = filters(b)
+                        head.append((b, skip))
+                        n_head += sites
+                    probe_dm.data_probe(lambda: (pipe.probs_of_native_batch(b, skip) for b, skip in head))
+                    for b, _ in head:
+                        b.close()
+                _print_data_probe(probe_dm, log)
+            if queue is not None:
+                verdict = queue.rendezvous("arithmetic", int(probe_dm.precision) if rank == 0 else None)[0]
+                if rank != 0:
+                    probe_dm.set_precision(int(verdict))
         part_path = out_path if world == 1 else "%s.part%d" % (out_path, rank)
         runs, chunk_log = [], []          # [(chunk, file start, file end, IndexRun)], [(chunk, first voffset, end voffset, records)]
         t_work = time.time()
@@ -556,6 +590,15 @@ def call_mods(args, log=sys.stderr, pipe=None):
                     qs, qe, ident = (np.array([x[k] for x in info]) for k in range(3))
                     askip, windows = _align_skip_and_window(np.array([r.flag for r in batch]), np.array([r.mapq for r in batch]), ident, qs, qe, L, args)
                     rds = [r._replace(fi=np.empty(0, np.uint8)) if sk else r for r, sk in zip(rds, askip)]
+                nonlocal probe_dm
+                if probe_dm is not None:        # the selection rule on this input's first reads (the native path probes up to 65536 sites; here: the first hole-batch)
+                    def p2():
+                        c0, _ = pipe.run(rds)
+                        p1 = np.concatenate([np.asarray(c.probs, np.float32) for c in c0] + [np.empty(0, np.float32)])
+                        yield np.stack([1.0 - p1, p1], 1)
+                    probe_dm.data_probe(p2)
+                    _print_data_probe(probe_dm, log)
+                    probe_dm = None
                 calls, failed = pipe.run(rds)
                 cnt_failed += failed
                 for ri, (rec, c) in enumerate(zip(batch, calls)):

@@ -98,6 +98,11 @@ struct ccsm_model {
     float* fcw = nullptr;                                // (2,1024)
     float* fcb = nullptr;                                // (2)
     float* embed = nullptr;                              // (5,8)
+    // the probe on the CALLER's data (ccsm_model_data_probe_*): |dprob| candidate vs split3 of every site handed in so far, and the verdict
+    std::vector<float> dprobe;
+    float dprobe_err = -1.f, dprobe_q999 = -1.f;
+    int dprobe_n = 0;
+    int dprobe_ok = -1;                                  // -1: not decided; 0: the candidate failed on the caller's data (split3 is served); 1: kept
 };
 
 struct ccsm_workspace {
@@ -1089,6 +1094,56 @@ float ccsm_model_probe_tail(const ccsm_model* m, int precision) {
 float ccsm_model_probe_q999(const ccsm_model* m) { return m ? m->probe_q999 : -1.f; }
 int ccsm_model_probe_sites(const ccsm_model* m) { return m ? m->probe_n : 0; }
 float ccsm_model_quant_error(const ccsm_model* m) { return m ? m->mx_quant_err : -1.f; }
+
+// ---- the probe on the caller's OWN data.  ccsm_create's probe runs synthetic sites: nothing ties its inputs to what the
+// caller will feed.  A caller that wants the selection rule applied to its real input runs its first batches through the arithmetic in
+// use AND through split3 (ccsm_model_set_precision switches between the two; both sets of weight streams are resident), hands both
+// results to ccsm_model_data_probe_add, and lets ccsm_model_data_probe_decide apply ccsm_create's rule to them: max |dprob| <= 1.25e-5 and
+// (from 8192 sites on) max <= 3 x the 99.9th percentile; a failed candidate is replaced by split3 for the rest of the model's life.
+// `call_mods` does this on the first <= 65536 sites of its input (reference call site: call_modifications.py:201-214).
+ccsm_status ccsm_model_set_precision(ccsm_model* m, int precision) {
+    if (!m) return fail(CCSM_ERR_INVALID_ARG, "model must be non-NULL");
+    const bool have = precision == CCSM_PRECISION_SPLIT3 || (precision == CCSM_PRECISION_SPLIT_F8 && m->wstmx[0]) ||
+                      (precision == CCSM_PRECISION_HYBRID && m->wsthy[0]) || (precision == CCSM_PRECISION_SPLIT_MXD && m->wstmd[0]);
+    if (!have) return fail(CCSM_ERR_INVALID_ARG, "ccsm_model_set_precision: this model holds no weight streams of that arithmetic (split3 always; "
+                                                  "of the split-mx family what ccsm_create probed or was asked for)");
+    m->precision = precision;
+    return CCSM_OK;
+}
+ccsm_status ccsm_model_data_probe_add(ccsm_model* m, const float* probs_candidate, const float* probs_split3, int n_sites) {
+    if (!m || !probs_candidate || !probs_split3 || n_sites < 0) return fail(CCSM_ERR_INVALID_ARG, "ccsm_model_data_probe_add: NULL argument");
+    m->dprobe.reserve(m->dprobe.size() + (size_t)n_sites);
+    for (int i = 0; i < n_sites; ++i) {
+        const float a = probs_candidate[2 * i + 1], b = probs_split3[2 * i + 1];
+        m->dprobe.push_back(std::isfinite(a) && std::isfinite(b) ? std::fabs(a - b) : 1.0f);
+    }
+    return CCSM_OK;
+}
+int ccsm_model_data_probe_decide(ccsm_model* m) {
+    if (!m) return -1;
+    float err = 0.f, q999 = 0.f;
+    std::vector<float>& all = m->dprobe;
+    for (float d : all) err = std::fmax(err, d);
+    if (!all.empty()) {
+        const size_t r = std::min(all.size() - 1, (size_t)std::floor(0.999 * (double)all.size()));
+        std::nth_element(all.begin(), all.begin() + (long)r, all.end());
+        q999 = all[r];
+    }
+    m->dprobe_err = all.empty() ? -1.f : err;
+    m->dprobe_q999 = all.empty() ? -1.f : q999;
+    m->dprobe_n = (int)all.size();
+    // fewer than one synthetic probe batch of sites: the percentile is not a tail statistic yet, the bound on the maximum alone decides
+    const bool ok = all.empty() || (err <= kProbeMaxErr && ((int)all.size() < kProbeSites || err <= kProbeTailRatio * q999));
+    m->dprobe_ok = ok ? 1 : 0;
+    if (!ok && m->precision != CCSM_PRECISION_SPLIT3 && std::getenv("CCSM_NO_PRECISION_FALLBACK") == nullptr) m->precision = CCSM_PRECISION_SPLIT3;
+    all.clear();
+    all.shrink_to_fit();
+    return m->precision;
+}
+float ccsm_model_data_probe_error(const ccsm_model* m) { return m ? m->dprobe_err : -1.f; }
+float ccsm_model_data_probe_q999(const ccsm_model* m) { return m ? m->dprobe_q999 : -1.f; }
+int ccsm_model_data_probe_sites(const ccsm_model* m) { return m ? m->dprobe_n : 0; }
+int ccsm_model_data_probe_verdict(const ccsm_model* m) { return m ? m->dprobe_ok : -1; }
 
 void ccsm_destroy(ccsm_model* m) {
     if (!m) return;

@@ -58,7 +58,56 @@ class DeviceModel:
         self.probe_q999 = float(lib.ccsm_model_probe_q999(handle))                     # 99.9th percentile of |dprob| split-mx vs split3 over the probe sites
         self.probe_sites = int(lib.ccsm_model_probe_sites(handle))                     # probe sites run (0: a precision was forced)
         self.quant_error = float(lib.ccsm_model_quant_error(handle))
+        self.auto_precision = int(precision) == 0
+        self.data_probe_error, self.data_probe_q999, self.data_probe_sites, self.data_probe_verdict = -1.0, -1.0, 0, -1
         self._workspaces = []
+
+    # ---- the selection rule on the caller's own data (include/ccsm.h: ccsm_model_data_probe_*) -------------------------------------
+    def set_precision(self, precision):
+        """Switch between the arithmetics whose weight streams are resident: split3 (3) always; 4 / 5 / 6 if ccsm_create probed or was
+        asked for it."""
+        _lib.check(self._lib.ccsm_model_set_precision(self.handle, int(precision)))
+        self.precision = int(precision)
+
+    def data_probe_add(self, probs_candidate, probs_split3):
+        a = np.ascontiguousarray(probs_candidate, np.float32)
+        b = np.ascontiguousarray(probs_split3, np.float32)
+        if a.shape != b.shape or a.ndim != 2 or a.shape[1] != 2:
+            raise ValueError("two (n, 2) probability arrays")
+        _lib.check(self._lib.ccsm_model_data_probe_add(self.handle, a.ctypes.data, b.ctypes.data, int(a.shape[0])))
+
+    def data_probe_decide(self):
+        """-> the precision in use after the rule has seen every site added (split3 if the candidate failed on them)."""
+        lib = self._lib
+        self.precision = int(lib.ccsm_model_data_probe_decide(self.handle))
+        self.data_probe_error = float(lib.ccsm_model_data_probe_error(self.handle))
+        self.data_probe_q999 = float(lib.ccsm_model_data_probe_q999(self.handle))
+        self.data_probe_sites = int(lib.ccsm_model_data_probe_sites(self.handle))
+        self.data_probe_verdict = int(lib.ccsm_model_data_probe_verdict(self.handle))
+        return self.precision
+
+    def data_probe(self, run, max_sites=65536):
+        """Apply ccsm_create's rule to the caller's own sites.  `run()` yields (n, 2) probability arrays of the SAME sites every time it is
+        iterated (a generator function over the first batches of the input); it is iterated once in the arithmetic in use and once in
+        split3.  No-op (returns the precision in use) unless the default picked split-mx."""
+        if self.precision == _lib.PRECISION_SPLIT3:
+            return self.precision
+        cand = self.precision
+        got = []
+        for arith in (cand, _lib.PRECISION_SPLIT3):
+            self.set_precision(arith)
+            part, n = [], 0
+            for p in run():
+                part.append(np.array(p, np.float32, copy=True))
+                n += len(p)
+                if n >= max_sites:
+                    break
+            got.append(np.concatenate(part) if part else np.empty((0, 2), np.float32))
+        self.set_precision(cand)
+        if got[0].shape != got[1].shape:
+            raise RuntimeError("data probe: the two passes saw different sites")
+        self.data_probe_add(got[0][:max_sites], got[1][:max_sites])
+        return self.data_probe_decide()
 
     def workspace(self, max_sites):
         ws = Workspace(self, max_sites)
@@ -428,6 +477,8 @@ class ModelAttRNN:
         self._dev = None
         self._ws = None
         self._calls = 0
+
+    coalesces_calls = True      # call_modifications._call_mods2s may hand this model more sites per call than --batch_size (same results)
 
     def get_model_type(self):
         return self.model_type

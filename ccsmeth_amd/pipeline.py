@@ -188,6 +188,30 @@ class CallModsPipeline:
             self._turn += 1
         return job
 
+    def probs_of_native_batch(self, batch, skip=None):
+        """The raw (n_sites, 2) probabilities of one bamnative.Batch in the model's CURRENT arithmetic (synchronous; chunks as
+        feed_native_batch cuts them): what the data probe compares between two arithmetics (DeviceModel.data_probe)."""
+        cnt = np.where(batch.length > 0, batch.n_sites, 0).astype(np.int64)
+        if skip is not None:
+            cnt[np.asarray(skip, bool)] = 0
+        idx = np.flatnonzero(cnt > 0)
+        out, start = [], 0
+        while start < len(idx):
+            csum = np.cumsum(cnt[idx[start:]])
+            take = max(1, int(np.searchsorted(csum, self.batch_size, side="right")))
+            sel = idx[start:start + take]
+            csites = int(cnt[sel].sum())
+            if self._rwss[0] is None or self._rwss[0].max_sites < csites:
+                if self._rwss[0] is not None:
+                    self._rwss[0].close()
+                self._rwss[0] = self.dm.workspace(max(csites, self.batch_size))
+            self._rwss[0].submit_reads_arrays(batch.offset[sel], batch.length[sel], batch.seq, batch.fi, batch.ri, batch.fp, batch.rp,
+                                              batch.fn[sel], batch.rn[sel], site_counts=cnt[sel], seed=self.seed,
+                                              stream=self._slots[0].stream, read_keys=batch.name_hash[sel])
+            out.append(self._rwss[0].wait_reads()[3].copy())
+            start += take
+        return np.concatenate(out) if out else np.empty((0, 2), np.float32)
+
     def _collect_one(self):
         k, job, sel = self._inflight.pop(0)
         f, lc, _, pr = self._rwss[k].wait_reads()

@@ -6,19 +6,35 @@ import time
 import numpy as np
 
 
-def write_synthetic_hifi_bam(path, n_reads, read_len, cpg=0.012, seed=3):
+def write_synthetic_hifi_bam(path, n_reads, read_len, cpg=0.012, seed=3, planted=0.0):
     """Unaligned HiFi reads with kinetics tags (fi/fp/ri/rp uint8 per base, fn/rn passes): SURVEY.md 8(d)'s configs[2] shape,
-    ~600 CpG sites per 15 kb read after the window filter.  Returns (seconds, bytes)."""
+    ~600 CpG sites per 15 kb read after the window filter.  planted > 0: every second read is "methylated" - the IPD / PW codes around
+    each of its CpGs carry the shift pattern of synth.synth_labeled_sites (in units of the codes' standard deviation, x `planted`, a
+    log-normal amplitude per site; forward strand around the C, reverse strand around the C opposite the G, x 0.7): kinetics with the
+    structure a trained checkpoint responds to.  Returns (seconds, bytes)."""
     from .. import bamio
     rng = np.random.default_rng(seed)
     t0 = time.time()
     acgt = np.frombuffer(b"ACGT", np.uint8)
+    pat_i = np.array([0.25, 0.55, 1.30, 0.80, 0.30]) * 28.0       # gamma(2, 20): sigma 28 codes
+    pat_p = np.array([0.10, -0.20, 0.45, 0.30, 0.00]) * 28.0
     with bamio.BamWriter(path, "@HD\tVN:1.5\tSO:unknown\n", [], level=1) as w:
         for i in range(n_reads):
             seq = acgt[rng.choice(4, size=read_len, p=[0.3, 0.2, 0.2, 0.3])]
             pos = rng.integers(0, read_len - 1, int(read_len * cpg))
             seq[pos], seq[pos + 1] = ord("C"), ord("G")
             kin = np.clip(rng.gamma(2.0, 20.0, size=(4, read_len)), 0, 255).astype(np.uint8)
+            if planted > 0 and i % 2 == 1:
+                kf = kin.astype(np.float64)
+                c = np.flatnonzero((seq[:-1] == ord("C")) & (seq[1:] == ord("G")))
+                c = c[(c >= 12) & (c < read_len - 13)]
+                amp = planted * np.exp(rng.normal(0.0, 0.45, len(c)))
+                for d in range(5):
+                    kf[0, c - 2 + d] += amp * pat_i[d]                          # fi / fp: the forward strand, around the C
+                    kf[1, c - 2 + d] += amp * pat_p[d]
+                    kf[2, read_len - 2 - c - 2 + d] += 0.7 * amp * pat_i[d]     # ri / rp (reverse-strand order): around the C opposite the G
+                    kf[3, read_len - 2 - c - 2 + d] += 0.7 * amp * pat_p[d]
+                kin = np.clip(np.rint(kf), 0, 255).astype(np.uint8)
             tags = [("fi", "BC", kin[0]), ("fp", "BC", kin[1]), ("ri", "BC", kin[2]), ("rp", "BC", kin[3]), ("fn", "C", 12), ("rn", "C", 13),
                     ("np", "C", 25)]
             w.write(bamio.BamRecord("m/%d/ccs" % i, flag=4, ref_id=-1, seq=seq.tobytes().decode(), qual=np.full(read_len, 40, np.uint8), tags=tags))

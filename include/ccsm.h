@@ -224,6 +224,22 @@ float ccsm_model_probe_tail(const ccsm_model* m, int precision);
 float ccsm_model_probe_q999(const ccsm_model* m);
 int ccsm_model_probe_sites(const ccsm_model* m);
 float ccsm_model_quant_error(const ccsm_model* m);
+/* The same rule on the CALLER's data.  ccsm_create's probe runs synthetic sites; a caller that wants the rule applied to what it
+ * actually feeds (call_mods: the first <= 65536 sites of its input; reference call site call_modifications.py:201-214) runs those sites
+ * through the arithmetic in use and through SPLIT3 - ccsm_model_set_precision switches between the two: SPLIT3's weight streams are
+ * always resident, of the split-mx family the one ccsm_create probed or was asked for, anything else is CCSM_ERR_INVALID_ARG - and hands
+ * both (n, 2) probability arrays to ccsm_model_data_probe_add (any number of calls).  ccsm_model_data_probe_decide applies the rule to all
+ * sites added (max |dprob| <= 1.25e-5 and, from 8192 sites on, max <= 3 x the 99.9th percentile), switches the model to SPLIT3 if the
+ * candidate fails (unless CCSM_NO_PRECISION_FALLBACK is set), forgets the sites and returns the precision now in use.
+ * _data_probe_error / _q999 / _sites: the figures of the last decision (-1 / -1 / 0 before one); _verdict: -1 none, 0 failed, 1 kept.
+ * Not thread-safe against forwards on the same model (single-threaded use per model, as everywhere in this interface). */
+ccsm_status ccsm_model_set_precision(ccsm_model* m, int precision);
+ccsm_status ccsm_model_data_probe_add(ccsm_model* m, const float* probs_candidate, const float* probs_split3, int n_sites);
+int ccsm_model_data_probe_decide(ccsm_model* m);
+float ccsm_model_data_probe_error(const ccsm_model* m);
+float ccsm_model_data_probe_q999(const ccsm_model* m);
+int ccsm_model_data_probe_sites(const ccsm_model* m);
+int ccsm_model_data_probe_verdict(const ccsm_model* m);
 size_t ccsm_workspace_bytes(const ccsm_workspace* ws);
 /* Times (ms, HIP events on `stream`) of the kernels of the LAST forward issued on this workspace with timing
  * enabled: out[0..2] = GRU layers 0..2, out[3] = attention+FC, out[4] = logits/softmax finalize.  Blocks. */

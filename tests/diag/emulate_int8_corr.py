@@ -1,0 +1,278 @@
+"""Emulation of candidate fp32-class arithmetics with FEWER than three MFMA passes per product, on the committed trained checkpoints
+(VERDICT r04 item 1).  Every product W x of the GRU layers (and, with --attn, of the attention pool) is evaluated as
+
+    main term   fp16(W) . fp16(x)                    one v_mfma_f32_32x32x16_f16 pass, fp32 accumulation            (1.0 pass per flop)
+    corrections W_lo . x_hi + W_hi . x_lo            in the format under test
+
+  split3        both corrections as fp16 passes (what trained checkpoints are served with today)                     3.0 passes
+  i8            both corrections on v_mfma_i32_32x32x32_i8 (2x the fp16 rate): every operand as int8 under ONE scale per matrix
+                row / activation row (the i32 accumulator cannot be rescaled inside a K loop), lo parts under the hi scale x 2^-11,
+                so both terms share one accumulator and one conversion                                               2.0 passes
+                variants: scale = max/127 (exact) or the next power of two; activation scale per row over all of K, per
+                (row, 256-k half) [= one fold in the middle of a K = 512 phase], or the bound max(1, previous step's row max) a kernel
+                can have without a reduction in front of the conversion
+  i8+f16        W_hi . x_lo on int8, W_lo . x_hi as an fp16 pass                                                     2.5 passes
+  mx-pair       both correction operands as PAIRS of fp6 e2m3 values under per-(row, 32-k block) E8M0 scales
+                (8-bit-class significands out of 4-bit MX operands; three quarter-rate products per term)            2.5 passes
+against the same forward in float64.  Quantities per (checkpoint, arithmetic): max |dprob|, quantiles, sites beyond 1e-5 ... 1e-4, the
+light-tail criterion of ccsm_create's selection rule (max <= 1.25e-5 and max <= 3 x the 99.9th percentile).
+
+torch on whatever device is there (cuda on the GPU box: 2^20 sites x 3 checkpoints in minutes; CPU for small n).  Test infrastructure:
+uses oracle/ only to check this file's own float64 forward against the NumPy oracle (--selfcheck).
+usage: python tests/diag/emulate_int8_corr.py [--sites N] [--ckpt name ...] [--modes a,b,...] [--attn] [--selfcheck]"""
+import argparse, os, sys, time
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from ccsmeth_amd.utils import synth  # noqa: E402
+
+RHO = 2.0 ** -11          # |v - fp16(v)| <= 2^-11 |v|: the lo image's scale relative to the hi image's
+
+
+def hi16(a):
+    return a.to(torch.float16).to(torch.float32)
+
+
+def q_int8(v, scale):
+    """round-to-nearest-even image of v / scale, clamped to int8's symmetric range; returned as fp32 integers (their products and K <= 512
+    sums are exact in fp32: 127 * 127 * 512 < 2^24)"""
+    return torch.clamp(torch.round(v / scale), -127.0, 127.0)
+
+
+def pow2_ceil(a):
+    return torch.exp2(torch.ceil(torch.log2(torch.clamp(a, min=1e-30))))
+
+
+def q_e2m3(v):
+    """nearest fp6 e2m3 value (sign, 2 exponent bits, 3 mantissa bits, bias 1: subnormal step 0.125, max 7.5)"""
+    a = v.abs()
+    e = torch.clamp(torch.floor(torch.log2(torch.clamp(a, min=1e-30))), min=0.0, max=2.0)
+    step = torch.exp2(e - 3.0)
+    return torch.sign(v) * torch.clamp(torch.round(a / step) * step, max=7.5)
+
+
+def mx_pair(v):
+    """v (rows, K) as p1 + p2, both fp6 e2m3 under E8M0 scales per (row, 32-k block), p2's scale = p1's x 2^-4"""
+    r, k = v.shape
+    b = v.reshape(r, k // 32, 32)
+    s1 = pow2_ceil(b.abs().amax(-1, keepdim=True) / 7.5)
+    p1 = q_e2m3(b / s1) * s1
+    s2 = s1 * 2.0 ** -4
+    p2 = q_e2m3((b - p1) / s2) * s2
+    return p1.reshape(r, k), p2.reshape(r, k)
+
+
+class Weight:
+    """one matrix (U, K) with every image a mode may ask for (prepared once per checkpoint, as ccsm_create would)"""
+
+    def __init__(self, w, dev):
+        w = torch.as_tensor(np.asarray(w, np.float32), device=dev)
+        u, k = w.shape
+        self.k_real = k
+        kp = (k + 31) // 32 * 32
+        if kp != k:
+            w = torch.nn.functional.pad(w, (0, kp - k))
+        self.w = w
+        self.w64 = w.double()
+        self.hi = hi16(w)
+        self.lo = w - self.hi
+        self.lo16 = hi16(self.lo)
+        amax = w.abs().amax(1, keepdim=True).clamp(min=1e-30)
+        self.i8 = {}
+        for name, s in (("exact", amax / 127.0), ("pow2", pow2_ceil(amax) / 128.0)):
+            self.i8[name] = (s, q_int8(self.hi, s), q_int8(self.lo, s * RHO))
+        # scales per (row, 256-k half): the halves of a layer input are the two directions of the layer below
+        if kp % 256 == 0 and kp > 256:
+            hs = []
+            for c in range(0, kp, 256):
+                a = w[:, c:c + 256].abs().amax(1, keepdim=True).clamp(min=1e-30) / 127.0
+                hs.append((a, q_int8(self.hi[:, c:c + 256], a), q_int8(self.lo[:, c:c + 256], a * RHO)))
+            self.i8["exact_half"] = hs
+        self.mx_hi = mx_pair(self.hi)
+        self.mx_lo = mx_pair(self.lo * 2.0 ** 11)
+
+
+def act_scale(x, kind, bound=None):
+    if kind == "bound":      # what a kernel has without a reduction in front of the conversion: max(1, row max of the previous step)
+        return bound / 127.0
+    a = x.abs().amax(1, keepdim=True).clamp(min=1e-30)
+    return (a / 127.0) if kind == "exact" else pow2_ceil(a) / 128.0
+
+
+def mm(x, wt, mode, bound=None):
+    """x (N, K) fp32 . wt^T -> (N, U) in the arithmetic `mode`"""
+    if x.shape[1] != wt.w.shape[1]:
+        x = torch.nn.functional.pad(x, (0, wt.w.shape[1] - x.shape[1]))
+    if mode == "f64":
+        return x.double() @ wt.w64.T
+    xh = hi16(x)
+    xl = x - xh
+    main = xh @ wt.hi.T
+    if mode == "fp16":
+        return main
+    if mode == "split3":
+        return main + (xh @ wt.lo16.T + hi16(xl) @ wt.hi.T)
+    kind = mode.split(":")
+    if kind[0] == "i8":
+        wkind, akind = kind[1], kind[2]         # weight scale exact|pow2, activation scale exact|pow2|bound|half
+        if akind == "half" and "exact_half" in wt.i8:
+            out = main
+            for c, (sw, whi8, wlo8) in zip(range(0, wt.w.shape[1], 256), wt.i8["exact_half"]):
+                sx = act_scale(x[:, c:c + 256], "exact")
+                acc = q_int8(xh[:, c:c + 256], sx) @ wlo8.T + q_int8(xl[:, c:c + 256], sx * RHO) @ whi8.T
+                out = out + acc * (sx * RHO) * sw.T
+            return out
+        sw, whi8, wlo8 = wt.i8[wkind]
+        sx = act_scale(x, "exact" if akind == "half" else akind, bound)
+        acc = q_int8(xh, sx) @ wlo8.T + q_int8(xl, sx * RHO) @ whi8.T          # one i32 accumulator for both terms
+        return main + acc * (sx * RHO) * sw.T
+    if kind[0] == "i8f16":
+        sw, whi8, _ = wt.i8["exact"]
+        sx = act_scale(x, "exact")
+        return main + xh @ wt.lo16.T + (q_int8(xl, sx * RHO) @ whi8.T) * (sx * RHO) * sw.T
+    if kind[0] == "mxpair":
+        # mxpair = all three piece products per term (2.5 passes); mxpair:w = both weight pieces against the first activation piece only,
+        # mxpair:x = the other way round (two products per term: 2.0 passes); mxpair:1 = first pieces only (split-mx-d with fp6 weights: 1.5)
+        sub = kind[1] if len(kind) > 1 else "all"
+        xh1, xh2 = mx_pair(xh)
+        xl1, xl2 = mx_pair(xl * 2.0 ** 11)
+        wl1, wl2 = wt.mx_lo
+        wh1, wh2 = wt.mx_hi
+        c = xh1 @ wl1.T + xl1 @ wh1.T
+        if sub in ("all", "w"):
+            c = c + xh1 @ wl2.T + xl1 @ wh2.T
+        if sub in ("all", "x"):
+            c = c + xh2 @ wl1.T + xl2 @ wh1.T
+        return main + c * 2.0 ** -11
+    raise ValueError(mode)
+
+
+def gru_direction(x, h0, wih, whh, bih, bhh, reverse, mode, first_layer):
+    n, L, _ = x.shape
+    H = h0.shape[1]
+    dt = torch.float64 if mode == "f64" else torch.float32
+    h = h0.to(dt)
+    out = torch.empty((n, L, H), dtype=dt, device=x.device)
+    # layer 0's input part is K = 11 (z-scores, pass counts): it stays on three fp16 passes in every candidate (one k-block)
+    hmode = mode
+    if mode.startswith("x="):                     # "x=<mode of the input part>;h=<mode of the recurrent part>"
+        xm, hm = mode.split(";")
+        mode, hmode = xm[2:], hm[2:]
+    xmode = mode if (mode == "f64" or not first_layer) else "split3"
+    if mode.endswith(":bound"):
+        xmode = mode.replace(":bound", ":exact") if not first_layer else "split3"     # the layer input's row max travels with it (written by the layer below)
+    mode = hmode
+    gi_all = (mm(x.reshape(n * L, -1).to(torch.float32), wih, xmode) + bih.to(dt)).reshape(n, L, 3 * H)
+    bound = torch.clamp(h0.abs().amax(1, keepdim=True), min=1.0).to(torch.float32)
+    for t in (range(L - 1, -1, -1) if reverse else range(L)):
+        gi = gi_all[:, t]
+        gh = mm(h.to(torch.float32) if mode != "f64" else h, whh, mode, bound) + bhh.to(dt)
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        nn_ = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = (h - nn_) * z + nn_
+        bound = torch.clamp(h.abs().amax(1, keepdim=True), min=1.0).to(torch.float32)
+        out[:, t] = h
+    return out, h
+
+
+def forward(W, s, h0s, mode, attn_mode, dev):
+    dt = torch.float64 if mode == "f64" else torch.float32
+    ctxs = []
+    for si in (1, 2):
+        kmer = torch.as_tensor(s["kmer%d" % si].astype(np.int64), device=dev)
+        feats = [W["embed"].to(dt)[kmer]] + [torch.as_tensor(s["%s%d" % (nm, si)], device=dev).to(dt)[..., None] for nm in ("ipd", "pw")]
+        npass = torch.as_tensor(s["npass%d" % si], device=dev).to(dt)
+        feats.append(npass[:, None, None].expand(-1, 21, 1))
+        inp = torch.cat(feats, 2)
+        h0 = h0s[si - 1]
+        hn = []
+        for layer in range(3):
+            outs = []
+            for d, sfx in enumerate(("", "_reverse")):
+                o, hl = gru_direction(inp, h0[2 * layer + d], W["rnn.weight_ih_l%d%s" % (layer, sfx)], W["rnn.weight_hh_l%d%s" % (layer, sfx)],
+                                      W["rnn.bias_ih_l%d%s" % (layer, sfx)], W["rnn.bias_hh_l%d%s" % (layer, sfx)], bool(d), mode, layer == 0)
+                outs.append(o); hn.append(hl)
+            inp = torch.cat(outs, 2)
+        q = torch.cat([hn[4], hn[5]], 1)
+        am = "f64" if mode == "f64" else attn_mode
+        n = q.shape[0]
+        qa = mm(q.to(torch.float32) if am != "f64" else q, W["_att3.Wa.weight"], am)
+        ka = mm(inp.reshape(n * 21, -1).to(torch.float32) if am != "f64" else inp.reshape(n * 21, -1), W["_att3.Ua.weight"], am).reshape(n, 21, -1)
+        e = torch.tanh(qa[:, None, :] + ka) @ W["va"].to(ka.dtype)
+        a = torch.softmax(e, 1)
+        ctxs.append((a[:, :, None] * inp.to(a.dtype)).sum(1))
+    feat = torch.cat(ctxs, 1)
+    logits = feat @ W["fc1.weight"].to(feat.dtype).T + W["fc1.bias"].to(feat.dtype)
+    return torch.softmax(logits.double(), 1)
+
+
+def prepare(wt, dev):
+    W = {}
+    for k, v in wt.items():
+        if k.startswith("rnn.weight") or k in ("_att3.Wa.weight", "_att3.Ua.weight"):
+            W[k] = Weight(v, dev)
+        elif k.startswith("rnn.bias"):
+            W[k] = torch.as_tensor(np.asarray(v, np.float64), device=dev)
+    W["embed"] = torch.as_tensor(np.asarray(wt["embed.weight"], np.float64), device=dev)
+    W["va"] = torch.as_tensor(np.asarray(wt["_att3.va.weight"], np.float64).reshape(-1), device=dev)
+    W["fc1.weight"] = torch.as_tensor(np.asarray(wt["fc1.weight"], np.float64), device=dev)
+    W["fc1.bias"] = torch.as_tensor(np.asarray(wt["fc1.bias"], np.float64), device=dev)
+    return W
+
+
+MODES = ["split3", "i8:exact:exact", "i8:pow2:pow2", "i8:exact:half", "i8:exact:bound", "i8f16", "mxpair", "fp16"]
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sites", type=int, default=8192)
+    ap.add_argument("--block", type=int, default=8192)
+    ap.add_argument("--ckpt", nargs="*", default=["toy41_960", "planted7_5000", "planted11_12000_nodrop"])
+    ap.add_argument("--modes", default=",".join(MODES))
+    ap.add_argument("--attn", action="store_true", help="the attention pool's products in the mode under test as well (default: split3)")
+    ap.add_argument("--selfcheck", action="store_true")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+    log = open(args.out, "a") if args.out else None
+
+    def say(*a):
+        line = " ".join(str(x) for x in a)
+        print(line, flush=True)
+        if log:
+            log.write(line + "\n"); log.flush()
+
+    say("# emulate_int8_corr: device %s, %d sites per checkpoint in blocks of %d, attention pool in %s" % (
+        dev, args.sites, args.block, "the mode under test" if args.attn else "split3"))
+    B = min(args.block, args.sites)
+    nblk = max(1, args.sites // B)
+    gen = torch.Generator(device=dev); gen.manual_seed(20260930)
+    modes = args.modes.split(",")
+    for name in args.ckpt:
+        wt = synth.synth_weights(7) if name == "synthetic_init_7" else dict(np.load(os.path.join(ROOT, "tests", "golden", "trained", name + ".npz")))
+        W = prepare(wt, dev)
+        if args.selfcheck:
+            from oracle import attbigru2s_oracle as orc
+            s = synth.synth_sites(64, 5); h1, h2 = synth.synth_h0(64, 6)
+            ref = orc.attbigru2s_forward(wt, s["kmer1"], s["ipd1"], s["pw1"], s["npass1"], s["kmer2"], s["ipd2"], s["pw2"], s["npass2"], h1, h2)[1]
+            mine = forward(W, s, (torch.as_tensor(h1, device=dev), torch.as_tensor(h2, device=dev)), "f64", "f64", dev).cpu().numpy()
+            say("selfcheck %s: this file's float64 forward against the NumPy oracle: max |dprob| %.2e" % (name, np.abs(mine - ref).max()))
+        d = {m: [] for m in modes}
+        t0 = time.time()
+        for b in range(nblk):
+            s = synth.synth_sites(B, 70000 + b) if b % 2 == 0 else synth.synth_labeled_sites(B, 70000 + b)[0]
+            h0s = tuple(torch.randn((6, B, 256), generator=gen, device=dev, dtype=torch.float32) for _ in range(2))
+            ref = forward(W, s, h0s, "f64", "f64", dev)[:, 1]
+            for m in modes:
+                p = forward(W, s, h0s, m, (m[2:].split(";")[0] if m.startswith("x=") else m) if args.attn else "split3", dev)[:, 1]
+                d[m].append((p - ref).abs().cpu().numpy())
+        say("== %s: %d sites, %.0f s" % (name, nblk * B, time.time() - t0))
+        for m in modes:
+            e = np.concatenate(d[m])
+            q999, q9999 = np.quantile(e, 0.999), np.quantile(e, 0.9999)
+            light = e.max() <= 1.25e-5 and e.max() <= 3.0 * q999
+            say("   %-26s max %.2e | >1e-5 %6d  >2.5e-5 %6d  >5e-5 %5d  >1e-4 %4d | 99.9%% %.2e 99.99%% %.2e mean %.2e | max/q99.9 %.1f | rule: %s" % (
+                m, e.max(), (e > 1e-5).sum(), (e > 2.5e-5).sum(), (e > 5e-5).sum(), (e > 1e-4).sum(), q999, q9999, e.mean(), e.max() / max(q999, 1e-30),
+                "light-tailed, within 1.25e-5" if light else "NOT served by the rule"))

@@ -1153,3 +1153,44 @@ def test_call_mods_other_normalisations_and_raw_codes(tmp_path):
         assert a.shape == base.shape and np.array_equal(a, b), extra
         assert all(not np.array_equal(a, s) for s in seen), extra          # another normalisation, other probabilities
         seen.append(a)
+
+
+def test_call_mods2s_at_the_reference_batch_size_coalesces_its_calls():
+    """the class-level drop-in at the reference's default --batch_size 512 (call_modifications.py:177-226 cuts a
+    hole-batch into 512-site model calls; one such call fills 11 of 256 workgroups).  The mirror hands this library's model the
+    hole-batch in launches of >= 24576 sites instead: identical results (device-drawn initial states are keyed by the running site index;
+    every launch form computes the same bits), the reference's batch count, and the time of the run with a launch-filling batch size."""
+    import time
+    from ccsmeth_amd import call_modifications as cm
+    from ccsmeth_amd.models import ModelAttRNN
+    n = 30000                                           # a hole-batch of 50 reads x ~600 sites
+    s = synth.synth_sites(n, 321)
+    info = ["chr\t%d\t+\thole%d\t%d" % (i, i // 600, i % 600) for i in range(n)]
+    z = [0] * n
+    cols = []
+    for sfx in ("1", "2"):
+        cols += [list(s["kmer" + sfx].astype(np.float64)), list(np.repeat(s["npass" + sfx][:, None], 21, 1)), list(s["ipd" + sfx].astype(np.float64)), z,
+                 list(s["pw" + sfx].astype(np.float64)), z, z, z]
+    fb = (info, *cols, [0] * n)
+
+    def model():
+        m = ModelAttRNN(21, 3, 2, 0, 256, model_type="attbigru2s", device=0, seed=77)
+        m.load_state_dict(synth.synth_weights(5))
+        return m.cuda(0).eval()
+    m_ref = model()
+    m_ref.coalesces_calls = False                       # the reference's cut: 59 calls of 512 sites
+    t0 = time.time(); pred_cut, nb_cut = cm._call_mods2s(fb, m_ref, 512, 0); t_cut = time.time() - t0
+    m_def = model()
+    cm._call_mods2s(fb, m_def, 512, 0)                  # (first call: workspace allocation)
+    m_def._calls = 0
+    t0 = time.time(); pred, nb = cm._call_mods2s(fb, m_def, 512, 0); t_def = time.time() - t0
+    m_big = model()
+    cm._call_mods2s(fb, m_big, 24576, 0)
+    m_big._calls = 0
+    t0 = time.time(); pred_big, nb_big = cm._call_mods2s(fb, m_big, 24576, 0); t_big = time.time() - t0
+    assert nb == nb_cut == 59 and nb_big == 2
+    assert [(a, b) for a, b, _ in pred] == [(a, b) for a, b, _ in pred_cut]
+    assert np.array_equal(np.array([p[2] for p in pred]), np.array([p[2] for p in pred_cut]))      # the same bits as the reference's cut
+    assert np.array_equal(np.array([p[2] for p in pred]), np.array([p[2] for p in pred_big]))
+    print("_call_mods2s over %d sites: --batch_size 512 cut as the reference %.3f s, coalesced %.3f s, --batch_size 24576 %.3f s" % (n, t_cut, t_def, t_big))
+    assert t_def <= 1.15 * t_big + 0.02
