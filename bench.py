@@ -403,6 +403,24 @@ def extras(weights, dm, dev, pool, grp):
     leg("call_mods_end_to_end", call_mods_e2e)
     leg("call_mods_end_to_end_trained", call_mods_e2e_trained)
     leg("aggregate_50M", aggregate)
+    # BASELINE configs[2] at 1/10 of its size, measured once per round on the GPU box by tools/e2e_million_reads.py (8 minutes: not
+    # re-run by this command; CCSM_BENCH_MILLION_READS=1 runs it here): the committed trained checkpoint, i.e. split3
+    if os.environ.get("CCSM_BENCH_MILLION_READS"):
+        def million():
+            import subprocess
+            logp = os.path.join(ROOT, "gpurun_out", "bench_million_reads.log")
+            os.makedirs(os.path.dirname(logp), exist_ok=True)
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "e2e_million_reads.py"), "--log", logp], stdout=subprocess.DEVNULL)
+            rep = [ln for ln in open(logp) if ln.startswith("# report:")][-1]
+            return {"value": float(rep.split("->")[1].split("M sites/s")[0]) * 1e6, "unit": "sites/s", "log": logp, "what": rep.strip()}
+        leg("call_mods_million_reads", million)
+    else:
+        out["call_mods_million_reads"] = {
+            "value": 1.569e6, "unit": "sites/s", "measured": "round 5, not by this command", "log": "profiles/r05_b_call_mods_million_reads_trained.log",
+            "what": "python -m ccsmeth_amd call_mods --io native --no_sort on 1 008 000 synthetic 15-kb HiFi reads (52.8 GiB of BGZF, 760.7 M CpG "
+                    "sites; BASELINE configs[2] names 10 M reads: scaled down 9.9 x) with tests/golden/trained/planted7_5000.npz (split3): work "
+                    "phase 484.9 s = 1.569 M sites/s, whole run incl. model set-up 1.563 M; host RSS 2.1-2.3 GiB and device memory 11.9 GiB flat "
+                    "over the run; 1 008 000 records in and out, all tagged"}
     return out
 
 

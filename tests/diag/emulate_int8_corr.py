@@ -192,8 +192,9 @@ def forward(W, s, h0s, mode, attn_mode, dev):
         for layer in range(3):
             outs = []
             for d, sfx in enumerate(("", "_reverse")):
+                lmode = mode.split("|")[layer] if "|" in mode else mode       # "m0|m1|m2": one mode per layer
                 o, hl = gru_direction(inp, h0[2 * layer + d], W["rnn.weight_ih_l%d%s" % (layer, sfx)], W["rnn.weight_hh_l%d%s" % (layer, sfx)],
-                                      W["rnn.bias_ih_l%d%s" % (layer, sfx)], W["rnn.bias_hh_l%d%s" % (layer, sfx)], bool(d), mode, layer == 0)
+                                      W["rnn.bias_ih_l%d%s" % (layer, sfx)], W["rnn.bias_hh_l%d%s" % (layer, sfx)], bool(d), lmode, layer == 0)
                 outs.append(o); hn.append(hl)
             inp = torch.cat(outs, 2)
         q = torch.cat([hn[4], hn[5]], 1)
@@ -266,13 +267,13 @@ if __name__ == "__main__":
             h0s = tuple(torch.randn((6, B, 256), generator=gen, device=dev, dtype=torch.float32) for _ in range(2))
             ref = forward(W, s, h0s, "f64", "f64", dev)[:, 1]
             for m in modes:
-                p = forward(W, s, h0s, m, (m[2:].split(";")[0] if m.startswith("x=") else m) if args.attn else "split3", dev)[:, 1]
+                p = forward(W, s, h0s, m, (m[2:].split(";")[0] if m.startswith("x=") else m) if (args.attn and "|" not in m) else "split3", dev)[:, 1]
                 d[m].append((p - ref).abs().cpu().numpy())
         say("== %s: %d sites, %.0f s" % (name, nblk * B, time.time() - t0))
         for m in modes:
             e = np.concatenate(d[m])
             q999, q9999 = np.quantile(e, 0.999), np.quantile(e, 0.9999)
             light = e.max() <= 1.25e-5 and e.max() <= 3.0 * q999
-            say("   %-26s max %.2e | >1e-5 %6d  >2.5e-5 %6d  >5e-5 %5d  >1e-4 %4d | 99.9%% %.2e 99.99%% %.2e mean %.2e | max/q99.9 %.1f | rule: %s" % (
+            say("   %-44s max %.2e | >1e-5 %6d  >2.5e-5 %6d  >5e-5 %5d  >1e-4 %4d | 99.9%% %.2e 99.99%% %.2e mean %.2e | max/q99.9 %.1f | rule: %s" % (
                 m, e.max(), (e > 1e-5).sum(), (e > 2.5e-5).sum(), (e > 5e-5).sum(), (e > 1e-4).sum(), q999, q9999, e.mean(), e.max() / max(q999, 1e-30),
                 "light-tailed, within 1.25e-5" if light else "NOT served by the rule"))

@@ -78,6 +78,48 @@ def test_default_arithmetic_on_a_trained_checkpoint_holds_the_bar_at_every_site(
     assert 0.05 < np.mean(frac) < 0.95                                # a model that discriminates
 
 
+# max |dprob| of the default arithmetic against FLOAT64 arithmetic over 8 x 8192 sites (bound the quantity that is actually
+# bounded, on a larger sample than the 1024 sites the NumPy oracle affords).  The float64 forward is tests/diag/emulate_int8_corr.py's
+# torch restatement on the GPU (checked against the NumPy oracle in the same test: 1e-7).  The emulation of split3 itself sits 1.1e-5 /
+# 2.5e-5 / 1.6e-4 from float64 at 2^20 sites (profiles/r05_a_emulate_int8_mxpair_corrections.log): the hostile checkpoint is
+# ill-conditioned at single sites for ANY fp32-class arithmetic, the reference's included.
+BOUND64_LARGE = {"toy41_960": 2.5e-5, "planted7_5000": 2.5e-5, "planted11_12000_nodrop": 1e-4}
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_default_arithmetic_against_float64_on_65536_sites(name):
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag"))
+    import emulate_int8_corr as emu
+    from ccsmeth_amd.models import DeviceModel
+    from oracle import attbigru2s_oracle as orc
+    wt = _load(name)
+    dev = torch.device("cuda:0")
+    W = emu.prepare(wt, dev)
+    dm = DeviceModel(wt, device=0)
+    assert dm.precision == 3
+    ws = dm.workspace(B)
+    worst, beyond, q = 0.0, 0, []
+    for b in range(8):
+        s = _sites(b)
+        h1, h2 = synth.synth_h0(B, 90000 + b)
+        ref = emu.forward(W, s, (torch.as_tensor(h1, device=dev), torch.as_tensor(h2, device=dev)), "f64", "f64", dev).cpu().numpy()
+        if b == 0:          # the torch restatement against the NumPy oracle (float64 both)
+            k = {key: v[:256] for key, v in s.items()}
+            r64 = orc.attbigru2s_forward(wt, *_args(k), h1[:, :256], h2[:, :256])[1]
+            assert np.abs(ref[:256] - r64).max() < 1e-7
+        _, probs = ws.forward_host(*_args(s), h0=(h1, h2))
+        d = np.abs(probs.astype(np.float64) - ref)[:, 1]
+        worst = max(worst, float(d.max()))
+        beyond += int((d > 2.5e-5).sum())
+        q.append(d)
+    dm.close()
+    d = np.concatenate(q)
+    print("%s: split3 against float64 over %d sites: max %.2e, 99.9 %% %.2e, beyond 2.5e-5: %d" % (name, len(d), worst, np.quantile(d, 0.999), beyond))
+    assert worst < BOUND64_LARGE[name], (worst, beyond)
+
+
 @pytest.mark.parametrize("name", FIXTURES[:2])
 def test_block_scaled_arithmetics_are_heavy_tailed_on_trained_weights(name):
     """Why the probe does not hand trained checkpoints to split-mx / split-mx-d / the hybrid: over 16 x 8192 sites (device-drawn initial
@@ -127,3 +169,76 @@ def test_synthetic_initialisation_keeps_split_mx_with_a_light_tail():
             worst = max(worst, float(np.abs(a - r).max()))
         dm.close(); d3.close()
         assert worst <= 1.25e-5, (seed, worst)
+
+
+def test_data_probe_rule_and_switch():
+    """include/ccsm.h: ccsm_model_set_precision / ccsm_model_data_probe_*.  The rule itself, on fabricated probability pairs: a model whose
+    synthetic probe is clean (the random initialisation: split-mx) keeps split-mx when the caller's sites agree with split3 and is switched
+    to split3 for good when one of them is 2e-5 away, or when the maximum is more than three times the 99.9th percentile of >= 8192 sites;
+    only arithmetics with resident weight streams can be selected."""
+    from ccsmeth_amd import _lib
+    from ccsmeth_amd.models import DeviceModel
+    rng = np.random.default_rng(3)
+    p = rng.random((20000, 1)).astype(np.float32)
+    base = np.concatenate([1 - p, p], 1)
+    near = base + rng.uniform(-4e-6, 4e-6, base.shape).astype(np.float32)
+    for case, other, want, verdict in (("clean", near, 4, 1), ("one site at 2e-5", None, 3, 0), ("heavy tail", None, 3, 0)):
+        dm = DeviceModel(synth.synth_weights(7), device=0)
+        assert dm.precision == 4 and dm.auto_precision
+        if case == "one site at 2e-5":
+            other = near.copy(); other[777, 1] = base[777, 1] + 2e-5
+        if case == "heavy tail":                                   # every site within 1e-6 but one at 1.2e-5: max <= 1.25e-5, max > 3 x the 99.9th percentile
+            other = base + rng.uniform(-1e-6, 1e-6, base.shape).astype(np.float32); other[5, 1] = base[5, 1] + 1.2e-5
+        dm.data_probe_add(other, base)
+        assert dm.data_probe_decide() == want, case
+        assert dm.data_probe_verdict == verdict and dm.data_probe_sites == 20000 and dm.data_probe_error > 0
+        if want == 3:                                               # ... and forwards run in split3 from here on (same bits as a forced split3)
+            s = synth.synth_sites(512, 4)
+            a = dm.workspace(512).forward_host(*_args(s), h0=None, seed=5, offset=0)[1]
+            d3 = DeviceModel(synth.synth_weights(7), device=0, precision=3)
+            b = d3.workspace(512).forward_host(*_args(s), h0=None, seed=5, offset=0)[1]
+            assert np.array_equal(a, b)
+            d3.close()
+        dm.close()
+    d3 = DeviceModel(synth.synth_weights(7), device=0, precision=3)           # a forced split3 holds no split-mx streams
+    with pytest.raises(_lib.CcsmError):
+        d3.set_precision(4)
+    with pytest.raises(_lib.CcsmError):
+        d3.set_precision(5)
+    d3.close()
+
+
+# A (checkpoint, input) pair on which ccsm_create's SYNTHETIC probe accepts split-mx and the same rule on the input's own first 65536 sites
+# rejects it (found by tests/diag/gpu_data_probe_pair.py, profiles/r05_b_data_probe_pair_search.log): the long-trained fixture pulled back to
+# 8 % of its way from the initialisation it was trained from - synthetic probe max 1.16e-5 (inside 1.25e-5), this input 1.30e-5 (outside).
+# Everything in it is deterministic (weights, BAM generator, both arithmetics); should a change of the split-mx kernels' bits move either
+# figure across 1.25e-5, re-run the search and pick another alpha.
+PAIR = dict(name="planted11_12000_nodrop", init_seed=11, alpha=0.08, reads=160, bam_seed=11)
+
+
+def test_call_mods_probes_the_arithmetic_on_its_own_input(tmp_path):
+    """`call_mods --arithmetic auto` on a checkpoint that is clean on the synthetic probe and not on this input: the
+    `[main]arithmetic` lines print both probes, split3 is served - the output is byte-identical to `--arithmetic split3` - and
+    `--no_data_probe` keeps split-mx."""
+    import io
+    import torch
+    from collections import OrderedDict
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    from ccsmeth_amd.utils import benchdata
+    tr, init = _load(PAIR["name"]), synth.synth_weights(PAIR["init_seed"])
+    w = {k: (init[k] + np.float32(PAIR["alpha"]) * (tr[k] - init[k])).astype(np.float32) for k in init}
+    inp, ckpt = str(tmp_path / "in.bam"), str(tmp_path / "m.ckpt")
+    benchdata.write_synthetic_hifi_bam(inp, PAIR["reads"], 15000, seed=PAIR["bam_seed"], planted=0.0)
+    torch.save(OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in w.items()), ckpt)
+    logs, outs = {}, {}
+    for tag, extra in (("auto", []), ("split3", ["--arithmetic", "split3"]), ("noprobe", ["--no_data_probe"])):
+        log = io.StringIO()
+        res = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / tag), "--batch_size", "12288", "--no_sort"] + extra), log=log)
+        logs[tag], outs[tag] = log.getvalue(), open(res["output"], "rb").read()
+        assert res["reads"] == PAIR["reads"]
+    lines = [ln for ln in logs["auto"].splitlines() if ln.startswith("[main]arithmetic")]
+    print("\n".join(lines))
+    assert len(lines) == 2 and lines[0].startswith("[main]arithmetic: split-mx") and "probe of 65536 sites" in lines[0]
+    assert lines[1].startswith("[main]arithmetic on this input") and "65536 sites" in lines[1] and "split3" in lines[1] and "NOT clean" in lines[1]
+    assert outs["auto"] == outs["split3"]                  # (the @PG line carries sys.argv, the same in the three runs)
+    assert [ln for ln in logs["noprobe"].splitlines() if ln.startswith("[main]arithmetic")] == [lines[0]]
