@@ -397,7 +397,8 @@ def call_mods(args, log=sys.stderr, pipe=None):
                     header = _set_coordinate_order(header)             # no reference: every record sorts equal, input order is kept
                 header_inflated = rd.inflated_bytes
                 first_voffset = rd.tell()
-                eof_voffset = rd.eof_voffset() if queue is not None else None      # where the hand-over chain has to end (block headers only)
+                # where the hand-over chain has to end (block headers only): rank 0 looks, the others are told
+                eof_voffset = None if queue is None else queue.rendezvous("eof_voffset", rd.eof_voffset() if rank == 0 else None)[0]
                 n_ref = rd.n_ref
                 with NativeBamWriter(part_path, header, rd.raw_refs, rd.n_ref, threads=args.threads) as wr, \
                         ThreadPoolExecutor(1) as rpool, ThreadPoolExecutor(1) as wpool:

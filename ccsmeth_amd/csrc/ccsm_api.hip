@@ -1202,6 +1202,11 @@ ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_works
     if (st == CCSM_OK) {   // padding rows are computed (and ignored): give them finite contents once
         hipError_t e = hipMemset(ws->x0, 0, x0_b);
         if (e == hipSuccess) e = hipMemset(ws->h0buf, 0, h0_b);
+        // hipMemset of device memory returns before it has run, on the NULL stream - which a caller's non-blocking streams (every
+        // torch.cuda.Stream) do not wait for: a workspace created while another one is busy could be zeroed AFTER its first call's
+        // extraction kernels had filled x0 (round 5: found by the byte comparison of test_call_mods_probes_the_arithmetic_on_its_own_input -
+        // the second chunk of a call_mods run came out wrong in one run of three).  The creation is rare: wait here.
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
     }
     if (st == CCSM_OK) {

@@ -1,6 +1,7 @@
 // libccsm_bam: native BGZF / BAM reader and modbam writer of the call_mods path (include/ccsm_bam.h).
 // Host only.  Follows the SAM/BAM specification v1 (BGZF = gzip members with a 'BC' extra subfield, little-endian records);
 // mirrors ccsmeth_amd/bamio.py + ccsmeth_amd/_bam2modbam.py, which the tests compare it with.
+#define _FILE_OFFSET_BITS 64      // off_t / fseeko / ftello are 64-bit on every ABI (inputs pass 100 GiB)
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -811,7 +812,7 @@ namespace {
 // continue reading at a BGZF virtual offset; limit = last block file offset that may be read (~0: none), stop = chunk end (~0: none)
 int reposition(ccsm_bam_reader* r, uint64_t voffset_start, uint64_t limit, uint64_t stop) {
     const uint64_t coff = voffset_start >> 16, uoff = voffset_start & 0xffffu;
-    if (std::fseek(r->fh, (long)coff, SEEK_SET) != 0) return fail("seek failed");
+    if (fseeko(r->fh, (off_t)coff, SEEK_SET) != 0) return fail("seek failed");
     r->erased += r->stream.size();          // absolute positions stay monotonic (the virtual-offset bookkeeping keys on them)
     r->stream.clear();
     r->pos = 0;
@@ -872,12 +873,12 @@ int ccsm_bam_seek_chunk(ccsm_bam_reader* r, uint64_t coffset_lo, uint64_t coffse
     *voffset_first = 0;
     // 1. the first BGZF block at or behind coffset_lo: a gzip member header with the 'BC' subfield whose size leads to another one (or
     //    to the end of the file), three deep
-    if (std::fseek(r->fh, 0, SEEK_END) != 0) return fail("seek failed");
-    const uint64_t fsize = (uint64_t)std::ftell(r->fh);
+    if (fseeko(r->fh, 0, SEEK_END) != 0) return fail("seek failed");
+    const uint64_t fsize = (uint64_t)ftello(r->fh);
     auto block_at = [&](uint64_t off, uint64_t* next) -> bool {      // header check only
         uint8_t h[18];
         if (off + 18 > fsize) return false;
-        if (std::fseek(r->fh, (long)off, SEEK_SET) != 0 || std::fread(h, 1, 18, r->fh) != 18) return false;
+        if (fseeko(r->fh, (off_t)off, SEEK_SET) != 0 || std::fread(h, 1, 18, r->fh) != 18) return false;
         if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) return false;
         const uint32_t xlen = rd16(h + 10);
         if (xlen < 6) return false;
@@ -923,13 +924,13 @@ int ccsm_bam_seek_chunk(ccsm_bam_reader* r, uint64_t coffset_lo, uint64_t coffse
     {
         // a block is at most 64 KiB, so one lies in any 64 KiB window that is not the tail of the last block
         std::vector<uint8_t> win((size_t)std::min<uint64_t>(fsize - coffset_lo, 65536 + 4));
-        if (std::fseek(r->fh, (long)coffset_lo, SEEK_SET) != 0 || std::fread(win.data(), 1, win.size(), r->fh) != win.size()) return fail("read failed");
+        if (fseeko(r->fh, (off_t)coffset_lo, SEEK_SET) != 0 || std::fread(win.data(), 1, win.size(), r->fh) != win.size()) return fail("read failed");
         for (size_t i = 0; i + 4 <= win.size(); ++i)
             if (win[i] == 0x1f && win[i + 1] == 0x8b && win[i + 2] == 8 && win[i + 3] == 4 && chain_ok(coffset_lo + i)) { blk = coffset_lo + i; break; }
     }
     if (blk == ~0ull || blk >= coffset_hi) return 0;                    // no block starts in [lo, hi)
     // 2. the first record that starts in a block of [blk, hi): inflate from blk and test every offset
-    if (std::fseek(r->fh, (long)blk, SEEK_SET) != 0) return fail("seek failed");
+    if (fseeko(r->fh, (off_t)blk, SEEK_SET) != 0) return fail("seek failed");
     r->erased += r->stream.size();
     r->stream.clear();
     r->pos = 0;
@@ -984,13 +985,13 @@ int ccsm_bam_eof_voffset(ccsm_bam_reader* r, uint64_t* voffset) try {
     FILE* fh = std::fopen(r->path.c_str(), "rb");
     if (!fh) return fail("cannot reopen " + r->path);
     struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{fh};
-    if (std::fseek(fh, 0, SEEK_END) != 0) return fail("seek failed");
-    const uint64_t fsize = (uint64_t)std::ftell(fh);
+    if (fseeko(fh, 0, SEEK_END) != 0) return fail("seek failed");
+    const uint64_t fsize = (uint64_t)ftello(fh);
     // one block header + trailer: -> 1 ok (next, isize), 0 not a block, sets `why`
     std::string why;
     auto block_at = [&](uint64_t off, uint64_t* next, uint32_t* isize) -> bool {
         uint8_t h[12];
-        if (off + 12 > fsize || std::fseek(fh, (long)off, SEEK_SET) != 0 || std::fread(h, 1, 12, fh) != 12) { why = "truncated BGZF block"; return false; }
+        if (off + 12 > fsize || fseeko(fh, (off_t)off, SEEK_SET) != 0 || std::fread(h, 1, 12, fh) != 12) { why = "truncated BGZF block"; return false; }
         if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4) { why = "not a BGZF stream (bad gzip member header)"; return false; }
         const uint32_t xlen = rd16(h + 10);
         std::vector<uint8_t> x(xlen);
@@ -1004,7 +1005,7 @@ int ccsm_bam_eof_voffset(ccsm_bam_reader* r, uint64_t* voffset) try {
         if (bsize < 0) { why = "gzip member without the BGZF 'BC' field"; return false; }
         if ((uint64_t)bsize + 1 < (uint64_t)xlen + 20 || off + (uint64_t)bsize + 1 > fsize) { why = "truncated BGZF block"; return false; }
         uint8_t t[4];
-        if (std::fseek(fh, (long)(off + (uint64_t)bsize + 1 - 4), SEEK_SET) != 0 || std::fread(t, 1, 4, fh) != 4) { why = "truncated BGZF block"; return false; }
+        if (fseeko(fh, (off_t)(off + (uint64_t)bsize + 1 - 4), SEEK_SET) != 0 || std::fread(t, 1, 4, fh) != 4) { why = "truncated BGZF block"; return false; }
         *isize = rd32(t);
         if (*isize > 65536) { why = "corrupt BGZF block (ISIZE > 64 KiB)"; return false; }
         *next = off + (uint64_t)bsize + 1;
@@ -1022,11 +1023,14 @@ int ccsm_bam_eof_voffset(ccsm_bam_reader* r, uint64_t* voffset) try {
         return true;
     };
     uint64_t last = ~0ull; uint32_t last_isize = 0;
-    // the tail of a large file first: a candidate header in its last 256 KiB from which the block chain reaches the end of the file
-    if (fsize > (1u << 18)) {
-        const uint64_t base = fsize - (1u << 18);
+    // the tail of a large file first: a candidate header in a 64 KiB window (a BGZF block is at most 64 KiB: a window inside the data holds
+    // at least one true header) from which the block chain reaches the end of the file with data in it.  The window steps back - 256 KiB,
+    // 4 MiB, 64 MiB before the end - before the walk from the first block is paid (one seek + two reads per block: millions of system
+    // calls on a 100 GiB input): only a tail of more than 64 MiB of EMPTY blocks gets there.
+    for (uint64_t back = 1u << 18; last == ~0ull && back <= (1u << 26) && fsize > back; back <<= 4) {
+        const uint64_t base = fsize - back;
         std::vector<uint8_t> win(65536 + 4);
-        if (std::fseek(fh, (long)base, SEEK_SET) == 0 && std::fread(win.data(), 1, win.size(), fh) == win.size()) {
+        if (fseeko(fh, (off_t)base, SEEK_SET) == 0 && std::fread(win.data(), 1, win.size(), fh) == win.size()) {
             for (size_t i = 0; i + 4 <= win.size(); ++i) {
                 if (win[i] != 0x1f || win[i + 1] != 0x8b || win[i + 2] != 8 || win[i + 3] != 4) continue;
                 if (walk(base + i, &last, &last_isize) && last != ~0ull) break;

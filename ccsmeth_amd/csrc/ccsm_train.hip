@@ -822,6 +822,7 @@ ccsm_status ccsm_train_create(const ccsm_weights* w, int device, int max_sites, 
     if (d_grads) t->grads = d_grads; else { TRY(dalloc(&t->grads, kOff.total)); t->own_grads = true; }
     HIPCHK(hipMemset(t->adam_m, 0, sizeof(float) * kOff.total));
     HIPCHK(hipMemset(t->adam_v, 0, sizeof(float) * kOff.total));
+    HIPCHK(hipStreamSynchronize(nullptr));      // (device memsets are asynchronous, on the NULL stream, which the trainer's own stream does not wait for)
     TRY(dalloc(&t->kmer, M * T));
     TRY(dalloc(&t->ipd, M * T)); TRY(dalloc(&t->pw, M * T)); TRY(dalloc(&t->npass, M * T));
     TRY(dalloc(&t->labels, (size_t)max_sites));
