@@ -83,7 +83,7 @@ def test_default_arithmetic_on_a_trained_checkpoint_holds_the_bar_at_every_site(
 # torch restatement on the GPU (checked against the NumPy oracle in the same test: 1e-7).  The emulation of split3 itself sits 1.1e-5 /
 # 2.5e-5 / 1.6e-4 from float64 at 2^20 sites (profiles/r05_a_emulate_int8_mxpair_corrections.log): the hostile checkpoint is
 # ill-conditioned at single sites for ANY fp32-class arithmetic, the reference's included.
-BOUND64_LARGE = {"toy41_960": 2.5e-5, "planted7_5000": 2.5e-5, "planted11_12000_nodrop": 1e-4}
+BOUND64_LARGE = {"toy41_960": 1.25e-5, "planted7_5000": 2.5e-5, "planted11_12000_nodrop": 7.5e-5}      # measured 3.1e-6 / 6.3e-6 / 5.5e-5 (profiles/r05_d_pytest_trained_checkpoints.log)
 
 
 @pytest.mark.parametrize("name", FIXTURES)
