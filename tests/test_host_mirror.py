@@ -136,3 +136,34 @@ def test_every_kinetics_normalisation_matches_the_reference():
     assert not np.any(_normalize_signals(CODE2FRAMES[g["codes_flat"]], "mad"))
     with pytest.raises(ValueError):
         _normalize_signals(x, "median")
+
+
+def test_call_mods2s_coalesces_only_for_a_model_that_says_so():
+    """_call_mods2s (call_modifications.py:170-227) against a stand-in model: a model with `coalesces_calls` gets launches of >=
+    COALESCE_SITES sites and the reference's batch COUNT; any other model (the reference's own) gets the reference's cut; pinned initial
+    states keep the cut either way; the per-site results are the same in all cases."""
+    from ccsmeth_amd import call_modifications as cm
+
+    class Fake:
+        def __init__(self, coalesce):
+            self.coalesces_calls = coalesce
+            self.calls = []
+
+        def __call__(self, kmer, *rest, h0=None):
+            self.calls.append(len(kmer))
+            p = (np.asarray(rest[1], np.float32)[:, 10] * 0.1 + 0.5).clip(0.01, 0.99)       # a function of the site's own features only
+            probs = np.stack([1 - p, p], 1).astype(np.float32)
+            return probs, probs
+    n = 1300
+    rng = np.random.default_rng(5)
+    info = ["c\t%d\t+\th%d\t%d" % (i, i // 100, i) for i in range(n)]
+    col = lambda: [rng.standard_normal(21) for _ in range(n)]  # noqa: E731
+    fb = (info, *[col() for _ in range(16)], [0] * n)
+    ref_model, co_model, pin_model = Fake(False), Fake(True), Fake(True)
+    pred_ref, nb_ref = cm._call_mods2s(fb, ref_model, 512)
+    pred_co, nb_co = cm._call_mods2s(fb, co_model, 512)
+    pred_pin, nb_pin = cm._call_mods2s(fb, pin_model, 512, h0_provider=lambda b, k: None)
+    assert ref_model.calls == [512, 512, 276] and co_model.calls == [1300] and pin_model.calls == [512, 512, 276]
+    assert nb_ref == nb_co == nb_pin == 3
+    assert pred_ref == pred_co == pred_pin
+    assert cm._call_mods2s((info[:0], *[[] for _ in range(16)], []), Fake(True), 512) == ([], 0)
