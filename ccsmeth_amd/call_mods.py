@@ -284,7 +284,9 @@ def call_mods(args, log=sys.stderr, pipe=None):
             print("[main]--norm %s%s: feature extraction on the host (--extract host --io python)" % (args.norm, " --no_decode" if args.no_decode else ""), file=log)
         args.extract, args.io = "host", "python"
     from collections import OrderedDict
-    probe_dm = None         # the device model whose default arithmetic (split-mx after a clean synthetic probe) is still to be probed on this input
+    # the device model whose default arithmetic (split-mx after a clean synthetic probe) is still to be probed on this input (a stand-in
+    # pipe of the CPU tests may bring a stand-in for it)
+    probe_dm = getattr(pipe, "data_probe_model", None)
     if pipe is None and os.environ.get("CCSM_NULL_MODEL") == "2":      # diagnostics: the host side alone (tools/host_feed_probe.py)
         from .pipeline import HostNullPipe
         pipe = HostNullPipe()

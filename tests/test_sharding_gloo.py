@@ -163,12 +163,77 @@ def test_two_ranks_many_small_batches_per_block(tmp_path, monkeypatch):
     assert sum(res[0]["rank_chunks"]) >= 2 and res[0]["sites"] == one["sites"] and res[0]["reads"] == 23
 
 
-def _worker_small(rank, world, ports, inp, out, q):
+class FakeProbeModel:
+    """What call_mods needs of DeviceModel for the probe on its own input: rank 0's probe "finds" split-mx unclean on the input."""
+
+    def __init__(self):
+        self.auto_precision, self.precision = True, 4
+        self.data_probe_error, self.data_probe_q999, self.data_probe_sites = -1.0, -1.0, 0
+        self.probed, self.told = 0, []
+
+    def data_probe(self, run, max_sites=65536):
+        self.probed = sum(len(p) for p in run())
+        self.data_probe_error, self.data_probe_q999, self.data_probe_sites = 3e-5, 1e-5, self.probed
+        self.precision = 3
+        return 3
+
+    def set_precision(self, p):
+        self.told.append(p)
+        self.precision = p
+
+
+class StubPipeWithProbe(StubPipe):
+    def __init__(self):
+        self.data_probe_model = FakeProbeModel()
+
+    def probs_of_native_batch(self, batch, skip=None):
+        _, _, p1, _, _ = self.run_native_batch(batch, skip)
+        return np.stack([1 - p1, p1], 1).astype(np.float32)
+
+
+def _worker_small(rank, world, ports, inp, out, q, with_probe=False):
     from ccsmeth_amd.call_mods import build_parser, call_mods
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[0]))
     sys.argv = list(ARGV)
     a = build_parser().parse_args(["-i", inp, "-m", "x", "-o", out, "--holes_batch", "3", "--threads", "2", "--no_sort", "--chunk_mb", "0.0005"])
-    q.put((rank, call_mods(a, log=open(os.devnull, "w"), pipe=StubPipe())))
+    pipe = StubPipeWithProbe() if with_probe else StubPipe()
+    res = call_mods(a, log=open(os.devnull, "w"), pipe=pipe)
+    if with_probe:
+        m = pipe.data_probe_model
+        res = dict(res or {}, probe=(m.precision, m.probed, list(m.told)))
+    q.put((rank, res))
+
+
+def test_data_probe_verdict_travels_from_rank_0_to_the_other_ranks(tmp_path, monkeypatch):
+    """The probe of the arithmetic on the input itself (call_mods) under several ranks: rank 0 alone reads the head of
+    the file and decides; the verdict reaches every other rank over the chunk board BEFORE any of them calls a site - one arithmetic for
+    the whole run, so the output does not depend on the sharding."""
+    from ccsmeth_amd import bamio
+    rng = np.random.default_rng(78)
+    inp = str(tmp_path / "p.bam")
+    with bamio.BamWriter(inp, "@HD\tVN:1.5\tSO:unknown\n", []) as w:
+        for i in range(17):
+            n = int(rng.integers(400, 2500))
+            seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n)
+            pos = rng.integers(0, n - 1, n // 40)
+            seq[pos], seq[pos + 1] = ord("C"), ord("G")
+            kin = lambda: rng.integers(0, 256, n).astype(np.uint8)  # noqa: E731
+            w.write(bamio.BamRecord("y/%d/ccs" % i, flag=4, seq=seq.tobytes().decode(),
+                                    tags=[("fi", "BC", kin()), ("fp", "BC", kin()), ("ri", "BC", kin()), ("rp", "BC", kin()), ("fn", "C", 9), ("rn", "C", 11)]))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ports = (_free_port(), _free_port())
+    procs = [ctx.Process(target=_worker_small, args=(r, 3, ports, inp, str(tmp_path / "three"), q, True)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["probe"][0] == 3 and res[0]["probe"][1] > 0 and res[0]["probe"][2] == []          # rank 0 probed (every called site of the head) and decided
+    for r in (1, 2):
+        assert res[r]["probe"] == (3, 0, [3])                                                      # the others probed nothing and were told
+    assert res[0]["reads"] == 17
 
 
 def test_shard_indices_edges():
