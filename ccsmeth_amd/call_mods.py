@@ -372,18 +372,23 @@ def call_mods(args, log=sys.stderr, pipe=None):
             # through split3, and split-mx stays only if it is clean on them too.  Rank 0 probes and publishes the verdict: one arithmetic
             # for the whole run, whatever the number of ranks (the bytes written do not depend on the sharding).
             if rank == 0:
-                with NativeBamReader(args.input, threads=min(args.threads, 4)) as prd:
-                    head, n_head = [], 0
-                    while n_head < 65536:
-                        b = prd.next_batch(min(holes_batch, 64))
-                        if b is None:
-                            break
-                        skip, _, sites = filters(b)
-                        head.append((b, skip))
-                        n_head += sites
-                    probe_dm.data_probe(lambda: (pipe.probs_of_native_batch(b, skip) for b, skip in head))
-                    for b, _ in head:
-                        b.close()
+                try:
+                    with NativeBamReader(args.input, threads=min(args.threads, 4)) as prd:
+                        head, n_head = [], 0
+                        while n_head < 65536:
+                            b = prd.next_batch(min(holes_batch, 64))
+                            if b is None:
+                                break
+                            skip, _, sites = filters(b)
+                            head.append((b, skip))
+                            n_head += sites
+                        probe_dm.data_probe(lambda: (pipe.probs_of_native_batch(b, skip) for b, skip in head))
+                        for b, _ in head:
+                            b.close()
+                except BaseException as e:      # noqa: BLE001 - the other ranks wait for the verdict: release them with the cause
+                    if queue is not None:
+                        queue.fail("%s: %s" % (type(e).__name__, e))
+                    raise
                 _print_data_probe(probe_dm, log)
             if queue is not None:
                 verdict = queue.rendezvous("arithmetic", int(probe_dm.precision) if rank == 0 else None)[0]
