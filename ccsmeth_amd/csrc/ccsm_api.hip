@@ -1073,6 +1073,9 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     if (st == CCSM_OK && prec >= CCSM_PRECISION_SPLIT_F8 && !auto_prec) st = ensure_streams(prec);
     if (st == CCSM_OK && auto_prec) st = probe_arithmetic(m, ensure_streams);      // leaves split-mx (a clean, light-tailed probe) or split-fp16 in m->precision
     if (st == CCSM_OK && m->precision >= CCSM_PRECISION_SPLIT_F8) m->mx_quant_err = qerr[m->precision];
+    // every upload above went over the NULL stream, which a caller's non-blocking streams do not wait for: nothing of this model may still be
+    // in flight when the first forward is issued on such a stream (see ccsm_workspace_create)
+    if (st == CCSM_OK && hipDeviceSynchronize() != hipSuccess) st = fail(CCSM_ERR_HIP, "hipDeviceSynchronize at the end of ccsm_create");
     if (st != CCSM_OK) {
         ccsm_destroy(m);
         return st;
@@ -1926,6 +1929,7 @@ ccsm_status ccsm_aggr_create(const ccsm_aggr_weights* w, int device, uint64_t se
         m->n_normals = (int64_t)nrm.size();
         st = upload(&m->normals, nrm.data(), nrm.size() * sizeof(float));
     }
+    if (st == CCSM_OK && hipDeviceSynchronize() != hipSuccess) st = fail(CCSM_ERR_HIP, "hipDeviceSynchronize at the end of ccsm_aggr_create");   // (as ccsm_create)
     if (st != CCSM_OK) { ccsm_aggr_destroy(m); return st; }
     *out = m;
     return CCSM_OK;
