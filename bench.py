@@ -43,7 +43,7 @@ PEAK_HBM = 8.0e12
 # HBM/fabric bytes of ONE launch of the dominant kernel per site, from rocprofv3 PMC passes on the launch shape timed here
 # (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
 # read from inside this process)
-TRAFFIC = {4: ((2 * 989800 + 451600) * 1024 / 6144.0, "profiles/r04_z_pmc.md"),       # mean of layers 1 and 2 (the last layer writes 3 of 4 fragments per pair)
+TRAFFIC = {4: ((2 * 990975 + 451585) * 1024 / 6144.0, "profiles/r05_f_pmc.md"),       # mean of layers 1 and 2 (FETCH 9.9232e5 / 9.8963e5, WRITE 5.161e5 / 3.8707e5 KB per 6144-site launch; the last layer writes 3 of 4 fragments per pair)
            5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced_hybrid.md"),
            6: ((2 * 1002900 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_prec6.md"),
            3: ((2 * 1049800 + 516100) * 1024 / 6144.0, "profiles/r04_z_pmc_split3.md")}
