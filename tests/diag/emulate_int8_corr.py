@@ -107,6 +107,8 @@ def mm(x, wt, mode, bound=None):
         x = torch.nn.functional.pad(x, (0, wt.w.shape[1] - x.shape[1]))
     if mode == "f64":
         return x.double() @ wt.w64.T
+    if mode == "f32":        # plain fp32 products (the reference's arithmetic class, models.py:125-130; this device's BLAS summation order)
+        return x @ wt.w.T
     xh = hi16(x)
     xl = x - xh
     main = xh @ wt.hi.T
