@@ -57,13 +57,15 @@ constexpr int kPairsX = 16, kPairsH = 8, kRS = 4;
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // phase X
-template <int NW, int UT, int NB>
+// DIAG (results meaningless, hazards ignored on purpose): 1 = no barrier (each wave still waits for its own transfers); 2 = no transfers either
+// (x stays what the prologue put into the ring): where phase X's idle cycles come from
+template <int NW, int UT, int NB, int G = 2, int DIAG = 0>
 __global__ __launch_bounds__(NW * 64, 1) void phase_x(const uint4* __restrict__ xin, const uint4* __restrict__ wst, float* __restrict__ out,
                                                       unsigned long long* __restrict__ cyc, int steps) {
     constexpr int FR = 4 * NB;                          // fragments (1 KiB) of one x pair: [kbl 2][bt NB][hi | blob]
     constexpr int SLOT = FR * 1024;
-    constexpr int PW = (4 * UT + 2 * UT) * 1024 + UT * 256;        // weight bytes of one pair and wave
-    constexpr int WOPS = 4 * UT + 2 * UT + UT;          // vector-memory requests of one weight slot
+    constexpr int PW = (2 * G * UT + G * UT) * 1024 + UT * 256;    // weight bytes of one pair and wave
+    constexpr int WOPS = 2 * G * UT + G * UT + UT;      // vector-memory requests of one weight slot
     constexpr int DHI = (FR + NW - 1) / NW, DLO = FR / NW, NHIW = FR - DLO * NW;     // transfers per wave: waves < NHIW move DHI, the others DLO
     constexpr int NSA = 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(NW * 64, 1) void phase_x(const uint4* __restrict__ 
             if (f < FR) dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(base + (f << 10)), __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT + (f << 10))));
         }
     };
-    uint4 wh[NSA][2][2][UT], wb[NSA][2][UT];
+    uint4 wh[NSA][2][G][UT], wb[NSA][G][UT];
     uint32_t wsc[NSA][UT];
     auto ld_slot = [&](int ws, int p) {
 #pragma unroll
@@ -90,10 +92,10 @@ __global__ __launch_bounds__(NW * 64, 1) void phase_x(const uint4* __restrict__ 
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) wh[ws][k][g][u] = buf_load(wrs, lane16, p * PW + (((u * 2 + k) * 2 + g) << 10));
+                for (int g = 0; g < G; ++g) wh[ws][k][g][u] = buf_load(wrs, lane16, p * PW + (((u * 2 + k) * G + g) << 10));
 #pragma unroll
-            for (int g = 0; g < 2; ++g) wb[ws][g][u] = buf_load(wrs, lane16, p * PW + ((4 * UT + u * 2 + g) << 10));
-            wsc[ws][u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, p * PW + ((6 * UT) << 10) + u * 256, 0);
+            for (int g = 0; g < G; ++g) wb[ws][g][u] = buf_load(wrs, lane16, p * PW + ((2 * G * UT + u * G + g) << 10));
+            wsc[ws][u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, p * PW + ((3 * G * UT) << 10) + u * 256, 0);
         }
     };
 #pragma unroll
@@ -101,9 +103,9 @@ __global__ __launch_bounds__(NW * 64, 1) void phase_x(const uint4* __restrict__ 
     ld_slot(0, 0); ld_slot(1, 1); ld_slot(2, 2);
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSA * WOPS) : "memory");
     __syncthreads();
-    f32x16 acc[2][UT][NB];
+    f32x16 acc[G][UT][NB];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int u = 0; u < UT; ++u)
 #pragma unroll
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(NW * 64, 1) void phase_x(const uint4* __restrict__ 
 #pragma unroll
                 for (int u = 0; u < UT; ++u)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g][u][b] = mfma16(wh[WS][0][g][u], xh[b], acc[g][u][b]);
+                    for (int g = 0; g < G; ++g) acc[g][u][b] = mfma16(wh[WS][0][g][u], xh[b], acc[g][u][b]);
             FENCE;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -143,20 +145,23 @@ __global__ __launch_bounds__(NW * 64, 1) void phase_x(const uint4* __restrict__ 
 #pragma unroll
                 for (int u = 0; u < UT; ++u)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g][u][b] = mfma16(wh[WS][1][g][u], xh1[b], acc[g][u][b]);
+                    for (int g = 0; g < G; ++g) acc[g][u][b] = mfma16(wh[WS][1][g][u], xh1[b], acc[g][u][b]);
             FENCE;
             // this wave's part of the next pair's transfer has landed: younger operations = (RS - 1) weight slots + (RS - 2) refills
-            if (wave < NHIW) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kRS - 1) * WOPS + (kRS - 2) * DHI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kRS - 1) * WOPS + (kRS - 2) * DLO) : "memory");
-            __syncthreads();
-            dma_pair(slot, s + (P + kRS) / kPairsX, (P + kRS) % kPairsX);
+            if constexpr (DIAG < 2) {
+                if (wave < NHIW) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kRS - 1) * WOPS + (kRS - 2) * DHI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kRS - 1) * WOPS + (kRS - 2) * DLO) : "memory");
+            }
+            if constexpr (DIAG == 0) __syncthreads();
+            if constexpr (DIAG < 2) dma_pair(slot, s + (P + kRS) / kPairsX, (P + kRS) % kPairsX);
             FENCE;
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int u = 0; u < UT; ++u) {
                     acc[0][u][b] = mfma_mx<0>(wb[WS][0][u], wsc[WS][u], xc0[b], xc1[b], acc[0][u][b], 125);
-                    acc[1][u][b] = mfma_mx<1>(wb[WS][1][u], wsc[WS][u], xc0[b], xc1[b], acc[1][u][b], 125);
+                    if constexpr (G > 1) acc[1][u][b] = mfma_mx<1>(wb[WS][1][u], wsc[WS][u], xc0[b], xc1[b], acc[1][u][b], 125);
+                    if constexpr (G > 2) acc[2][u][b] = mfma_mx<2>(wb[WS][2][u], wsc[WS][u], xc0[b], xc1[b], acc[2][u][b], 125);
                 }
             FENCE;
             ld_slot(WS, (P + NSA) % kPairsX);           // the slot just consumed: three pairs ahead
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(NW * 64, 1) void phase_x(const uint4* __restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float sum = 0.f;
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int u = 0; u < UT; ++u)
 #pragma unroll
@@ -308,6 +313,29 @@ void run(const char* name, int n_cu, int steps) {
     }
 }
 
+// the input part in one pass (three gates per operand read, as the recurrent phase has them) against the shipping two passes (r, z | n)
+template <int NW, int UT, int NB, int G, int DIAG = 0>
+void run_x(const char* name, int n_cu, int steps) {
+    const int rows = 32 * NB, lds = kRS * 4 * NB * 1024;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&phase_x<NW, UT, NB, G, DIAG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    float ms = 0.f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((phase_x<NW, UT, NB, G, DIAG>), dim3(n_cu), dim3(NW * 64), lds, 0, g_x, g_w, g_out, g_cyc, steps);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    unsigned long long c[8] = {};
+    CK(hipMemcpy(c, g_cyc, sizeof(c), hipMemcpyDeviceToHost));
+    const double mfma = 3.0 * G * UT * NB, cyc_pair = (double)c[0] / ((double)steps * kPairsX);
+    std::printf("%-18s input part, %d gate(s) per pass: %3d rows: %8.0f cycles per pair (%5.1f MFMAs per pair and wave = %4.0f %% of the SIMD's MFMA time), %7.3f ns per (row, pair)\n",
+                name, G, rows, cyc_pair, mfma, 100.0 * mfma * (NW / 4.0) * 32.0 / cyc_pair, ms * 1e6 / ((double)steps * kPairsX * rows));
+    std::fflush(stdout);
+}
+
 int main(int argc, char** argv) {
     const int steps = argc > 1 ? std::atoi(argv[1]) : 2000;
     int dev = 0;
@@ -329,5 +357,16 @@ int main(int argc, char** argv) {
     run<4, 2, 4>("S128", n_cu, steps);
     run<4, 2, 3>("S96w", n_cu, steps);
     run<8, 1, 2>("S64", n_cu, steps);
+    std::printf("# one pass over x_t (r, z, n together: a fourth accumulator set, which fits at 64 rows only) against the shipping two passes\n");
+    run_x<8, 1, 3, 2>("S96 rz", n_cu, steps);
+    run_x<8, 1, 3, 1>("S96 n", n_cu, steps);
+    run_x<8, 1, 2, 3>("S64 rzn", n_cu, steps);
+    run_x<8, 1, 2, 2>("S64 rz", n_cu, steps);
+    run_x<8, 1, 2, 1>("S64 n", n_cu, steps);
+    std::printf("# where the input-part phase's idle cycles come from (diagnostic variants, hazards ignored): no barrier / no barrier and no transfers\n");
+    run_x<8, 1, 3, 2, 1>("S96 rz nobar", n_cu, steps);
+    run_x<8, 1, 3, 2, 2>("S96 rz nobar nodma", n_cu, steps);
+    run_x<8, 1, 3, 1, 1>("S96 n nobar", n_cu, steps);
+    run_x<8, 1, 3, 1, 2>("S96 n nobar nodma", n_cu, steps);
     return 0;
 }
