@@ -5,7 +5,6 @@ usage: python tools/multi_rank_one_gpu.py [ranks=8] [reads=6000]"""
 import hashlib, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
 from collections import OrderedDict
 from ccsmeth_amd.utils import benchdata, synth
