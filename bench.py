@@ -570,7 +570,7 @@ def main():
                                   "checkpoint is served with: see trained_checkpoint below (ccsm_create serves trained weights in split3)",
                        "trained_checkpoint": "not measured (--extras none or N > 1)",
                        "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else "gru_layer12_f3_kernel") + " (BiGRU layers 1-2)",
+            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else ("gru_layer12_f3_kernel" if os.environ.get("CCSM_F3_SHAPE32") else "gru_layer12_f3s_kernel")) + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
                          "traffic": None if traffic is None else traffic * sites_per_launch,

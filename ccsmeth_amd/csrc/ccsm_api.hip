@@ -16,6 +16,7 @@
 #include "ccsm_gru_f8.hip"
 #include "ccsm_gru_mx.hip"
 #include "ccsm_gru_f3.hip"
+#include "ccsm_gru_f3s.hip"
 #include "ccsm_aggr.hip"
 #include "ccsm_extract.hip"
 #include "ccsm_ceiling.hip"
@@ -84,6 +85,9 @@ struct ccsm_model {
     uint4* wstmd[kLayers] = {nullptr, nullptr, nullptr};// split-mx-d weight streams (fp6 recurrent blobs)
     uint4* wstmx[kLayers] = {nullptr, nullptr, nullptr};// split-mx weight streams (ccsm_gru_mx.hip: hi fragments + MX correction blobs)
     uint4* wstf3[kLayers] = {nullptr, nullptr, nullptr};// split3 on the split-mx schedule (ccsm_gru_f3.hip): [0] = the hybrid's layer-0 stream, [1], [2] three-pass streams
+    uint4* wstf3s[kLayers] = {nullptr, nullptr, nullptr};// split3, layers 1-2 on v_mfma_f32_16x16x32_f16 (ccsm_gru_f3s.hip): the same stream sizes, unit tiles of 16 ([0] unused)
+    float* biasn[kLayers] = {nullptr, nullptr, nullptr}; // its biases in natural unit order [dir][wave][4][32] ([0] unused)
+    bool f3_shape32 = false;                             // CCSM_F3_SHAPE32=1 at ccsm_create: split3's layers 1-2 on the 32x32x16 kernel of round 4 (A/B)
     uint4* wsthy[kLayers] = {nullptr, nullptr, nullptr};// hybrid weight streams (the same with fp16 lo fragments for the recurrent part)
     uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
     uint4* ua3 = nullptr;
@@ -439,6 +443,104 @@ void pack_wstream_f3(const float* const wih[2], const float* const whh[2], std::
     for (std::thread& t : pool) t.join();
 }
 
+// The same streams for gru_layer12_f3s_kernel (ccsm_gru_f3s.hip): fragments of v_mfma_f32_16x16x32_f16 - lane (m, q) <- row m of a 16-unit
+// tile, k = 32 pair + 8 q + j - with unit tile T, row m <-> hidden unit 32 wave + 8 (m >> 2) + 4 T + (m & 3); offsets as in pack_wstream_f3
+// with the k-block index of a pair replaced by the unit tile
+void pack_wstream_f3s(const float* const wih[2], const float* const whh[2], std::vector<uint8_t>& out) {
+    const int k_in = 2 * kHidden;
+    out.assign((size_t)2 * kWaves * kF3WBytes, 0);
+    std::vector<std::thread> pool;
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave)
+            pool.emplace_back([&, dir, wave] {
+            uint8_t* base = out.data() + (size_t)(dir * kWaves + wave) * kF3WBytes;
+            auto unit = [=](int T, int m) { return kUnitTile * wave + 8 * (m >> 2) + 4 * T + (m & 3); };
+            auto frag = [&](size_t off_hi, size_t off_lo, const float* w, int ld, int g, int T, int pair) {
+                _Float16* hi = reinterpret_cast<_Float16*>(base + off_hi);
+                _Float16* lo = reinterpret_cast<_Float16*>(base + off_lo);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = w[(size_t)(g * kHidden + unit(T, lane & 15)) * ld + 32 * pair + 8 * (lane >> 4) + j];
+                        const HalfPair hp = split_host(v);
+                        hi[lane * 8 + j] = hp.hi;
+                        lo[lane * 8 + j] = hp.lo;
+                    }
+            };
+            for (int p = 0; p < kKB12 / 2; ++p) {
+                const size_t pa = (size_t)p * kF3PairA;
+                for (int T = 0; T < 2; ++T)
+                    for (int g = 0; g < 2; ++g) frag(pa + (size_t)(2 * T + g) * 1024, pa + (size_t)(4 + 2 * T + g) * 1024, wih[dir], k_in, g, T, p);
+            }
+            for (int q = 0; q < kKBH / 2; ++q) {
+                const size_t pb = (size_t)kF3OffB + (size_t)q * kF3PairB;
+                for (int T = 0; T < 2; ++T)
+                    for (int g = 0; g < 3; ++g) frag(pb + (size_t)(3 * T + g) * 1024, pb + (size_t)(6 + 3 * T + g) * 1024, whh[dir], kHidden, g, T, q);
+            }
+            for (int pp = 0; pp < kKB12 / 2; ++pp) {
+                const size_t pc = (size_t)kF3OffC + (size_t)pp * kF3PairC;
+                const int p = kMxZigZag ? kKB12 / 2 - 1 - pp : pp;          // the pair phase C consumes at position pp
+                for (int T = 0; T < 2; ++T) frag(pc + (size_t)T * 1024, pc + (size_t)(2 + T) * 1024, wih[dir], k_in, 2, T, p);
+            }
+            });
+    for (std::thread& t : pool) t.join();
+}
+
+// Layer 0's stream for gru_layer0_f3s_kernel: x-part fragments A1 = [W_hi | W_hi], A2 = [W_lo | 0] over the one k-block of input columns
+// (k >= feat0: zero), the recurrent part as in pack_wstream_f3s
+void pack_wstream_f3s0(int feat0, const float* const wih[2], const float* const whh[2], std::vector<uint8_t>& out) {
+    out.assign((size_t)2 * kWaves * kF3s0WBytes, 0);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave) {
+            uint8_t* base = out.data() + (size_t)(dir * kWaves + wave) * kF3s0WBytes;
+            auto unit = [=](int T, int m) { return kUnitTile * wave + 8 * (m >> 2) + 4 * T + (m & 3); };
+            auto xfrag = [&](size_t off, int g, int T) {          // A1 at off, A2 at off + 1 KiB
+                _Float16* a1 = reinterpret_cast<_Float16*>(base + off);
+                _Float16* a2 = reinterpret_cast<_Float16*>(base + off + 1024);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int q = lane >> 4, k = 8 * (q & 1) + j;
+                        const float v = k < feat0 ? wih[dir][(size_t)(g * kHidden + unit(T, lane & 15)) * feat0 + k] : 0.f;
+                        const HalfPair hp = split_host(v);
+                        a1[lane * 8 + j] = hp.hi;
+                        a2[lane * 8 + j] = (q >> 1) ? (_Float16)0.f : hp.lo;
+                    }
+            };
+            for (int T = 0; T < 2; ++T) {
+                for (int g = 0; g < 2; ++g) xfrag((size_t)(4 * T + 2 * g) * 1024, g, T);
+                xfrag((size_t)kF3s0OffC + (size_t)(2 * T) * 1024, 2, T);
+            }
+            for (int q = 0; q < kKBH / 2; ++q) {
+                const size_t pb = (size_t)kF3s0OffB + (size_t)q * kF3PairB;
+                for (int T = 0; T < 2; ++T)
+                    for (int g = 0; g < 3; ++g) {
+                        _Float16* hi = reinterpret_cast<_Float16*>(base + pb + (size_t)(3 * T + g) * 1024);
+                        _Float16* lo = reinterpret_cast<_Float16*>(base + pb + (size_t)(6 + 3 * T + g) * 1024);
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const HalfPair hp = split_host(whh[dir][(size_t)(g * kHidden + unit(T, lane & 15)) * kHidden + 32 * q + 8 * (lane >> 4) + j]);
+                                hi[lane * 8 + j] = hp.hi;
+                                lo[lane * 8 + j] = hp.lo;
+                            }
+                    }
+            }
+        }
+}
+
+// biases in natural unit order for the 16x16x32 kernels: [dir][wave][set r, z, n_x, n_h][32]
+void pack_bias_natural(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
+    out.assign((size_t)2 * kWaves * 4 * 32, 0.f);
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave)
+            for (int i = 0; i < 32; ++i) {
+                const int u = kUnitTile * wave + i;
+                float* o = &out[(size_t)(dir * kWaves + wave) * 4 * 32];
+                o[0 * 32 + i] = bih[dir][u] + bhh[dir][u];
+                o[1 * 32 + i] = bih[dir][kHidden + u] + bhh[dir][kHidden + u];
+                o[2 * 32 + i] = bih[dir][2 * kHidden + u];
+                o[3 * 32 + i] = bhh[dir][2 * kHidden + u];
+            }
+}
+
 void pack_bias(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
     out.assign((size_t)2 * kWaves * 4 * 32, 0.f);
     for (int dir = 0; dir < 2; ++dir)
@@ -644,15 +746,22 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
         // layers 1-2 = gru_layer12_f3_kernel (ccsm_gru_f3.hip)
         auto layer = [&](auto nbc, int l, const uint4* in, uint4* out_) {
             constexpr int NBF = decltype(nbc)::value;
-            if (l == 0 && NBF == 3 && m->l0_stag)
+            if (l == 0 && !m->f3_shape32)
+                hipLaunchKernelGGL((gru_layer0_f3s_kernel<NBF>), ggrid, dim3(512), mx0_lds(NBF), st, in, out_, m->wstf3s[0], m->biasn[0], ws->h0buf, ws->rows_p);
+            else if (l == 0 && NBF == 3 && m->l0_stag)
                 hipLaunchKernelGGL((gru_layer0_mx_kernel<false, true, false, 3, true, true>), ggrid, dim3(512), mx0_lds(3), st, in, out_, m->wstf3[0], m->bias[0],
                                    ws->h0buf, ws->rows_p, nullptr);
             else if (l == 0) hipLaunchKernelGGL((gru_layer0_mx_kernel<false, true, false, NBF, true>), ggrid, dim3(512), mx0_lds(NBF), st, in, out_, m->wstf3[0], m->bias[0],
                                            ws->h0buf, ws->rows_p, nullptr);
 #ifdef CCSM_PHASE_STAMPS
             else if (NBF == 3 && ws->dbg && l == (dbg_layer == 2 ? 2 : 1))
-                hipLaunchKernelGGL((gru_layer12_f3_kernel<3, true>), ggrid, dim3(512), f3_lds(3), st, in, out_, m->wstf3[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, ws->dbg);
+                {
+                    if (m->f3_shape32) hipLaunchKernelGGL((gru_layer12_f3_kernel<3, true>), ggrid, dim3(512), f3_lds(3), st, in, out_, m->wstf3[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, ws->dbg);
+                    else hipLaunchKernelGGL((gru_layer12_f3s_kernel<3, true>), ggrid, dim3(512), f3_lds(3), st, in, out_, m->wstf3s[l], m->biasn[l], ws->h0buf + l * slab, ws->rows_p, ws->dbg);
+                }
 #endif
+            else if (!m->f3_shape32)
+                hipLaunchKernelGGL((gru_layer12_f3s_kernel<NBF>), ggrid, dim3(512), f3_lds(NBF), st, in, out_, m->wstf3s[l], m->biasn[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
             else hipLaunchKernelGGL((gru_layer12_f3_kernel<NBF>), ggrid, dim3(512), f3_lds(NBF), st, in, out_, m->wstf3[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
         };
         auto all = [&](auto nbc) -> ccsm_status {
@@ -990,8 +1099,15 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
         set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<3>), f3_lds(3));
         set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<2>), f3_lds(2));
         set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<1>), f3_lds(1));
+        set_lds(reinterpret_cast<const void*>(&gru_layer12_f3s_kernel<3>), f3_lds(3));
+        set_lds(reinterpret_cast<const void*>(&gru_layer12_f3s_kernel<2>), f3_lds(2));
+        set_lds(reinterpret_cast<const void*>(&gru_layer12_f3s_kernel<1>), f3_lds(1));
+        set_lds(reinterpret_cast<const void*>(&gru_layer0_f3s_kernel<3>), mx0_lds(3));
+        set_lds(reinterpret_cast<const void*>(&gru_layer0_f3s_kernel<2>), mx0_lds(2));
+        set_lds(reinterpret_cast<const void*>(&gru_layer0_f3s_kernel<1>), mx0_lds(1));
 #ifdef CCSM_PHASE_STAMPS
         set_lds(reinterpret_cast<const void*>(&gru_layer12_f3_kernel<3, true>), f3_lds(3));
+        set_lds(reinterpret_cast<const void*>(&gru_layer12_f3s_kernel<3, true>), f3_lds(3));
 #endif
         if (prec >= CCSM_PRECISION_SPLIT_F8) {
             set_lds(reinterpret_cast<const void*>(&gru_layer0_mx_kernel<false, false>), kMx0Lds);
@@ -1046,13 +1162,34 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     // split3's streams on the split-mx schedule (always: it is the reference of the probe and the arithmetic of explicit large initial states)
     m->split3_v2 = std::getenv("CCSM_SPLIT3_V2") != nullptr;
     m->l0_stag = std::getenv("CCSM_L0_LOCKSTEP") == nullptr;
+    m->f3_shape32 = std::getenv("CCSM_F3_SHAPE32") != nullptr;
+#ifdef CCSM_STAGGER_DIAG
+    {
+        const int stagger = std::getenv("CCSM_STAGGER") ? std::atoi(std::getenv("CCSM_STAGGER")) : 0;
+        if (st == CCSM_OK && hipMemcpyToSymbol(HIP_SYMBOL(g_ccsm_stagger), &stagger, sizeof(int)) != hipSuccess) st = fail(CCSM_ERR_HIP, "hipMemcpyToSymbol(g_ccsm_stagger)");
+    }
+#endif
     if (st == CCSM_OK) {
         std::vector<uint8_t> bbuf;
         pack_wstream_mx(0, m->feat0, wih_l0, w->weight_hh[0], true, bbuf);
         st = upload(&m->wstf3[0], bbuf.data(), bbuf.size());
+        std::vector<float> nbuf;
+        if (!m->f3_shape32 && st == CCSM_OK) {
+            pack_wstream_f3s0(m->feat0, wih_l0, w->weight_hh[0], bbuf);
+            st = upload(&m->wstf3s[0], bbuf.data(), bbuf.size());
+            pack_bias_natural(w->bias_ih[0], w->bias_hh[0], nbuf);
+            if (st == CCSM_OK) st = upload(&m->biasn[0], nbuf.data(), nbuf.size() * sizeof(float));
+        }
         for (int l = 1; l < kLayers && st == CCSM_OK; ++l) {
-            pack_wstream_f3(w->weight_ih[l], w->weight_hh[l], bbuf);
-            st = upload(&m->wstf3[l], bbuf.data(), bbuf.size());
+            if (m->f3_shape32) {
+                pack_wstream_f3(w->weight_ih[l], w->weight_hh[l], bbuf);
+                st = upload(&m->wstf3[l], bbuf.data(), bbuf.size());
+            } else {
+                pack_wstream_f3s(w->weight_ih[l], w->weight_hh[l], bbuf);
+                st = upload(&m->wstf3s[l], bbuf.data(), bbuf.size());
+                pack_bias_natural(w->bias_ih[l], w->bias_hh[l], nbuf);
+                if (st == CCSM_OK) st = upload(&m->biasn[l], nbuf.data(), nbuf.size() * sizeof(float));
+            }
         }
     }
     // the weight streams of one arithmetic of the split-mx family (a forced precision: that one; the default: what the probe gets to)
@@ -1157,6 +1294,8 @@ void ccsm_destroy(ccsm_model* m) {
         (void)hipFree(m->wstmd[l]);
         (void)hipFree(m->wsthy[l]);
         (void)hipFree(m->wstf3[l]);
+        (void)hipFree(m->wstf3s[l]);
+        (void)hipFree(m->biasn[l]);
         (void)hipFree(m->bias[l]);
     }
     (void)hipFree(m->wa); (void)hipFree(m->ua); (void)hipFree(m->va);

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3_kernel(const uint4* __r
     const int dir = blockIdx.x & 1;
     const int tile0 = (blockIdx.x >> 1) * NB;
     const int lane16 = lane * 16;
+    start_stagger((blockIdx.x >> 1) & 3);
 
     if (threadIdx.x < kWaves * 4 * 32 / 4)
         reinterpret_cast<float4*>(smem + BIAS_OFF)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];

@@ -844,6 +844,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     const int hh = lane >> 5;
     const int lane16 = lane * 16;
     const int sb = hh ? kMxScaleLo : kMxScaleHi;
+    start_stagger((blockIdx.x >> 1) & 3);
 
     if (threadIdx.x < kWaves * 4 * 32 / 4)
         reinterpret_cast<float4*>(smem + kMx12BiasOff)[threadIdx.x] = reinterpret_cast<const float4*>(bias + (size_t)dir * kWaves * 4 * 32)[threadIdx.x];

@@ -77,6 +77,18 @@ __device__ __forceinline__ void dma16_buf_nt(u32x4_t rsrc, int voff, int soff, u
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen nt lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base)
                  : "memory");
 }
+// Start-time stagger of the GRU workgroups (diagnostic, only in a -DCCSM_STAGGER_DIAG build; CCSM_STAGGER=<n> at ccsm_create): workgroup
+// pair p waits (p & 3) * n sleeps of 127 x 64 cycles before its first instruction, so that the compute units are not all in the same phase
+// of the step at the same time.  Measured (profiles/r05_p_stagger.log): nothing to gain - the kernels get slower by the delay itself.
+#ifdef CCSM_STAGGER_DIAG
+__device__ int g_ccsm_stagger = 0;
+__device__ __forceinline__ void start_stagger(int group) {
+    const int n = __builtin_amdgcn_readfirstlane(g_ccsm_stagger) * group;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#else
+__device__ __forceinline__ void start_stagger(int) {}
+#endif
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ half8 as_half8(uint4 v) { return __builtin_bit_cast(half8, v); }

@@ -40,7 +40,7 @@ for name in os.environ.get("MODES", "normal,zero_weights,normal").split(","):
     w = synth.synth_weights(7)
     if name == "zero_weights":
         w = {k: np.zeros_like(v) for k, v in w.items()}
-    dm = DeviceModel(w, 0, precision=4)
+    dm = DeviceModel(w, 0, precision=int(os.environ.get("PREC", "4")))
     ws = dm.workspace(n * g)
     ws.set_timing(True)
     t0 = time.perf_counter()
