@@ -43,10 +43,10 @@ PEAK_HBM = 8.0e12
 # HBM/fabric bytes of ONE launch of the dominant kernel per site, from rocprofv3 PMC passes on the launch shape timed here
 # (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
 # read from inside this process)
-TRAFFIC = {4: ((2 * 990975 + 451585) * 1024 / 6144.0, "profiles/r05_f_pmc.md"),       # mean of layers 1 and 2 (FETCH 9.9232e5 / 9.8963e5, WRITE 5.161e5 / 3.8707e5 KB per 6144-site launch; the last layer writes 3 of 4 fragments per pair)
+TRAFFIC = {4: ((2 * 993445 + 451630) * 1024 / 6144.0, "profiles/r05_w_pmc.md"),       # mean of layers 1 and 2 (FETCH 9.9556e5 / 9.9133e5, WRITE 5.1619e5 / 3.8707e5 KB per 6144-site launch; the last layer writes 3 of 4 fragments per pair)
            5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced_hybrid.md"),
            6: ((2 * 1002900 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_prec6.md"),
-           3: ((2 * 1049800 + 516100) * 1024 / 6144.0, "profiles/r04_z_pmc_split3.md")}
+           3: ((2 * 1058000 + 516100) * 1024 / 6144.0, "profiles/r05_w_pmc_split3.md")}      # gru_layer12_f3s_kernel (FETCH 1.058e6, WRITE 5.161e5 KB)
 ARITH_NAME = {3: "split3", 4: "split-mx", 5: "hybrid", 6: "split-mx-d"}
 ARITH = {4: ("fp32 reference; computed as f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate (within 1e-4 on this config's random-init weights)",
              "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp4 e2m1 for the "

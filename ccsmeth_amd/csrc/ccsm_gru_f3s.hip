@@ -51,6 +51,11 @@ __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memo
 #endif
 
 #define CCSM_FENCE asm volatile("" ::: "memory")
+#ifdef CCSM_F3S_NO_SKEW
+constexpr bool kF3sSkew = false;
+#else
+constexpr bool kF3sSkew = true;
+#endif
 
 // Step tail: n = tanh(N); h' = n + z (h_{t-1} - n) for this lane's eight units of row n' of every 16-row sub-tile; fp16 hi + lo into the
 // lane's own 16 bytes of the state fragments (LDS) and of the layer output (HBM).  accz = sigmoid(Z) already, accn = N.
@@ -107,8 +112,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 
     // ---- x transfers: fragment f = (kbl * NB + bt) * 2 + hl of a ring slot; wave w moves fragment w, waves 0-3 also w + 8 (NB = 3)
     const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * KX * 2 * kFragU4);
-    const unsigned sx_base = NB == 1 ? (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)X_OFF
-                                     : (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + X_OFF);
+    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)X_OFF;    // (cast first: see gru_layer0_mx_kernel)
     auto dma_pair = [&](int slot, int sd, int jd) {
         const int sc_ = sd < kSeqLen ? sd : kSeqLen - 1;
         const int td = dir ? kSeqLen - 1 - sc_ : sc_;
@@ -270,7 +274,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
             pstamp(P, 2);
             __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
             pstamp(P, 3);
-            if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once (pair 15: behind phase B)
+            // the vacated slot is refilled at once (pair 15: behind phase B) - by waves 0-3 in front of the W_hi x_lo group, by waves 4-7 behind
+            // it (kF3sSkew): the same order among a wave's vector-memory operations, but the eight waves' transfer instructions no longer
+            // reach the CU's vector-memory path in one burst while no MFMA runs
+            if constexpr (P + 1 < NPAIR) { if (!kF3sSkew || wave < 4) dma_ahead(slot, s, P); } else slot_a15 = slot;
             if constexpr (P + 1 < NPAIR) rdx(xh[0], slot_off(slot_n), 0, 0);
             CCSM_FENCE;
 #pragma unroll
@@ -281,6 +288,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
                     for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
                         for (int g = 0; g < 2; ++g) acc[g][T][bt][h] = mfma32k(wah[WS][T][g], xl[h][bt], acc[g][T][bt][h]);
+            CCSM_FENCE;
+            if constexpr (P + 1 < NPAIR) { if (kF3sSkew && wave >= 4) dma_ahead(slot, s, P); }
             CCSM_FENCE;
             if constexpr (P + 2 < NPAIR) {
                 wah[WS][0][0] = a_hi(P + 2, 0, 0); wah[WS][0][1] = a_hi(P + 2, 0, 1); wah[WS][1][0] = a_hi(P + 2, 1, 0); wah[WS][1][1] = a_hi(P + 2, 1, 1);
@@ -294,10 +303,11 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 
         stamp(1);
         // ---------------- phase B: R, Z, N += W_h{r,z,n} h_{t-1}  (N starts at b_hn): three passes per pair of k-blocks on the fp16 hi + lo
-        // state; one pair of weights resident.  Unit tile 0 against both row halves (six B operands live at a time), its six fragments refilled
-        // with the next pair's, then unit tile 1 likewise (the B operands are read from LDS a second time: with the halves outermost a
-        // fragment's refill had 27 MFMAs of lead instead of 54, and the phase ran 30 % over its MFMA time: profiles/r05_o); the last
-        // pair's positions take phase C's first two pair slots ----------------------------------------------------------------------
+        // state; one pair of weights resident.  Row halves in turn: half 0 against both unit tiles, half 1 against unit tile 0 - its six
+        // fragments refilled with the next pair's - then against unit tile 1, refilled likewise; the last pair's positions take phase C's
+        // first two pair slots.  The other order (unit tiles outermost: 54 instead of 27 MFMAs between a refill and its use, every B operand
+        // read from LDS twice) needs 1 % fewer CYCLES and 1 % more TIME (profiles/r05_v_ab_b_order.log): at the power cap the extra LDS
+        // reads cost more than the idle cycles they remove -------------------------------------------------------------------------------
         {
             f32x4 b3[2];
             bias_set(3, b3);
@@ -339,6 +349,29 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 #pragma unroll
                     for (int g = 0; g < 3; ++g) acc[g][T][bt][h] = mfma32k(wbh[T][g], xl[0][bt], acc[g][T][bt][h]);
             };
+#ifndef CCSM_F3S_B_TMAJOR        // row halves outermost: each B operand is read from LDS once per pair (-DCCSM_F3S_B_TMAJOR: unit tiles outermost, below)
+            static_for<0, 2>([&](auto HC) {
+                constexpr int H = decltype(HC)::value;
+                if constexpr (H == 0) rdh(QC, std::integral_constant<int, 1>{});
+                else if constexpr (Q + 1 < kKBH / 2) rdh(std::integral_constant<int, Q + 1>{}, std::integral_constant<int, 0>{});
+                rdl(QC, HC);
+                CCSM_FENCE;
+                static_for<0, 2>([&](auto TC) {
+                    constexpr int T = decltype(TC)::value;
+                    group(TC, HC);
+                    CCSM_FENCE;
+                    if constexpr (H == 1) {
+                        if constexpr (Q + 1 < kKBH / 2) {
+#pragma unroll
+                            for (int g = 0; g < 3; ++g) { wbh[T][g] = w_at(NXT + ((3 * T + g) << 10)); wbl[T][g] = w_at(NXT + ((6 + 3 * T + g) << 10)); }
+                        } else {
+                            wch[T][0] = c_hi(T, 0); wch[T][1] = c_hi(T, 1); wcl[T][0] = c_lo(T, 0); wcl[T][1] = c_lo(T, 1);
+                        }
+                        CCSM_FENCE;
+                    }
+                });
+            });
+#else
             static_for<0, 2>([&](auto TC) {
                 constexpr int T = decltype(TC)::value;
                 static_for<0, 2>([&](auto HC) {
@@ -360,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
                 }
                 CCSM_FENCE;
             });
+#endif
         });
         // r = sigmoid(R) ; N = b_in + r * N
         mfma_drain();
@@ -439,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
             pstamp(NPAIR + P, 2);
             __syncthreads();
             pstamp(NPAIR + P, 3);
-            dma_ahead(slot, s, NPAIR + P);                              // the vacated slot is refilled at once
+            if (!kF3sSkew || wave < 4) dma_ahead(slot, s, NPAIR + P);   // the vacated slot is refilled at once (waves 4-7: behind the group, as in phase A)
             if constexpr (P + 1 < NPAIR) rdx(xh[0], slot_off(slot_n), 0, 0);
             CCSM_FENCE;
 #pragma unroll
@@ -448,6 +482,8 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int bt = 0; bt < NB; ++bt) acc[2][T][bt][h] = mfma32k(wch[WS][T], xl[h][bt], acc[2][T][bt][h]);
+            CCSM_FENCE;
+            if (kF3sSkew && wave >= 4) dma_ahead(slot, s, NPAIR + P);
             CCSM_FENCE;
             if constexpr (P + 4 < NPAIR) { wch[WS][0] = c_hi(P + 4, 0); wch[WS][1] = c_hi(P + 4, 1); }
             else if constexpr (AH == 0) { wal[AS][1][0] = a_lo(AS, 1, 0); wal[AS][1][1] = a_lo(AS, 1, 1); }
@@ -505,8 +541,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
     mx_h0_to_lds<true, false, NB>(smem, 0, h0 + (size_t)dir * rows_p * kHidden, tile0, wave, lane);
 
     const u32x4_t xrs = dma_rsrc(xin + (size_t)tile0 * kSeqLen * 2 * kFragU4);
-    const unsigned sx_base = NB == 1 ? (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)X_OFF
-                                     : (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + X_OFF);
+    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)X_OFF;    // (cast first: see gru_layer0_mx_kernel)
     auto stage_load = [&](int t, int buf) {                         // 2 NB fragments per step (bt x hi|lo); every wave issues ONE transfer (the
         const int f = wave < 2 * NB ? wave : 2 * NB - 1;            // spare waves re-stage the last fragment: same bytes, same place)
         const int hl = f & 1, bt = f >> 1;
@@ -646,6 +681,29 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
 #pragma unroll
                     for (int g = 0; g < 3; ++g) acc[g][T][bt][h] = mfma32k(wbh[T][g], xl[0][bt], acc[g][T][bt][h]);
             };
+#ifndef CCSM_F3S_B_TMAJOR        // row halves outermost: each B operand is read from LDS once per pair (-DCCSM_F3S_B_TMAJOR: unit tiles outermost, below)
+            static_for<0, 2>([&](auto HC) {
+                constexpr int H = decltype(HC)::value;
+                if constexpr (H == 0) rdh(QC, std::integral_constant<int, 1>{});
+                else if constexpr (Q + 1 < kKBH / 2) rdh(std::integral_constant<int, Q + 1>{}, std::integral_constant<int, 0>{});
+                rdl(QC, HC);
+                CCSM_FENCE;
+                static_for<0, 2>([&](auto TC) {
+                    constexpr int T = decltype(TC)::value;
+                    group(TC, HC);
+                    CCSM_FENCE;
+                    if constexpr (H == 1) {
+                        if constexpr (Q + 1 < kKBH / 2) {
+#pragma unroll
+                            for (int g = 0; g < 3; ++g) { wbh[T][g] = w_at(NXT + ((3 * T + g) << 10)); wbl[T][g] = w_at(NXT + ((6 + 3 * T + g) << 10)); }
+                        } else {
+                            wxc[T][0] = w_at(OFF_C + ((2 * T) << 10)); wxc[T][1] = w_at(OFF_C + ((2 * T + 1) << 10));
+                        }
+                        CCSM_FENCE;
+                    }
+                });
+            });
+#else
             static_for<0, 2>([&](auto TC) {
                 constexpr int T = decltype(TC)::value;
                 static_for<0, 2>([&](auto HC) {
@@ -666,6 +724,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
                 }
                 CCSM_FENCE;
             });
+#endif
         });
         // r = sigmoid(R) ; N = b_in + r * N
         mfma_drain();

@@ -287,6 +287,40 @@ def test_layer0_staggered_and_lock_step_agree_bitwise(model7, monkeypatch):
         dl.close()
 
 
+def test_split3_on_both_mfma_shapes(monkeypatch):
+    """split3 runs its GRU layers on v_mfma_f32_16x16x32_f16 (ccsm_gru_f3s.hip: the shape that sustains 17 % more under the power cap); a
+    model created with CCSM_F3_SHAPE32=1 keeps the 32x32x16 kernels of round 4 (same inputs, outputs and weight-stream sizes, another
+    order of the k sum inside an instruction).  Both stay within split3's tolerance of the oracle and within 5e-7 of each other, for a
+    coalesced-size launch, a ragged one and the small-launch forms; trained weights: tests/test_gpu_zz_trained_checkpoints.py runs on the
+    default (16x16x32) kernels."""
+    from ccsmeth_amd.models import DeviceModel
+    w = synth.synth_weights(7)
+    d16 = DeviceModel(w, device=0, precision=3)
+    monkeypatch.setenv("CCSM_F3_SHAPE32", "1")
+    d32 = DeviceModel(w, device=0, precision=3)
+    monkeypatch.delenv("CCSM_F3_SHAPE32")
+    try:
+        for n, form in ((6144, None), (1000, None), (513, "2"), (64, "1"), (200, "3")):
+            if form is None:
+                monkeypatch.delenv("CCSM_WG_TILES", raising=False)
+            else:
+                monkeypatch.setenv("CCSM_WG_TILES", form)
+            s = synth.synth_sites(n, 277 + n)
+            h1, h2 = synth.synth_h0(n, 278 + n)
+            wa, wb = d16.workspace(n), d32.workspace(n)
+            _, pa = _fwd(wa, s, (h1, h2))
+            _, pb = _fwd(wb, s, (h1, h2))
+            wa.close(); wb.close()
+            pa, pb = np.asarray(pa), np.asarray(pb)
+            assert np.abs(pa - pb).max() < 5e-7, (n, form, np.abs(pa - pb).max())
+            if n <= 1000:
+                ref = _oracle(w, s, h1, h2)[1]
+                assert np.abs(pa - ref).max() < SPLIT3_TOL and np.abs(pb - ref).max() < SPLIT3_TOL, (n, form)
+    finally:
+        monkeypatch.delenv("CCSM_WG_TILES", raising=False)
+        d16.close(); d32.close()
+
+
 def test_input_layout_variants_agree(model7):
     """float32 k-mers and per-base npass (what the reference's FloatTensor call passes) == u8 k-mers + per-site npass."""
     w, dm = model7
