@@ -416,10 +416,11 @@ def extras(weights, dm, dev, pool, grp):
         leg("call_mods_million_reads", million)
     else:
         out["call_mods_million_reads"] = {
-            "value": 1.569e6, "unit": "sites/s", "measured": "round 5, not by this command", "log": "profiles/r05_b_call_mods_million_reads_trained.log",
+            "value": 1.681e6, "unit": "sites/s", "measured": "round 5, not by this command", "log": "profiles/r05_y_call_mods_million_reads_trained.log",
             "what": "python -m ccsmeth_amd call_mods --io native --no_sort on 1 008 000 synthetic 15-kb HiFi reads (52.8 GiB of BGZF, 760.7 M CpG "
                     "sites; BASELINE configs[2] names 10 M reads: scaled down 9.9 x) with tests/golden/trained/planted7_5000.npz (split3): work "
-                    "phase 484.9 s = 1.569 M sites/s, whole run incl. model set-up 1.563 M; host RSS 2.1-2.3 GiB and device memory 11.9 GiB flat "
+                    "phase 452.6 s = 1.681 M sites/s, whole run incl. model set-up 1.675 M (split3 on the 16x16x32 kernels; with the 32x32x16 kernels of "
+                    "the round's first half, another box: 484.9 s = 1.569 M, profiles/r05_b_*); host RSS 2.1-2.2 GiB and device memory 11.9 GiB flat "
                     "over the run; 1 008 000 records in and out, all tagged"}
     return out
 

@@ -39,11 +39,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma32k(uint4 a, uint4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(as_half8(a), as_half8(b), c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfma32k_first(uint4 a, uint4 b, f32x4 c) { return mfma32k(a, b, c); }
 __device__ __forceinline__ void mfma_drain() {}
 #else
 __device__ __forceinline__ f32x4 mfma32k(uint4 a, uint4 b, f32x4 c) {
     const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+    return c;
+}
+// the FIRST product into an accumulator that the vector ALU has just written (the bias copies, which the compiler places right in front of
+// their use; N behind the gate math): the two wait states a VALU write -> MFMA read wants, inside the statement (48 of a step's 2592 instructions)
+__device__ __forceinline__ f32x4 mfma32k_first(uint4 a, uint4 b, f32x4 c) {
+    const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
     return c;
 }
 // every MFMA issued so far has written its result (4-pass instruction: 8 states would do; 16 here, once per phase)
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g][0][bt][h] = mfma32k(wah[WS][0][g], xh[h][bt], acc[g][0][bt][h]);
+                    for (int g = 0; g < 2; ++g) acc[g][0][bt][h] = P == 0 ? mfma32k_first(wah[WS][0][g], xh[h][bt], acc[g][0][bt][h]) : mfma32k(wah[WS][0][g], xh[h][bt], acc[g][0][bt][h]);
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g][1][bt][h] = mfma32k(wah[WS][1][g], xh[h][bt], acc[g][1][bt][h]);
+                    for (int g = 0; g < 2; ++g) acc[g][1][bt][h] = P == 0 ? mfma32k_first(wah[WS][1][g], xh[h][bt], acc[g][1][bt][h]) : mfma32k(wah[WS][1][g], xh[h][bt], acc[g][1][bt][h]);
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[g][T][bt][h] = mfma32k(wbh[T][g], xh[h][bt], acc[g][T][bt][h]);
+                    for (int g = 0; g < 3; ++g) acc[g][T][bt][h] = Q == 0 ? mfma32k_first(wbh[T][g], xh[h][bt], acc[g][T][bt][h]) : mfma32k(wbh[T][g], xh[h][bt], acc[g][T][bt][h]);
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) acc[2][0][bt][h] = mfma32k(wch[WS][0], xh[h][bt], acc[2][0][bt][h]);
+                for (int bt = 0; bt < NB; ++bt) acc[2][0][bt][h] = P == 0 ? mfma32k_first(wch[WS][0], xh[h][bt], acc[2][0][bt][h]) : mfma32k(wch[WS][0], xh[h][bt], acc[2][0][bt][h]);
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) acc[2][0][bt][h] = mfma32k(wcl[WS][0], xh[h][bt], acc[2][0][bt][h]);
             }
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) acc[2][1][bt][h] = mfma32k(wch[WS][1], xh[h][bt], acc[2][1][bt][h]);
+                for (int bt = 0; bt < NB; ++bt) acc[2][1][bt][h] = P == 0 ? mfma32k_first(wch[WS][1], xh[h][bt], acc[2][1][bt][h]) : mfma32k(wch[WS][1], xh[h][bt], acc[2][1][bt][h]);
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) acc[2][1][bt][h] = mfma32k(wcl[WS][1], xh[h][bt], acc[2][1][bt][h]);
             }
@@ -628,7 +636,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g][T][bt][h] = mfma32k(wxa[T][g][0], x0[h][bt], acc[g][T][bt][h]);
+                    for (int g = 0; g < 2; ++g) acc[g][T][bt][h] = mfma32k_first(wxa[T][g][0], x0[h][bt], acc[g][T][bt][h]);
 #pragma unroll
         for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                    for (int g = 0; g < 3; ++g) acc[g][T][bt][h] = mfma32k(wbh[T][g], xh[h][bt], acc[g][T][bt][h]);
+                    for (int g = 0; g < 3; ++g) acc[g][T][bt][h] = Q == 0 ? mfma32k_first(wbh[T][g], xh[h][bt], acc[g][T][bt][h]) : mfma32k(wbh[T][g], xh[h][bt], acc[g][T][bt][h]);
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
@@ -748,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int bt = 0; bt < NB; ++bt) acc[2][T][bt][h] = mfma32k(wxc[T][0], x0[h][bt], acc[2][T][bt][h]);
+                for (int bt = 0; bt < NB; ++bt) acc[2][T][bt][h] = mfma32k_first(wxc[T][0], x0[h][bt], acc[2][T][bt][h]);       // (N was just written by the gate math)
 #pragma unroll
         for (int T = 0; T < 2; ++T)
 #pragma unroll
