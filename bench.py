@@ -595,11 +595,21 @@ def main():
             import ctypes as C
             from ccsmeth_amd import _lib as L
             capped = {}
-            for mode, key in ((1, "mix"), (2, "mix_lds")):
+            for mode, key in ((1, "mix"), (2, "mix_lds"), (0, "f16_32x32x16"), (3, "f16_16x16x32"), (4, "mix_16wide")):
                 tf, gc = C.c_float(0), C.c_float(0)
-                L.check(dm._lib.ccsm_measure_mfma_ceiling(local_rank, mode, float(a.ceiling_seconds), C.byref(tf), C.byref(gc)))
+                L.check(dm._lib.ccsm_measure_mfma_ceiling(local_rank, mode, float(a.ceiling_seconds) if mode in (1, 2) else min(2.0, float(a.ceiling_seconds)),
+                                                          C.byref(tf), C.byref(gc)))
                 capped[key] = (float(tf.value), float(gc.value))
             rl = line["roofline"]
+            # round 5: the ceiling depends on the instruction's SHAPE.  split3's GRU layers issue v_mfma_f32_16x16x32_f16 (three
+            # passes per flop); the split-mx kernels still issue the 32-wide instructions
+            rl["peak_power_capped_by_shape"] = {"f16_32x32x16": capped["f16_32x32x16"][0], "f16_16x16x32": capped["f16_16x16x32"][0],
+                                                "split_mx_mix_32wide": capped["mix"][0], "split_mx_mix_16wide": capped["mix_16wide"][0],
+                                                "unit": "fp16-MFMA TFLOP/s, random register-resident operands"}
+            if dm.precision == 3:
+                f16c = capped["f16_32x32x16" if os.environ.get("CCSM_F3_SHAPE32") else "f16_16x16x32"][0]
+                rl["frac_of_capped_split3"] = achieved * passes / 1e12 / f16c
+                rl["frac_of_capped_split3_note"] = "achieved x 3 passes per flop / the fp16 ceiling of the instruction this kernel issues"
             rl["peak_power_capped"] = capped["mix"][0]
             rl["frac_of_capped"] = achieved / 1e12 / capped["mix"][0]
             rl["peak_power_capped_lds_fed"] = capped["mix_lds"][0]

@@ -2132,8 +2132,8 @@ ccsm_status ccsm_aggr_forward_host(ccsm_aggr_model* m, int64_t n_sites, const in
 // See include/ccsm.h.  Launches run back to back for `seconds`; only the second half is averaged (the power governor needs
 // about a second to settle at the cap).
 ccsm_status ccsm_measure_mfma_ceiling(int device, int mode, double seconds, float* tflops, float* issue_gcycles) {
-    if (!tflops || mode < 0 || mode > 2 || !(seconds > 0.0) || seconds > 60.0)
-        return fail(CCSM_ERR_INVALID_ARG, "mode must be 0 (f16), 1 (mix) or 2 (mix, LDS-fed), 0 < seconds <= 60, tflops non-NULL");
+    if (!tflops || mode < 0 || mode > 4 || !(seconds > 0.0) || seconds > 60.0)
+        return fail(CCSM_ERR_INVALID_ARG, "mode must be 0 (f16), 1 (mix), 2 (mix, LDS-fed), 3 (f16 on 16x16x32) or 4 (mix on 16-wide instructions), 0 < seconds <= 60, tflops non-NULL");
     HIP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -2149,6 +2149,8 @@ ccsm_status ccsm_measure_mfma_ceiling(int device, int mode, double seconds, floa
         switch (mode) {
             case 0: hipLaunchKernelGGL((ccsm_ceiling::k<512, 0>), dim3(grid), dim3(512), 0, 0, rnd, out, it); break;
             case 1: hipLaunchKernelGGL((ccsm_ceiling::k<512, 1>), dim3(grid), dim3(512), 0, 0, rnd, out, it); break;
+            case 3: hipLaunchKernelGGL((ccsm_ceiling::k16<512, 0>), dim3(grid), dim3(512), 0, 0, rnd, out, it); break;
+            case 4: hipLaunchKernelGGL((ccsm_ceiling::k16<512, 1>), dim3(grid), dim3(512), 0, 0, rnd, out, it); break;
             default: hipLaunchKernelGGL((ccsm_ceiling::k<512, 2>), dim3(grid), dim3(512), 0, 0, rnd, out, it); break;
         }
     };
@@ -2177,8 +2179,10 @@ ccsm_status ccsm_measure_mfma_ceiling(int device, int mode, double seconds, floa
     if (st != CCSM_OK) return st;
     if (launches == 0) return fail(CCSM_ERR_INVALID_ARG, "seconds too short for one averaged launch");
     const double waves = (double)grid * 8, sec = ms_sum * 1e-3;
+    // per iteration of either kernel: the flops of 8 v_mfma_f32_32x32x16_f16 (k16: 16 v_mfma_f32_16x16x32_f16 on 8 accumulators x 2 groups)
     *tflops = (float)(launches * waves * iters * (8.0 * 2 * 32 * 32 * 16) / sec * 1e-12);
-    if (issue_gcycles) *issue_gcycles = (float)(launches * (waves / (grid * 4.0)) * iters * (8 * 32 + (mode ? 4 * 35 : 0)) / sec * 1e-9);
+    const bool mixed = mode == 1 || mode == 2 || mode == 4;
+    if (issue_gcycles) *issue_gcycles = (float)(launches * (waves / (grid * 4.0)) * iters * (8 * 32 + (mixed ? 4 * 35 : 0)) / sec * 1e-9);
     return CCSM_OK;
 }
 

@@ -66,6 +66,44 @@ __global__ __launch_bounds__(T) void k(const uint4* __restrict__ rnd, float* out
     out[tid] = s;
 }
 
+// The same on the 16-wide instructions (round 5: tools/ubench/mfma_power_shapes.hip found them 15-17 % cheaper per flop at the cap):
+//   MIX 0: v_mfma_f32_16x16x32_f16 only          MIX 1: per two of them one fp4 x fp6 v_mfma_scale_f32_16x16x128_f8f6f4 (the same MACs per product)
+// 8 independent accumulator tiles; one iteration = the flops of k<T, MODE>'s iteration (8 x 32x32x16 = 16 x 16x16x32).
+typedef float f32x4c __attribute__((ext_vector_type(4)));
+template <int T, int MIX>
+__global__ __launch_bounds__(T) void k16(const uint4* __restrict__ rnd, float* out, int iters) {
+    const int tid = blockIdx.x * T + threadIdx.x;
+    uint4 w[6], x[4], xb[4];
+    for (int i = 0; i < 6; ++i) w[i] = rnd[(tid * 14 + i) & 0xffff];
+    for (int i = 0; i < 4; ++i) { x[i] = rnd[(tid * 14 + 6 + i) & 0xffff]; xb[i] = rnd[(tid * 14 + 10 + i) & 0xffff]; }
+    f32x4c acc[8];
+    for (int t = 0; t < 8; ++t) for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    auto m16 = [](uint4 a, uint4 b, f32x4c c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0); };
+    auto c16 = [](uint4 a0, uint4 b0, uint2 b1, f32x4c c) {
+        const i32x8 a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, 0, 0, 0, 0};
+        const i32x8 b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, 0, 0};
+        return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 4, 2, 0, 123, 0, 123);
+    };
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = m16(w[half * 3 + 0], x[t & 3], acc[t]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = m16(w[half * 3 + 1], x[(t + 1) & 3], acc[t]);
+            if (MIX != 0) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = c16(w[half * 3 + 2], xb[t & 3], make_uint2(xb[(t + 2) & 3].x, xb[(t + 2) & 3].y), acc[t]);
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+    float s = 0.f;
+    for (int t = 0; t < 8; ++t) for (int r = 0; r < 4; ++r) s += acc[t][r];
+    out[tid] = s;
+}
+
 inline std::vector<uint4> random_operands() {
     // fp16 values uniform in (-1, 1) scaled by 1/8 (GRU weights / activations are of that order); the same bit patterns serve as
     // random fp6 / fp4 codes for the block-scaled products (any code is a finite number in those formats)

@@ -271,7 +271,8 @@ ccsm_status ccsm_selftest_split_mx(int device, int weight_fmt /* 2 = fp6 blob, 4
 
 /* What the MFMA pipe of THIS device sustains under its package power cap with random register-resident operands, in fp16-MFMA
  * TFLOP/s (correction products are overhead, as in bench.py's roofline.achieved): mode 0 = v_mfma_f32_32x32x16_f16 only, 1 = the GRU
- * kernels' issue mix (per two fp16 MFMAs one block-scaled fp4 x fp6 K = 64 MFMA), 2 = that mix with the B operands re-read from LDS.
+ * kernels' issue mix (per two fp16 MFMAs one block-scaled fp4 x fp6 K = 64 MFMA), 2 = that mix with the B operands re-read from LDS,
+ * 3 = v_mfma_f32_16x16x32_f16 only (what split3's GRU layers issue), 4 = the mix on the 16-wide instructions (16x16x32 + 16x16x128).
  * One 512-thread workgroup per CU (2 waves per SIMD), run for `seconds` (the second half is averaged).  *issue_gcycles (optional) =
  * MFMA issue cycles per second and SIMD, in GHz.  bench.py quotes mode 1 as roofline.peak_power_capped. */
 ccsm_status ccsm_measure_mfma_ceiling(int device, int mode, double seconds, float* tflops, float* issue_gcycles);
