@@ -39,12 +39,18 @@ __device__ __forceinline__ f32x4 mc16(uint4 a0, uint4 b0, uint2 b1, f32x4 c) {
 }
 
 // SHAPE 0: 32-wide, 1: 16-wide.  MIX 0: fp16 only, 1: two fp16 per scaled instruction
+// MIX 2 (16-wide only): the scaled instruction's A operand is ZERO in lanes 32-63, i.e. K = 128 with the upper 64 empty, and it is issued once
+// per 16x16x32 instead of once per two: the form in which the split-mx correction product of ONE pair of k-blocks (K = 64) fits the 16-wide
+// instruction without a second pair's operands - twice the issue time of mix16's corrections for (if zeros are as cheap as they are for the
+// fp16 instruction) the same energy
 template <int SHAPE, int MIX>
 __global__ __launch_bounds__(512) void k(const uint4* __restrict__ rnd, float* out, int iters) {
     const int tid = blockIdx.x * 512 + threadIdx.x;
     constexpr int NACC = SHAPE == 0 ? 4 : 16;
     uint4 w[8], x[8];
     for (int i = 0; i < 8; ++i) { w[i] = rnd[(tid * 16 + i) & 0xffff]; x[i] = rnd[(tid * 16 + 8 + i) & 0xffff]; }
+    uint4 wz[8];
+    for (int i = 0; i < 8; ++i) wz[i] = (threadIdx.x & 32) ? make_uint4(0, 0, 0, 0) : w[i];
     using acc_t = typename std::conditional<SHAPE == 0, f32x16, f32x4>::type;
     constexpr int NR = SHAPE == 0 ? 16 : 4;
     acc_t acc[NACC];
@@ -68,6 +74,15 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ rnd, float* o
                     if constexpr (SHAPE == 0) acc[t] = mc32(w[(q + 2) & 7], xa, make_uint2(xb.x, xb.y), acc[t]);
                     else acc[t] = mc16(w[(q + 2) & 7], xa, make_uint2(xb.x, xb.y), acc[t]);
                 }
+            }
+            if constexpr (MIX == 2) {
+#pragma unroll
+                for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+                    for (int t = 0; t < NACC; ++t) {
+                        const uint4 xa = x[(t + q + 5 + rep) & 7], xb = x[(t + q + 6 + rep) & 7];
+                        acc[t] = mc16(wz[(q + 2 + rep) & 7], xa, make_uint2(xb.x, xb.y), acc[t]);
+                    }
             }
         }
         asm volatile("" ::: "memory");
@@ -119,7 +134,9 @@ int main(int argc, char** argv) {
     run<1, 0>("f16_16 (16x16x32 only)", rnd, out, seconds);
     run<0, 1>("mix32 (2 x 32x32x16 f16 + 1 x 32x32x64 fp4 x fp6)", rnd, out, seconds);
     run<1, 1>("mix16 (2 x 16x16x32 f16 + 1 x 16x16x128 fp4 x fp6)", rnd, out, seconds);
+    run<1, 2>("mix16z (2 x 16x16x32 f16 + 2 x 16x16x128 fp4 x fp6 with A zero in lanes 32-63: one correction instruction per fp16 one)", rnd, out, seconds);
     run<0, 1>("mix32 again", rnd, out, seconds);
     run<1, 1>("mix16 again", rnd, out, seconds);
+    run<1, 2>("mix16z again", rnd, out, seconds);
     return 0;
 }
