@@ -56,6 +56,23 @@ def test_mfma_fragment_convention(lib):
     assert err.value < 1e-3
 
 
+def test_mfma_ceiling_probe_modes(lib):
+    """ccsm_measure_mfma_ceiling: what the matrix cores of this device sustain under its power cap on register-resident random operands, by
+    instruction: 0 / 3 = fp16 on 32x32x16 / 16x16x32, 1 / 4 = the split-mx mix on the 32- / 16-wide instructions, 2 = the 32-wide mix fed from
+    LDS.  Short runs (the figures bench.py quotes take 2-3 s per mode): every mode returns a rate between a tenth of and the datasheet peak, the
+    mixes lie below their fp16 instruction, and an unknown mode is refused."""
+    l = lib.load()
+    tf = {}
+    for mode in (0, 1, 2, 3, 4):
+        v, g = C.c_float(0), C.c_float(0)
+        lib.check(l.ccsm_measure_mfma_ceiling(0, mode, 0.4, C.byref(v), C.byref(g)))
+        tf[mode] = v.value
+        assert 250.0 < v.value < 2600.0 and g.value > 0.1, (mode, v.value, g.value)
+    assert tf[1] < tf[0] and tf[4] < tf[3] and tf[2] <= tf[1] * 1.05, tf
+    v = C.c_float(0)
+    assert l.ccsm_measure_mfma_ceiling(0, 5, 0.4, C.byref(v), None) != 0
+
+
 def test_split_f8_product_selftest(lib):
     """One 32x32x32 product in SPLIT_F8 arithmetic (attention pool): the fp8 correction MFMA must remove most of the fp16 operand error."""
     a, b = C.c_float(1.0), C.c_float(0.0)
