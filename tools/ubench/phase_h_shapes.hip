@@ -11,6 +11,12 @@
 //          lane position n' + 32 (q & 1) + 16 h): no new activation format.  Weights in two register slots of six fragments in use order
 //          (hi of pair 2D | hi of pair 2D + 1 | blobs of D), each refilled right behind its use (36 MFMAs of lead); accumulators tied by asm
 //          statements (the register allocator moves 4-register accumulators around otherwise: profiles/r05_q).
+//   px32 / px16 : the INPUT-part phase (gru_layer12_mx_kernel's phase A: r and z gates, 16 pairs per step; x_t HBM -> LDS by LDS-DMA into a
+//          four-slot ring refilled right behind the pair's barrier, counted s_waitcnt, weights three pairs ahead in register slots) in the same two
+//          forms.  px16 answers the design question of the 16-wide family: the correction product of pairs (P - 1, P) needs both pairs' blobs, and
+//          the ring releases a slot at its pair's barrier - so the lanes that take pair P - 1's blob (q < 2: lanes 0-31) read it WHILE PAIR P - 1 IS
+//          IN ITS SLOT and keep it in registers across the barrier; at pair P lanes 32-63 read theirs into the same registers (exec-masked
+//          ds_reads), then the 24 correction instructions issue.  The ring, its refills and its waits stay as they are.
 // Both: 256 workgroups of 512 threads, state and weights RANDOM (rows128_phase.hip's state is a constant pattern: fine for cycles, not for
 // watts), 2000 steps of 8 pairs; prints cycles per pair (wave 0) and ns per (row, pair) from HIP events, three repetitions each, alternating.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/phase_h_shapes.hip -o tools/ubench/_build/phase_h_shapes
@@ -56,6 +62,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
 }
 __device__ __forceinline__ uint4 buf_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ u32x4_t dma_rsrc(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    return u32x4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)b), (unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) & 0xffffu, 0x7fffffffu, 0x00020000u};
+}
+__device__ __forceinline__ void dma16_buf(u32x4_t rsrc, int voff, int soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "memory");
 }
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -253,6 +266,248 @@ __global__ __launch_bounds__(512, 1) void ph16(const uint4* __restrict__ wst, co
     if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// input-part phase: rows128_phase.hip's phase_x<8, 1, 3, 2> (px32) and its 16-wide form (px16)
+constexpr int kPairsX = 16, kRS = 4, FR = 4 * NB, SLOT = FR * 1024, NSA = 3;
+
+__global__ __launch_bounds__(512, 1) void px32(const uint4* __restrict__ xin, const uint4* __restrict__ wst, float* __restrict__ out,
+                                               unsigned long long* __restrict__ cyc, int steps) {
+    constexpr int G = 2, PW = (2 * G + G) * 1024 + 256, WOPS = 2 * G + G + 1;
+    constexpr int DHI = (FR + 7) / 8, DLO = FR / 8, NHIW = FR - DLO * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane16 = lane * 16;
+    const size_t x_rows = (size_t)kPairsX * SLOT;
+    const u32x4_t xrs = dma_rsrc(reinterpret_cast<const char*>(xin) + (size_t)blockIdx.x * 21 * x_rows);
+    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)((blockIdx.x & 1) * 8 + wave) * kPairsX * PW);
+    auto dma_pair = [&](int slot, int s, int p) {
+        const int base = ((s % 21) * kPairsX + p) * SLOT;
+#pragma unroll
+        for (int i = 0; i < DHI; ++i) {
+            const int f = wave + i * 8;
+            if (f < FR) dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(base + (f << 10)), __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT + (f << 10))));
+        }
+    };
+    uint4 wh[NSA][2][G], wb[NSA][G];
+    uint32_t wsc[NSA];
+    auto ld_slot = [&](int ws, int p) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int g = 0; g < G; ++g) wh[ws][k][g] = buf_load(wrs, lane16, p * PW + ((k * G + g) << 10));
+#pragma unroll
+        for (int g = 0; g < G; ++g) wb[ws][g] = buf_load(wrs, lane16, p * PW + ((2 * G + g) << 10));
+        wsc[ws] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, p * PW + ((3 * G) << 10), 0);
+    };
+#pragma unroll
+    for (int g = 0; g < kRS; ++g) dma_pair(g, 0, g);
+    ld_slot(0, 0); ld_slot(1, 1); ld_slot(2, 2);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSA * WOPS) : "memory");
+    __syncthreads();
+    f32x16 acc[G][NB];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][b][r] = 0.f;
+    int slot = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int s = 0; s < steps; ++s) {
+        uint4 xh[NB], xh1[NB], xc0[NB];
+        uint2 xc1[NB];
+        static_for<0, kPairsX>([&](auto PC_) {
+            constexpr int P = decltype(PC_)::value;
+            constexpr int WS = P % NSA;
+            const int xs = slot * SLOT + lane16;
+            const int slot_n = slot == kRS - 1 ? 0 : slot + 1;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                xh[b] = *reinterpret_cast<const uint4*>(smem + xs + (((0 * NB + b) * 2 + 0) << 10));
+                xh1[b] = *reinterpret_cast<const uint4*>(smem + xs + (((1 * NB + b) * 2 + 0) << 10));
+            }
+            FENCE;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g][b] = mfma16(wh[WS][0][g], xh[b], acc[g][b]);
+            FENCE;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                xc0[b] = *reinterpret_cast<const uint4*>(smem + xs + (((0 * NB + b) * 2 + 1) << 10));
+                xc1[b] = *reinterpret_cast<const uint2*>(smem + xs + (((1 * NB + b) * 2 + 1) << 10));
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g][b] = mfma16(wh[WS][1][g], xh1[b], acc[g][b]);
+            FENCE;
+            if (wave < NHIW) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kRS - 1) * WOPS + (kRS - 2) * DHI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"((kRS - 1) * WOPS + (kRS - 2) * DLO) : "memory");
+            __syncthreads();
+            dma_pair(slot, s + (P + kRS) / kPairsX, (P + kRS) % kPairsX);
+            FENCE;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[0][b] = mfma_mx<0>(wb[WS][0], wsc[WS], xc0[b], xc1[b], acc[0][b], 125);
+                acc[1][b] = mfma_mx<1>(wb[WS][1], wsc[WS], xc0[b], xc1[b], acc[1][b], 125);
+            }
+            FENCE;
+            ld_slot(WS, (P + NSA) % kPairsX);
+            FENCE;
+            slot = slot_n;
+        });
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[g][b][r];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
+}
+
+// weight stream per wave and pair (uniform slots of 10 KiB + 512 B): hi (T, g) at (2 T + g) KiB | [odd pairs: the double pair's blobs (T, g) at
+// 4 + (2 T + g) KiB | scale dwords of T = 0, 1 at 8 KiB, 8 KiB + 256]
+__global__ __launch_bounds__(512, 1) void px16(const uint4* __restrict__ xin, const uint4* __restrict__ wst, float* __restrict__ out,
+                                               unsigned long long* __restrict__ cyc, int steps) {
+    constexpr int PW = 8 * 1024 + 512, WE = 4, WO = 10;              // vector-memory requests of a weight slot: even / odd pair
+    constexpr int DHI = (FR + 7) / 8, DLO = FR / 8, NHIW = FR - DLO * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane16 = lane * 16;
+    const size_t x_rows = (size_t)kPairsX * SLOT;
+    const u32x4_t xrs = dma_rsrc(reinterpret_cast<const char*>(xin) + (size_t)blockIdx.x * 21 * x_rows);
+    const unsigned sx_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(reinterpret_cast<const char*>(wst) + (size_t)((blockIdx.x & 1) * 8 + wave) * kPairsX * PW);
+    auto dma_pair = [&](int slot, int s, int p) {
+        const int base = ((s % 21) * kPairsX + p) * SLOT;
+#pragma unroll
+        for (int i = 0; i < DHI; ++i) {
+            const int f = wave + i * 8;
+            if (f < FR) dma16_buf(xrs, lane16, __builtin_amdgcn_readfirstlane(base + (f << 10)), __builtin_amdgcn_readfirstlane((int)(sx_base + slot * SLOT + (f << 10))));
+        }
+    };
+    // per-lane offsets inside a ring slot ([kbl][bt][hl] fragments): k-block q >> 1, lane position n' + 32 (q & 1); and for a blob: lane position only
+    const int lpos = (((lane >> 4) & 1) * 32 + (lane & 15)) << 4;
+    const int kbo = (lane & 32) << 6;
+    const int lxs = lpos + kbo + (kbo << 1);                         // NB = 3
+    const uint32_t sbv = (lane & 16) ? 113u : 125u;
+    uint4 wh[2][4], wb[2][4];                                        // hi (T, g) of TWO pairs (three pairs of lead as in px32 spill: 256 registers + 40 B of scratch); blobs of two double pairs
+    uint32_t wsc[2][2];
+    auto ld_slot = [&](auto PC_) {                                  // pair p (static): hi into slot p % 3; odd p: the double pair's blobs into slot (p >> 1) & 1
+        constexpr int p = decltype(PC_)::value % kPairsX;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wh[p & 1][i] = buf_load(wrs, lane16, p * PW + (i << 10));
+        if constexpr (p & 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wb[(p >> 1) & 1][i] = buf_load(wrs, lane16, p * PW + ((4 + i) << 10));
+            wsc[(p >> 1) & 1][0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, p * PW + (8 << 10), 0);
+            wsc[(p >> 1) & 1][1] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, p * PW + (8 << 10) + 256, 0);
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < kRS; ++g) dma_pair(g, 0, g);
+    ld_slot(std::integral_constant<int, 0>{}); ld_slot(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WE + WO) : "memory");
+    __syncthreads();
+    f32x4 acc[2][2][NB][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[g][T][b][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 xc0[2][NB];                                               // the double pair's blob operands: lanes 0-31 pair P - 1, lanes 32-63 pair P
+    uint2 xc1[2][NB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { xc0[h][b] = make_uint4(0, 0, 0, 0); xc1[h][b] = make_uint2(0, 0); }
+    int slot = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int s = 0; s < steps; ++s) {
+        static_for<0, kPairsX>([&](auto PC_) {
+            constexpr int P = decltype(PC_)::value;
+            constexpr int WS = P & 1, BS = (P >> 1) & 1;
+            const int xs = slot * SLOT;
+            const int slot_n = slot == kRS - 1 ? 0 : slot + 1;
+            uint4 xh[2][NB];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) xh[h][b] = *reinterpret_cast<const uint4*>(smem + xs + lxs + ((b * 2) << 10) + h * 256);
+            // this pair's blob, for the lanes that take it: lanes 0-31 at an even pair (kept across the barrier), lanes 32-63 at an odd one
+            if ((lane >> 5) == (P & 1)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        xc0[h][b] = *reinterpret_cast<const uint4*>(smem + xs + lpos + ((b * 2 + 1) << 10) + h * 256);
+                        xc1[h][b] = *reinterpret_cast<const uint2*>(smem + xs + lpos + (((NB + b) * 2 + 1) << 10) + h * 256);
+                    }
+            }
+            FENCE;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int T = 0; T < 2; ++T)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) acc[g][T][b][h] = m16(wh[WS][2 * T + g], xh[h][b], acc[g][T][b][h]);
+            FENCE;
+            // younger operations than this wave's part of the next pair's transfer (issued behind the barrier of pair P - 3): the weight slots
+            // requested behind pairs P - 3, P - 2, P - 1 (for pairs P - 1, P, P + 1) and two refills
+            {
+                constexpr int W3 = (P & 1) ? WE + WO + WE : WO + WE + WO;
+                if (wave < NHIW) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W3 + (kRS - 2) * DHI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(W3 + (kRS - 2) * DLO) : "memory");
+            }
+            __syncthreads();
+            dma_pair(slot, s + (P + kRS) / kPairsX, (P + kRS) % kPairsX);
+            FENCE;
+            if constexpr (P & 1) {                                  // the double pair's correction products
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int T = 0; T < 2; ++T)
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            acc[0][T][b][h] = c16<0>(wb[BS][2 * T + 0], wsc[BS][T], xc0[h][b], xc1[h][b], sbv, acc[0][T][b][h]);
+                            acc[1][T][b][h] = c16<1>(wb[BS][2 * T + 1], wsc[BS][T], xc0[h][b], xc1[h][b], sbv, acc[1][T][b][h]);
+                        }
+                FENCE;
+            }
+            ld_slot(std::integral_constant<int, P + 2>{});         // the slot just consumed: two pairs ahead
+            FENCE;
+            slot = slot_n;
+        });
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15" ::: "memory");
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) sum += acc[g][T][b][h][0] + acc[g][T][b][h][1] + acc[g][T][b][h][2] + acc[g][T][b][h][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+    if (lane == 0 && blockIdx.x == 0) cyc[wave] = t1 - t0;
+}
+
 #define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(e_)); std::exit(1); } } while (0)
 
 int main(int argc, char** argv) {
@@ -272,6 +527,16 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> hr(65536 * 4);
     for (auto& v : hr) { sd = sd * 1664525u + 1013904223u; v = (sd & 0x83ff83ffu) | 0x30003000u; }
     CK(hipMemcpy(g_rnd, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
+    uint4* g_x;
+    const size_t xbytes = (size_t)n_cu * 21 * kPairsX * SLOT;
+    CK(hipMalloc(&g_x, xbytes));
+    {
+        std::vector<uint32_t> hx(xbytes / 4);
+        for (auto& v : hx) { sd = sd * 1664525u + 1013904223u; v = (sd & 0x83ff83ffu) | 0x30003000u; }
+        CK(hipMemcpy(g_x, hx.data(), xbytes, hipMemcpyHostToDevice));
+    }
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&px32), hipFuncAttributeMaxDynamicSharedMemorySize, kRS * SLOT));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&px16), hipFuncAttributeMaxDynamicSharedMemorySize, kRS * SLOT));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ph32), hipFuncAttributeMaxDynamicSharedMemorySize, kStateBytes));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ph16), hipFuncAttributeMaxDynamicSharedMemorySize, kStateBytes));
     hipEvent_t e0, e1;
@@ -292,6 +557,24 @@ int main(int argc, char** argv) {
             const double cyc_pair = (double)c[0] / ((double)steps * kPairsH);
             std::printf("%s run %d: %8.0f cycles per pair (wave 0; MFMA time of the SIMD's two waves: 1728), %7.3f ns per (row, pair), %.1f ms\n",
                         shape == 0 ? "ph32 (32x32x16 + 32x32x64) " : "ph16 (16x16x32 + 16x16x128)", rep, cyc_pair, ms * 1e6 / ((double)steps * kPairsH * 96), ms);
+            std::fflush(stdout);
+        }
+    std::printf("# input-part phase (r, z gates): 16 pairs per step, x_t by LDS-DMA through a four-slot ring, one barrier per pair\n");
+    for (int rep = 0; rep < 4; ++rep)
+        for (int shape = 0; shape < 2; ++shape) {
+            float ms = 0.f;
+            CK(hipEventRecord(e0, 0));
+            if (shape == 0) hipLaunchKernelGGL(px32, dim3(n_cu), dim3(512), kRS * SLOT, 0, g_x, g_w, g_out, g_cyc, steps);
+            else hipLaunchKernelGGL(px16, dim3(n_cu), dim3(512), kRS * SLOT, 0, g_x, g_w, g_out, g_cyc, steps);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long c[8] = {};
+            CK(hipMemcpy(c, g_cyc, sizeof(c), hipMemcpyDeviceToHost));
+            std::printf("%s run %d: %8.0f cycles per pair (wave 0; MFMA time of the SIMD's two waves: 1152), %7.3f ns per (row, pair), %.1f ms\n",
+                        shape == 0 ? "px32 (32x32x16 + 32x32x64) " : "px16 (16x16x32 + 16x16x128)", rep, (double)c[0] / ((double)steps * kPairsX),
+                        ms * 1e6 / ((double)steps * kPairsX * 96), ms);
             std::fflush(stdout);
         }
     return 0;
