@@ -40,13 +40,24 @@ FLOP_PER_SITE = 2.0 * (MAC_GRU0 + 2 * MAC_GRU12 + MAC_ATT + 2048)   # = 244.23e6
 BYTES_PER_SITE = 680.0
 PEAK_F16_MFMA = 2.5e15       # dense fp16/bf16 MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12
-# HBM/fabric bytes of ONE launch of the dominant kernel per site, from rocprofv3 PMC passes on the launch shape timed here
-# (2 x FETCH_SIZE + WRITE_SIZE in KiB over 6144 sites, gfx950 read correction per MI355X_MICROARCH.md; PMC counters cannot be
-# read from inside this process)
-TRAFFIC = {4: ((2 * 993445 + 451630) * 1024 / 6144.0, "profiles/r05_w_pmc.md"),       # mean of layers 1 and 2 (FETCH 9.9556e5 / 9.9133e5, WRITE 5.1619e5 / 3.8707e5 KB per 6144-site launch; the last layer writes 3 of 4 fragments per pair)
-           5: ((2 * 1223800 + 516160) * 1024 / 6144.0, "profiles/r02_w_pmc_coalesced_hybrid.md"),
-           6: ((2 * 1002900 + 516100) * 1024 / 6144.0, "profiles/r03_z_pmc_prec6.md"),
-           3: ((2 * 1058000 + 516100) * 1024 / 6144.0, "profiles/r05_w_pmc_split3.md")}      # gru_layer12_f3s_kernel (FETCH 1.058e6, WRITE 5.161e5 KB)
+# HBM/fabric bytes of ONE launch of the dominant kernel per site: read from the file tools/pmc_summary.py --emit writes out of the round's
+# rocprofv3 --pmc CSVs (separate FETCH_SIZE / WRITE_SIZE passes over the launch shape timed here - 6 x 2048 sites = 512 workgroups -, FETCH
+# doubled per MI355X_MICROARCH.md's gfx950 note); PMC counters cannot be read from inside this process.  No file / no entry: traffic = null
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def traffic_of(precision, kernel):
+    """-> (bytes per site of one launch of `kernel`, source) or (None, None)"""
+    try:
+        t = json.load(open(TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, None
+    for e in t.get("kernels", []):
+        if e.get("precision") == precision and e.get("kernel") == kernel:
+            return float(e["bytes_per_site"]), "%s (%s; %d sites per launch)" % (t.get("source", TRAFFIC_FILE), e.get("formula", ""), e.get("sites_per_launch", 0))
+    return None, None
+
+
 ARITH_NAME = {3: "split3", 4: "split-mx", 5: "hybrid", 6: "split-mx-d"}
 ARITH = {4: ("fp32 reference; computed as f16 + MX(fp6|fp4 x fp6) split operands, f32 accumulate (within 1e-4 on this config's random-init weights)",
              "hi*hi on v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4 (GRU layers: weight blobs fp4 e2m1 for the "
@@ -416,12 +427,10 @@ def extras(weights, dm, dev, pool, grp):
         leg("call_mods_million_reads", million)
     else:
         out["call_mods_million_reads"] = {
-            "value": 1.681e6, "unit": "sites/s", "measured": "round 5, not by this command", "log": "profiles/r05_y_call_mods_million_reads_trained.log",
-            "what": "python -m ccsmeth_amd call_mods --io native --no_sort on 1 008 000 synthetic 15-kb HiFi reads (52.8 GiB of BGZF, 760.7 M CpG "
-                    "sites; BASELINE configs[2] names 10 M reads: scaled down 9.9 x) with tests/golden/trained/planted7_5000.npz (split3): work "
-                    "phase 452.6 s = 1.681 M sites/s, whole run incl. model set-up 1.675 M (split3 on the 16x16x32 kernels; with the 32x32x16 kernels of "
-                    "the round's first half, another box: 484.9 s = 1.569 M, profiles/r05_b_*); host RSS 2.1-2.2 GiB and device memory 11.9 GiB flat "
-                    "over the run; 1 008 000 records in and out, all tagged"}
+            "value": None, "unit": "sites/s", "measured": "not by this command (CCSM_BENCH_MILLION_READS=1 runs it here: ~8 minutes)",
+            "cited": {"sites_per_s": 1.681e6, "round": 5, "log": "profiles/r05_y_call_mods_million_reads_trained.log",
+                      "what": "python -m ccsmeth_amd call_mods --io native --no_sort on 1 008 000 synthetic 15-kb HiFi reads (52.8 GiB of BGZF, 760.7 M CpG sites; "
+                              "BASELINE configs[2] names 10 M reads: scaled down 9.9 x) with tests/golden/trained/planted7_5000.npz (split3): work phase 452.6 s"}}
     return out
 
 
@@ -503,6 +512,24 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist.barrier()              # pays the communicator's lazy set-up (hundreds of ms of idle GPU) HERE, not in the fence in front of the timed region
     n_gpus = world
+    # N ranks are N GPUs only if they sit on N distinct physical devices: every rank reports what names its device, and the line is refused
+    # (rc 2) when fewer distinct devices than ranks answer (CCSM_BENCH_ALLOW_SHARED_DEVICE=1: tests of the path on a one-GPU box)
+    from ccsmeth_amd import sharding
+    idents = [sharding.device_identity(local_rank)]
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, idents[0])
+        idents = gathered
+    census = sharding.device_census(idents, world)
+    census["collective_library"] = sharding.collective_library() if use_dist else None
+    if not census["ok"] and os.environ.get("CCSM_BENCH_ALLOW_SHARED_DEVICE") != "1":
+        if rank == 0:
+            sys.stderr.write("bench.py: %d rank(s) but %d answered from %d distinct device(s) %s; refusing to report a %d-GPU number\n"
+                             % (world, census["ranks_seen"], census["distinct_devices"], census["devices"], world))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(2)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -555,7 +582,14 @@ def main():
         value = n_gpus * a.steps * BATCH / elapsed
         dtype, arith, passes = ARITH[dm.precision]
         achieved = 2.0 * MAC_GRU12 * sites_per_launch / (dom_ms * 1e-3)
-        traffic, traffic_src = TRAFFIC[dm.precision]
+        mx16 = dm.precision == 4 and bool(os.environ.get("CCSM_MX_SHAPE16"))    # opt-in: plain split-mx's layers 1-2 on the 16-wide instructions (ccsm_gru_mx16.hip)
+        dom_kernel = ("gru_layer12_mx16_kernel" if mx16 else "gru_layer12_mx_kernel" if dm.precision >= 4 else
+                      "gru_layer12_f3_kernel" if os.environ.get("CCSM_F3_SHAPE32") else "gru_layer12_f3s_kernel")
+        traffic, traffic_src = traffic_of(dm.precision, dom_kernel)
+        if mx16:
+            arith = arith.replace("v_mfma_f32_32x32x16_f16 + (lo*hi, hi*lo) on v_mfma_scale_f32_32x32x64_f8f6f4",
+                                  "v_mfma_f32_16x16x32_f16 + (lo*hi, hi*lo) of two pairs of k-blocks on v_mfma_scale_f32_16x16x128_f8f6f4 in layers 1-2 "
+                                  "(layer 0 and the attention pool: v_mfma_f32_32x32x16_f16 + v_mfma_scale_f32_32x32x64_f8f6f4)")
         line = {
             "metric": "CpG sites/sec (call_mods, attbigru2s b21)", "value": value, "unit": "sites/s",
             "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -570,8 +604,10 @@ def main():
                                   "synthetic random initialisation (seed 20260928), as BASELINE.json configs[1] defines the benchmark.  NOT what a trained "
                                   "checkpoint is served with: see trained_checkpoint below (ccsm_create serves trained weights in split3)",
                        "trained_checkpoint": "not measured (--extras none or N > 1)",
-                       "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": ("gru_layer12_mx_kernel" if dm.precision >= 4 else ("gru_layer12_f3_kernel" if os.environ.get("CCSM_F3_SHAPE32") else "gru_layer12_f3s_kernel")) + " (BiGRU layers 1-2)",
+                       "parallelism": "reads sharded per GPU, no collective" if n_gpus > 1 else "single GPU",
+                       "ranks_seen": census["ranks_seen"], "distinct_devices": census["distinct_devices"], "devices": census["devices"],
+                       "collective_library": census["collective_library"]},
+            "roofline": {"bound": "mfma", "kernel": dom_kernel + " (BiGRU layers 1-2)",
                          "achieved": achieved / 1e12, "peak": PEAK_F16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA,
                          "traffic": None if traffic is None else traffic * sites_per_launch,
@@ -589,6 +625,7 @@ def main():
         }
         if sustained is not None:
             line["sustained"] = sustained
+            line["value_sustained_240"] = sustained["value"]
         # the same device's MFMA ceiling under its power cap, measured live (3 s each; after the timed region): the GRU kernels'
         # instruction mix with random register-resident operands, and the same with the activations re-read from LDS
         if a.ceiling_seconds > 0:
@@ -601,8 +638,8 @@ def main():
                                                           C.byref(tf), C.byref(gc)))
                 capped[key] = (float(tf.value), float(gc.value))
             rl = line["roofline"]
-            # round 5: the ceiling depends on the instruction's SHAPE.  split3's GRU layers issue v_mfma_f32_16x16x32_f16 (three
-            # passes per flop); the split-mx kernels still issue the 32-wide instructions
+            # the ceiling depends on the instruction's SHAPE.  split3's GRU layers issue v_mfma_f32_16x16x32_f16 (three passes per flop);
+            # plain split-mx issues the 32-wide mix (its 16-wide form, round 6, is opt-in: CCSM_MX_SHAPE16=1)
             rl["peak_power_capped_by_shape"] = {"f16_32x32x16": capped["f16_32x32x16"][0], "f16_16x16x32": capped["f16_16x16x32"][0],
                                                 "split_mx_mix_32wide": capped["mix"][0], "split_mx_mix_16wide": capped["mix_16wide"][0],
                                                 "unit": "fp16-MFMA TFLOP/s, random register-resident operands"}
@@ -610,8 +647,17 @@ def main():
                 f16c = capped["f16_32x32x16" if os.environ.get("CCSM_F3_SHAPE32") else "f16_16x16x32"][0]
                 rl["frac_of_capped_split3"] = achieved * passes / 1e12 / f16c
                 rl["frac_of_capped_split3_note"] = "achieved x 3 passes per flop / the fp16 ceiling of the instruction this kernel issues"
-            rl["peak_power_capped"] = capped["mix"][0]
-            rl["frac_of_capped"] = achieved / 1e12 / capped["mix"][0]
+            mixkey = "mix_16wide" if mx16 else "mix"                # the ceiling of the instruction mix the dominant kernel issues
+            rl["peak_power_capped"] = capped[mixkey][0]
+            rl["frac_of_capped"] = achieved / 1e12 / capped[mixkey][0]
+            rl["peak_power_capped_mix"] = "split_mx_mix_16wide" if mx16 else "split_mx_mix_32wide"
+            # how far the north star's 5 M sites/s is from physics: the whole path's 244.23 MFLOP per site at the capped ceiling of the split-mx
+            # mix (every cycle of every SIMD an MFMA of the kernel's mix, nothing else drawing power), and of three fp16 passes for split3
+            rl["ceiling_sites_per_s"] = {"split_mx_at_capped_mix_16wide": capped["mix_16wide"][0] * 1e12 / FLOP_PER_SITE,
+                                         "split_mx_at_capped_mix_32wide": capped["mix"][0] * 1e12 / FLOP_PER_SITE,
+                                         "split3_at_capped_f16_16x16x32": capped["f16_16x16x32"][0] * 1e12 / 3.0 / FLOP_PER_SITE,
+                                         "at_datasheet_f16_peak_one_pass": PEAK_F16_MFMA / FLOP_PER_SITE,
+                                         "note": "capped ceiling (fp16-MFMA TFLOP/s; the correction products are overhead) / 244.23 MFLOP per site"}
             rl["peak_power_capped_lds_fed"] = capped["mix_lds"][0]
             rl["frac_of_capped_lds_fed"] = achieved / 1e12 / capped["mix_lds"][0]
             rl["power_capped_note"] = ("ccsm_measure_mfma_ceiling on this device, %.0f s per mode: one 512-thread workgroup per CU issuing the kernel's "

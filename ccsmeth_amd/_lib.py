@@ -65,7 +65,7 @@ _lib = None
 EXPORTS = ("ccsm_create", "ccsm_destroy", "ccsm_workspace_create", "ccsm_workspace_destroy", "ccsm_forward_host",
            "ccsm_submit_host", "ccsm_wait_host", "ccsm_forward_device", "ccsm_last_error", "ccsm_version",
            "ccsm_model_precision", "ccsm_model_probe_error", "ccsm_model_probe_error_hybrid", "ccsm_model_probe_error_of", "ccsm_model_probe_tail", "ccsm_model_probe_q999", "ccsm_model_probe_sites", "ccsm_model_quant_error",
-           "ccsm_model_set_precision", "ccsm_model_data_probe_add", "ccsm_model_data_probe_decide", "ccsm_model_data_probe_error", "ccsm_model_data_probe_q999",
+           "ccsm_model_set_precision", "ccsm_workspace_force_split3", "ccsm_model_data_probe_add", "ccsm_model_data_probe_decide", "ccsm_model_data_probe_error", "ccsm_model_data_probe_q999",
            "ccsm_model_data_probe_sites", "ccsm_model_data_probe_verdict", "ccsm_workspace_bytes", "ccsm_workspace_set_timing", "ccsm_workspace_last_timing",
            "ccsm_selftest_mfma", "ccsm_debug_read", "ccsm_debug_rows_padded", "ccsm_debug_rows_capacity",
            "ccsm_group_add_device", "ccsm_group_run", "ccsm_group_pending", "ccsm_workspace_timing_mean",
@@ -116,6 +116,7 @@ def load():
     lib.ccsm_model_quant_error.argtypes = [vp]
     lib.ccsm_model_quant_error.restype = C.c_float
     lib.ccsm_model_set_precision.argtypes = [vp, ci]
+    lib.ccsm_workspace_force_split3.argtypes = [vp]
     lib.ccsm_model_data_probe_add.argtypes = [vp, vp, vp, ci]
     lib.ccsm_model_data_probe_decide.argtypes = [vp]
     lib.ccsm_model_data_probe_error.argtypes = [vp]

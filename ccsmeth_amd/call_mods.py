@@ -66,6 +66,11 @@ def build_parser():
                    help="--arithmetic auto picks split-mx only for a checkpoint whose 65536-site SYNTHETIC probe is clean; call_mods then\n"
                         "repeats the comparison against split3 on the first <= 65536 sites of THIS input and falls back to split3 if\n"
                         "split-mx is not clean on them as well (costs one extra pass over those sites).  This flag skips that second probe.")
+    p.add_argument("--shadow_every", type=int, default=64,
+                   help="with split-mx served behind both probes: one chunk in this many is also computed in split3 and compared (max |dprob|\n"
+                        "<= 1.25e-5: the rule's first condition), so that the rule covers the whole input, not its first 65536 sites (~1.5 %% of\n"
+                        "the run's model time at 64).  A violation starts the run again in split3 (single process) or stops every rank with the\n"
+                        "message.  0 switches the shadow off.")
     p.add_argument("--ref", default=None)
     p.add_argument("--mapq", type=int, default=1)
     p.add_argument("--identity", type=float, default=0.0)
@@ -266,7 +271,28 @@ def _print_data_probe(dm, log):
 
 def call_mods(args, log=sys.stderr, pipe=None):
     """`pipe`: an object with CallModsPipeline's run_native_batch / close (the CPU tests of the multi-rank hand-out pass a
-    stand-in; None = the GPU pipeline on the checkpoint of --model_file)."""
+    stand-in; None = the GPU pipeline on the checkpoint of --model_file).
+
+    --arithmetic auto serves split-mx only behind two probes (the checkpoint on synthetic sites, then the input's first <= 65536 sites) AND
+    a running shadow: one chunk in --shadow_every is also computed in split3 and compared under the rule's first condition.  A violation
+    anywhere in the file aborts the run, removes what it wrote and starts again in split3 (single process; several ranks: every rank stops
+    with the message): the output is then byte-identical to --arithmetic split3."""
+    from .pipeline import ArithmeticViolation
+    try:
+        return _call_mods_once(args, log, pipe)
+    except ArithmeticViolation as e:
+        if pipe is not None or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise
+        print("[main]arithmetic on this input: %s -> the run starts again in split3 (three fp16 passes, fp32-class)" % e, file=log)
+        out_path = args.output + ".modbam.bam"
+        for pth in (out_path, out_path + ".bai", out_path + ".tmp"):
+            if os.path.exists(pth):
+                os.remove(pth)
+        args.arithmetic = "split3"
+        return _call_mods_once(args, log, None)
+
+
+def _call_mods_once(args, log=sys.stderr, pipe=None):
     t0 = time.time()
     if pipe is None and not os.path.exists(args.model_file):
         raise ValueError("--model_file is not set right!")            # call_modifications.py:484-485
@@ -372,28 +398,45 @@ def call_mods(args, log=sys.stderr, pipe=None):
             # through split3, and split-mx stays only if it is clean on them too.  Rank 0 probes and publishes the verdict: one arithmetic
             # for the whole run, whatever the number of ranks (the bytes written do not depend on the sharding).
             if rank == 0:
+                head = []
                 try:
                     with NativeBamReader(args.input, threads=min(args.threads, 4)) as prd:
-                        head, n_head = [], 0
-                        while n_head < 65536:
+                        # only batches that hold called sites are kept, and the scan is bounded (an input whose filters leave few sites -
+                        # --holeids_e, a strict --mode align - must not be read and held whole): at most 16384 reads looked at
+                        n_head = n_seen = 0
+                        while n_head < 65536 and n_seen < 16384:
                             b = prd.next_batch(min(holes_batch, 64))
                             if b is None:
                                 break
+                            n_seen += b.n_reads
                             skip, _, sites = filters(b)
-                            head.append((b, skip))
-                            n_head += sites
-                        probe_dm.data_probe(lambda: (pipe.probs_of_native_batch(b, skip) for b, skip in head))
-                        for b, _ in head:
-                            b.close()
+                            if sites > 0:
+                                head.append((b, skip))
+                                n_head += sites
+                            else:
+                                b.close()
+                        if n_head > 0:
+                            probe_dm.data_probe(lambda: (pipe.probs_of_native_batch(b, skip) for b, skip in head))
+                        else:
+                            print("[main]arithmetic on this input: no called site among its first %d reads: the probe on the input is skipped "
+                                  "(the running shadow still applies)" % n_seen, file=log)
                 except BaseException as e:      # noqa: BLE001 - the other ranks wait for the verdict: release them with the cause
                     if queue is not None:
                         queue.fail("%s: %s" % (type(e).__name__, e))
                     raise
-                _print_data_probe(probe_dm, log)
+                finally:
+                    for b, _ in head:
+                        b.close()
+                if probe_dm.data_probe_sites > 0:
+                    _print_data_probe(probe_dm, log)
             if queue is not None:
                 verdict = queue.rendezvous("arithmetic", int(probe_dm.precision) if rank == 0 else None)[0]
                 if rank != 0:
                     probe_dm.set_precision(int(verdict))
+            # split-mx survived both probes: the rule keeps being applied to one chunk in --shadow_every for the rest of the file
+            if int(probe_dm.precision) == 4 and getattr(args, "shadow_every", 64) > 0 and hasattr(pipe, "shadow_every"):
+                pipe.shadow_every = int(args.shadow_every)
+                pipe.shadow_limit = float(os.environ.get("CCSM_CALLMODS_SHADOW_LIMIT", "1.25e-5"))
         part_path = out_path if world == 1 else "%s.part%d" % (out_path, rank)
         runs, chunk_log = [], []          # [(chunk, file start, file end, IndexRun)], [(chunk, first voffset, end voffset, records)]
         t_work = time.time()
@@ -501,12 +544,19 @@ def call_mods(args, log=sys.stderr, pipe=None):
                 work_inflated = rd.inflated_bytes - header_inflated
         except BaseException as e:      # noqa: BLE001 - the other ranks must not wait for this one's share
             if queue is not None:
-                queue.fail("%s: %s" % (type(e).__name__, e))
+                queue.fail("%s: %s%s" % (type(e).__name__, e, " - run again with --arithmetic split3" if type(e).__name__ == "ArithmeticViolation" else ""))
+            if type(e).__name__ == "ArithmeticViolation":
+                pipe.close(discard=True)
+                if os.path.exists(part_path):
+                    os.remove(part_path)
             raise
         pipe.close()
+        if getattr(pipe, "shadow_chunks", 0) and rank == 0:
+            print("[main]arithmetic on this input: %d chunks (%d sites) shadowed in split3 behind the probes: max |dprob| %.1e (limit %.1e) -> split-mx kept"
+                  % (pipe.shadow_chunks, pipe.shadow_sites, pipe.shadow_max, pipe.shadow_limit), file=log)
         t_work = time.time() - t_work
         stats = dict(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, output=out_path, inflated_bytes=work_inflated, chunks=len(runs),
-                     seconds_work=t_work)
+                     seconds_work=t_work, ranks_seen=1, distinct_devices=1)
         ordered = [(k, part_path, a, e, ir) for k, a, e, ir in runs]
         t_stitch = time.time()
         if world > 1:
@@ -514,13 +564,16 @@ def call_mods(args, log=sys.stderr, pipe=None):
             # a rank that fails anywhere from here on releases the others with its error instead of leaving them in a collective
             try:
                 gathered = queue.rendezvous("gather", dict(rank=rank, header_end=header_end, runs=runs, chunks=chunk_log,
-                                                           counts=(cnt_w, cnt_mm, cnt_failed, cnt_sites), inflated=work_inflated, work=t_work))
+                                                           counts=(cnt_w, cnt_mm, cnt_failed, cnt_sites), inflated=work_inflated, work=t_work,
+                                                           device=sharding.device_identity()))
                 cnt_w, cnt_mm, cnt_failed, cnt_sites = (sum(g["counts"][k] for g in gathered) for k in range(4))
                 n_chain = sharding.verify_chain(first_voffset, [c for g in gathered for c in g["chunks"]], n_chunks=queue.n_chunks, eof_voffset=eof_voffset)
                 if n_chain != cnt_w:
                     raise RuntimeError("the chunks hold %d records but %d were written" % (n_chain, cnt_w))
                 stats.update(reads=cnt_w, tagged=cnt_mm, failed=cnt_failed, sites=cnt_sites, rank_inflated_bytes=[g["inflated"] for g in gathered],
                              rank_chunks=[len(g["runs"]) for g in gathered], rank_seconds_work=[g["work"] for g in gathered])
+                census = sharding.device_census([g.get("device") for g in gathered], world)
+                stats.update(ranks_seen=census["ranks_seen"], distinct_devices=census["distinct_devices"], collective_library=sharding.collective_library())
                 ordered = sorted((k, "%s.part%d" % (out_path, g["rank"]), a, e, ir) for g in gathered for k, a, e, ir in g["runs"])
                 spans = [(p, a, e) for _, p, a, e, _ in ordered]
                 dst, total = stitch_layout(header_end, spans)
@@ -563,8 +616,8 @@ def call_mods(args, log=sys.stderr, pipe=None):
                         _post_sort_index(out_path, args, log)
                 stats.update(seconds_stitch=t_stitch, seconds_index=time.time() - t_idx)
                 print("wrote {} reads, in which {} were added mm tags".format(cnt_w, cnt_mm), file=log)     # :456
-                print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d GPU(s); ccsmeth_amd %s)" %
-                      (time.time() - t0, cnt_failed, world, __version__), file=log)
+                print("[main]call_mods costs %.1f seconds.. (%d reads skipped/failed; %d rank(s) on %d distinct GPU(s); ccsmeth_amd %s)" %
+                      (time.time() - t0, cnt_failed, world, stats.get("distinct_devices", 1), __version__), file=log)
                 if os.environ.get("CCSM_CALLMODS_REPORT"):      # machine-readable run summary (tools/host_feed_probe.py)
                     import json
                     with open(os.environ["CCSM_CALLMODS_REPORT"], "w") as rf:
@@ -584,6 +637,8 @@ def call_mods(args, log=sys.stderr, pipe=None):
         with BamWriter(out_path, header, rd.references) as wr:
             batch = []
 
+            probe_seen = 0
+
             def flush():
                 nonlocal cnt_w, cnt_mm, cnt_failed
                 if not batch:
@@ -598,15 +653,22 @@ def call_mods(args, log=sys.stderr, pipe=None):
                     qs, qe, ident = (np.array([x[k] for x in info]) for k in range(3))
                     askip, windows = _align_skip_and_window(np.array([r.flag for r in batch]), np.array([r.mapq for r in batch]), ident, qs, qe, L, args)
                     rds = [r._replace(fi=np.empty(0, np.uint8)) if sk else r for r, sk in zip(rds, askip)]
-                nonlocal probe_dm
-                if probe_dm is not None:        # the selection rule on this input's first reads (the native path probes up to 65536 sites; here: the first hole-batch)
+                nonlocal probe_dm, probe_seen
+                if probe_dm is not None:
+                    # the selection rule on this input's first reads (the native path probes up to 65536 sites; here: hole-batch by hole-batch
+                    # until 8192 sites have been compared - a first batch without sites decides nothing).  RAW probabilities, as in the
+                    # native path and in the library's rule: the calls' own values are normalised and rounded to 6 decimals
                     def p2():
-                        c0, _ = pipe.run(rds)
-                        p1 = np.concatenate([np.asarray(c.probs, np.float32) for c in c0] + [np.empty(0, np.float32)])
-                        yield np.stack([1.0 - p1, p1], 1)
+                        pipe.raw_log = []
+                        pipe.run(rds)
+                        raw, pipe.raw_log = pipe.raw_log, None
+                        yield np.concatenate(raw + [np.empty((0, 2), np.float32)])
                     probe_dm.data_probe(p2)
-                    _print_data_probe(probe_dm, log)
-                    probe_dm = None
+                    probe_seen += probe_dm.data_probe_sites
+                    if probe_dm.data_probe_sites > 0:
+                        _print_data_probe(probe_dm, log)
+                    if probe_seen >= 8192 or int(probe_dm.precision) != 4:
+                        probe_dm = None
                 calls, failed = pipe.run(rds)
                 cnt_failed += failed
                 for ri, (rec, c) in enumerate(zip(batch, calls)):

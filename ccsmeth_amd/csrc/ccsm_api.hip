@@ -17,6 +17,7 @@
 #include "ccsm_gru_mx.hip"
 #include "ccsm_gru_f3.hip"
 #include "ccsm_gru_f3s.hip"
+#include "ccsm_gru_mx16.hip"
 #include "ccsm_aggr.hip"
 #include "ccsm_extract.hip"
 #include "ccsm_ceiling.hip"
@@ -88,6 +89,9 @@ struct ccsm_model {
     uint4* wstf3s[kLayers] = {nullptr, nullptr, nullptr};// split3, layers 1-2 on v_mfma_f32_16x16x32_f16 (ccsm_gru_f3s.hip): the same stream sizes, unit tiles of 16 ([0] unused)
     float* biasn[kLayers] = {nullptr, nullptr, nullptr}; // its biases in natural unit order [dir][wave][4][32] ([0] unused)
     bool f3_shape32 = false;                             // CCSM_F3_SHAPE32=1 at ccsm_create: split3's layers 1-2 on the 32x32x16 kernel of round 4 (A/B)
+    uint4* wstmx16[kLayers] = {nullptr, nullptr, nullptr};// split-mx, layers 1-2 on the 16-wide instructions (ccsm_gru_mx16.hip; [0] unused)
+    bool mx_shape16 = false;                             // CCSM_MX_SHAPE16=1 at ccsm_create: plain split-mx's layers 1-2 on gru_layer12_mx16_kernel (round 6: parity-green,
+                                                         // 10 % slower than gru_layer12_mx_kernel - both sit on the CU's vector-memory path, DESIGN 7 - so not the default)
     uint4* wsthy[kLayers] = {nullptr, nullptr, nullptr};// hybrid weight streams (the same with fp16 lo fragments for the recurrent part)
     uint4* wa3 = nullptr;                                // split-f8 attention projections [wave][32][hi|corr][64]
     uint4* ua3 = nullptr;
@@ -107,6 +111,7 @@ struct ccsm_model {
     float dprobe_err = -1.f, dprobe_q999 = -1.f;
     int dprobe_n = 0;
     int dprobe_ok = -1;                                  // -1: not decided; 0: the candidate failed on the caller's data (split3 is served); 1: kept
+    mutable int slices_bound = 0;                        // slices added to workspaces of this model and not yet run (ccsm_model_set_precision refuses while > 0)
 };
 
 struct ccsm_workspace {
@@ -526,6 +531,77 @@ void pack_wstream_f3s0(int feat0, const float* const wih[2], const float* const 
         }
 }
 
+// Layers 1-2 in split-mx for gru_layer12_mx16_kernel (layout in ccsm_gru_mx16.hip): per DOUBLE pair the hi fragments of both pairs
+// (v_mfma_f32_16x16x32_f16: lane (m, q) <- unit-tile row m, k = 32 pair + 8 q + j) and the MX blobs of the scaled instruction, whose lane (m, q)
+// holds the 32 values (kMxPerm order) of unit-tile row m of the double pair's pair q >> 1, term q & 1 (0: W_lo 2^11, 1: W_hi), one E8M0 scale byte
+// per lane and blob; unit tile T, row m <-> hidden unit 32 wave + 8 (m >> 2) + 4 T + (m & 3) (pack_wstream_f3s).  Formats as pack_wstream_mx:
+// fp4 for the r, z input part and the recurrent part, fp6 for the n gate's input part, whose pairs come in phase C's zig-zag order.
+float pack_wstream_mx16(const float* const wih[2], const float* const whh[2], std::vector<uint8_t>& out) {
+    const int k_in = 2 * kHidden;
+    out.assign((size_t)2 * kWaves * kMx16WBytes, 0);
+    BlobErr bes[2 * kWaves];
+    std::vector<std::thread> pool;
+    for (int dir = 0; dir < 2; ++dir)
+        for (int wave = 0; wave < kWaves; ++wave)
+            pool.emplace_back([&, dir, wave] {
+            BlobErr& be = bes[dir * kWaves + wave];
+            uint8_t* base = out.data() + (size_t)(dir * kWaves + wave) * kMx16WBytes;
+            auto unit = [=](int T, int m) { return kUnitTile * wave + 8 * (m >> 2) + 4 * T + (m & 3); };
+            auto hi_frag = [&](size_t off, const float* w, int ld, int g, int T, int pair) {
+                _Float16* hi = reinterpret_cast<_Float16*>(base + off);
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) hi[lane * 8 + j] = (_Float16)w[(size_t)(g * kHidden + unit(T, lane & 15)) * ld + 32 * pair + 8 * (lane >> 4) + j];
+            };
+            // pair_of(0 | 1) = the pair the lanes q >> 1 = 0 | 1 take; off8 < 0: fp4 (16 bytes per lane), else bytes 16-23 of the fp6 blob there
+            auto blob = [&](size_t off16, long off8, size_t sc_off, int sc_byte, int fmt, const float* w, int ld, int g, int T, int pair0, int pair1) {
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int m = lane & 15, q = lane >> 4, term = q & 1, pair = (q >> 1) ? pair1 : pair0;
+                    float val[32];
+                    for (int j = 0; j < 32; ++j) {
+                        const float v = w[(size_t)(g * kHidden + unit(T, m)) * ld + 32 * pair + mx_perm(j)];
+                        const float h = (float)(_Float16)v;
+                        val[j] = term ? h : std::ldexp(v - h, 11);
+                    }
+                    emit_blob(base + off16 + lane * 16, off8 >= 0 ? base + off8 + lane * 8 : nullptr, base + sc_off + lane * 4 + sc_byte, val, fmt, term ? 0 : -11,
+                              &be.e2[term], &be.r2[term]);
+                }
+            };
+            for (int DA = 0; DA < kKB12 / 4; ++DA) {
+                const size_t pa = (size_t)DA * kMx16PA;
+                for (int T = 0; T < 2; ++T)
+                    for (int g = 0; g < 2; ++g) {
+                        hi_frag(pa + (size_t)(2 * T + g) * 1024, wih[dir], k_in, g, T, 2 * DA);
+                        hi_frag(pa + (size_t)(4 + 2 * T + g) * 1024, wih[dir], k_in, g, T, 2 * DA + 1);
+                        blob(pa + (size_t)(8 + 2 * T + g) * 1024, -1, pa + 12 * 1024, 2 * T + g, kMxWFmtH, wih[dir], k_in, g, T, 2 * DA, 2 * DA + 1);
+                    }
+            }
+            for (int D = 0; D < kKBH / 4; ++D) {
+                const size_t pb = (size_t)kMx16OffB + (size_t)D * kMx16PB;
+                for (int T = 0; T < 2; ++T)
+                    for (int g = 0; g < 3; ++g) {
+                        hi_frag(pb + (size_t)(3 * T + g) * 1024, whh[dir], kHidden, g, T, 2 * D);
+                        hi_frag(pb + (size_t)(6 + 3 * T + g) * 1024, whh[dir], kHidden, g, T, 2 * D + 1);
+                        blob(pb + (size_t)(12 + 3 * T + g) * 1024, -1, pb + 18 * 1024 + (size_t)T * 256, g, kMxWFmtH, whh[dir], kHidden, g, T, 2 * D, 2 * D + 1);
+                    }
+            }
+            for (int DC = 0; DC < kKB12 / 4; ++DC) {
+                const size_t pc = (size_t)kMx16OffC + (size_t)DC * kMx16PC;
+                auto pair_at = [](int pp) { return kMxZigZag ? kKB12 / 2 - 1 - pp : pp; };      // the pair phase C consumes at position pp
+                for (int T = 0; T < 2; ++T) {
+                    hi_frag(pc + (size_t)T * 1024, wih[dir], k_in, 2, T, pair_at(2 * DC));
+                    hi_frag(pc + (size_t)(2 + T) * 1024, wih[dir], k_in, 2, T, pair_at(2 * DC + 1));
+                    blob(pc + (size_t)(4 + T) * 1024, (long)(pc + 6 * 1024 + (size_t)T * 512), pc + 7 * 1024, T, kMxWFmtX, wih[dir], k_in, 2, T, pair_at(2 * DC), pair_at(2 * DC + 1));
+                }
+            }
+            });
+    for (std::thread& t : pool) t.join();
+    BlobErr be;
+    for (const BlobErr& b : bes)
+        for (int g = 0; g < 2; ++g) { be.e2[g] += b.e2[g]; be.r2[g] += b.r2[g]; }
+    const double a = be.r2[0] > 0 ? std::sqrt(be.e2[0] / be.r2[0]) : 0.0, b = be.r2[1] > 0 ? std::sqrt(be.e2[1] / be.r2[1]) : 0.0;
+    return (float)std::fmax(a, b);
+}
+
 // biases in natural unit order for the 16x16x32 kernels: [dir][wave][set r, z, n_x, n_h][32]
 void pack_bias_natural(const float* const bih[2], const float* const bhh[2], std::vector<float>& out) {
     out.assign((size_t)2 * kWaves * 4 * 32, 0.f);
@@ -717,6 +793,28 @@ ccsm_status launch_run(const ccsm_model* m, ccsm_workspace* ws, hipStream_t st) 
     if constexpr (F8) {
         uint4* const* wst = HS3 ? m->wsthy : DYN ? m->wstmd : m->wstmx;
         auto layer = [&](int l, const uint4* in, uint4* out_, unsigned long long* dbg) {
+            if constexpr (!HS3 && !DYN) {
+                if (l >= 1 && m->wstmx16[l]) {                  // plain split-mx: layers 1-2 on the 16-wide instructions (ccsm_gru_mx16.hip)
+                    auto go = [&](auto nbc, auto f8c) {
+                        constexpr int NBX = decltype(nbc)::value;
+                        constexpr bool F8O = decltype(f8c)::value;
+#ifdef CCSM_PHASE_STAMPS
+                        if (dbg && NBX == 3) {
+                            hipLaunchKernelGGL((gru_layer12_mx16_kernel<F8O, 3, true>), ggrid, dim3(512), mx12_lds(3), st, in, out_, m->wstmx16[l], m->biasn[l], ws->h0buf + l * slab, ws->rows_p, dbg);
+                            return;
+                        }
+#endif
+                        hipLaunchKernelGGL((gru_layer12_mx16_kernel<F8O, NBX>), ggrid, dim3(512), mx12_lds(NBX), st, in, out_, m->wstmx16[l], m->biasn[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
+                    };
+                    auto by_nb = [&](auto f8c) {
+                        if (nb_run == 1) go(std::integral_constant<int, 1>{}, f8c);
+                        else if (nb_run == 2) go(std::integral_constant<int, 2>{}, f8c);
+                        else go(std::integral_constant<int, 3>{}, f8c);
+                    };
+                    if (l == 2) by_nb(std::true_type{}); else by_nb(std::false_type{});
+                    return;
+                }
+            }
             if (nb_run == 1) launch_gru_mx<HS3, DYN, 1>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
             else if (nb_run == 2) launch_gru_mx<HS3, DYN, 2>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, nullptr);
             else launch_gru_mx<HS3, DYN>(l, ggrid, st, in, out_, wst[l], m->bias[l], ws->h0buf + l * slab, ws->rows_p, dbg, m->l0_stag);
@@ -1155,6 +1253,16 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<false, true, false, true>), kMx12Lds);
             set_lds(reinterpret_cast<const void*>(&gru_layer12_mx_kernel<true, true, false, true>), kMx12Lds);
 #endif
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx16_kernel<false, 3>), mx12_lds(3));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx16_kernel<true, 3>), mx12_lds(3));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx16_kernel<false, 2>), mx12_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx16_kernel<true, 2>), mx12_lds(2));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx16_kernel<false, 1>), mx12_lds(1));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx16_kernel<true, 1>), mx12_lds(1));
+#ifdef CCSM_PHASE_STAMPS
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx16_kernel<false, 3, true>), mx12_lds(3));
+            set_lds(reinterpret_cast<const void*>(&gru_layer12_mx16_kernel<true, 3, true>), mx12_lds(3));
+#endif
             set_lds(reinterpret_cast<const void*>(&attn_fc_f8_kernel), kAttF8Lds);
         }
         if (e != hipSuccess) st = fail(CCSM_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
@@ -1163,6 +1271,7 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
     m->split3_v2 = std::getenv("CCSM_SPLIT3_V2") != nullptr;
     m->l0_stag = std::getenv("CCSM_L0_LOCKSTEP") == nullptr;
     m->f3_shape32 = std::getenv("CCSM_F3_SHAPE32") != nullptr;
+    m->mx_shape16 = std::getenv("CCSM_MX_SHAPE16") != nullptr;
 #ifdef CCSM_STAGGER_DIAG
     {
         const int stagger = std::getenv("CCSM_STAGGER") ? std::atoi(std::getenv("CCSM_STAGGER")) : 0;
@@ -1205,6 +1314,17 @@ ccsm_status ccsm_create(const ccsm_config* cfg, const ccsm_weights* w, int devic
             const ccsm_status s2 = upload(&dst[l], bbuf.data(), bbuf.size());
             if (s2 != CCSM_OK) return s2;
         }
+        if (which == CCSM_PRECISION_SPLIT_F8 && m->mx_shape16)           // layers 1-2 on the 16-wide instructions (ccsm_gru_mx16.hip): the same values, other fragments
+            for (int l = 1; l < kLayers; ++l) {
+                qerr[which] = std::fmax(qerr[which], pack_wstream_mx16(w->weight_ih[l], w->weight_hh[l], bbuf));
+                ccsm_status s2 = upload(&m->wstmx16[l], bbuf.data(), bbuf.size());
+                if (s2 == CCSM_OK && !m->biasn[l]) {
+                    std::vector<float> nbuf;
+                    pack_bias_natural(w->bias_ih[l], w->bias_hh[l], nbuf);
+                    s2 = upload(&m->biasn[l], nbuf.data(), nbuf.size() * sizeof(float));
+                }
+                if (s2 != CCSM_OK) return s2;
+            }
         return CCSM_OK;
     };
     if (st == CCSM_OK && prec >= CCSM_PRECISION_SPLIT_F8 && !auto_prec) st = ensure_streams(prec);
@@ -1247,7 +1367,14 @@ ccsm_status ccsm_model_set_precision(ccsm_model* m, int precision) {
                       (precision == CCSM_PRECISION_HYBRID && m->wsthy[0]) || (precision == CCSM_PRECISION_SPLIT_MXD && m->wstmd[0]);
     if (!have) return fail(CCSM_ERR_INVALID_ARG, "ccsm_model_set_precision: this model holds no weight streams of that arithmetic (split3 always; "
                                                   "of the split-mx family what ccsm_create probed or was asked for)");
+    if (m->slices_bound > 0 && precision != m->precision)
+        return fail(CCSM_ERR_BUSY, "ccsm_model_set_precision: slices of a group are bound to a workspace of this model and not yet run");
     m->precision = precision;
+    return CCSM_OK;
+}
+ccsm_status ccsm_workspace_force_split3(ccsm_workspace* ws) {
+    if (!ws) return fail(CCSM_ERR_INVALID_ARG, "workspace must be non-NULL");
+    ws->force_split3 = true;
     return CCSM_OK;
 }
 ccsm_status ccsm_model_data_probe_add(ccsm_model* m, const float* probs_candidate, const float* probs_split3, int n_sites) {
@@ -1295,6 +1422,7 @@ void ccsm_destroy(ccsm_model* m) {
         (void)hipFree(m->wsthy[l]);
         (void)hipFree(m->wstf3[l]);
         (void)hipFree(m->wstf3s[l]);
+        (void)hipFree(m->wstmx16[l]);
         (void)hipFree(m->biasn[l]);
         (void)hipFree(m->bias[l]);
     }
@@ -1420,15 +1548,19 @@ ccsm_status ccsm_group_add_device(const ccsm_model* m, ccsm_workspace* ws, int n
     const int mode = h0 ? h0->mode : CCSM_H0_DEVICE_RNG;
     SiteKeys sk;
     if (h0) { sk.key = reinterpret_cast<const unsigned long long*>(h0->site_key); sk.sub = reinterpret_cast<const unsigned int*>(h0->site_sub); }
-    return add_slice(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
-                     h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
-                     static_cast<hipStream_t>(stream), sk);
+    st = add_slice(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
+                   h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
+                   static_cast<hipStream_t>(stream), sk);
+    if (st == CCSM_OK) m->slices_bound++;           // (until ccsm_group_run: ccsm_model_set_precision refuses in between)
+    return st;
 }
 
 ccsm_status ccsm_group_run(const ccsm_model* m, ccsm_workspace* ws, void* stream) {
     if (!m || !ws) return fail(CCSM_ERR_INVALID_ARG, "model and workspace must be non-NULL");
     if (ws->n_slices == 0) return CCSM_OK;
     HIP_TRY(hipSetDevice(m->device));
+    m->slices_bound -= ws->n_slices;
+    if (m->slices_bound < 0) m->slices_bound = 0;
     return dispatch_run(m, ws, static_cast<hipStream_t>(stream));
 }
 

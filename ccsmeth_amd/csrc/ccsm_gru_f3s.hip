@@ -41,6 +41,7 @@ __device__ __forceinline__ f32x4 mfma32k(uint4 a, uint4 b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 mfma32k_first(uint4 a, uint4 b, f32x4 c) { return mfma32k(a, b, c); }
 __device__ __forceinline__ void mfma_drain() {}
+template <int NB> __device__ __forceinline__ void mfma_drained(f32x4 (&)[2][NB][2]) {}
 #else
 __device__ __forceinline__ f32x4 mfma32k(uint4 a, uint4 b, f32x4 c) {
     const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
@@ -49,13 +50,35 @@ __device__ __forceinline__ f32x4 mfma32k(uint4 a, uint4 b, f32x4 c) {
 }
 // the FIRST product into an accumulator that the vector ALU has just written (the bias copies, which the compiler places right in front of
 // their use; N behind the gate math): the two wait states a VALU write -> MFMA read wants, inside the statement (48 of a step's 2592 instructions)
+// (-DCCSM_F3S_NO_FIRST_NOP, -DCCSM_F3S_NO_DRAINED: deliberately broken builds that tools/isa_gate.py must reject - tests/test_isa_gate.py)
 __device__ __forceinline__ f32x4 mfma32k_first(uint4 a, uint4 b, f32x4 c) {
     const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
+#ifdef CCSM_F3S_NO_FIRST_NOP
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+#else
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+#endif
     return c;
 }
 // every MFMA issued so far has written its result (4-pass instruction: 8 states would do; 16 here, once per phase)
 __device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15" ::: "memory"); }
+// ... and the vector ALU's readers of these accumulators take them from HERE: the drain's memory clobber orders loads and stores only - a
+// register-only reader (the gate math's first multiply) may otherwise be scheduled between the last product and the drain, inside the wait
+// states an XDL write -> VALU read needs (round 6: tools/isa_gate.py found exactly that in the 32-row instantiations).  asm volatile
+// statements keep their order among themselves; these emit no instruction.
+template <int NB>
+__device__ __forceinline__ void mfma_drained(f32x4 (&a)[2][NB][2]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#ifndef CCSM_F3S_NO_DRAINED
+                asm volatile("" : "+v"(a[T][bt][h]));
+#endif
+            }
+}
 #endif
 
 #define CCSM_FENCE asm volatile("" ::: "memory")
@@ -405,6 +428,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
         });
         // r = sigmoid(R) ; N = b_in + r * N
         mfma_drain();
+        mfma_drained<NB>(acc[0]);
+        mfma_drained<NB>(acc[1]);
+        mfma_drained<NB>(acc[2]);
         {
             f32x4 b2[2];
             bias_set(2, b2);
@@ -505,6 +531,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
         });
         stamp(3);
         mfma_drain();
+        mfma_drained<NB>(acc[2]);
         {
             int v = lane;
             asm volatile("" : "+v"(v));
@@ -736,6 +763,9 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
         });
         // r = sigmoid(R) ; N = b_in + r * N
         mfma_drain();
+        mfma_drained<NB>(acc[0]);
+        mfma_drained<NB>(acc[1]);
+        mfma_drained<NB>(acc[2]);
         {
             f32x4 b2[2];
             bias_set(2, b2);
@@ -765,6 +795,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
                 for (int bt = 0; bt < NB; ++bt) acc[2][T][bt][h] = mfma32k(wxc[T][1], x0[h][bt], acc[2][T][bt][h]);
         CCSM_FENCE;
         mfma_drain();
+        mfma_drained<NB>(acc[2]);
         ld_first();                                                 // the next step's first weight fragments: in flight during the tail
         CCSM_FENCE;
 #pragma unroll

@@ -94,16 +94,18 @@ class DeviceModel:
             return self.precision
         cand = self.precision
         got = []
-        for arith in (cand, _lib.PRECISION_SPLIT3):
-            self.set_precision(arith)
-            part, n = [], 0
-            for p in run():
-                part.append(np.array(p, np.float32, copy=True))
-                n += len(p)
-                if n >= max_sites:
-                    break
-            got.append(np.concatenate(part) if part else np.empty((0, 2), np.float32))
-        self.set_precision(cand)
+        try:
+            for arith in (cand, _lib.PRECISION_SPLIT3):
+                self.set_precision(arith)
+                part, n = [], 0
+                for p in run():
+                    part.append(np.array(p, np.float32, copy=True))
+                    n += len(p)
+                    if n >= max_sites:
+                        break
+                got.append(np.concatenate(part) if part else np.empty((0, 2), np.float32))
+        finally:
+            self.set_precision(cand)            # (also when the second pass raises: the model must not be left in split3 by accident)
         if got[0].shape != got[1].shape:
             raise RuntimeError("data probe: the two passes saw different sites")
         self.data_probe_add(got[0][:max_sites], got[1][:max_sites])
@@ -142,6 +144,10 @@ class Workspace:
         if self.handle:
             self.model._lib.ccsm_workspace_destroy(self.handle)
             self.handle = None
+
+    def force_split3(self):
+        """The next forward / submit / group run on this workspace runs in split3 whatever the model's arithmetic (one-shot)."""
+        _lib.check(self.model._lib.ccsm_workspace_force_split3(self.handle))
 
     def _batch(self, kmer1, ipd1, pw1, npass1, kmer2, ipd2, pw2, npass2, ptr_of, extra=None):
         """extra: for a model with is_stds / is_sn / is_map, one dict per strand with the keys "ipd_std", "pw_std" (N, 21), "sn" (N, 4),

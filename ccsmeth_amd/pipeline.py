@@ -19,6 +19,10 @@ from .extract_features import count_kept_sites, extract_read_arrays
 Read = namedtuple("Read", "name seq fi ri fp rp fn rn is_reverse")
 
 
+class ArithmeticViolation(RuntimeError):
+    """The running split3 shadow found split-mx outside the selection rule later in the input (Pipeline.shadow_every)."""
+
+
 def read_key(name):
     """64-bit FNV-1a of the read name: the key of a read's device-drawn initial states (ccsm_reads.h0_key; the native reader
     hands the same value over as ccsm_bam_batch.name_hash).  A site draws from (this key, position of its C in the read), so its
@@ -58,12 +62,29 @@ class CallModsPipeline:
         dev = torch.device("cuda", device_model.device)
         self._streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
         self._slots = [_Slot(device_model, self.batch_size, s.cuda_stream) for s in self._streams]
-        self._inflight = []                             # [(workspace slot, job, selection)] of the native-batch path, oldest first
+        self._inflight = []                             # [(workspace slot, job, selection, shadowed)] of the native-batch path, oldest first
         self._turn = 0
+        # The running split3 shadow (call_mods, split-mx behind both probes): one chunk in `shadow_every` is ALSO run in split3, on a workspace
+        # of its own behind the chunk's launch, and compared when the chunk is collected; a chunk beyond `shadow_limit` raises
+        # ArithmeticViolation (the caller restarts in split3).  0 = off
+        self.raw_log = None                             # a list: run() also appends every device batch's raw (n, 2) probabilities (call_mods' probe on the record-level path)
+        self.shadow_every, self.shadow_limit = 0, 1.25e-5
+        self._shadow_ws = None
+        self.shadow_chunks, self.shadow_sites, self.shadow_max = 0, 0, -1.0
 
-    def close(self):
+    def close(self, discard=False):
+        """discard: drop what is still in flight (an aborted run) instead of collecting - and checking - it"""
         while self._inflight:
-            self._collect_one()
+            if discard:
+                k, _, _, shadowed = self._inflight.pop(0)
+                self._rwss[k].wait_reads()
+                if shadowed:
+                    self._shadow_ws.wait_reads()
+            else:
+                self._collect_one()
+        if self._shadow_ws is not None:
+            self._shadow_ws.close()
+            self._shadow_ws = None
         for s in self._slots:
             s.ws.close()
         if self._rws is not None:
@@ -96,6 +117,8 @@ class CallModsPipeline:
             rd = [(reads[i].seq, reads[i].fi, reads[i].ri, reads[i].fp, reads[i].rp, reads[i].fn, reads[i].rn) for i in chunk]
             first, locs, _, probs = self._rws.forward_reads(rd, seed=self.seed, stream=self._slots[0].stream,
                                                            read_keys=np.array([read_key(reads[i].name) for i in chunk], np.uint64))
+            if self.raw_log is not None:
+                self.raw_log.append(np.array(probs, np.float32, copy=True))
             p1 = prob1_norm_round6(probs)
             for j, i in enumerate(chunk):
                 a, b = int(first[j]), int(first[j + 1])
@@ -143,6 +166,8 @@ class CallModsPipeline:
         logits = np.empty((n, 2), np.float32)
         probs = np.empty((n, 2), np.float32)
         _lib.check(self.dm._lib.ccsm_wait_host(slot.ws.handle, logits.ctypes.data, probs.ctypes.data))
+        if self.raw_log is not None:
+            self.raw_log.append(probs.copy())
         p1 = prob1_norm_round6(probs)
         pos = 0
         for ridx, locs in meta:
@@ -182,7 +207,20 @@ class CallModsPipeline:
             self._rwss[k].submit_reads_arrays(batch.offset[sel], batch.length[sel], batch.seq, batch.fi, batch.ri, batch.fp, batch.rp,
                                               batch.fn[sel], batch.rn[sel], site_counts=cnt[sel], seed=self.seed,
                                               stream=self._slots[k].stream, read_keys=batch.name_hash[sel])
-            self._inflight.append((k, job, sel))
+            shadowed = False
+            if self.shadow_every and self._shadow_ws_free() and self._turn % self.shadow_every == self.shadow_every - 1:
+                # the same chunk again in split3 (ccsm_workspace_force_split3: the model itself keeps serving split-mx), same stream, same keyed
+                # initial states: compared at collection
+                if self._shadow_ws is None or self._shadow_ws.max_sites < csites:
+                    if self._shadow_ws is not None:
+                        self._shadow_ws.close()
+                    self._shadow_ws = self.dm.workspace(max(csites, self.batch_size))
+                self._shadow_ws.force_split3()
+                self._shadow_ws.submit_reads_arrays(batch.offset[sel], batch.length[sel], batch.seq, batch.fi, batch.ri, batch.fp, batch.rp,
+                                                    batch.fn[sel], batch.rn[sel], site_counts=cnt[sel], seed=self.seed,
+                                                    stream=self._slots[k].stream, read_keys=batch.name_hash[sel])
+                shadowed = True
+            self._inflight.append((k, job, sel, shadowed))
             job["pending"] += 1
             start += take
             self._turn += 1
@@ -212,11 +250,23 @@ class CallModsPipeline:
             start += take
         return np.concatenate(out) if out else np.empty((0, 2), np.float32)
 
+    def _shadow_ws_free(self):
+        return not any(sh for _, _, _, sh in self._inflight)      # one shadow chunk in flight at a time (one shadow workspace)
+
     def _collect_one(self):
-        k, job, sel = self._inflight.pop(0)
+        k, job, sel, shadowed = self._inflight.pop(0)
         f, lc, _, pr = self._rwss[k].wait_reads()
         if not np.array_equal(np.diff(f), job["cnt"][sel]):
             raise RuntimeError("device and host site counts disagree")
+        if shadowed:
+            ps = self._shadow_ws.wait_reads()[3]
+            d = float(np.abs(np.asarray(pr, np.float32) - np.asarray(ps, np.float32)).max()) if len(pr) else 0.0
+            self.shadow_chunks += 1
+            self.shadow_sites += len(pr)
+            self.shadow_max = max(self.shadow_max, d)
+            if not (d <= self.shadow_limit):
+                raise ArithmeticViolation("split-mx left the rule on this input: max |dprob| %.3g against split3 over a shadowed chunk of %d sites "
+                                          "(limit %.3g; shadow chunk %d)" % (d, len(pr), self.shadow_limit, self.shadow_chunks))
         a = int(job["first"][sel[0]])
         job["locs"][a:a + len(lc)] = lc                 # sel is a run of consecutive usable reads: their spans are adjacent
         job["prob1"][a:a + len(lc)] = prob1_norm_round6(pr)

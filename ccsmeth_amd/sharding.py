@@ -103,6 +103,42 @@ class ChunkQueue:
         return [json.loads(self.store.get(k).decode("utf-8"), object_hook=_from_wire) for k in keys]
 
 
+
+def device_identity(index=None):
+    """What names the PHYSICAL device behind this rank's cuda index: its UUID where the runtime exposes one, else PCI domain:bus:device.
+    N ranks are N GPUs only if these differ (ranks can share a device: CUDA/HIP_VISIBLE_DEVICES, a launcher that maps every rank to cuda:0)."""
+    import torch
+    if not torch.cuda.is_available():
+        return None                                 # (CPU stand-ins of the tests: no device to name)
+    i = torch.cuda.current_device() if index is None else index
+    pr = torch.cuda.get_device_properties(i)
+    u = getattr(pr, "uuid", None)
+    if u is not None and str(u).strip("0-") != "":
+        return "uuid:%s" % u
+    ids = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if all(v is not None for v in ids):
+        return "pci:%04x:%02x:%02x" % tuple(int(v) for v in ids)
+    return "index:%d@%s" % (i, __import__("socket").gethostname())      # no identity available: distinct indices on one host count as distinct
+
+
+def device_census(identities, n_expected):
+    """-> dict(ranks_seen, distinct_devices, ok): `identities` = one device_identity() per rank (gathered); ok iff every one of the
+    n_expected ranks reported and they sit on n_expected DISTINCT devices.  The caller refuses to report an N-GPU number when not ok."""
+    ids = [str(x) for x in identities if x]
+    distinct = len(set(ids))
+    return dict(ranks_seen=len(ids), distinct_devices=distinct, ok=(len(ids) == n_expected and distinct == n_expected), devices=sorted(set(ids)))
+
+
+def collective_library():
+    """The collective library torch.distributed's "nccl" backend is bound to on this build (RCCL on ROCm), as a string for reports."""
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        name = "rccl" if getattr(torch.version, "hip", None) else "nccl"
+        return "%s %s" % (name, ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v))
+    except Exception as e:      # noqa: BLE001
+        return "unavailable (%s)" % type(e).__name__
+
 def verify_chain(first_voffset, chunks, n_chunks=None, eof_voffset=None):
     """chunks: [(k, voffset of the chunk's first record, voffset behind its last record, n_records)] of every rank, empty chunks with
     n_records == 0.  The first non-empty chunk must begin at the file's first record and every later one where its predecessor ended;

@@ -34,7 +34,8 @@ typedef enum {
                                  ValueError("--model_type not right!") call_modifications.py:340 */
     CCSM_ERR_HIP = 3,         /* a HIP runtime call failed; text in ccsm_last_error() */
     CCSM_ERR_NOMEM = 4,
-    CCSM_ERR_CAPACITY = 5     /* n_sites exceeds the workspace's max_sites */
+    CCSM_ERR_CAPACITY = 5,    /* n_sites exceeds the workspace's max_sites */
+    CCSM_ERR_BUSY = 6         /* the model has slices of a group bound to a workspace and not yet run (ccsm_group_add_device .. ccsm_group_run) */
 } ccsm_status;
 
 /* Arithmetic of the contraction (matmul) work; everything else is fp32.  The reference computes in fp32 (models.py:125-130,
@@ -232,8 +233,14 @@ float ccsm_model_quant_error(const ccsm_model* m);
  * sites added (max |dprob| <= 1.25e-5 and, from 8192 sites on, max <= 3 x the 99.9th percentile), switches the model to SPLIT3 if the
  * candidate fails (unless CCSM_NO_PRECISION_FALLBACK is set), forgets the sites and returns the precision now in use.
  * _data_probe_error / _q999 / _sites: the figures of the last decision (-1 / -1 / 0 before one); _verdict: -1 none, 0 failed, 1 kept.
- * Not thread-safe against forwards on the same model (single-threaded use per model, as everywhere in this interface). */
+ * Not thread-safe against forwards on the same model (single-threaded use per model, as everywhere in this interface); refused with
+ * CCSM_ERR_BUSY while slices of a group are bound to a workspace of this model and not yet run (they were packed for one arithmetic). */
 ccsm_status ccsm_model_set_precision(ccsm_model* m, int precision);
+/* The same without touching the model: the NEXT forward / submit / group run issued on this workspace runs in SPLIT3 whatever the model's
+ * arithmetic (one-shot; the flag is consumed by that run).  What a caller uses to shadow a sample of its launches with the fp32-class
+ * arithmetic while the model keeps serving split-mx on its other workspaces (call_mods: one chunk in 64, behind the two probes - the
+ * rule applied to the WHOLE input, not to its first 65536 sites; reference call site call_modifications.py:201-214). */
+ccsm_status ccsm_workspace_force_split3(ccsm_workspace* ws);
 ccsm_status ccsm_model_data_probe_add(ccsm_model* m, const float* probs_candidate, const float* probs_split3, int n_sites);
 int ccsm_model_data_probe_decide(ccsm_model* m);
 float ccsm_model_data_probe_error(const ccsm_model* m);

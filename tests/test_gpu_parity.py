@@ -338,6 +338,42 @@ def test_split3_on_both_mfma_shapes(monkeypatch):
         d16.close(); d32.close()
 
 
+def test_split_mx_on_both_mfma_shapes(monkeypatch):
+    """Plain split-mx has a second form of its layers 1-2 on v_mfma_f32_16x16x32_f16 + v_mfma_scale_f32_16x16x128_f8f6f4 (ccsm_gru_mx16.hip: the
+    shapes that sustain 15 % more under the power cap; built in round 6, measured 10 % SLOWER than gru_layer12_mx_kernel - both kernels sit on
+    the CU's vector-memory path, not on the matrix pipe - and therefore opt-in: a model created with CCSM_MX_SHAPE16=1).  Same operand values
+    (fp16 hi, the same fp4 / fp6 blobs and block scales), another order of the k sum: both within the default tolerance of the oracle and
+    within 2e-6 of each other, for a coalesced-size launch, a ragged one and the small-launch forms (explicit initial states: the coarse
+    first-step scale of the state blobs is exercised)."""
+    from ccsmeth_amd.models import DeviceModel
+    w = synth.synth_weights(7)
+    d32 = DeviceModel(w, device=0, precision=4)
+    monkeypatch.setenv("CCSM_MX_SHAPE16", "1")
+    d16 = DeviceModel(w, device=0, precision=4)
+    monkeypatch.delenv("CCSM_MX_SHAPE16")
+    try:
+        for n, form in ((6144, None), (1000, None), (513, "2"), (64, "1"), (200, "3"), (100, "2")):
+            if form is None:
+                monkeypatch.delenv("CCSM_WG_TILES", raising=False)
+            else:
+                monkeypatch.setenv("CCSM_WG_TILES", form)
+            s = synth.synth_sites(n, 377 + n)
+            h1, h2 = synth.synth_h0(n, 378 + n)
+            wa, wb = d16.workspace(n), d32.workspace(n)
+            la, pa = _fwd(wa, s, (h1, h2))
+            lb, pb = _fwd(wb, s, (h1, h2))
+            wa.close(); wb.close()
+            pa, pb = np.asarray(pa), np.asarray(pb)
+            assert np.isfinite(pa).all() and np.isfinite(np.asarray(la)).all()
+            assert np.abs(pa - pb).max() < 2e-6, (n, form, np.abs(pa - pb).max())
+            if n <= 1000:
+                ref = _oracle(w, s, h1, h2)[1]
+                assert np.abs(pa - ref).max() < DEFAULT_TOL and np.abs(pb - ref).max() < DEFAULT_TOL, (n, form, np.abs(pa - ref).max())
+    finally:
+        monkeypatch.delenv("CCSM_WG_TILES", raising=False)
+        d16.close(); d32.close()
+
+
 def test_input_layout_variants_agree(model7):
     """float32 k-mers and per-base npass (what the reference's FloatTensor call passes) == u8 k-mers + per-site npass."""
     w, dm = model7

@@ -252,3 +252,16 @@ def test_bench_refuses_more_gpus_than_visible():
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert "refusing" in p.stderr and "{" not in p.stdout
+
+
+def test_device_census_refuses_shared_devices():
+    """N ranks count as N GPUs only on N distinct devices (bench.py refuses its line, rc 2, otherwise; call_mods reports both numbers)."""
+    from ccsmeth_amd import sharding
+    ok = sharding.device_census(["uuid:a", "uuid:b", "uuid:c", "uuid:d"], 4)
+    assert ok["ok"] and ok["ranks_seen"] == 4 and ok["distinct_devices"] == 4
+    shared = sharding.device_census(["uuid:a", "uuid:a", "uuid:b", "uuid:b"], 4)
+    assert not shared["ok"] and shared["ranks_seen"] == 4 and shared["distinct_devices"] == 2
+    missing = sharding.device_census(["uuid:a", None, "uuid:b"], 4)
+    assert not missing["ok"] and missing["ranks_seen"] == 2
+    assert sharding.device_census(["pci:0000:05:00"], 1)["ok"]
+    assert isinstance(sharding.collective_library(), str)
