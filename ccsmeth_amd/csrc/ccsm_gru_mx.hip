@@ -44,6 +44,15 @@ constexpr float kMxH0Div = 4.0f;                   // what the initial-state blo
 constexpr float kMxLoScale = 65536.0f;             // a wave's private fp8 residuals carry lo * 2^16: |lo| <= 2^-8 (|h| < 16) stays below e4m3's 448.
                                                    // |h_t| <= max(1, |h0|): the state is NOT confined to (-1, 1) when the initial states are not
 
+// Diagnostic builds of the layer-1/2 kernel (results wrong on purpose; tools/ab_build.sh <name> -DCCSM_MX_DIAG=<bits>): what one consumer costs -
+// the decomposition of DESIGN 10's "everything else".  1: the gate math's sigmoids and tanh replaced by multiplies; 2: no barrier in the pairs of
+// phases A and C (the MFMAs, requests and waits stay); 4: no LDS reads of B operands in any phase (the MFMAs take what the registers hold);
+// 16: no ring refills; 32: no counted waits.  (Weight requests on L1-resident fragments: -DCCSM_PWR_W1, round 4.)
+#ifndef CCSM_MX_DIAG
+#define CCSM_MX_DIAG 0
+#endif
+constexpr int kMxDiag = CCSM_MX_DIAG;
+__device__ __forceinline__ float diag_sigmoid(float x) { return (kMxDiag & 1) ? x * 0.25f : sigmoid_f(x); }
 typedef _Float16 half32 __attribute__((ext_vector_type(32)));
 typedef int i32x6 __attribute__((ext_vector_type(6)));
 
@@ -304,7 +313,7 @@ __device__ __forceinline__ void mx_tail(char* smem, int lo_off, const f32x16 (&a
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float nn = tanh_fold(accn[bt][4 * q + e]);
+                const float nn = (kMxDiag & 1) ? accn[bt][4 * q + e] * 0.001f : tanh_fold(accn[bt][4 * q + e]);
                 hn[4 * q + e] = (hp[e] - nn) * accz[bt][4 * q + e] + nn;
             }
         }
@@ -817,6 +826,15 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_mx_kernel(const uint4* __re
 constexpr int lds_bt(int bt) { return CCSM_PWR_LDS1 == 1 || CCSM_PWR_LDS1 == 3 ? 0 : bt; }        // hi fragments
 constexpr int lds_btc(int bt) { return CCSM_PWR_LDS1 == 1 ? 0 : bt; }                              // blob fragments
 constexpr int kMxRS = 4;
+// Round 6 (profiles/r06_h: stamps of the 16-wide form of this kernel): the CU's vector-memory path takes one 1-KiB request per 16 cycles from all
+// eight waves together, and a wave that waits for its slot issues no MFMA - so requests are issued ONE at a time, each behind the last use of the
+// fragment it replaces (gate by gate: three MFMAs), instead of two or three in a row behind six.  Same requests in the same order among
+// themselves (the counted waits stand), same products into every accumulator in the same order (same bits).  -DCCSM_MX_NO_ILV: the round-5 order.
+#ifdef CCSM_MX_NO_ILV
+constexpr bool kMxIlv = false;
+#else
+constexpr bool kMxIlv = true;
+#endif
 constexpr int mx_slot_bytes(int nb) { return 2 * nb * 2 * 1024; }
 constexpr int mx12_xoff(int nb) { return mx_hbytes(nb); }
 constexpr int mx12_looff(int nb) { return mx12_xoff(nb) + kMxRS * mx_slot_bytes(nb); }
@@ -892,6 +910,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     // the transfer of consumption jj + RS of step s (jj: 0-15 phase A pairs, 16-31 phase C pairs) goes into the slot consumption jj
     // just vacated
     auto dma_ahead = [&](int slot, int s, int jj) {
+        if constexpr (kMxDiag & 16) return;
         const int g = jj + RS;
         const int c = g & (2 * NPAIR - 1);                           // consumption within its step: 0-15 phase A, 16-31 phase C
         dma_pair(slot, s + (g >> 5), kMxZigZag && c >= NPAIR ? 2 * NPAIR - 1 - c : c & (NPAIR - 1), c >= NPAIR);
@@ -899,6 +918,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
     // wait until this wave's part of a transfer has landed: at most NLO (waves 4-7) / NHI (waves 0-3) younger operations
 #define CCSM_WAIT_XFER(NLO, NHI)                                                        \
     do {                                                                                \
+        if constexpr (kMxDiag & 32) break;                                              \
         if (4 * NB > kWaves && wave < 4 * NB - kWaves) asm volatile("s_waitcnt vmcnt(" #NHI ")" ::: "memory"); \
         else if (4 * NB >= kWaves || wave < 4 * NB) asm volatile("s_waitcnt vmcnt(" #NLO ")" ::: "memory");   \
     } while (0)
@@ -995,10 +1015,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         uint2 xc1[NB];
         int xsc = 0;                                                // XD: the x blobs' E8M0 scales, byte bt = row tile bt (written beside the blob by the layer below)
         auto rdx = [&](uint4 (&x)[NB], int xs, int kbl, int f) {    // xs = byte offset of the slot + lane * 16
+            if constexpr (kMxDiag & 4) return;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) x[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((kbl * NB + lds_bt(bt)) * 2 + f) << 10));
         };
         auto rdx_blob = [&](int xs) {
+            if constexpr (kMxDiag & 4) return;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 xc0[bt] = *reinterpret_cast<const uint4*>(smem + xs + (((0 * NB + lds_btc(bt)) * 2 + 1) << 10));
@@ -1032,15 +1054,39 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             const int xs = slot_off(slot);
             const int slot_n = slot == RS - 1 ? 0 : slot + 1;
             rdx(xh1, xs, 1, 0);
+            if constexpr (kMxIlv && CCSM_PWR_LDS1 == 0 && P + NSA < NPAIR) {
+                static_for<0, 2>([&](auto GC) {
+                    constexpr int g = decltype(GC)::value;
+                    CCSM_FENCE;
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) acc[g][bt] = mfma16(wah[WS][0][g], xh[bt], acc[g][bt]);
+                    CCSM_FENCE;
+                    wah[WS][0][g] = w_at((P + NSA) * PA + ((2 * 0 + g) << 10));
+                });
+            } else {
             CCSM_MAIN(wah[WS][0], xh, 2, 0);
             if constexpr (P + NSA < NPAIR) ldAh(wah[WS][0], P + NSA, 0);
+            }
+            if constexpr (P + NSA < NPAIR) {}
             else if constexpr (P == 13) { wbh[0][0] = w_at(OFF_B + (0 << 10)); wbh[0][1] = w_at(OFF_B + (1 << 10)); }
             else if constexpr (P == 14) {
                 if constexpr (HS3) wbl[1][0] = w_at(OFF_B + (9 << 10)); else wbs = ws_at(OFF_B + OFF_BS);
             }
             rdx_blob(xs);
+            if constexpr (kMxIlv && CCSM_PWR_LDS1 == 0 && P + NSA < NPAIR) {
+                static_for<0, 2>([&](auto GC) {
+                    constexpr int g = decltype(GC)::value;
+                    CCSM_FENCE;
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) acc[g][bt] = mfma16(wah[WS][1][g], xh1[bt], acc[g][bt]);
+                    CCSM_FENCE;
+                    wah[WS][1][g] = w_at((P + NSA) * PA + ((2 * 1 + g) << 10));
+                });
+            } else {
             CCSM_MAIN(wah[WS][1], xh1, 2, 0);
             if constexpr (P + NSA < NPAIR) ldAh(wah[WS][1], P + NSA, 1);
+            }
+            if constexpr (P + NSA < NPAIR) {}
             else if constexpr (P == 13) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); }
             else if constexpr (P == 14 && HS3) { wbl[1][1] = w_at(OFF_B + (10 << 10)); wbl[1][2] = w_at(OFF_B + (11 << 10)); }
             else if constexpr (P == 14 && DYN) { wbb1[0] = w8_at(OFF_B + (9 << 10)); wbb1[1] = w8_at(OFF_B + (9 << 10) + 512); wbb1[2] = w8_at(OFF_B + (9 << 10) + 1024); }
@@ -1058,7 +1104,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             else if constexpr (P == NPAIR - 1) { if constexpr (HS3) CCSM_WAIT_XFER(17, 19); else if constexpr (DYN) CCSM_WAIT_XFER(18, 20); else CCSM_WAIT_XFER(15, 17); }
             else if constexpr (P == NPAIR - 2) { if constexpr (HS3) CCSM_WAIT_XFER(24, 26); else if constexpr (DYN) CCSM_WAIT_XFER(25, 27); else CCSM_WAIT_XFER(22, 24); }
             else CCSM_WAIT_XFER(23, 25);
-            __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
+            if constexpr (!(kMxDiag & 2)) __syncthreads();             // the next pair is in LDS; every wave has read this pair's operands
             if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once (0.4 pair more
                                                                                       // lead than as the pair's youngest operation: +1.4 %)
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
@@ -1069,6 +1115,17 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                     acc[0][bt] = mfma_corr_mx<0, bt>(wab[WS][0], was[WS], xc0[bt], xc1[bt], acc[0][bt], xsc);
                     acc[1][bt] = mfma_corr_mx<1, bt>(wab[WS][1], was[WS], xc0[bt], xc1[bt], acc[1][bt], xsc);
                 });
+            } else if constexpr (kMxIlv && P + NSA < NPAIR) {
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) acc[0][bt] = mfma_corr_mx<0>(wab[WS][0], was[WS], xc0[bt], xc1[bt], acc[0][bt], sb);
+                CCSM_FENCE;
+                wab[WS][0] = w_at((P + NSA) * PA + ((4 + 0) << 10));
+                CCSM_FENCE;
+#pragma unroll
+                for (int bt = 0; bt < NB; ++bt) acc[1][bt] = mfma_corr_mx<1>(wab[WS][1], was[WS], xc0[bt], xc1[bt], acc[1][bt], sb);
+                CCSM_FENCE;
+                wab[WS][1] = w_at((P + NSA) * PA + ((4 + 1) << 10));
+                was[WS] = ws_at((P + NSA) * PA + (6 << 10));
             } else {
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) {
@@ -1077,7 +1134,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 }
             }
             CCSM_FENCE;
-            if constexpr (P + NSA < NPAIR) ldAb(WS, P + NSA);
+            if constexpr (P + NSA < NPAIR) { if constexpr (!(kMxIlv && !XD)) ldAb(WS, P + NSA); }
             else if constexpr (P == 13) {       // (hybrid: fragments 6-8 are the fp16 lo of the pair's first k-block)
                 wbh[1][1] = w_at(OFF_B + (4 << 10)); wbh[1][2] = w_at(OFF_B + (5 << 10));
                 if constexpr (HS3) { wbl[0][0] = w_at(OFF_B + (6 << 10)); wbl[0][1] = w_at(OFF_B + (7 << 10)); wbl[0][2] = w_at(OFF_B + (8 << 10)); }
@@ -1138,27 +1195,54 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             constexpr bool LAST = Q == kKBH / 2 - 1;
             constexpr int NXT = OFF_B + (Q + 1) * PB;
             uint32_t pm[NB];                                            // split-mx-d: running max |x_hi| of the pair's block, this lane's values
+            if constexpr (!(kMxDiag & 4)) {
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) {
                 xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, lds_bt(bt), 0) + lane * 16);
                 xc0[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q, lds_btc(bt), 1) + lane * 16);
                 xc1[bt] = *reinterpret_cast<const uint2*>(smem + mx_hfrag<NB>(2 * Q + 1, lds_btc(bt), 1) + lane * 16);
             }
+            }
+            constexpr bool ILVB = kMxIlv && !DYN && !LAST && CCSM_PWR_LDS1 == 0;       // (one request behind each gate's three MFMAs: see kMxIlv)
+            if constexpr (ILVB) {
+                static_for<0, 3>([&](auto GC) {
+                    constexpr int g = decltype(GC)::value;
+                    CCSM_FENCE;
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) acc[g][bt] = mfma16(wbh[0][g], xh[bt], acc[g][bt]);
+                    CCSM_FENCE;
+                    wbh[0][g] = w_at(NXT + (g << 10));
+                });
+            } else
             CCSM_MAIN(wbh[0], xh, 3, 0);
             if constexpr (DYN) {
 #pragma unroll
                 for (int bt = 0; bt < NB; ++bt) pm[bt] = absmax8(xh[bt], 0u);
             }
-            if constexpr (!LAST) {
+            if constexpr (ILVB) {
+            } else if constexpr (!LAST) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbh[0][g] = w_at(NXT + (g << 10));
             } else {
                 wch[0][0] = w_at(OFF_C + 0 * PC + (0 << 10)); wch[0][1] = w_at(OFF_C + 0 * PC + (1 << 10)); wcb[0] = w_at(OFF_C + 0 * PC + (2 << 10));
             }
+            if constexpr (!(kMxDiag & 4)) {
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) xh[bt] = *reinterpret_cast<const uint4*>(smem + mx_hfrag<NB>(2 * Q + 1, lds_bt(bt), 0) + lane * 16);
+            }
+            if constexpr (ILVB) {
+                static_for<0, 3>([&](auto GC) {
+                    constexpr int g = decltype(GC)::value;
+                    CCSM_FENCE;
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) acc[g][bt] = mfma16(wbh[1][g], xh[bt], acc[g][bt]);
+                    CCSM_FENCE;
+                    wbh[1][g] = w_at(NXT + ((3 + g) << 10));
+                });
+            } else
             CCSM_MAIN(wbh[1], xh, 3, 0);
-            if constexpr (!LAST) {
+            if constexpr (ILVB) {
+            } else if constexpr (!LAST) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbh[1][g] = w_at(NXT + ((3 + g) << 10));
             } else {
@@ -1177,10 +1261,21 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                     acc[2][bt] = mfma_corr_mx6<2>(wbb[2], wbb1[2], wbs, xc0[bt], xc1[bt], acc[2][bt], sbd[bt]);
                 }
                 CCSM_FENCE;
+            } else if constexpr (ILVB) {
+                static_for<0, 3>([&](auto GC) {
+                    constexpr int g = decltype(GC)::value;
+                    CCSM_FENCE;
+#pragma unroll
+                    for (int bt = 0; bt < NB; ++bt) acc[g][bt] = mfma_corr_mx<g>(wbb[g], wbs, xc0[bt], xc1[bt], acc[g][bt], sbh);
+                    CCSM_FENCE;
+                    wbb[g] = w_at(NXT + ((6 + g) << 10));
+                });
+                wbs = ws_at(NXT + OFF_BS);
             } else {
                 CCSM_CORR_G(3, wbb, wbs, sbh);
             }
-            if constexpr (!LAST) {
+            if constexpr (ILVB) {
+            } else if constexpr (!LAST) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g) wbb[g] = w_at(NXT + ((6 + g) << 10));
                 if constexpr (DYN) {
@@ -1200,7 +1295,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + sigmoid_f(acc[0][bt][r]) * acc[2][bt][r];
+                for (int r = 0; r < 16; ++r) acc[2][bt][r] = b2[r] + diag_sigmoid(acc[0][bt][r]) * acc[2][bt][r];
         }
         // the blob of phase C's pair slot 1 and its slots 2 and 3: requested once R is dead (the accumulators drop from 144 to 96
         // registers; slot 0 and the hi fragments of slot 1 came with phase B's last pair)
@@ -1215,7 +1310,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
         auto zwork = [&](int bt) {                                  // z = sigmoid(Z) in place, inside phase C (vector ALU otherwise idle)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = sigmoid_f(acc[1][bt][r]);
+                float v = diag_sigmoid(acc[1][bt][r]);
 #ifndef CCSM_ZWORK_FREE
                 asm volatile("" : "+v"(v));                         // pins the evaluation HERE: the compiler otherwise sinks it to its first use, the tail
 #endif
@@ -1252,7 +1347,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             else if constexpr (AF == 0) wah[AS][0][1] = w_at(AS * PA + (1 << 10)); else wab[AS][1] = w_at(AS * PA + (5 << 10));
             // operations since the awaited refill: the 3 requests behind it, two pairs of 5 + d (pairs 13 and 15: 2 + d), 2 of this pair
             if constexpr (P >= NPAIR - 2) CCSM_WAIT_XFER(14, 16); else CCSM_WAIT_XFER(17, 19);
-            __syncthreads();
+            if constexpr (!(kMxDiag & 2)) __syncthreads();
             dma_ahead(slot, s, NPAIR + P);                              // the vacated slot is refilled at once
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
             CCSM_FENCE;

@@ -242,3 +242,41 @@ def test_call_mods_probes_the_arithmetic_on_its_own_input(tmp_path):
     assert lines[1].startswith("[main]arithmetic on this input") and "65536 sites" in lines[1] and "split3" in lines[1] and "NOT clean" in lines[1]
     assert outs["auto"] == outs["split3"]                  # (the @PG line carries sys.argv, the same in the three runs)
     assert [ln for ln in logs["noprobe"].splitlines() if ln.startswith("[main]arithmetic")] == [lines[0]]
+
+
+def test_call_mods_shadows_the_arithmetic_behind_its_probes(tmp_path, monkeypatch):
+    """the two probes look at the checkpoint and at the input's first 65536 sites; behind them `call_mods --arithmetic
+    auto` keeps applying the rule's first condition to one chunk in --shadow_every (the same chunk again in split3 on a workspace of its own,
+    ccsm_workspace_force_split3).  (i) A clean input: the shadow line is printed, the bytes are those of the unshadowed run.  (ii) An input whose
+    head is clean and whose tail is not - the synthetic generator has no knob that makes split-mx worse later in a file, so the SHADOW's limit
+    alone is lowered below what split-mx holds on this checkpoint (CCSM_CALLMODS_SHADOW_LIMIT; both probes keep the rule's 1.25e-5): the first
+    shadowed chunk (sites 86016 .. 98303 of the file) violates it, the run starts again in split3 and writes what `--arithmetic split3` writes."""
+    import io
+    import torch
+    from collections import OrderedDict
+    from ccsmeth_amd.call_mods import build_parser, call_mods
+    from ccsmeth_amd.utils import benchdata
+    w = synth.synth_weights(7)
+    inp, ckpt = str(tmp_path / "in.bam"), str(tmp_path / "m.ckpt")
+    n_reads = 240
+    benchdata.write_synthetic_hifi_bam(inp, n_reads, 15000, seed=31, planted=0.0)
+    torch.save(OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in w.items()), ckpt)
+
+    def run(tag, extra):
+        log = io.StringIO()
+        res = call_mods(build_parser().parse_args(["-i", inp, "-m", ckpt, "-o", str(tmp_path / tag), "--batch_size", "12288", "--no_sort"] + extra), log=log)
+        assert res["reads"] == n_reads
+        return [ln for ln in log.getvalue().splitlines() if ln.startswith("[main]arithmetic")], open(res["output"], "rb").read()
+
+    l_plain, o_plain = run("plain", ["--shadow_every", "0"])
+    l_shadow, o_shadow = run("shadow", ["--shadow_every", "8"])
+    print("\n".join(l_shadow))
+    assert o_shadow == o_plain and len(l_shadow) == len(l_plain) + 1
+    assert "shadowed in split3" in l_shadow[-1] and "split-mx kept" in l_shadow[-1]
+    _, o_split3 = run("split3", ["--arithmetic", "split3"])
+    assert o_split3 != o_plain
+    monkeypatch.setenv("CCSM_CALLMODS_SHADOW_LIMIT", "1e-6")
+    l_viol, o_viol = run("viol", ["--shadow_every", "8"])
+    print("\n".join(l_viol))
+    assert any("starts again in split3" in ln for ln in l_viol), l_viol
+    assert o_viol == o_split3
