@@ -508,6 +508,8 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # RCCL's version banner goes to STDOUT (this image exports NCCL_DEBUG=VERSION): the line below must stay the only thing there
+        os.environ["NCCL_DEBUG"] = os.environ.get("CCSM_BENCH_NCCL_DEBUG", "WARN")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist.barrier()              # pays the communicator's lazy set-up (hundreds of ms of idle GPU) HERE, not in the fence in front of the timed region
@@ -692,6 +694,11 @@ def main():
                 line.setdefault("extras", {})["call_mods_multi_gpu"] = call_mods_multi_gpu(legs)
             except Exception as e:      # noqa: BLE001
                 line.setdefault("extras", {})["call_mods_multi_gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:                        # whatever a native library still holds in C stdio comes out BEFORE the line: the line is the last one on stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
         print(json.dumps(line), flush=True)
 
 
