@@ -82,7 +82,19 @@ __device__ __forceinline__ void mfma_drained(f32x4 (&a)[2][NB][2]) {
 #endif
 
 #define CCSM_FENCE asm volatile("" ::: "memory")
-#ifdef CCSM_F3S_NO_SKEW
+// Round 6 (profiles/r06_h, r06_j): the CU's vector-memory path takes one 1-KiB request per 16 cycles from all eight waves together and a wave
+// that waits for its slot issues no MFMA.  gru_layer12_mx_kernel gained 1 % from issuing its weight requests ONE at a time, each behind the
+// last use of the fragment it replaces (ccsm_gru_mx.hip: kMxIlv).  The same order for these kernels is written below (-DCCSM_F3S_ILV: same
+// requests in the same order among themselves - the counted waits stand -, same products into every accumulator in the same order: same
+// bits by construction, tools/isa_gate.py green) but was NOT measured: the GPU pool closed before its A/B run (tools/ab_bits.py +
+// tools/ab_variants.sh f3ilv f3noilv), so the product keeps the order that round 5 validated.  With it the transfer skew is off (it would put
+// waves 4-7's refill behind the interleaved requests; it measured nothing in round 5).
+#ifdef CCSM_F3S_ILV
+constexpr bool kF3sIlv = true;
+#else
+constexpr bool kF3sIlv = false;
+#endif
+#if defined(CCSM_F3S_NO_SKEW) || defined(CCSM_F3S_ILV)
 constexpr bool kF3sSkew = false;
 #else
 constexpr bool kF3sSkew = true;
@@ -263,6 +275,21 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
             pstamp(P, 0);
             rdx(xh[1], xs, 1, 0);
             CCSM_FENCE;
+if constexpr (kF3sIlv && P + 2 < NPAIR) {
+                static_for<0, 2>([&](auto GC) {
+                    constexpr int g = decltype(GC)::value;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int bt = 0; bt < NB; ++bt) acc[g][0][bt][h] = P == 0 ? mfma32k_first(wah[WS][0][g], xh[h][bt], acc[g][0][bt][h]) : mfma32k(wah[WS][0][g], xh[h][bt], acc[g][0][bt][h]);
+#pragma unroll
+                        for (int bt = 0; bt < NB; ++bt) acc[g][0][bt][h] = mfma32k(wal[WS][0][g], xh[h][bt], acc[g][0][bt][h]);
+                    }
+                    CCSM_FENCE;
+                    wal[WS][0][g] = a_lo(P + 2, 0, g);
+                    CCSM_FENCE;
+                });
+            } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -274,13 +301,30 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 #pragma unroll
                     for (int g = 0; g < 2; ++g) acc[g][0][bt][h] = mfma32k(wal[WS][0][g], xh[h][bt], acc[g][0][bt][h]);
             }
+            }
             CCSM_FENCE;
-            if constexpr (P + 2 < NPAIR) { wal[WS][0][0] = a_lo(P + 2, 0, 0); wal[WS][0][1] = a_lo(P + 2, 0, 1); }
+            if constexpr (kF3sIlv && P + 2 < NPAIR) {}
+            else if constexpr (P + 2 < NPAIR) { wal[WS][0][0] = a_lo(P + 2, 0, 0); wal[WS][0][1] = a_lo(P + 2, 0, 1); }
             else if constexpr (P == NPAIR - 2) { wbh[0][0] = w_at(OFF_B + (0 << 10)); wbh[0][1] = w_at(OFF_B + (1 << 10)); }
             else { wbh[1][2] = w_at(OFF_B + (5 << 10)); wbl[1][0] = w_at(OFF_B + (9 << 10)); }
             rdx(xl[0], xs, 0, 1);
             rdx(xl[1], xs, 1, 1);
             CCSM_FENCE;
+if constexpr (kF3sIlv && P + 2 < NPAIR) {
+                static_for<0, 2>([&](auto GC) {
+                    constexpr int g = decltype(GC)::value;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int bt = 0; bt < NB; ++bt) acc[g][1][bt][h] = P == 0 ? mfma32k_first(wah[WS][1][g], xh[h][bt], acc[g][1][bt][h]) : mfma32k(wah[WS][1][g], xh[h][bt], acc[g][1][bt][h]);
+#pragma unroll
+                        for (int bt = 0; bt < NB; ++bt) acc[g][1][bt][h] = mfma32k(wal[WS][1][g], xh[h][bt], acc[g][1][bt][h]);
+                    }
+                    CCSM_FENCE;
+                    wal[WS][1][g] = a_lo(P + 2, 1, g);
+                    CCSM_FENCE;
+                });
+            } else {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -292,8 +336,10 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
 #pragma unroll
                     for (int g = 0; g < 2; ++g) acc[g][1][bt][h] = mfma32k(wal[WS][1][g], xh[h][bt], acc[g][1][bt][h]);
             }
+            }
             CCSM_FENCE;
-            if constexpr (P + 2 < NPAIR) { wal[WS][1][0] = a_lo(P + 2, 1, 0); wal[WS][1][1] = a_lo(P + 2, 1, 1); }
+            if constexpr (kF3sIlv && P + 2 < NPAIR) {}
+            else if constexpr (P + 2 < NPAIR) { wal[WS][1][0] = a_lo(P + 2, 1, 0); wal[WS][1][1] = a_lo(P + 2, 1, 1); }
             else if constexpr (P == NPAIR - 2) { wbh[0][2] = w_at(OFF_B + (2 << 10)); wbl[0][0] = w_at(OFF_B + (6 << 10)); }
             else { wbl[1][1] = w_at(OFF_B + (10 << 10)); wbl[1][2] = w_at(OFF_B + (11 << 10)); }
             // counted wait for this wave's part of the next pair's transfer: ccsm_gru_f3.hip (the operation counts are the same)
@@ -311,6 +357,18 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
             if constexpr (P + 1 < NPAIR) { if (!kF3sSkew || wave < 4) dma_ahead(slot, s, P); } else slot_a15 = slot;
             if constexpr (P + 1 < NPAIR) rdx(xh[0], slot_off(slot_n), 0, 0);
             CCSM_FENCE;
+            if constexpr (kF3sIlv && P + 2 < NPAIR) {
+                static_for<0, 4>([&](auto FC) {
+                    constexpr int T = decltype(FC)::value >> 1, g = decltype(FC)::value & 1;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int bt = 0; bt < NB; ++bt) acc[g][T][bt][h] = mfma32k(wah[WS][T][g], xl[h][bt], acc[g][T][bt][h]);
+                    CCSM_FENCE;
+                    wah[WS][T][g] = a_hi(P + 2, T, g);
+                    CCSM_FENCE;
+                });
+            } else {
 #pragma unroll
             for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -319,10 +377,12 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
                     for (int bt = 0; bt < NB; ++bt)
 #pragma unroll
                         for (int g = 0; g < 2; ++g) acc[g][T][bt][h] = mfma32k(wah[WS][T][g], xl[h][bt], acc[g][T][bt][h]);
+            }
             CCSM_FENCE;
             if constexpr (P + 1 < NPAIR) { if (kF3sSkew && wave >= 4) dma_ahead(slot, s, P); }
             CCSM_FENCE;
-            if constexpr (P + 2 < NPAIR) {
+            if constexpr (kF3sIlv && P + 2 < NPAIR) {
+            } else if constexpr (P + 2 < NPAIR) {
                 wah[WS][0][0] = a_hi(P + 2, 0, 0); wah[WS][0][1] = a_hi(P + 2, 0, 1); wah[WS][1][0] = a_hi(P + 2, 1, 0); wah[WS][1][1] = a_hi(P + 2, 1, 1);
             } else if constexpr (P == NPAIR - 2) {
                 wbl[0][1] = w_at(OFF_B + (7 << 10)); wbl[0][2] = w_at(OFF_B + (8 << 10)); wbh[1][0] = w_at(OFF_B + (3 << 10)); wbh[1][1] = w_at(OFF_B + (4 << 10));
@@ -389,6 +449,23 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_f3s_kernel(const uint4* __
                 CCSM_FENCE;
                 static_for<0, 2>([&](auto TC) {
                     constexpr int T = decltype(TC)::value;
+                    if constexpr (kF3sIlv && H == 1 && Q + 1 < kKBH / 2) {
+                        // gate by gate: nine products, then the gate's hi and lo fragments of the next pair
+                        static_for<0, 3>([&](auto GC) {
+                            constexpr int g = decltype(GC)::value;
+#pragma unroll
+                            for (int bt = 0; bt < NB; ++bt) acc[g][T][bt][H] = Q == 0 ? mfma32k_first(wbh[T][g], xh[H][bt], acc[g][T][bt][H]) : mfma32k(wbh[T][g], xh[H][bt], acc[g][T][bt][H]);
+#pragma unroll
+                            for (int bt = 0; bt < NB; ++bt) acc[g][T][bt][H] = mfma32k(wbl[T][g], xh[H][bt], acc[g][T][bt][H]);
+#pragma unroll
+                            for (int bt = 0; bt < NB; ++bt) acc[g][T][bt][H] = mfma32k(wbh[T][g], xl[0][bt], acc[g][T][bt][H]);
+                            CCSM_FENCE;
+                            wbh[T][g] = w_at(NXT + ((3 * T + g) << 10));
+                            wbl[T][g] = w_at(NXT + ((6 + 3 * T + g) << 10));
+                            CCSM_FENCE;
+                        });
+                        return;
+                    }
                     group(TC, HC);
                     CCSM_FENCE;
                     if constexpr (H == 1) {
@@ -725,6 +802,23 @@ __global__ __launch_bounds__(512, 2) void gru_layer0_f3s_kernel(const uint4* __r
                 CCSM_FENCE;
                 static_for<0, 2>([&](auto TC) {
                     constexpr int T = decltype(TC)::value;
+                    if constexpr (kF3sIlv && H == 1 && Q + 1 < kKBH / 2) {
+                        // gate by gate: nine products, then the gate's hi and lo fragments of the next pair
+                        static_for<0, 3>([&](auto GC) {
+                            constexpr int g = decltype(GC)::value;
+#pragma unroll
+                            for (int bt = 0; bt < NB; ++bt) acc[g][T][bt][H] = Q == 0 ? mfma32k_first(wbh[T][g], xh[H][bt], acc[g][T][bt][H]) : mfma32k(wbh[T][g], xh[H][bt], acc[g][T][bt][H]);
+#pragma unroll
+                            for (int bt = 0; bt < NB; ++bt) acc[g][T][bt][H] = mfma32k(wbl[T][g], xh[H][bt], acc[g][T][bt][H]);
+#pragma unroll
+                            for (int bt = 0; bt < NB; ++bt) acc[g][T][bt][H] = mfma32k(wbh[T][g], xl[0][bt], acc[g][T][bt][H]);
+                            CCSM_FENCE;
+                            wbh[T][g] = w_at(NXT + ((3 * T + g) << 10));
+                            wbl[T][g] = w_at(NXT + ((6 + 3 * T + g) << 10));
+                            CCSM_FENCE;
+                        });
+                        return;
+                    }
                     group(TC, HC);
                     CCSM_FENCE;
                     if constexpr (H == 1) {
