@@ -156,7 +156,8 @@ struct ccsm_workspace {
     bool r_checked = false;
     int r_nreads = 0, r_nsites = 0;
     hipStream_t r_stream = nullptr;
-    bool force_split3 = false;               // the pending run holds explicit initial states outside split-mx's domain
+    bool force_split3 = false;               // the pending run holds explicit initial states outside split-mx's domain (or ccsm_workspace_force_split3: one-shot)
+    const ccsm_model* bound_to = nullptr;    // the model whose slices_bound counts this workspace's group slices (ccsm_group_add_device .. ccsm_group_run)
     bool timing = false;
     static constexpr int kEvSets = 128;      // ring of event sets: one per run while timing is enabled
     hipEvent_t evs[kEvSets][8] = {};
@@ -1500,6 +1501,10 @@ ccsm_status ccsm_workspace_create(const ccsm_model* m, int max_sites, ccsm_works
 
 void ccsm_workspace_destroy(ccsm_workspace* ws) {
     if (!ws) return;
+    if (ws->bound_to && ws->n_slices > 0) {          // slices added and never run: the model (destroyed after its workspaces) stops counting them
+        ws->bound_to->slices_bound -= ws->n_slices;
+        if (ws->bound_to->slices_bound < 0) ws->bound_to->slices_bound = 0;
+    }
     (void)hipSetDevice(ws->device);
     if (ws->pending_sites) (void)hipStreamSynchronize(ws->pending_stream);
     (void)hipFree(ws->x0); (void)hipFree(ws->act[0]); (void)hipFree(ws->act[1]);
@@ -1551,7 +1556,7 @@ ccsm_status ccsm_group_add_device(const ccsm_model* m, ccsm_workspace* ws, int n
     st = add_slice(m, ws, n_sites, s1, s2, b->kmer_is_f32, b->npass_per_base, mode, h0 ? h0->h0[0] : nullptr,
                    h0 ? h0->h0[1] : nullptr, h0 ? h0->seed : 0, h0 ? h0->offset : 0, logits, probs,
                    static_cast<hipStream_t>(stream), sk);
-    if (st == CCSM_OK) m->slices_bound++;           // (until ccsm_group_run: ccsm_model_set_precision refuses in between)
+    if (st == CCSM_OK) { m->slices_bound++; ws->bound_to = m; }     // (until ccsm_group_run: ccsm_model_set_precision refuses in between)
     return st;
 }
 
@@ -1559,8 +1564,11 @@ ccsm_status ccsm_group_run(const ccsm_model* m, ccsm_workspace* ws, void* stream
     if (!m || !ws) return fail(CCSM_ERR_INVALID_ARG, "model and workspace must be non-NULL");
     if (ws->n_slices == 0) return CCSM_OK;
     HIP_TRY(hipSetDevice(m->device));
-    m->slices_bound -= ws->n_slices;
-    if (m->slices_bound < 0) m->slices_bound = 0;
+    if (ws->bound_to == m) {
+        m->slices_bound -= ws->n_slices;
+        if (m->slices_bound < 0) m->slices_bound = 0;
+        ws->bound_to = nullptr;
+    }
     return dispatch_run(m, ws, static_cast<hipStream_t>(stream));
 }
 
