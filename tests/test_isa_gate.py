@@ -34,3 +34,22 @@ def test_gate_goes_red_on_a_broken_build(define, only, needle):
     bad, lines = isa_gate.run(defines=[define], only=[only], quiet=True)
     assert bad > 0, "\n".join(lines)
     assert any(needle in ln for ln in lines), "\n".join(lines)
+
+
+def test_shipped_library_has_no_scratch_in_any_gru_kernel():
+    """The BUILT libccsm.so (what travels to the GPU box), read from the code object inside it: every GRU instantiation - the compiler-scheduled
+    32-wide ones included, which the gate's translation unit does not recompile - without scratch and without spills; the one kernel that has
+    any (the fp8 pool: three registers saved once per launch, outside its loops) does not grow."""
+    import isa_gate
+    lib = os.path.join(ROOT, "ccsmeth_amd", "lib", "libccsm.so")
+    if not os.path.exists(lib):
+        pytest.skip("libccsm.so is not built")
+    k = isa_gate.shipped_kernels(lib)
+    gru = {n: v for n, v in k.items() if "gru_" in n}
+    assert len(gru) >= 45, sorted(k)                                  # mx (32-wide) x forms x arithmetics, f3, f3s, mx16, v2
+    for fam in ("gru_layer12_mx_kernel", "gru_layer0_mx_kernel", "gru_layer12_f3s_kernel", "gru_layer0_f3s_kernel", "gru_layer12_mx16_kernel"):
+        assert any(fam in n for n in gru), fam
+    bad = {n: v for n, v in gru.items() if v["private_segment_fixed_size"] or v["vgpr_spill_count"]}        # (SGPRs parked in VGPR lanes are not scratch)
+    assert not bad, bad
+    other = {n: v["private_segment_fixed_size"] for n, v in k.items() if v["private_segment_fixed_size"] and n not in gru}
+    assert all("attn_fc_f8_kernel" in n and b <= 16 for n, b in other.items()), other

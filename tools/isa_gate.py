@@ -312,6 +312,35 @@ def check_waits(name, ins, report):
     return bad, exact
 
 
+def shipped_kernels(lib=None):
+    """The kernels of a BUILT libccsm.so, read from the gfx950 code object inside it (no recompilation; seconds):
+    -> {kernel name: dict(vgpr_count, private_segment_fixed_size, vgpr_spill_count, sgpr_spill_count, group_segment_fixed_size)}"""
+    import tempfile
+    lib = lib or os.path.join(ROOT, "ccsmeth_amd", "lib", "libccsm.so")
+    llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
+    with tempfile.TemporaryDirectory(prefix="ccsm_co_") as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "dev.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, lib, os.path.join(d, "unused.so")], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--input=" + fat, "--output=" + co], check=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    out, cur = {}, None
+    for ln in notes.split("\n"):
+        m = re.match(r"^  (- | {2})\.(\w+):\s+(\S+)", ln)        # the keys of a kernel's own entry (its arguments sit deeper)
+        if not m:
+            continue
+        if m.group(1) == "- ":
+            cur = {}
+        k, v = m.group(2), m.group(3)
+        if cur is None:
+            continue
+        if k in ("vgpr_count", "private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count", "group_segment_fixed_size"):
+            cur[k] = int(v)
+        elif k == "name":
+            out[v] = cur
+    return out
+
+
 def run(defines=(), quiet=False, keep=False, only=None):
     """-> (number of findings, report lines); only = a subset of ALL (the instantiation macros of the translation unit)"""
     s = compile_asm(defines, keep, only)
