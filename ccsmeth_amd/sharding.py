@@ -112,12 +112,17 @@ def device_identity(index=None):
         return None                                 # (CPU stand-ins of the tests: no device to name)
     i = torch.cuda.current_device() if index is None else index
     pr = torch.cuda.get_device_properties(i)
+    # both names where both exist: two ranks share a device only if EVERYTHING the runtime says about theirs agrees (logical partitions of
+    # one package must not be refused as "one device" because one of the two names happens to be the package's)
+    parts = []
     u = getattr(pr, "uuid", None)
     if u is not None and str(u).strip("0-") != "":
-        return "uuid:%s" % u
+        parts.append("uuid:%s" % u)
     ids = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
     if all(v is not None for v in ids):
-        return "pci:%04x:%02x:%02x" % tuple(int(v) for v in ids)
+        parts.append("pci:%04x:%02x:%02x" % tuple(int(v) for v in ids))
+    if parts:
+        return " ".join(parts)
     return "index:%d@%s" % (i, __import__("socket").gethostname())      # no identity available: distinct indices on one host count as distinct
 
 

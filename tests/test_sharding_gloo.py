@@ -265,3 +265,25 @@ def test_device_census_refuses_shared_devices():
     assert not missing["ok"] and missing["ranks_seen"] == 2
     assert sharding.device_census(["pci:0000:05:00"], 1)["ok"]
     assert isinstance(sharding.collective_library(), str)
+
+
+def test_device_identity_uses_every_name_the_runtime_gives(monkeypatch):
+    """UUID and PCI address together: ranks share a device only if both agree (two logical partitions that carry their package's UUID but sit
+    behind different functions are two devices; one device seen twice is one); with neither, distinct indices on one host count as distinct."""
+    import types
+    import torch
+    from ccsmeth_amd import sharding
+    props = {0: types.SimpleNamespace(uuid="aa-bb", pci_domain_id=0, pci_bus_id=5, pci_device_id=0),
+             1: types.SimpleNamespace(uuid="aa-bb", pci_domain_id=0, pci_bus_id=6, pci_device_id=0),
+             2: types.SimpleNamespace(uuid="00000000-0000", pci_domain_id=0, pci_bus_id=7, pci_device_id=0),
+             3: types.SimpleNamespace()}
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: props[i])
+    ids = [sharding.device_identity(i) for i in range(4)]
+    assert ids[0] == "uuid:aa-bb pci:0000:05:00" and ids[1] == "uuid:aa-bb pci:0000:06:00"
+    assert ids[2] == "pci:0000:07:00"                                   # an all-zero UUID names nothing
+    assert ids[3].startswith("index:3@")
+    assert sharding.device_identity() == ids[0]
+    assert sharding.device_census(ids, 4)["ok"]
+    assert not sharding.device_census([ids[0], sharding.device_identity(0)], 2)["ok"]
