@@ -501,6 +501,10 @@ def main():
     if a.gpus != world:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with --nproc-per-node == --gpus\n" % (a.gpus, world))
         sys.exit(2)
+    if torch.cuda.device_count() == 1 and local_rank > 0:
+        # a launcher that gives every rank a visible device of its own (HIP_VISIBLE_DEVICES per rank): the one visible device is index 0
+        # (ranks that SHARE a device this way are what the census below refuses)
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         sys.stderr.write("bench.py: rank %d has no GPU (device_count %d)\n" % (local_rank, torch.cuda.device_count()))
         sys.exit(2)
