@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """What ONE STEP of a GRU kernel asks of each unit of a CU, counted on the code object, next to what the counters measured.
 
-The step loop of a GRU kernel is straight-line code (its inner loops are unrolled; the forward branches inside it skip single stamps or stores),
-so the instructions between the loop's label and its backward branch are what every wave executes per step.  From them, per step:
+The step loop of a GRU kernel is straight-line code (its inner loops are unrolled), so the instructions between the loop's label and its backward
+branch are what a wave executes per step; the only wave-dependent part is the x transfers' extra fragment (waves 0-3 of 8: counted at 0.5, see
+step_loop).  From them, per step, averaged over the eight waves:
 
   matrix pipe   cycles per SIMD = 2 waves x sum over MFMAs of (passes x 4)       [32x32x16 f16 and 32x32x64 fp4 x fp6: 8 passes; 16x16x32 f16 and
                                                                                   16x16x128 fp4 x fp6: 4 passes - what SQ_VALU_MFMA_BUSY_CYCLES counts]
@@ -13,7 +14,7 @@ so the instructions between the loop's label and its backward branch are what ev
 
 and beside them the launch's counters (tools/pmc_summary.py tables under profiles/): GRBM_GUI_ACTIVE / 8 XCDs = cycles per launch,
 SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs, TCC_REQ_sum.  The matrix-pipe and L2-request columns must AGREE with the counters (they do, to
-the digit / within 2 %): that pins the counting; the interesting column is the launch's cycles against the SUM and the MAXIMUM of the first two.
+the digit / within 3 %: the prologue's requests are not in the loop): that pins the counting; the interesting column is the launch's cycles against the SUM and the MAXIMUM of the first two.
 
     python tools/isa_step_mix.py [--asm api.s] [--pmc profiles/r06_p_pmc.md:2 profiles/r05_w_pmc_split3.md:1] [--out profiles/r06_q_step_mix.md]
     (--pmc file:rounds - rounds = workgroups of the profiled launch / 256 CUs; without --asm ccsm_api.hip is compiled to assembly, ~4 min)
@@ -40,46 +41,54 @@ def kernel_bodies(s):
 
 
 def step_loop(body):
-    """the instructions of the step loop: from the target of the kernel's longest backward branch to that branch"""
+    """[(instruction, weight)] of the step loop: from the target of the kernel's longest backward branch to that branch.  Weight 1, except
+    behind a forward branch on a SCALAR condition (s_cbranch_scc* / vcc*: wave-uniform - in these kernels the x transfers' extra fragment, which
+    waves 0-3 of the eight move and waves 4-7 skip, in one or both arms of the branch): 0.5.  (s_cbranch_exec* only skips code no lane wants.)"""
     lines = body.split("\n")
     labs = {m.group(1): i for i, ln in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", ln)] if m}
     best = None
     for i, ln in enumerate(lines):
         m = re.search(r"\b(?:s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", ln)
-        if m and labs.get(m.group(1), i) < i and (best is None or i - labs[m.group(1)] > best[1] - best[0] or labs[m.group(1)] == best[0]):
-            if best is None or labs[m.group(1)] <= best[0]:
-                best = (labs[m.group(1)], i)
+        if m and labs.get(m.group(1), i) < i and (best is None or labs[m.group(1)] <= best[0]):
+            best = (labs[m.group(1)], i)
     if best is None:
         return []
+    a, e = best
+    weight = [1.0] * len(lines)
+    for i in range(a, e):
+        m = re.search(r"\bs_cbranch_(?:scc|vcc)\w*\s+(\.LBB\d+_\d+)", lines[i])
+        if m and i < labs[m.group(1)] <= e:
+            for j in range(i + 1, labs[m.group(1)]):
+                weight[j] = 0.5
     out = []
-    for ln in lines[best[0]:best[1] + 1]:
-        t = ln.strip().split(";")[0].strip()
-        if ln.startswith("\t") and t and not t.startswith("."):
-            out.append(t)
+    for j in range(a, e + 1):
+        t = lines[j].strip().split(";")[0].strip()
+        if lines[j].startswith("\t") and t and not t.startswith("."):
+            out.append((t, weight[j]))
     return out
 
 
 def mix(ins):
     c = collections.Counter()
     mfma_cyc = req_bytes = lds_cyc = 0
-    for i in ins:
+    for i, w in ins:
         op = i.split()[0]
         if op.startswith("v_mfma"):
-            c[op] += 1
-            mfma_cyc += 4 * MFMA_PASSES[op]
+            c[op] += w
+            mfma_cyc += 4 * MFMA_PASSES[op] * w
         elif op.startswith(("buffer_load_", "global_load_", "buffer_store_", "global_store_")):
             width = op.split("_", 2)[2]
-            c[op + (" lds" if re.search(r"\blds\b", i) else "")] += 1
-            req_bytes += REQ_BYTES[width]
+            c[op + (" lds" if re.search(r"\blds\b", i) else "")] += w
+            req_bytes += REQ_BYTES[width] * w
         elif op.startswith("ds_read"):
-            c[op] += 1
-            lds_cyc += LDS_CYCLES[op]
+            c[op] += w
+            lds_cyc += LDS_CYCLES[op] * w
         elif op.startswith("ds_write"):
-            c[op] += 1
+            c[op] += w
         elif op in ("s_barrier", "v_exp_f32_e32", "v_rcp_f32_e32"):
-            c[op] += 1
+            c[op] += w
         elif op.startswith("v_"):
-            c["other vector ALU"] += 1
+            c["other vector ALU"] += w
     return c, mfma_cyc, req_bytes, lds_cyc
 
 
@@ -129,8 +138,8 @@ def main():
         c, mfma_cyc, req_bytes, lds_cyc = mix(ins)
         if not mfma_cyc:
             continue
-        pipe, path, lds = 2 * mfma_cyc, 8 * req_bytes // 64, 8 * lds_cyc
-        row = [nm, sum(v for k, v in c.items() if k.startswith("v_mfma")), sum(v for k, v in c.items() if "load" in k or "store" in k),
+        pipe, path, lds = int(2 * mfma_cyc), int(8 * req_bytes / 64), int(8 * lds_cyc)
+        row = [nm, "%g" % sum(v for k, v in c.items() if k.startswith("v_mfma")), "%g" % sum(v for k, v in c.items() if "load" in k or "store" in k),
                pipe, path, lds, pipe + path, max(pipe, path)]
         meas = pmc.get(nm)
         if meas:
@@ -159,7 +168,7 @@ def main():
         out.append("| `%s` | %s |" % (r[0], " | ".join(str(x) for x in r[1:])))
     out += ["", "## Instructions of the step loop, per wave", ""]
     for nm, n, c in sorted(detail):
-        out.append("* `%s` (%d instructions): %s" % (nm, n, ", ".join("%d %s" % (v, k) for k, v in sorted(c.items(), key=lambda x: -x[1]))))
+        out.append("* `%s` (%d instructions): %s" % (nm, n, ", ".join("%g %s" % (v, k) for k, v in sorted(c.items(), key=lambda x: -x[1]))))
     text = "\n".join(out) + "\n"
     if a.out:
         open(a.out, "w").write(text)
