@@ -1,0 +1,322 @@
+#!/usr/bin/env python
+"""A small issue-level MODEL of one CU running one 8-wave workgroup of a GRU kernel: the step loop's instructions, as the code object has
+them, replayed by eight in-order waves (two per SIMD) against four shared resources.  Not a measurement - a way to ask which of the
+machine's rules, as far as section 7 of DESIGN.md knows them, reproduce the cycles the counters measured, and what a schedule change
+would do under the same rules.  CPU only.  Calibration and what it does not explain: profiles/r06_r_cu_issue_model.md.
+
+Rules (parameters in Params; the defaults are the guides' figures or what round 6 measured):
+  * a wave issues in order, at most one instruction per `issue` cycles; an instruction issues when its unit takes it:
+      - MFMA: one matrix pipe per SIMD, busy passes x 4 cycles per instruction, first come first served between the SIMD's two waves;
+      - vector ALU: one per SIMD, `valu` cycles per instruction (`trans` for v_exp / v_rcp), concurrent with the matrix pipe;
+      - vector memory: ONE address path per CU, bytes / 64 cycles per request (a 1-KiB request: 16), requests taken in the order the waves
+        asked; the wave waits until its request is taken; the data is there `lat_l2` cycles (`lat_dma` for transfers into LDS)
+        after the path has moved it; a wave's loads return in order;
+      - LDS: one per CU, the guide's cycles per instruction, data `lat_lds` cycles later, in order; its queue takes an instruction at once
+        (the wave goes on) up to `lds_depth` outstanding per wave;
+      - scalar instructions and s_nop: the wave's own time only;
+  * s_waitcnt vmcnt(N) / lgkmcnt(N): the wave waits until at most N of its loads / LDS reads are outstanding; s_barrier: all eight waves;
+  * a vector-ALU (or memory) instruction that reads a register an MFMA writes waits for that MFMA to finish;
+  * the only wave-dependent code of the loops - the x transfers' extra fragment and the counted wait that goes with it, behind branches on
+    a scalar condition - is given to waves 0-3 (the arm with more transfers / the larger count) and waves 4-7 (the other arm).
+
+    python tools/cu_issue_sim.py --asm api.s --kernel gru_layer12_mx_kernel<true,false,false,false,3> [--steps 4] [--set lat_dma=1500 ...]
+"""
+import argparse
+import heapq
+import os
+import re
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa_step_mix as mixm         # noqa: E402
+
+
+class Params:
+    issue = 2           # cycles between two instructions of one wave
+    valu = 2            # vector ALU cycles per instruction (SIMD-32: a wave64 instruction issues over 2 cycles)
+    trans = 4           # v_exp / v_rcp
+    lat_l2 = 500        # request moved -> data in registers (weights: L2 hits)
+    lat_dma = 4000      # request moved -> data in LDS (x transfers from the layer below's output: 3.5-5 k measured)
+    lat_lds = 64        # LDS instruction served -> data in registers
+    lds_depth = 12      # LDS instructions a wave can have outstanding before it waits at issue
+    mfma_tail = 8       # cycles after an MFMA's passes before another unit may read its result
+    path_bytes = 64     # bytes per cycle of the CU's vector-memory path
+
+
+REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def regs(text):
+    out = []
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.append((int(m.group(1)), int(m.group(2))))
+        else:
+            out.append((int(m.group(3)), int(m.group(3))))
+    return out
+
+
+class Ins:
+    __slots__ = ("kind", "cyc", "n", "dst", "src", "lds", "group", "text")
+
+    def __init__(self, text, group):
+        self.text, self.group = text, group
+        op = text.split()[0]
+        ops = text[len(op):]
+        rr = regs(ops)
+        self.dst, self.src, self.lds, self.n, self.cyc = None, rr, False, 0, 0
+        if op.startswith("v_mfma"):
+            self.kind, self.cyc = "mfma", 4 * mixm.MFMA_PASSES[op]
+            self.dst, self.src = rr[0], rr[1:]
+        elif op.startswith(("buffer_load_", "global_load_")):
+            self.kind = "vload"
+            self.lds = re.search(r"\blds\b", text) is not None
+            self.n = mixm.REQ_BYTES[op.split("_", 2)[2]]
+            if not self.lds:
+                self.dst, self.src = rr[0], rr[1:]
+        elif op.startswith(("buffer_store_", "global_store_")):
+            self.kind, self.n = "vstore", mixm.REQ_BYTES[op.split("_", 2)[2]]
+        elif op.startswith("ds_read"):
+            self.kind, self.cyc = "lds", mixm.LDS_CYCLES[op]
+            self.dst, self.src = rr[0], rr[1:]
+        elif op.startswith("ds_write"):
+            self.kind, self.cyc = "ldsw", 13 if "b128" in op or "2_b64" in op else 6
+        elif op == "s_waitcnt":
+            self.kind = "wait"
+            vm, lg = re.search(r"vmcnt\((\d+)\)", text), re.search(r"lgkmcnt\((\d+)\)", text)
+            self.n = (int(vm.group(1)) if vm else None, int(lg.group(1)) if lg else None)
+        elif op == "s_barrier":
+            self.kind = "barrier"
+        elif op == "s_nop":
+            self.kind, self.cyc = "nop", int(ops.strip() or 0) + 1
+        elif op.startswith("v_"):
+            self.kind = "valu"
+            self.cyc = -1 if op.startswith(("v_exp", "v_rcp", "v_log", "v_sqrt", "v_rsq")) else 0      # (Params.trans / Params.valu at run time)
+            if op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                self.dst = None
+            elif rr:
+                self.dst, self.src = rr[0], rr[1:]
+        else:
+            self.kind = "salu"
+
+
+def program(body):
+    """[Ins] of the step loop, each with the wave group that executes it: 'all', 'hi' (waves 0-3) or 'lo' (waves 4-7)"""
+    lines = body.split("\n")
+    labs = {m.group(1): i for i, ln in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", ln)] if m}
+    best = None
+    for i, ln in enumerate(lines):
+        m = re.search(r"\b(?:s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", ln)
+        if m and labs.get(m.group(1), i) < i and (best is None or labs[m.group(1)] <= best[0]):
+            best = (labs[m.group(1)], i)
+    a, e = best
+
+    def text_of(j):
+        t = lines[j].strip().split(";")[0].strip()
+        return t if lines[j].startswith("\t") and t and not t.startswith(".") else None
+
+    regions = []                    # (first line, label line) of the code behind a forward branch on a scalar condition
+    for i in range(a, e):
+        m = re.search(r"\bs_cbranch_(?:scc|vcc)\w*\s+(\.LBB\d+_\d+)", lines[i])
+        if m and i < labs[m.group(1)] <= e:
+            regions.append((i + 1, labs[m.group(1)]))
+    group = {}
+
+    def weight(r):
+        dma = wait = 0
+        for j in range(*r):
+            t = text_of(j)
+            if not t:
+                continue
+            if re.search(r"\blds\b", t) and t.startswith("buffer_load"):
+                dma += 1
+            m = re.search(r"vmcnt\((\d+)\)", t)
+            if m:
+                wait = max(wait, int(m.group(1)))
+        return dma, wait
+
+    k = 0
+    while k < len(regions):
+        r = regions[k]
+        w = weight(r)
+        nxt = regions[k + 1] if k + 1 < len(regions) else None
+        paired = False
+        if nxt is not None and w != (0, 0):
+            gap = sum(1 for j in range(r[1], nxt[0]) if text_of(j))
+            w2 = weight(nxt)
+            if gap <= 6 and (w[0] > 0) == (w2[0] > 0) and (w[1] > 0) == (w2[1] > 0) and w2 != (0, 0):
+                hi, lo = (r, nxt) if w >= w2 else (nxt, r)
+                for j in range(*hi):
+                    group[j] = "hi"
+                for j in range(*lo):
+                    group[j] = "lo"
+                paired = True
+                k += 2
+        if not paired:
+            if w != (0, 0):
+                for j in range(*r):
+                    group[j] = "hi"
+            k += 1
+    prog = []
+    for j in range(a, e + 1):
+        t = text_of(j)
+        if t and not t.startswith(("s_cbranch", "s_branch")):
+            prog.append(Ins(t, group.get(j, "all")))
+    return prog
+
+
+class Wave:
+    def __init__(self, w, prog):
+        self.w, self.simd, self.hi = w, w % 4, w < 4
+        self.prog = [i for i in prog if i.group == "all" or (i.group == "hi") == self.hi]
+        self.pc, self.iter, self.t = 0, 0, 0
+        self.vm, self.lgkm = [], []             # completion times of outstanding loads / LDS reads, oldest first
+        self.busy = {}                          # register -> cycle its MFMA result can be read
+
+
+def simulate(prog, steps, p, trace=None):
+    waves = [Wave(w, prog) for w in range(8)]
+    mfma_free, valu_free = [0] * 4, [0] * 4
+    path_free = lds_free = 0
+    at_barrier = []
+    step_end = []
+    stat = dict(mfma=0, path=0, lds=0, wait_vm=0, wait_lgkm=0, wait_path=0, wait_mfma=0, wait_bar=0, wait_dep=0)
+    heap = [(0, w.w) for w in waves]
+    heapq.heapify(heap)
+    while heap:
+        t, wi = heapq.heappop(heap)
+        w = waves[wi]
+        if w.pc == len(w.prog):
+            w.pc, w.iter = 0, w.iter + 1
+            if wi == 0:
+                step_end.append(t)
+            if w.iter == steps:
+                continue
+        ins = w.prog[w.pc]
+        k = ins.kind
+        nxt = t + p.issue
+        dep = t
+        if k in ("valu", "lds", "vload", "vstore", "ldsw") and w.busy:
+            for a, b in ins.src:
+                for r in range(a, b + 1):
+                    if r in w.busy:
+                        dep = max(dep, w.busy[r])
+            if ins.dst and k != "mfma":
+                for r in range(ins.dst[0], ins.dst[1] + 1):
+                    if r in w.busy:
+                        dep = max(dep, w.busy[r])
+            stat["wait_dep"] += dep - t
+        if k == "mfma":
+            s = max(t, mfma_free[w.simd])
+            stat["wait_mfma"] += s - t
+            mfma_free[w.simd] = s + ins.cyc
+            stat["mfma"] += ins.cyc
+            done = s + ins.cyc + p.mfma_tail
+            for r in range(ins.dst[0], ins.dst[1] + 1):
+                w.busy[r] = done
+            if len(w.busy) > 400:
+                w.busy = {r: d for r, d in w.busy.items() if d > t}
+            nxt = s + p.issue
+        elif k == "valu":
+            s = max(dep, valu_free[w.simd])
+            valu_free[w.simd] = s + (p.trans if ins.cyc < 0 else p.valu)
+            nxt = s + p.issue
+        elif k in ("vload", "vstore"):
+            s = max(dep, path_free)
+            stat["wait_path"] += s - dep
+            cyc = ins.n / p.path_bytes
+            path_free = s + cyc
+            stat["path"] += cyc
+            if k == "vload":
+                done = path_free + (p.lat_dma if ins.lds else p.lat_l2)
+                if w.vm:
+                    done = max(done, w.vm[-1])
+                w.vm.append(done)
+            nxt = s + p.issue
+        elif k in ("lds", "ldsw"):
+            # the LDS queue takes the instruction at once (the wave goes on) unless `lds_depth` of its own are still outstanding
+            w.lgkm = [d for d in w.lgkm if d > dep]
+            s0 = dep if len(w.lgkm) < p.lds_depth else w.lgkm[len(w.lgkm) - p.lds_depth]
+            s = max(s0, lds_free)
+            lds_free = s + ins.cyc
+            stat["lds"] += ins.cyc
+            if k == "lds":
+                done = lds_free + p.lat_lds
+                if w.lgkm:
+                    done = max(done, w.lgkm[-1])
+                w.lgkm.append(done)
+            nxt = s0 + p.issue
+        elif k == "wait":
+            vm, lg = ins.n
+            s = t
+            if vm is not None:
+                w.vm = [d for d in w.vm if d > t]
+                if len(w.vm) > vm:
+                    s2 = w.vm[len(w.vm) - vm - 1]
+                    stat["wait_vm"] += max(0, s2 - s)
+                    s = max(s, s2)
+            if lg is not None:
+                w.lgkm = [d for d in w.lgkm if d > t]
+                if len(w.lgkm) > lg:
+                    s2 = w.lgkm[len(w.lgkm) - lg - 1]
+                    stat["wait_lgkm"] += max(0, s2 - s)
+                    s = max(s, s2)
+            nxt = max(s, t) + p.issue
+        elif k == "barrier":
+            at_barrier.append((t, wi))
+            w.pc += 1
+            if len(at_barrier) == 8:
+                rel = max(x for x, _ in at_barrier) + p.issue
+                for x, j in at_barrier:
+                    stat["wait_bar"] += rel - x
+                    heapq.heappush(heap, (rel, j))
+                at_barrier = []
+            continue
+        elif k == "nop":
+            nxt = t + ins.cyc
+        w.pc += 1
+        if trace is not None and wi == trace[0] and w.iter == 1 and trace[1] <= w.pc < trace[2]:
+            print("%7d +%-5d %s" % (t, nxt - t, ins.text[:110]))
+        stat["t_" + k] = stat.get("t_" + k, 0) + (nxt - t)
+        heapq.heappush(heap, (nxt, wi))
+    per_step = [b - a for a, b in zip(step_end, step_end[1:])]
+    return per_step, stat
+
+
+def find_kernel(asm_text, want):
+    want = want.replace(" ", "")
+    for name, body in mixm.kernel_bodies(asm_text):
+        if not any(k in name for k in mixm.WANTED):
+            continue
+        nm = mixm.short(subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()).replace(" ", "")
+        if nm == want:
+            return body
+    raise SystemExit("no kernel %s in the assembly" % want)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--asm", required=True)
+    ap.add_argument("--kernel", required=True)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--set", nargs="*", default=[], help="parameter=value ...")
+    ap.add_argument("--trace", nargs=3, type=int, default=None, help="wave, first and last instruction index: print that wave's issue times in step 1")
+    a = ap.parse_args()
+    p = Params()
+    for kv in a.set:
+        k, v = kv.split("=")
+        setattr(p, k, float(v) if "." in v else int(v))
+    prog = program(find_kernel(open(a.asm).read(), a.kernel))
+    per_step, stat = simulate(prog, a.steps, p, a.trace)
+    n = a.steps
+    print("%s: %d instructions per step (hi waves %d, lo waves %d)" % (a.kernel, len(prog), sum(1 for i in prog if i.group != "lo"), sum(1 for i in prog if i.group != "hi")))
+    print("cycles per step: %s" % ", ".join("%d" % x for x in per_step))
+    print("per step: matrix pipe %.0f per SIMD, path %.0f, LDS %.0f; waits per wave: path %.0f, matrix pipe %.0f, vmcnt %.0f, lgkmcnt %.0f, barrier %.0f, MFMA result %.0f"
+          % (stat["mfma"] / 4 / n, stat["path"] / n, stat["lds"] / n, stat["wait_path"] / 8 / n, stat["wait_mfma"] / 8 / n, stat["wait_vm"] / 8 / n,
+             stat["wait_lgkm"] / 8 / n, stat["wait_bar"] / 8 / n, stat["wait_dep"] / 8 / n))
+    print("a wave's time by the instruction it stood at: " + ", ".join("%s %.0f" % (k[2:], v / 8 / n) for k, v in sorted(stat.items()) if k.startswith("t_")))
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,7 @@ namespace ccsm {
 #define F3S12(NB) template __global__ void gru_layer12_f3s_kernel<NB, false>(const uint4*, uint4*, const uint4*, const float*, const float*, int, unsigned long long*);
 #define F3S0(NB) template __global__ void gru_layer0_f3s_kernel<NB>(const uint4*, uint4*, const uint4*, const float*, const float*, int);
 #define MX16(F8, NB) template __global__ void gru_layer12_mx16_kernel<F8, NB, false>(const uint4*, uint4*, const uint4*, const float*, const float*, int, unsigned long long*);
+#define MX12(F8, NB) template __global__ void gru_layer12_mx_kernel<F8, false, false, false, NB>(const uint4*, uint4*, const uint4*, const float*, const float*, int, unsigned long long*);   // (compiler-scheduled: not gated; tools/cu_issue_sim.py compiles variants of it)
 %(inst)s
 }
 """
