@@ -430,6 +430,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 #define CCSM_FENCE asm volatile("" ::: "memory")
+// -DCCSM_MX_PIN_READS (experiment, not measured: the pool was closed): the layer-1/2 kernel's B-operand reads are written one MFMA group AHEAD of
+// their first use, but its MFMAs are builtins - pure values the scheduler hoists over the loads, which the memory fence holds in place: in the
+// code object every k-block's reads stand right in front of their first MFMA.  This pins them where they are written.
+#ifdef CCSM_MX_PIN_READS
+#define CCSM_PIN_READS __builtin_amdgcn_sched_barrier(0)
+#else
+#define CCSM_PIN_READS ((void)0)
+#endif
 
 // Weight streams, per (direction, wave), in bytes.  hi / lo fragments and blobs are 1 KiB (lane * 16), the scale dwords of a pair
 // 256 B (lane * 4; byte g = gate g):
@@ -1054,6 +1062,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             const int xs = slot_off(slot);
             const int slot_n = slot == RS - 1 ? 0 : slot + 1;
             rdx(xh1, xs, 1, 0);
+            CCSM_PIN_READS;
             if constexpr (kMxIlv && CCSM_PWR_LDS1 == 0 && P + NSA < NPAIR) {
                 static_for<0, 2>([&](auto GC) {
                     constexpr int g = decltype(GC)::value;
@@ -1073,6 +1082,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
                 if constexpr (HS3) wbl[1][0] = w_at(OFF_B + (9 << 10)); else wbs = ws_at(OFF_B + OFF_BS);
             }
             rdx_blob(xs);
+            CCSM_PIN_READS;
             if constexpr (kMxIlv && CCSM_PWR_LDS1 == 0 && P + NSA < NPAIR) {
                 static_for<0, 2>([&](auto GC) {
                     constexpr int g = decltype(GC)::value;
@@ -1108,6 +1118,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             if constexpr (P + 1 < NPAIR) dma_ahead(slot, s, P); else slot_a15 = slot;   // the vacated slot is refilled at once (0.4 pair more
                                                                                       // lead than as the pair's youngest operation: +1.4 %)
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
+            CCSM_PIN_READS;
             CCSM_FENCE;
             if constexpr (XD) {
                 static_for<0, NB>([&](auto BC) {
@@ -1330,6 +1341,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             const int xs = slot_off(slot);
             const int slot_n = slot == RS - 1 ? 0 : slot + 1;
             rdx(xh1, xs, 1, 0);
+            CCSM_PIN_READS;
             CCSM_FENCE;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][0], xh[CCSM_PWR_LDS1 == 2 ? 0 : bt], acc[2][bt]);
@@ -1338,6 +1350,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             if constexpr (P + 4 < NPAIR) wch[WS][0] = w_at(OFF_C + (P + 4) * PC + (0 << 10));
             else if constexpr (AF == 0) wah[AS][0][0] = w_at(AS * PA + (0 << 10)); else was[AS] = ws_at(AS * PA + (6 << 10));
             rdx_blob(xs);
+            CCSM_PIN_READS;
             CCSM_FENCE;
 #pragma unroll
             for (int bt = 0; bt < NB; ++bt) acc[2][bt] = mfma16(wch[WS][1], xh1[CCSM_PWR_LDS1 == 2 ? 0 : bt], acc[2][bt]);
@@ -1350,6 +1363,7 @@ __global__ __launch_bounds__(512, 2) void gru_layer12_mx_kernel(const uint4* __r
             if constexpr (!(kMxDiag & 2)) __syncthreads();
             dma_ahead(slot, s, NPAIR + P);                              // the vacated slot is refilled at once
             if constexpr (P + 1 < NPAIR) rdx(xh, slot_off(slot_n), 0, 0);
+            CCSM_PIN_READS;
             CCSM_FENCE;
             if constexpr (XD) {
                 static_for<0, NB>([&](auto BC) {
